@@ -1,0 +1,210 @@
+/*
+ * pocketflow_hip.h -- C ABI of the MI355X (gfx950) kernel library for the PocketFlow
+ * compression-training hot path.
+ *
+ * The reference (Tencent/PocketFlow) has NO native boundary: every "kernel" is a chain of stock
+ * TensorFlow ops stitched into the graph from Python.  This header is therefore the boundary a
+ * maintainer would bind (ctypes / cffi / pybind) in place of those op chains; each entry point
+ * cites the reference op chain (file:line under /root/reference) it replaces.  See INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / TF types.
+ *   - every pointer is a DEVICE pointer unless the name ends in _host.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - functions never allocate, never synchronise, never own memory; they enqueue kernels and
+ *     return 0 (hipSuccess) or a hipError_t value.  pf_error_string() names it.
+ *   - dtype codes: PF_F32 = 0, PF_BF16 = 1 (storage type; arithmetic is always float32).
+ *   - activation codes: PF_ACT_NONE = 0, PF_ACT_RELU = 1, PF_ACT_RELU6 = 2.
+ *   - weight layout: KRSC = [cout][kh][kw][cin] (dense: [out][in]); the reference's HWIO flat
+ *     index (needed by 'split' buckets) is recovered by index arithmetic, never by a transpose.
+ *   - activation layout: NHWC, i.e. a [rows = N*H*W][C] row-major matrix.
+ *   - min/max slots are pairs of uint32 holding an order-preserving encoding of a float
+ *     ({enc(min), ~enc(max)}), initialised to 0xFFFFFFFF (one memset) so that both are updated with
+ *     atomicMin and the result is independent of the order of arrival (bit-deterministic).
+ */
+#ifndef POCKETFLOW_HIP_H_
+#define POCKETFLOW_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { PF_F32 = 0, PF_BF16 = 1 };
+enum { PF_ACT_NONE = 0, PF_ACT_RELU = 1, PF_ACT_RELU6 = 2 };
+enum { PF_BUCKET_TENSOR = 0, PF_BUCKET_CHANNEL = 1, PF_BUCKET_SPLIT = 2 };
+
+/* One weight tensor inside the flat parameter buffer (64 bytes, mirrored by ctypes/numpy). */
+typedef struct PfSeg {
+  int64_t offset;       /* first element in the flat buffers                                  */
+  int64_t len;          /* RS*I*O                                                             */
+  int32_t RS;           /* kh*kw of the reference HWIO = [kh][kw][I][O] kernel (dense: 1)     */
+  int32_t layout;       /* storage: 0 = KRSC [O][kh][kw][I] (dense [O][I]); 1 = CRS depthwise */
+  int32_t I, O;         /* reference cin / cout (depthwise: I = C, O = channel multiplier 1)  */
+  int32_t mode;         /* PF_BUCKET_*                                                        */
+  int32_t bits;         /* quantisation bits of this tensor (fed per step in the reference)   */
+  int32_t bucket_size;  /* 'split' buckets only                                               */
+  int32_t n_bucket;     /* number of (alpha,beta) pairs: 1 | O | ceil(len/bucket_size)        */
+  int64_t slot_offset;  /* first min/max slot (pair index) of this tensor                     */
+  int64_t cb_offset;    /* NUQ: first codebook float; layout [k][n_bucket]                    */
+} PfSeg;
+
+/* block -> (segment, chunk) map entry; built once per model on the host.  For the apply kernels in
+ * channel mode, row0 / nrows are the first output channel and the number of output channels the
+ * chunk touches (their alpha/beta are staged in LDS); 0 / 1 otherwise.                        */
+typedef struct PfBlock { int32_t seg; int32_t chunk; int32_t row0; int32_t nrows; } PfBlock;
+
+#define PF_CHUNK 4096   /* elements per block in the segment kernels (256 threads x 16) */
+
+const char* pf_error_string(int err);
+int pf_version(void);
+
+/* ---- K1: min/max calibration -------------------------------------------------------------
+ * replaces tf.reduce_max / tf.reduce_min (+stop_gradient) of __scale,
+ * learners/uniform_quantization/utils.py:224-225 == learners/nonuniform_quantization/utils.py:411-412 */
+int pf_minmax_slots_init(uint32_t* slots, int64_t n_pairs, void* stream);
+/* whole-tensor min/max of act(x); one pass, wave-shuffle + LDS block reduce, 2 atomics / block */
+int pf_minmax_tensor(const void* x, int64_t n, int dtype, int act, uint32_t* slot, void* stream);
+/* decode slots -> alpha = max - min + 1e-10, beta = min (float pairs), for logging / tests */
+int pf_minmax_decode(const uint32_t* slots, int64_t n_pairs, float* alpha_beta, void* stream);
+
+/* ---- K2/K4: uniform fake-quant, forward ----------------------------------------------------
+ * replaces (x-beta)/alpha -> *k -> round -> /k -> alpha*.+beta of __uniform_quantize,
+ * learners/uniform_quantization/utils.py:163-199, 228-245, and the activation variant
+ * insert_quant_op_for_activations :51-79 (act(x) recomputed, per-tensor min/max).            */
+int pf_uq_apply(const void* x, void* y, int64_t n, int in_dtype, int out_dtype, int act,
+                const uint32_t* slot, int bits, void* stream);
+/* backward of act -> fake-quant: STE through round, then ReluGrad / Relu6Grad: dx = g * mask(u) */
+int pf_act_grad(const void* g, const void* u, void* dx, int64_t n, int dtype, int act,
+                void* stream);
+
+/* ---- K1+K2+K3 over ALL weight tensors of a model in two launches ---------------------------
+ * replaces insert_quant_op_for_weights (uq utils.py:81-113) incl. __split_bucket / __channel_bucket
+ * (:247-289).  w_flat is the fp32 master buffer, qw_flat the fake-quantised copy the convolutions
+ * read (fp32 or bf16).                                                                        */
+int pf_seg_minmax(const float* w_flat, const PfSeg* segs, const PfBlock* blocks, int n_blocks,
+                  uint32_t* slots, void* stream);
+int pf_seg_uq_apply(const float* w_flat, void* qw_flat, int out_dtype, const PfSeg* segs,
+                    const PfBlock* blocks, int n_blocks, const uint32_t* slots, void* stream);
+
+/* ---- K5: non-uniform (codebook) fake-quant -------------------------------------------------
+ * replaces tile/abs/argmin/gather of __build_norm_quant_point / __build_bucket_norm_quant_point,
+ * learners/nonuniform_quantization/utils.py:284-347.  idx (uint8, k <= 256) is kept for backward. */
+int pf_seg_nuq_apply(const float* w_flat, void* qw_flat, int out_dtype, uint8_t* idx_flat,
+                     const float* codebooks, const PfSeg* segs, const PfBlock* blocks,
+                     int n_blocks, const uint32_t* slots, void* stream);
+/* dL/dc[j][b] = sum_{i in bucket b, idx_i = j} alpha_b * g_i   (gather-grad scatter-add under the
+ * override map {'Mul':'Add','Sign':'Identity'}, nuq utils.py:305-306, 345-346).  dcodebooks must be
+ * zeroed by the caller (one memset).                                                          */
+int pf_seg_nuq_codebook_grad(const void* g_flat, int g_dtype, const uint8_t* idx_flat,
+                             float* dcodebooks, const PfSeg* segs, const PfBlock* blocks,
+                             int n_blocks, const uint32_t* slots, void* stream);
+/* normalised weights x_hat = (w - beta) / alpha of ONE tensor (for the quantile initialiser,
+ * nuq utils.py:349-366, which then sorts them).                                               */
+int pf_seg_normalize(const float* w_flat, float* xn_out, const PfSeg* segs, int seg_index,
+                     const uint32_t* slots, void* stream);
+
+/* ---- K7/K9: weight sparsification ----------------------------------------------------------
+ * replaces the prune_op chain of WeightSparseLearner.__build_masks,
+ * learners/weight_sparsification/learner.py:283-288.                                          */
+int pf_ws_bkup_merge_abs(const float* var, float* bkup, const float* mask, float* abs_out,
+                         int64_t n, void* stream);
+/* k-th largest of a non-negative float array by 4-pass radix select on the bit pattern
+ * (tf.contrib.distributions.percentile = descending sort + index).  workspace: 1024 uint32.   */
+int pf_kth_largest_nonneg(const float* a, int64_t n, int64_t k_desc_index, float* out,
+                          uint32_t* workspace, void* stream);
+int pf_ws_mask_apply(float* var, const float* bkup, float* mask, const float* thr, int64_t n,
+                     void* stream);
+/* count_nonzero (ws learner.py:51-65) */
+int pf_count_nonzero(const float* x, int64_t n, unsigned long long* out, void* stream);
+
+/* ---- K8 (channel pruning): per-channel binary gradient masks -------------------------------
+ * replaces mask = ones; mask[:,:,~keep_in,:]=0; mask[:,:,:,~keep_out]=0 ; g*mask of
+ * ChannelPrunedLearner.__calc_grads_pruned, learners/channel_pruning/learner.py:406-419.
+ * KRSC storage; keep_in[I], keep_out[O] are staged in LDS.                                     */
+int pf_cp_build_mask(float* mask, const uint8_t* keep_in, const uint8_t* keep_out, int O, int RS,
+                     int I, void* stream);
+int pf_cp_mask_grad(float* g, const uint8_t* keep_in, const uint8_t* keep_out, int O, int RS,
+                    int I, void* stream);
+
+/* ---- K8+K14: fused (L2-coupled, masked) optimiser steps over a flat buffer ------------------
+ * replaces tf.train.AdamOptimizer / MomentumOptimizer + `grad * mask` + the L2 term of calc_loss:
+ *   uq learner.py:244-253, ws learner.py:201-212,314-332, cp learner.py:357-368,
+ *   nets/resnet_at_ilsvrc12.py:132-135 (loss_w_dcy * sum l2_loss).
+ * g_eff = (g * g_scale + wd * p) * mask for the first n_decay elements, (g * g_scale) * mask after;
+ * mask may be NULL.  g may be fp32 or bf16.  g_scale = 1/world_size folds the all-reduce average. */
+int pf_adam_flat(float* p, const void* g, int g_dtype, float* m, float* v, const float* mask,
+                 int64_t n, int64_t n_decay, float wd, float g_scale, float lr, float beta1,
+                 float beta2, float eps, float beta1_power, float beta2_power, void* stream);
+int pf_momentum_flat(float* p, const void* g, int g_dtype, float* acc, const float* mask,
+                     int64_t n, int64_t n_decay, float wd, float g_scale, float lr, float momentum,
+                     void* stream);
+
+/* ---- K10+K11: distillation + hard-label losses, forward and backward in one kernel ---------
+ * replaces tf.losses.softmax_cross_entropy(labels, logits) (nets/<model>.py calc_loss) and
+ * DistillationHelper.calc_loss (learners/distillation_helper.py:86-103).
+ *   L_model = mean_n CE(labels_n, z_s_n) ; L_dst = loss_w * mean_n CE(softmax(z_t/T), z_s/T)
+ *   dz_s = (softmax(z_s)*sum(labels) - labels)/B + loss_w/(B*T) * (softmax(z_s/T) - softmax(z_t/T))
+ * labels: float one-hot / soft [B][C].  z_t may be NULL (no distillation).  losses[0] = L_model,
+ * losses[1] = L_dst.  row_ws: B*2 floats of scratch.  One workgroup per row, wave-shuffle
+ * reductions, fixed summation order (bit-deterministic).                                      */
+int pf_ce_distill_fwd_bwd(const void* z_s, int zs_dtype, const float* labels, const void* z_t,
+                          int zt_dtype, int B, int C, float tempr, float loss_w, float* losses,
+                          void* dz_s, int dz_dtype, float* row_ws, void* stream);
+
+/* ---- K13 fused with K4: batch-norm (training) + ReLU + activation fake-quant ----------------
+ * replaces tf.layers.batch_normalization(fused=True) -> tf.nn.relu -> (min/max, quantise) of
+ * utils/external/resnet_model.py:55-62 + uq utils.py:51-79 for the BN->ReLU->conv chains of
+ * ResNet-v2 / MobileNet-v1.  x is [rows][C] (NHWC).
+ * pass 1 (pf_bn_stats): per-channel sum, sum of squares, min, max of x in ONE read.
+ * finalize: mean/var -> scale/shift, moving averages (unbiased variance), and -- because
+ *   y = act(scale*x+shift) is monotone in x per channel -- the exact whole-tensor min/max of y
+ *   from the per-channel min/max of x, written into the activation's min/max slot.
+ * pass 2 (pf_bn_act_quant_apply): read x, write q = fake_quant(act(scale*x+shift)).            */
+int pf_bn_stats(const void* x, int dtype, int64_t rows, int C, float* partial /*[nblk][4][C]*/,
+                int n_blocks, void* stream);
+int pf_bn_finalize(const float* partial, int n_blocks, int64_t rows, int C, const void* x_row0,
+                   int dtype, const float* gamma, const float* beta, float* moving_mean,
+                   float* moving_var, float momentum, float eps, int training /*0: use moving stats*/,
+                   int act, float* scale_shift /*[2][C]*/, float* mean_invstd /*[2][C]*/,
+                   uint32_t* slot /*may be NULL*/, void* stream);
+int pf_bn_act_quant_apply(const void* x, void* q, int dtype, int64_t rows, int C,
+                          const float* scale_shift, int act, const uint32_t* slot, int bits,
+                          int quantize, void* stream);
+/* backward: dy = dq * actmask(scale*x+shift) (STE); per-channel sum(dy), sum(dy*xhat) */
+int pf_bn_bwd_stats(const void* dq, const void* x, int dtype, int64_t rows, int C,
+                    const float* scale_shift, const float* mean_invstd, int act,
+                    float* partial /*[nblk][2][C]*/, int n_blocks, void* stream);
+int pf_bn_bwd_finalize(const float* partial, int n_blocks, int C, float* dgamma, float* dbeta,
+                       void* stream);
+int pf_bn_bwd_apply(const void* dq, const void* x, void* dx, int dtype, int64_t rows, int C,
+                    const float* scale_shift, const float* mean_invstd,
+                    const float* dgamma, const float* dbeta, int act, void* stream);
+/* inference-mode BN + act (teacher forward, eval graphs): y = act(scale*x+shift) */
+int pf_bn_eval_scale_shift(const float* gamma, const float* beta, const float* moving_mean,
+                           const float* moving_var, float eps, int C, float* scale_shift,
+                           void* stream);
+
+/* ---- K12: dense contraction on the matrix cores (MFMA) --------------------------------------
+ * replaces tf.nn.conv2d / tf.matmul forward, Conv2DBackpropInput and Conv2DBackpropFilter for the
+ * 1x1 convolutions and dense layers (utils/external/resnet_model.py:92-103; uq utils.py:92-103):
+ * in NHWC a 1x1 stride-1 convolution IS a row-major GEMM.  bf16 in, fp32 accumulate.
+ *   pf_gemm_bf16_nt : C[M][N]  = A[M][K] * B[N][K]^T   (forward:  X[rows][Cin]  x W[Cout][Cin])
+ *   pf_gemm_bf16_nn : C[M][N]  = A[M][K] * B[K][N]     (bwd-data: dY[rows][Cout] x W[Cout][Cin])
+ *   pf_gemm_bf16_tn : C[M][N] += A[K][M]^T * B[K][N]     (bwd-filter: dY[rows][Cout]^T x X[rows][Cin];
+ *                     split-K over the huge rows dimension, fp32 atomic accumulation into C, which
+ *                     is the flat fp32 gradient buffer; out_dtype must be PF_F32)
+ * out_dtype selects bf16 or fp32 C for nt/nn.  Requirements: K % 32 == 0 for nt/nn; M % 8 == 0,
+ * N % 8 == 0 for nn/tn (16-byte row segments); checked, hipErrorInvalidValue otherwise.          */
+int pf_gemm_bf16_nt(const void* A, const void* B, void* C, int M, int N, int K, int out_dtype,
+                    void* stream);
+int pf_gemm_bf16_nn(const void* A, const void* B, void* C, int M, int N, int K, int out_dtype,
+                    void* stream);
+int pf_gemm_bf16_tn(const void* A, const void* B, void* C, int M, int N, int K, int out_dtype,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* POCKETFLOW_HIP_H_ */

@@ -1,0 +1,18 @@
+#!/usr/bin/env bash
+# Build the gfx950 kernel library in-tree:  pocketflow_amd/csrc/libpocketflow_hip.so
+# (cross-compiles without a GPU).  -ffp-contract=off: one rounding per float op, like the
+# reference's one-TF-op-per-rounding chains; fused multiply-adds are written as fmaf().
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function"
+OBJS=()
+for f in pf_api pf_quant pf_normalize pf_sparse pf_optim pf_loss pf_bn pf_gemm; do
+  if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ] || [ pf_common.h -nt "$f.o" ] || [ ../../include/pocketflow_hip.h -nt "$f.o" ]; then
+    $HIPCC $FLAGS -c "$f.hip" -o "$f.o" &
+  fi
+  OBJS+=("$f.o")
+done
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libpocketflow_hip.so "${OBJS[@]}"
+echo "built $(pwd)/libpocketflow_hip.so"

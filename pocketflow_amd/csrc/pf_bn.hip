@@ -1,0 +1,492 @@
+// K13 fused with K4: batch-norm (training / inference) + ReLU/ReLU6 + activation fake-quant over
+// NHWC activations viewed as a [rows][C] matrix, forward and backward.
+//
+//   forward : pass 1 reads x once -> per-channel {sum, sumsq, min, max} (block partials)
+//             finalize            -> mean/var, scale/shift, moving stats, and the EXACT whole-tensor
+//                                    min/max of y = act(scale*x+shift) from per-channel min/max of x
+//                                    (y is monotone in x per channel), written to the min/max slot
+//             pass 2 reads x, writes q = fake_quant(y)
+//   i.e. 2 reads + 1 write per element instead of the reference's ~9 separate TF elementwise /
+//   reduction kernels (batch_norm, relu, reduce_max, reduce_min, sub, div, mul, round, div, mul, add).
+//   backward: pass 1 reads dq, x -> per-channel {sum dy, sum dy*xhat}; pass 2 reads dq, x, writes dx.
+//             The ReLU mask is recomputed from x, so neither y nor a mask tensor is ever stored.
+//
+// Reference semantics restated here (paths under /root/reference; BN maths is TF's fused kernel):
+//   utils/external/resnet_model.py:55-62   tf.layers.batch_normalization(momentum=.997, eps=1e-5, fused)
+//   utils/external/mobilenet_v1.py:428-477 slim.batch_norm(decay=.9997, epsilon=1e-3)
+//   learners/uniform_quantization/utils.py:51-79  activation fake-quant after every Relu / Relu6
+#include "pf_common.h"
+
+// Fast path: C % 8 == 0, G = C/8 <= 256, 256 % G == 0 (C = 8 .. 2048, powers of two): a thread owns
+// one group of 8 consecutive channels and walks rows; a wavefront reads 1 KiB contiguous.
+static inline bool bn_fast_ok(int C) {
+  if (C % 8) return false;
+  const int G = C / 8;
+  return G <= 256 && (256 % G) == 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward pass 1
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(PF_THREADS) void k_bn_stats_fast(const T* __restrict__ x, int64_t rows, int C,
+                                                              float* __restrict__ partial) {
+  extern __shared__ float lds[];                 // [256/G][4][C] staged in 4 rounds of [256][8]
+  const int G = C >> 3;
+  const int RPS = PF_THREADS / G;                // rows per slab
+  const int cg = threadIdx.x % G, rsub = threadIdx.x / G;
+  float piv[8];
+  load8<T>(x + (cg << 3), piv);                  // pivot = row 0 (shifted sums: no cancellation)
+  float s[8], ss[8], mn[8], mx[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[j] = 0.f; ss[j] = 0.f; mn[j] = INFINITY; mx[j] = -INFINITY; }
+  for (int64_t r = (int64_t)blockIdx.x * RPS + rsub; r < rows; r += (int64_t)gridDim.x * RPS) {
+    float v[8];
+    load8<T>(x + r * C + (cg << 3), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float d = v[j] - piv[j];
+      s[j] += d;
+      ss[j] = fmaf(d, d, ss[j]);
+      mn[j] = fminf(mn[j], v[j]);
+      mx[j] = fmaxf(mx[j], v[j]);
+    }
+  }
+  // cross-thread (same cg, different rsub) reduction through LDS, one statistic at a time
+  float* out = partial + (int64_t)blockIdx.x * 4 * C;
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    float* a = (st == 0) ? s : (st == 1) ? ss : (st == 2) ? mn : mx;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lds[threadIdx.x * 8 + j] = a[j];
+    __syncthreads();
+    if (rsub == 0) {
+      for (int j = 0; j < 8; ++j) {
+        float acc = lds[cg * 8 + j];
+        for (int q = 1; q < RPS; ++q) {
+          const float o = lds[(q * G + cg) * 8 + j];
+          acc = (st < 2) ? (acc + o) : (st == 2 ? fminf(acc, o) : fmaxf(acc, o));
+        }
+        out[st * C + (cg << 3) + j] = acc;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(PF_THREADS) void k_bn_stats_generic(const T* __restrict__ x, int64_t rows, int C,
+                                                                 float* __restrict__ partial) {
+  // thread = channel (grid.x over channel tiles), grid.y = row split
+  const int c = blockIdx.x * PF_THREADS + threadIdx.x;
+  if (c >= C) return;
+  const float piv = load_one<T>(x + c);
+  float s = 0.f, ss = 0.f, mn = INFINITY, mx = -INFINITY;
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    const float v = load_one<T>(x + r * C + c);
+    const float d = v - piv;
+    s += d; ss = fmaf(d, d, ss);
+    mn = fminf(mn, v); mx = fmaxf(mx, v);
+  }
+  float* out = partial + (int64_t)blockIdx.y * 4 * C;
+  out[c] = s; out[C + c] = ss; out[2 * C + c] = mn; out[3 * C + c] = mx;
+}
+
+extern "C" int pf_bn_stats(const void* x, int dtype, int64_t rows, int C, float* partial,
+                           int n_blocks, void* stream) {
+  if (rows <= 0 || C <= 0 || n_blocks <= 0) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  if (bn_fast_ok(C) && pf_aligned16(x)) {
+    const size_t shm = PF_THREADS * 8 * sizeof(float);
+    if (dtype == PF_F32) k_bn_stats_fast<float><<<n_blocks, PF_THREADS, shm, st>>>((const float*)x, rows, C, partial);
+    else if (dtype == PF_BF16) k_bn_stats_fast<bf16_t><<<n_blocks, PF_THREADS, shm, st>>>((const bf16_t*)x, rows, C, partial);
+    else return (int)hipErrorInvalidValue;
+  } else {
+    dim3 grid((C + PF_THREADS - 1) / PF_THREADS, n_blocks);
+    if (dtype == PF_F32) k_bn_stats_generic<float><<<grid, PF_THREADS, 0, st>>>((const float*)x, rows, C, partial);
+    else if (dtype == PF_BF16) k_bn_stats_generic<bf16_t><<<grid, PF_THREADS, 0, st>>>((const bf16_t*)x, rows, C, partial);
+    else return (int)hipErrorInvalidValue;
+  }
+  PF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// finalize: 64 channels per block; thread (cl = t & 63, part = t >> 6) sums partial blocks
+// part, part+4, ... in a fixed order, then 4-way LDS combine.  Deterministic.
+// ---------------------------------------------------------------------------------------------
+template <int ACT>
+__device__ __forceinline__ void y_range(float scale, float shift, float xmin, float xmax, float& ymin,
+                                        float& ymax) {
+  const float a = fmaf(scale, xmin, shift), b = fmaf(scale, xmax, shift);
+  ymin = apply_act<ACT>(fminf(a, b));
+  ymax = apply_act<ACT>(fmaxf(a, b));
+}
+
+__global__ __launch_bounds__(PF_THREADS) void k_bn_finalize(
+    const float* __restrict__ partial, int n_blocks, int64_t rows, int C, const void* __restrict__ x_row0,
+    int dtype, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ moving_mean, float* __restrict__ moving_var, float momentum, float eps,
+    int training, int act, float* __restrict__ scale_shift, float* __restrict__ mean_invstd,
+    uint32_t* __restrict__ slot) {
+  __shared__ float l_s[4][64], l_ss[4][64], l_mn[4][64], l_mx[4][64];
+  const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float s = 0.f, ss = 0.f, mn = INFINITY, mx = -INFINITY;
+  if (c < C) {
+    for (int b = part; b < n_blocks; b += 4) {
+      const float* p = partial + (int64_t)b * 4 * C;
+      s += p[c]; ss += p[C + c];
+      mn = fminf(mn, p[2 * C + c]); mx = fmaxf(mx, p[3 * C + c]);
+    }
+  }
+  l_s[part][cl] = s; l_ss[part][cl] = ss; l_mn[part][cl] = mn; l_mx[part][cl] = mx;
+  __syncthreads();
+  float ymin = INFINITY, ymax = -INFINITY;
+  if (part == 0 && c < C) {
+    s = (l_s[0][cl] + l_s[1][cl]) + (l_s[2][cl] + l_s[3][cl]);
+    ss = (l_ss[0][cl] + l_ss[1][cl]) + (l_ss[2][cl] + l_ss[3][cl]);
+    mn = fminf(fminf(l_mn[0][cl], l_mn[1][cl]), fminf(l_mn[2][cl], l_mn[3][cl]));
+    mx = fmaxf(fmaxf(l_mx[0][cl], l_mx[1][cl]), fmaxf(l_mx[2][cl], l_mx[3][cl]));
+    float mean, var;
+    if (training) {
+      const float piv = (dtype == PF_F32) ? ((const float*)x_row0)[c] : bf16_to_f32(((const bf16_t*)x_row0)[c]);
+      const double n = (double)rows;
+      const double m1 = (double)s / n;
+      double v = (double)ss / n - m1 * m1;             // biased variance of (x - pivot) == of x
+      if (v < 0.0) v = 0.0;
+      mean = (float)((double)piv + m1);
+      var = (float)v;
+      // moving averages: tf.layers BN  moving -= (moving - batch) * (1 - momentum); the fused
+      // kernel hands the UNBIASED variance to the moving average
+      const float unbiased = (float)(v * (n / (n > 1.0 ? n - 1.0 : 1.0)));
+      const float omm = 1.0f - momentum;
+      moving_mean[c] = moving_mean[c] - (moving_mean[c] - mean) * omm;
+      moving_var[c] = moving_var[c] - (moving_var[c] - unbiased) * omm;
+    } else {
+      mean = moving_mean[c];
+      var = moving_var[c];
+    }
+    const float invstd = 1.0f / sqrtf(var + eps);
+    const float sc = gamma[c] * invstd;
+    const float sh = fmaf(-mean, sc, beta[c]);
+    scale_shift[c] = sc;
+    scale_shift[C + c] = sh;
+    mean_invstd[c] = mean;
+    mean_invstd[C + c] = invstd;
+    if (act == PF_ACT_RELU) y_range<PF_ACT_RELU>(sc, sh, mn, mx, ymin, ymax);
+    else if (act == PF_ACT_RELU6) y_range<PF_ACT_RELU6>(sc, sh, mn, mx, ymin, ymax);
+    else y_range<PF_ACT_NONE>(sc, sh, mn, mx, ymin, ymax);
+  }
+  if (part == 0 && slot != nullptr) {
+    ymin = wave_min(ymin);
+    ymax = wave_max(ymax);
+    if (cl == 0 && ymin <= ymax) {
+      atomicMin(&slot[0], enc_f32(ymin));
+      atomicMin(&slot[1], ~enc_f32(ymax));
+    }
+  }
+}
+
+extern "C" int pf_bn_finalize(const float* partial, int n_blocks, int64_t rows, int C,
+                              const void* x_row0, int dtype, const float* gamma, const float* beta,
+                              float* moving_mean, float* moving_var, float momentum, float eps,
+                              int training, int act, float* scale_shift, float* mean_invstd,
+                              uint32_t* slot, void* stream) {
+  if (C <= 0) return (int)hipErrorInvalidValue;
+  k_bn_finalize<<<(C + 63) / 64, PF_THREADS, 0, (hipStream_t)stream>>>(
+      partial, n_blocks, rows, C, x_row0, dtype, gamma, beta, moving_mean, moving_var, momentum, eps,
+      training, act, scale_shift, mean_invstd, slot);
+  PF_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void k_bn_eval_scale_shift(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ mm, const float* __restrict__ mv, float eps,
+                                      int C, float* __restrict__ ss) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float invstd = 1.0f / sqrtf(mv[c] + eps);
+    const float sc = gamma[c] * invstd;
+    ss[c] = sc;
+    ss[C + c] = fmaf(-mm[c], sc, beta[c]);
+  }
+}
+extern "C" int pf_bn_eval_scale_shift(const float* gamma, const float* beta, const float* moving_mean,
+                                      const float* moving_var, float eps, int C, float* scale_shift,
+                                      void* stream) {
+  k_bn_eval_scale_shift<<<(C + 255) / 256, 256, 0, (hipStream_t)stream>>>(gamma, beta, moving_mean, moving_var, eps, C, scale_shift);
+  PF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward pass 2:  q = fake_quant(act(scale*x + shift))
+// ---------------------------------------------------------------------------------------------
+template <typename T, int ACT, bool FAST>
+__global__ __launch_bounds__(PF_THREADS) void k_bn_apply(const T* __restrict__ x, T* __restrict__ q,
+                                                         int64_t rows, int C,
+                                                         const float* __restrict__ scale_shift,
+                                                         const uint32_t* __restrict__ slot, float k,
+                                                         int quantize) {
+  float alpha = 1.f, beta = 0.f;
+  if (quantize) slot_alpha_beta(slot, alpha, beta);
+  if (FAST) {
+    const int G = C >> 3, RPS = PF_THREADS / G;
+    const int cg = threadIdx.x % G, rsub = threadIdx.x / G;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = scale_shift[(cg << 3) + j]; sh[j] = scale_shift[C + (cg << 3) + j]; }
+#pragma unroll 2
+    for (int64_t r = (int64_t)blockIdx.x * RPS + rsub; r < rows; r += (int64_t)gridDim.x * RPS) {
+      float v[8];
+      const int64_t off = r * C + (cg << 3);
+      load8<T>(x + off, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float y = apply_act<ACT>(fmaf(sc[j], v[j], sh[j]));
+        v[j] = quantize ? uq_point(y, alpha, beta, k) : y;
+      }
+      store8<T>(q + off, v);
+    }
+  } else {
+    const int64_t n = rows * C;
+    for (int64_t e = (int64_t)blockIdx.x * PF_THREADS + threadIdx.x; e < n;
+         e += (int64_t)gridDim.x * PF_THREADS) {
+      const int c = (int)(e % C);
+      const float y = apply_act<ACT>(fmaf(scale_shift[c], load_one<T>(x + e), scale_shift[C + c]));
+      store_one<T>(q + e, quantize ? uq_point(y, alpha, beta, k) : y);
+    }
+  }
+}
+
+template <typename T>
+static int launch_bn_apply(const T* x, T* q, int64_t rows, int C, const float* ss, int act,
+                           const uint32_t* slot, float k, int quantize, hipStream_t st) {
+  const bool fast = bn_fast_ok(C) && pf_aligned16(x) && pf_aligned16(q);
+  const int grid = fast ? pf_grid_for(rows, (PF_THREADS / (C / 8)) * 2) : pf_grid_for(rows * C, PF_THREADS * 4);
+#define PF_BA(ACTV)                                                                                     \
+  do {                                                                                                  \
+    if (fast) k_bn_apply<T, ACTV, true><<<grid, PF_THREADS, 0, st>>>(x, q, rows, C, ss, slot, k, quantize);   \
+    else k_bn_apply<T, ACTV, false><<<grid, PF_THREADS, 0, st>>>(x, q, rows, C, ss, slot, k, quantize);       \
+  } while (0)
+  if (act == PF_ACT_RELU) PF_BA(PF_ACT_RELU);
+  else if (act == PF_ACT_RELU6) PF_BA(PF_ACT_RELU6);
+  else PF_BA(PF_ACT_NONE);
+#undef PF_BA
+  PF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pf_bn_act_quant_apply(const void* x, void* q, int dtype, int64_t rows, int C,
+                                     const float* scale_shift, int act, const uint32_t* slot, int bits,
+                                     int quantize, void* stream) {
+  if (rows <= 0 || C <= 0) return (int)hipErrorInvalidValue;
+  if (quantize && (bits < 1 || bits > 32 || slot == nullptr)) return (int)hipErrorInvalidValue;
+  const float k = uq_k_of_bits(quantize ? bits : 8);
+  if (dtype == PF_F32) return launch_bn_apply<float>((const float*)x, (float*)q, rows, C, scale_shift, act, slot, k, quantize, (hipStream_t)stream);
+  if (dtype == PF_BF16) return launch_bn_apply<bf16_t>((const bf16_t*)x, (bf16_t*)q, rows, C, scale_shift, act, slot, k, quantize, (hipStream_t)stream);
+  return (int)hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward pass 1: per-channel sum(dy), sum(dy * xhat),  dy = dq * act'(scale*x+shift)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int ACT>
+__global__ __launch_bounds__(PF_THREADS) void k_bn_bwd_stats_fast(const T* __restrict__ dq, const T* __restrict__ x,
+                                                                  int64_t rows, int C,
+                                                                  const float* __restrict__ scale_shift,
+                                                                  const float* __restrict__ mean_invstd,
+                                                                  float* __restrict__ partial) {
+  extern __shared__ float lds[];
+  const int G = C >> 3, RPS = PF_THREADS / G;
+  const int cg = threadIdx.x % G, rsub = threadIdx.x / G;
+  float sc[8], sh[8], mu[8], is[8], s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = (cg << 3) + j;
+    sc[j] = scale_shift[c]; sh[j] = scale_shift[C + c];
+    mu[j] = mean_invstd[c]; is[j] = mean_invstd[C + c];
+    s1[j] = 0.f; s2[j] = 0.f;
+  }
+  for (int64_t r = (int64_t)blockIdx.x * RPS + rsub; r < rows; r += (int64_t)gridDim.x * RPS) {
+    float g[8], v[8];
+    const int64_t off = r * C + (cg << 3);
+    load8<T>(dq + off, g);
+    load8<T>(x + off, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float dy = g[j] * act_mask<ACT>(fmaf(sc[j], v[j], sh[j]));
+      s1[j] += dy;
+      s2[j] = fmaf(dy, (v[j] - mu[j]) * is[j], s2[j]);
+    }
+  }
+  float* out = partial + (int64_t)blockIdx.x * 2 * C;
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    float* a = (st == 0) ? s1 : s2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lds[threadIdx.x * 8 + j] = a[j];
+    __syncthreads();
+    if (rsub == 0) {
+      for (int j = 0; j < 8; ++j) {
+        float acc = lds[cg * 8 + j];
+        for (int q = 1; q < RPS; ++q) acc += lds[(q * G + cg) * 8 + j];
+        out[st * C + (cg << 3) + j] = acc;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T, int ACT>
+__global__ __launch_bounds__(PF_THREADS) void k_bn_bwd_stats_generic(const T* __restrict__ dq, const T* __restrict__ x,
+                                                                     int64_t rows, int C,
+                                                                     const float* __restrict__ scale_shift,
+                                                                     const float* __restrict__ mean_invstd,
+                                                                     float* __restrict__ partial) {
+  const int c = blockIdx.x * PF_THREADS + threadIdx.x;
+  if (c >= C) return;
+  const float sc = scale_shift[c], sh = scale_shift[C + c], mu = mean_invstd[c], is = mean_invstd[C + c];
+  float s1 = 0.f, s2 = 0.f;
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    const float v = load_one<T>(x + r * C + c);
+    const float dy = load_one<T>(dq + r * C + c) * act_mask<ACT>(fmaf(sc, v, sh));
+    s1 += dy;
+    s2 = fmaf(dy, (v - mu) * is, s2);
+  }
+  float* out = partial + (int64_t)blockIdx.y * 2 * C;
+  out[c] = s1; out[C + c] = s2;
+}
+
+template <typename T>
+static int launch_bn_bwd_stats(const T* dq, const T* x, int64_t rows, int C, const float* ss,
+                               const float* mi, int act, float* partial, int n_blocks, hipStream_t st) {
+  const bool fast = bn_fast_ok(C) && pf_aligned16(x) && pf_aligned16(dq);
+  const size_t shm = PF_THREADS * 8 * sizeof(float);
+  dim3 ggrid((C + PF_THREADS - 1) / PF_THREADS, n_blocks);
+#define PF_BS(ACTV)                                                                                             \
+  do {                                                                                                          \
+    if (fast) k_bn_bwd_stats_fast<T, ACTV><<<n_blocks, PF_THREADS, shm, st>>>(dq, x, rows, C, ss, mi, partial);  \
+    else k_bn_bwd_stats_generic<T, ACTV><<<ggrid, PF_THREADS, 0, st>>>(dq, x, rows, C, ss, mi, partial);         \
+  } while (0)
+  if (act == PF_ACT_RELU) PF_BS(PF_ACT_RELU);
+  else if (act == PF_ACT_RELU6) PF_BS(PF_ACT_RELU6);
+  else PF_BS(PF_ACT_NONE);
+#undef PF_BS
+  PF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pf_bn_bwd_stats(const void* dq, const void* x, int dtype, int64_t rows, int C,
+                               const float* scale_shift, const float* mean_invstd, int act,
+                               float* partial, int n_blocks, void* stream) {
+  if (rows <= 0 || C <= 0 || n_blocks <= 0) return (int)hipErrorInvalidValue;
+  if (dtype == PF_F32) return launch_bn_bwd_stats<float>((const float*)dq, (const float*)x, rows, C, scale_shift, mean_invstd, act, partial, n_blocks, (hipStream_t)stream);
+  if (dtype == PF_BF16) return launch_bn_bwd_stats<bf16_t>((const bf16_t*)dq, (const bf16_t*)x, rows, C, scale_shift, mean_invstd, act, partial, n_blocks, (hipStream_t)stream);
+  return (int)hipErrorInvalidValue;
+}
+
+__global__ __launch_bounds__(PF_THREADS) void k_bn_bwd_finalize(const float* __restrict__ partial, int n_blocks,
+                                                                int C, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta) {
+  __shared__ float l1[4][64], l2[4][64];
+  const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C)
+    for (int b = part; b < n_blocks; b += 4) {
+      const float* p = partial + (int64_t)b * 2 * C;
+      s1 += p[c]; s2 += p[C + c];
+    }
+  l1[part][cl] = s1; l2[part][cl] = s2;
+  __syncthreads();
+  if (part == 0 && c < C) {
+    dbeta[c] = (l1[0][cl] + l1[1][cl]) + (l1[2][cl] + l1[3][cl]);
+    dgamma[c] = (l2[0][cl] + l2[1][cl]) + (l2[2][cl] + l2[3][cl]);
+  }
+}
+extern "C" int pf_bn_bwd_finalize(const float* partial, int n_blocks, int C, float* dgamma, float* dbeta,
+                                  void* stream) {
+  k_bn_bwd_finalize<<<(C + 63) / 64, PF_THREADS, 0, (hipStream_t)stream>>>(partial, n_blocks, C, dgamma, dbeta);
+  PF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward pass 2: dx = gamma*invstd * (dy - dbeta/n - xhat * dgamma/n)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int ACT, bool FAST>
+__global__ __launch_bounds__(PF_THREADS) void k_bn_bwd_apply(const T* __restrict__ dq, const T* __restrict__ x,
+                                                             T* __restrict__ dx, int64_t rows, int C,
+                                                             const float* __restrict__ scale_shift,
+                                                             const float* __restrict__ mean_invstd,
+                                                             const float* __restrict__ dgamma,
+                                                             const float* __restrict__ dbeta) {
+  const float inv_n = 1.0f / (float)rows;
+  if (FAST) {
+    const int G = C >> 3, RPS = PF_THREADS / G;
+    const int cg = threadIdx.x % G, rsub = threadIdx.x / G;
+    float sc[8], sh[8], mu[8], is[8], a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = (cg << 3) + j;
+      sc[j] = scale_shift[c]; sh[j] = scale_shift[C + c];
+      mu[j] = mean_invstd[c]; is[j] = mean_invstd[C + c];
+      a[j] = dbeta[c] * inv_n; b[j] = dgamma[c] * inv_n;
+    }
+#pragma unroll 2
+    for (int64_t r = (int64_t)blockIdx.x * RPS + rsub; r < rows; r += (int64_t)gridDim.x * RPS) {
+      float g[8], v[8];
+      const int64_t off = r * C + (cg << 3);
+      load8<T>(dq + off, g);
+      load8<T>(x + off, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float dy = g[j] * act_mask<ACT>(fmaf(sc[j], v[j], sh[j]));
+        const float xh = (v[j] - mu[j]) * is[j];
+        g[j] = sc[j] * (dy - a[j] - xh * b[j]);
+      }
+      store8<T>(dx + off, g);
+    }
+  } else {
+    const int64_t n = rows * C;
+    for (int64_t e = (int64_t)blockIdx.x * PF_THREADS + threadIdx.x; e < n;
+         e += (int64_t)gridDim.x * PF_THREADS) {
+      const int c = (int)(e % C);
+      const float v = load_one<T>(x + e);
+      const float sc = scale_shift[c];
+      const float dy = load_one<T>(dq + e) * act_mask<ACT>(fmaf(sc, v, scale_shift[C + c]));
+      const float xh = (v - mean_invstd[c]) * mean_invstd[C + c];
+      store_one<T>(dx + e, sc * (dy - dbeta[c] * inv_n - xh * (dgamma[c] * inv_n)));
+    }
+  }
+}
+
+template <typename T>
+static int launch_bn_bwd_apply(const T* dq, const T* x, T* dx, int64_t rows, int C, const float* ss,
+                               const float* mi, const float* dgamma, const float* dbeta, int act,
+                               hipStream_t st) {
+  const bool fast = bn_fast_ok(C) && pf_aligned16(x) && pf_aligned16(dq) && pf_aligned16(dx);
+  const int grid = fast ? pf_grid_for(rows, (PF_THREADS / (C / 8)) * 2) : pf_grid_for(rows * C, PF_THREADS * 4);
+#define PF_BB(ACTV)                                                                                                    \
+  do {                                                                                                                 \
+    if (fast) k_bn_bwd_apply<T, ACTV, true><<<grid, PF_THREADS, 0, st>>>(dq, x, dx, rows, C, ss, mi, dgamma, dbeta);    \
+    else k_bn_bwd_apply<T, ACTV, false><<<grid, PF_THREADS, 0, st>>>(dq, x, dx, rows, C, ss, mi, dgamma, dbeta);        \
+  } while (0)
+  if (act == PF_ACT_RELU) PF_BB(PF_ACT_RELU);
+  else if (act == PF_ACT_RELU6) PF_BB(PF_ACT_RELU6);
+  else PF_BB(PF_ACT_NONE);
+#undef PF_BB
+  PF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pf_bn_bwd_apply(const void* dq, const void* x, void* dx, int dtype, int64_t rows, int C,
+                               const float* scale_shift, const float* mean_invstd, const float* dgamma,
+                               const float* dbeta, int act, void* stream) {
+  if (rows <= 0 || C <= 0) return (int)hipErrorInvalidValue;
+  if (dtype == PF_F32) return launch_bn_bwd_apply<float>((const float*)dq, (const float*)x, (float*)dx, rows, C, scale_shift, mean_invstd, dgamma, dbeta, act, (hipStream_t)stream);
+  if (dtype == PF_BF16) return launch_bn_bwd_apply<bf16_t>((const bf16_t*)dq, (const bf16_t*)x, (bf16_t*)dx, rows, C, scale_shift, mean_invstd, dgamma, dbeta, act, (hipStream_t)stream);
+  return (int)hipErrorInvalidValue;
+}
