@@ -431,7 +431,9 @@ __global__ __launch_bounds__(PF_THREADS) void k_seg_apply(const float* __restric
         bucket = (ej < len ? hwio_flat_index(sg, ej) : 0u) % (uint32_t)sg.n_bucket;
         slot_alpha_beta(sl + 2 * bucket, alpha, beta);
       }
-      if (!NUQ) {
+      if (sg.bits <= 0) {
+        // bits == 0: tensor is not quantised (first / last layer): plain cast to the compute dtype
+      } else if (!NUQ) {
         v[j] = uq_point(v[j], alpha, beta, kf);
       } else {
         const float xn = (v[j] - beta) / alpha;

@@ -1,0 +1,643 @@
+"""Variables, ops and the explicit layer executor that stand in for the reference's TF-1.x graph.
+
+The reference builds a tf.Graph from a ModelHelper's forward function, then *rewrites* it with
+tf.contrib.graph_editor to splice fake-quant ops in front of every Conv2D / MatMul /
+DepthwiseConv2dNative weight and behind every Relu / Relu6 output
+(learners/uniform_quantization/utils.py:51-134).  Here the same information is explicit:
+
+  * `VarStore`  -- every variable of one model scope, named like the TF checkpoint
+                   (`model/resnet_model/conv2d_3/kernel`), living in a few flat device buffers:
+                   all matmul kernels in ONE fp32 master buffer (+ one compute-dtype copy that the
+                   quantiser writes and the convolutions read, + one flat gradient buffer), all other
+                   trainables in a second, BN moving statistics in a third.  One launch quantises
+                   every kernel, one launch applies the optimiser, one collective reduces gradients.
+  * `Graph`     -- ops in creation order (`matmul_ops`, `activation_ops`), which is what
+                   `search_matmul_op` / `search_activation_op` enumerate; a learner "rewrites" the
+                   graph by assigning bit widths to those ops.
+  * layer classes -- Conv2D / DepthwiseConv2D / Dense / BatchNormAct / Activation / pooling, executed
+                   eagerly on HIP streams; the HBM-bound ones call the hand-written kernels through
+                   the C ABI (pocketflow_amd.hip), convolutions go through MIOpen / the MFMA GEMM.
+
+Storage layouts are chosen for the GPU (activations NHWC = torch channels_last, kernels KRSC =
+[cout][kh][kw][cin]); `VarStore.export_numpy` / `load_numpy` speak the reference's layouts (HWIO
+kernels, [in, out] dense) so that checkpoints and the oracle see TF-shaped tensors.
+"""
+from __future__ import annotations
+
+import math
+import threading
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from pocketflow_amd import hip
+from pocketflow_amd.plan import WeightDesc
+
+ALIGN = 64  # elements; keeps every tensor 256-byte aligned inside the flat buffers
+
+
+def _align(n: int) -> int:
+  return (n + ALIGN - 1) // ALIGN * ALIGN
+
+
+# =================================================================================================
+# variables
+# =================================================================================================
+
+@dataclass
+class Variable:
+  name: str                      # TF-style name without ':0'
+  ref_shape: Tuple[int, ...]     # reference layout: HWIO conv, [in,out] dense, [kh,kw,C,1] depthwise
+  kind: str                      # conv | dense | depthwise | bias | bn_gamma | bn_beta | bn_mean | bn_var | other
+  trainable: bool = True
+  l2: bool = True                # enters the loss_w_dcy * l2_loss sum of ModelHelper.calc_loss
+  init: Optional[Callable[[np.random.RandomState], np.ndarray]] = field(default=None, repr=False)
+  group: str = ''                # 'W' matmul kernels | 'O' other trainables | 'S' non-trainable state
+  offset: int = 0
+  numel: int = 0
+  tensor: Optional[torch.Tensor] = field(default=None, repr=False)  # forward view (leaf; compute copy for 'W')
+  store: Optional[object] = field(default=None, repr=False)   # owning VarStore
+  master: Optional[torch.Tensor] = field(default=None, repr=False)  # fp32 master view
+
+  @property
+  def storage_shape(self) -> Tuple[int, ...]:
+    s = self.ref_shape
+    if self.kind == 'conv':
+      return (s[3], s[0], s[1], s[2])          # KRSC
+    if self.kind == 'dense':
+      return (s[1], s[0])                      # [out, in]
+    if self.kind == 'depthwise':
+      return (s[2], s[0], s[1])                # CRS
+    return tuple(s)
+
+  def to_storage(self, ref: np.ndarray) -> np.ndarray:
+    ref = np.asarray(ref, dtype=np.float32).reshape(self.ref_shape)
+    if self.kind == 'conv':
+      return np.ascontiguousarray(ref.transpose(3, 0, 1, 2))
+    if self.kind == 'dense':
+      return np.ascontiguousarray(ref.T)
+    if self.kind == 'depthwise':
+      return np.ascontiguousarray(ref[:, :, :, 0].transpose(2, 0, 1))
+    return ref
+
+  def to_ref(self, st: np.ndarray) -> np.ndarray:
+    st = np.asarray(st, dtype=np.float32).reshape(self.storage_shape)
+    if self.kind == 'conv':
+      return np.ascontiguousarray(st.transpose(1, 2, 3, 0))
+    if self.kind == 'dense':
+      return np.ascontiguousarray(st.T)
+    if self.kind == 'depthwise':
+      return np.ascontiguousarray(st.transpose(1, 2, 0)[:, :, :, None])
+    return st
+
+  def weight_desc(self) -> WeightDesc:
+    s = self.ref_shape
+    if self.kind == 'conv':
+      return WeightDesc(self.name, self.offset, s[0] * s[1], s[2], s[3], 0)
+    if self.kind == 'dense':
+      return WeightDesc(self.name, self.offset, 1, s[0], s[1], 0)
+    if self.kind == 'depthwise':
+      return WeightDesc(self.name, self.offset, s[0] * s[1], s[2], 1, 1)
+    raise ValueError('not a matmul kernel: %s' % self.name)
+
+
+class VarStore:
+  """All variables of one model scope in three flat device buffers (see module docstring)."""
+
+  def __init__(self, scope: str):
+    self.scope = scope
+    self.vars: List[Variable] = []
+    self.by_name: Dict[str, Variable] = {}
+    self.finalized = False
+    self.device = None
+    self.compute_dtype = torch.float32
+    self.weight_decay = 0.0                    # set by ModelHelper.calc_loss (loss_w_dcy)
+
+  # -- declaration ------------------------------------------------------------------------------
+  def add(self, name: str, ref_shape, kind: str, trainable: bool = True, l2: bool = True,
+          init=None) -> Variable:
+    full = self.scope + '/' + name if self.scope else name
+    if full in self.by_name:
+      return self.by_name[full]                  # tf.AUTO_REUSE
+    if self.finalized:
+      raise RuntimeError('variable %s created after the store was finalized' % full)
+    v = Variable(full, tuple(int(d) for d in ref_shape), kind, trainable, l2 and trainable, init)
+    v.numel = int(np.prod(v.ref_shape))
+    v.group = 'W' if kind in ('conv', 'dense', 'depthwise') else ('O' if trainable else 'S')
+    v.store = self
+    self.vars.append(v)
+    self.by_name[full] = v
+    return v
+
+  @property
+  def trainable_vars(self) -> List[Variable]:
+    return [v for v in self.vars if v.trainable]
+
+  @property
+  def matmul_vars(self) -> List[Variable]:
+    return [v for v in self.vars if v.group == 'W']
+
+  # -- allocation -------------------------------------------------------------------------------
+  def finalize(self, device, compute_dtype=torch.float32, separate_compute: bool = False,
+               seed: int = 42, requires_grad: bool = True) -> None:
+    """Lay variables out and allocate.  `separate_compute`: keep a compute-dtype copy of the matmul
+    kernels distinct from the fp32 master (needed when they are fake-quantised or cast to bf16)."""
+    if self.finalized:
+      return
+    self.device = torch.device(device)
+    self.compute_dtype = compute_dtype
+    separate_compute = separate_compute or compute_dtype != torch.float32
+    self.separate_compute = separate_compute
+    # matmul kernels: [l2-regularised | not regularised] so that one n_decay splits the buffer
+    off = 0
+    for flag in (True, False):
+      for v in self.vars:
+        if v.group == 'W' and v.l2 == flag:
+          v.offset = off
+          off += _align(v.numel)
+      if flag:
+        self.w_decay = off
+    self.w_size = off
+    # other trainables: [l2-regularised | not regularised] so that one n_decay splits them
+    off = 0
+    for flag in (True, False):
+      for v in self.vars:
+        if v.group == 'O' and v.l2 == flag:
+          v.offset = off
+          off += _align(v.numel)
+      if flag:
+        self.o_decay = off
+    self.o_size = off
+    off = 0
+    for v in self.vars:
+      if v.group == 'S':
+        v.offset = off
+        off += _align(v.numel)
+    self.s_size = off
+    dev = self.device
+    self.w_master = torch.zeros(max(self.w_size, ALIGN), dtype=torch.float32, device=dev)
+    self.w_compute = (torch.zeros(max(self.w_size, ALIGN), dtype=compute_dtype, device=dev)
+                      if separate_compute else self.w_master)
+    self.o_master = torch.zeros(max(self.o_size, ALIGN), dtype=torch.float32, device=dev)
+    self.state = torch.zeros(max(self.s_size, ALIGN), dtype=torch.float32, device=dev)
+    self.w_grad = torch.zeros_like(self.w_compute) if requires_grad else None
+    self.o_grad = torch.zeros_like(self.o_master) if requires_grad else None
+    for v in self.vars:
+      n = v.numel
+      if v.group == 'W':
+        v.master = self.w_master[v.offset:v.offset + n].view(v.storage_shape)
+        t = self.w_compute[v.offset:v.offset + n].view(v.storage_shape)
+        if v.kind == 'conv':
+          t = t.permute(0, 3, 1, 2)            # logical OIHW, physical KRSC (= channels_last)
+        elif v.kind == 'depthwise':
+          t = t.unsqueeze(1)                   # [C, 1, kh, kw]
+        if requires_grad and v.trainable:
+          t = t.detach().requires_grad_(True)
+          g = self.w_grad[v.offset:v.offset + n].view(v.storage_shape)
+          if v.kind == 'conv':
+            g = g.permute(0, 3, 1, 2)
+          elif v.kind == 'depthwise':
+            g = g.unsqueeze(1)
+          t.grad = g
+        v.tensor = t
+      elif v.group == 'O':
+        v.master = self.o_master[v.offset:v.offset + n].view(v.storage_shape)
+        t = v.master
+        if requires_grad:
+          t = t.detach().requires_grad_(True)
+          t.grad = self.o_grad[v.offset:v.offset + n].view(v.storage_shape)
+        v.tensor = t
+      else:
+        v.master = self.state[v.offset:v.offset + n].view(v.storage_shape)
+        v.tensor = v.master
+    self.finalized = True
+    self.initialize(seed)
+
+  def initialize(self, seed: int = 42) -> None:
+    rng = np.random.RandomState(seed)
+    vals = {}
+    for v in self.vars:
+      if v.init is not None:
+        vals[v.name] = v.init(rng)
+    self.load_numpy(vals, strict=False)
+
+  # -- (de)serialisation in the REFERENCE layout --------------------------------------------------
+  def load_numpy(self, values: Dict[str, np.ndarray], strict: bool = True, rename_scope: str = None) -> None:
+    for v in self.vars:
+      key = v.name
+      if rename_scope is not None:             # distillation_helper.py:122-145: first path component
+        key = rename_scope + '/' + '/'.join(v.name.split('/')[1:])
+      if key not in values:
+        if strict:
+          raise KeyError('variable %s missing from checkpoint' % key)
+        continue
+      st = torch.from_numpy(v.to_storage(values[key])).to(self.device)
+      v.master.copy_(st)
+    self.sync_compute()
+
+  def export_numpy(self) -> Dict[str, np.ndarray]:
+    out = {}
+    for v in self.vars:
+      out[v.name] = v.to_ref(v.master.detach().float().cpu().numpy())
+    return out
+
+  def sync_compute(self) -> None:
+    """compute copy <- master (plain cast); quantising learners overwrite it every step."""
+    if self.separate_compute:
+      self.w_compute.copy_(self.w_master)
+
+  def zero_grad(self) -> None:
+    if self.w_grad is not None:
+      self.w_grad.zero_()
+      self.o_grad.zero_()
+
+  def weight_descs(self, variables: Sequence[Variable]) -> List[WeightDesc]:
+    return [v.weight_desc() for v in variables]
+
+  def l2_loss_sum(self) -> torch.Tensor:
+    """sum_v l2_loss(v) over the regularised trainables (only evaluated for logging)."""
+    tot = torch.zeros((), dtype=torch.float32, device=self.device)
+    for v in self.vars:
+      if v.trainable and v.l2:
+        tot = tot + 0.5 * (v.master.float() ** 2).sum()
+    return tot
+
+
+# =================================================================================================
+# ops and graph
+# =================================================================================================
+
+@dataclass
+class MatmulOp:
+  type: str                  # Conv2D | MatMul | DepthwiseConv2dNative   (uq utils.py:49)
+  name: str
+  var: Variable
+  flops_per_out: int = 0
+
+
+@dataclass
+class ActivationOp:
+  type: str                  # Relu | Relu6
+  name: str
+  index: int = 0
+  bits: Optional[int] = None           # None: no fake-quant inserted behind this activation
+
+
+_tls = threading.local()
+
+
+def get_default_graph() -> 'Graph':
+  g = getattr(_tls, 'graph', None)
+  if g is None:
+    raise RuntimeError('no default Graph: call forward functions inside `with graph.as_default():`')
+  return g
+
+
+class Graph:
+  """One model scope: its variables, its ops in creation order, and the per-step scratch."""
+
+  def __init__(self, scope: str = 'model', device='cuda', compute_dtype=torch.float32):
+    self.scope = scope
+    self.device = torch.device(device)
+    self.compute_dtype = compute_dtype
+    self.store = VarStore(scope)
+    self.matmul_ops: List[MatmulOp] = []
+    self.activation_ops: List[ActivationOp] = []
+    self.nets: Dict[str, object] = {}          # cached net objects (tf.AUTO_REUSE)
+    self.training = True
+    self.frozen = False                        # teacher: BN scale/shift cached
+    self.act_slots: Optional[torch.Tensor] = None
+    self._scratch: Optional[torch.Tensor] = None
+    self._names: Dict[str, int] = {}
+
+  # -- naming like tf.layers (conv2d, conv2d_1, ...) ---------------------------------------------
+  def unique_name(self, base: str) -> str:
+    k = self._names.get(base, 0)
+    self._names[base] = k + 1
+    return base if k == 0 else '%s_%d' % (base, k)
+
+  def as_default(self):
+    graph = self
+
+    class _Ctx:
+      def __enter__(self_inner):
+        self_inner.prev = getattr(_tls, 'graph', None)
+        _tls.graph = graph
+        return graph
+
+      def __exit__(self_inner, *exc):
+        _tls.graph = self_inner.prev
+        return False
+    return _Ctx()
+
+  def add_matmul_op(self, op_type: str, name: str, var: Variable) -> MatmulOp:
+    op = MatmulOp(op_type, self.scope + '/' + name, var)
+    self.matmul_ops.append(op)
+    return op
+
+  def add_activation_op(self, op_type: str, name: str) -> ActivationOp:
+    op = ActivationOp(op_type, self.scope + '/' + name, len(self.activation_ops))
+    self.activation_ops.append(op)
+    return op
+
+  def finalize(self, separate_compute: bool = False, seed: int = 42, requires_grad: bool = True) -> None:
+    self.store.finalize(self.device, self.compute_dtype, separate_compute, seed, requires_grad)
+    n_act = max(len(self.activation_ops), 1)
+    self.act_slots = torch.empty((n_act, 2), dtype=torch.int32, device=self.device)
+
+  def begin_step(self) -> None:
+    """Reset the activation min/max slots (ONE memset for all activations of the step)."""
+    hip.minmax_slots_init(self.act_slots)
+
+  def scratch(self, n_floats: int) -> torch.Tensor:
+    if self._scratch is None or self._scratch.numel() < n_floats:
+      self._scratch = torch.empty(max(n_floats, 1 << 20), dtype=torch.float32, device=self.device)
+    return self._scratch
+
+  def act_alpha_beta(self) -> torch.Tensor:
+    return hip.minmax_decode(self.act_slots)
+
+
+# =================================================================================================
+# autograd functions over the HIP kernels
+# =================================================================================================
+
+def _nhwc(x: torch.Tensor) -> torch.Tensor:
+  if x.dim() == 4:
+    return x.contiguous(memory_format=torch.channels_last)
+  return x.contiguous()
+
+
+def _bn_blocks(rows: int, C: int) -> int:
+  if C % 8 == 0 and (C // 8) <= 256 and 256 % (C // 8) == 0:
+    rps = 256 // (C // 8)
+    return int(min(1024, max(1, rows // (rps * 8))))
+  return int(min(256, max(1, rows // 64)))
+
+
+class _BnActQuant(torch.autograd.Function):
+  """BN (batch stats) -> act -> activation fake-quant, fused (pf_bn_* kernels)."""
+
+  @staticmethod
+  def forward(ctx, x, gamma, beta, layer, graph, training, slot, bits):
+    x = _nhwc(x)
+    C = gamma.numel()
+    rows = x.numel() // C
+    nblk = _bn_blocks(rows, C)
+    partial = graph.scratch(nblk * 4 * C)
+    scale_shift = torch.empty((2, C), dtype=torch.float32, device=x.device)
+    mean_invstd = torch.empty((2, C), dtype=torch.float32, device=x.device)
+    quantize = bits is not None
+    hip.bn_stats(x, rows, C, partial, nblk)
+    hip.bn_finalize(partial, nblk, rows, C, x, gamma, beta, layer.moving_mean.tensor, layer.moving_var.tensor,
+                    layer.momentum, layer.eps, training, layer.act, scale_shift, mean_invstd,
+                    slot if quantize else None)
+    q = torch.empty_like(x)
+    hip.bn_act_quant_apply(x, q, rows, C, scale_shift, layer.act, slot, bits if quantize else 8, quantize)
+    ctx.save_for_backward(x, scale_shift, mean_invstd)
+    ctx.meta = (layer.act, graph, rows, C, nblk)
+    return q
+
+  @staticmethod
+  def backward(ctx, dq):
+    x, scale_shift, mean_invstd = ctx.saved_tensors
+    act, graph, rows, C, nblk = ctx.meta
+    dq = _nhwc(dq)
+    if dq.dtype != x.dtype:
+      dq = dq.to(x.dtype)
+    partial = graph.scratch(nblk * 2 * C)
+    hip.bn_bwd_stats(dq, x, rows, C, scale_shift, mean_invstd, act, partial, nblk)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    hip.bn_bwd_finalize(partial, nblk, C, dgamma, dbeta)
+    dx = torch.empty_like(x)
+    hip.bn_bwd_apply(dq, x, dx, rows, C, scale_shift, mean_invstd, dgamma, dbeta, act)
+    return dx, dgamma, dbeta, None, None, None, None, None
+
+
+class _ActQuant(torch.autograd.Function):
+  """act -> per-tensor fake-quant (pf_minmax_tensor + pf_uq_apply); backward = STE o act'."""
+
+  @staticmethod
+  def forward(ctx, u, act, slot, bits):
+    u = _nhwc(u)
+    y = torch.empty_like(u)
+    hip.minmax_tensor(u, slot, act)
+    hip.uq_apply(u, y, slot, bits, act)
+    ctx.save_for_backward(u)
+    ctx.act = act
+    return y
+
+  @staticmethod
+  def backward(ctx, g):
+    (u,) = ctx.saved_tensors
+    g = _nhwc(g)
+    if g.dtype != u.dtype:
+      g = g.to(u.dtype)
+    dx = torch.empty_like(u)
+    hip.act_grad(g, u, dx, ctx.act)
+    return dx, None, None, None
+
+
+# =================================================================================================
+# layers
+# =================================================================================================
+
+def _same_pads(size: int, k: int, stride: int) -> Tuple[int, int]:
+  """TF 'SAME' padding: total = max((ceil(in/s)-1)*s + k - in, 0); extra pixel goes at the END."""
+  out = -(-size // stride)
+  total = max((out - 1) * stride + k - size, 0)
+  return total // 2, total - total // 2
+
+
+def variance_scaling_init(ref_shape, fan_in: int):
+  """tf.variance_scaling_initializer() defaults (scale=1, fan_in, truncated normal); TF >= 1.9
+  divides the stddev by .87962566103423978 to correct for the truncation (resnet_model.py:102)."""
+  std = math.sqrt(1.0 / max(1.0, fan_in)) / .87962566103423978
+
+  def init(rng: np.random.RandomState):
+    from scipy.stats import truncnorm
+    return truncnorm.rvs(-2, 2, size=ref_shape, random_state=rng).astype(np.float32) * np.float32(std)
+  return init
+
+
+def glorot_uniform_init(ref_shape, fan_in: int, fan_out: int):
+  limit = math.sqrt(6.0 / (fan_in + fan_out))
+  return lambda rng: rng.uniform(-limit, limit, size=ref_shape).astype(np.float32)
+
+
+def truncated_normal_init(ref_shape, stddev: float):
+  def init(rng: np.random.RandomState):
+    from scipy.stats import truncnorm
+    return truncnorm.rvs(-2, 2, size=ref_shape, random_state=rng).astype(np.float32) * np.float32(stddev)
+  return init
+
+
+def constant_init(ref_shape, value: float):
+  return lambda rng: np.full(ref_shape, value, dtype=np.float32)
+
+
+class Conv2D:
+  """tf.layers.conv2d / slim.conv2d: NHWC, kernel HWIO (stored KRSC), padding 'SAME' | 'VALID'."""
+
+  def __init__(self, graph: Graph, name: str, cin: int, cout: int, k: int, stride: int = 1,
+               padding: str = 'SAME', use_bias: bool = False, kernel_name: str = 'kernel',
+               bias_name: str = 'bias', init=None, l2: bool = True):
+    self.graph, self.k, self.stride, self.padding = graph, k, stride, padding
+    ref_shape = (k, k, cin, cout)
+    init = init or variance_scaling_init(ref_shape, k * k * cin)
+    self.kernel = graph.store.add(name + '/' + kernel_name, ref_shape, 'conv', True, l2, init)
+    self.bias = (graph.store.add(name + '/' + bias_name, (cout,), 'bias', True, l2, constant_init((cout,), 0.0))
+                 if use_bias else None)
+    self.op = graph.add_matmul_op('Conv2D', name + '/Conv2D', self.kernel)
+
+  def __call__(self, x: torch.Tensor) -> torch.Tensor:
+    w = self.kernel.tensor
+    b = self.bias.tensor.to(x.dtype) if self.bias is not None else None
+    pad = 0
+    if self.padding == 'SAME' and self.k > 1:
+      ph = _same_pads(x.shape[2], self.k, self.stride)
+      pw = _same_pads(x.shape[3], self.k, self.stride)
+      if ph[0] == ph[1] and pw[0] == pw[1]:
+        pad = (ph[0], pw[0])
+      else:
+        x = F.pad(x, (pw[0], pw[1], ph[0], ph[1]))
+    return F.conv2d(x, w, b, stride=self.stride, padding=pad)
+
+
+class DepthwiseConv2D:
+  """slim.separable_conv2d(num_outputs=None, depth_multiplier=1): DepthwiseConv2dNative."""
+
+  def __init__(self, graph: Graph, name: str, channels: int, k: int, stride: int,
+               kernel_name: str = 'depthwise_weights', init=None, l2: bool = True):
+    self.graph, self.k, self.stride, self.channels = graph, k, stride, channels
+    ref_shape = (k, k, channels, 1)
+    init = init or truncated_normal_init(ref_shape, 0.09)
+    self.kernel = graph.store.add(name + '/' + kernel_name, ref_shape, 'depthwise', True, l2, init)
+    self.op = graph.add_matmul_op('DepthwiseConv2dNative', name + '/depthwise', self.kernel)
+
+  def __call__(self, x: torch.Tensor) -> torch.Tensor:
+    ph = _same_pads(x.shape[2], self.k, self.stride)
+    pw = _same_pads(x.shape[3], self.k, self.stride)
+    pad = 0
+    if ph[0] == ph[1] and pw[0] == pw[1]:
+      pad = (ph[0], pw[0])
+    else:
+      x = F.pad(x, (pw[0], pw[1], ph[0], ph[1]))
+    return F.conv2d(x, self.kernel.tensor, None, stride=self.stride, padding=pad, groups=self.channels)
+
+
+class Dense:
+  """tf.layers.dense: kernel [in, out] (stored [out, in]) + bias."""
+
+  def __init__(self, graph: Graph, name: str, cin: int, cout: int, init=None, l2: bool = True):
+    ref_shape = (cin, cout)
+    init = init or glorot_uniform_init(ref_shape, cin, cout)
+    self.kernel = graph.store.add(name + '/kernel', ref_shape, 'dense', True, l2, init)
+    self.bias = graph.store.add(name + '/bias', (cout,), 'bias', True, l2, constant_init((cout,), 0.0))
+    self.op = graph.add_matmul_op('MatMul', name + '/MatMul', self.kernel)
+
+  def __call__(self, x: torch.Tensor) -> torch.Tensor:
+    return F.linear(x, self.kernel.tensor, self.bias.tensor.to(x.dtype))
+
+
+class Activation:
+  """A stand-alone Relu / Relu6 op (followed by activation fake-quant when the learner asks)."""
+
+  def __init__(self, graph: Graph, name: str, act: str = 'Relu'):
+    self.graph, self.act = graph, act
+    self.op = graph.add_activation_op(act, name)
+
+  def __call__(self, x: torch.Tensor) -> torch.Tensor:
+    g = self.graph
+    if self.op.bits is None:
+      return F.relu(x) if self.act == 'Relu' else F.relu6(x)
+    return _ActQuant.apply(x, self.act, g.act_slots[self.op.index], self.op.bits)
+
+
+class BatchNormAct:
+  """tf.layers.batch_normalization(fused) [+ Relu / Relu6 right behind it], one fused op chain.
+
+  ResNet-v2 and MobileNet-v1 only ever use BN followed by an activation, which is what lets the
+  BN statistics pass also deliver the activation's whole-tensor min/max (pf_bn_finalize).
+  """
+
+  def __init__(self, graph: Graph, name: str, channels: int, act: Optional[str], momentum: float, eps: float,
+               l2: bool = False, act_name: Optional[str] = None, names=('gamma', 'beta', 'moving_mean',
+                                                                       'moving_variance')):
+    self.graph, self.act, self.momentum, self.eps, self.C = graph, act, momentum, eps, channels
+    st = graph.store
+    self.gamma = st.add(name + '/' + names[0], (channels,), 'bn_gamma', True, l2, constant_init((channels,), 1.0))
+    self.beta = st.add(name + '/' + names[1], (channels,), 'bn_beta', True, l2, constant_init((channels,), 0.0))
+    self.moving_mean = st.add(name + '/' + names[2], (channels,), 'bn_mean', False, False,
+                              constant_init((channels,), 0.0))
+    self.moving_var = st.add(name + '/' + names[3], (channels,), 'bn_var', False, False,
+                             constant_init((channels,), 1.0))
+    self.op = graph.add_activation_op(act, act_name or (name + '/' + act)) if act else None
+    self._frozen_ss = None
+
+  def __call__(self, x: torch.Tensor) -> torch.Tensor:
+    g = self.graph
+    bits = self.op.bits if self.op is not None else None
+    slot = g.act_slots[self.op.index] if (self.op is not None and bits is not None) else None
+    if g.training and torch.is_grad_enabled():
+      return _BnActQuant.apply(x, self.gamma.tensor, self.beta.tensor, self, g, True, slot, bits)
+    x = _nhwc(x)
+    C = self.C
+    rows = x.numel() // C
+    q = torch.empty_like(x)
+    if bits is None:
+      # inference BN + act only: y = act(scale*x + shift); the teacher's (frozen) scale/shift is cached
+      if g.frozen and self._frozen_ss is not None:
+        ss = self._frozen_ss
+      else:
+        ss = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        hip.bn_eval_scale_shift(self.gamma.tensor, self.beta.tensor, self.moving_mean.tensor,
+                                self.moving_var.tensor, self.eps, ss)
+        if g.frozen:
+          self._frozen_ss = ss
+      hip.bn_act_quant_apply(x, q, rows, C, ss, self.act, None, 8, False)
+      return q
+    # eval graph of a quantising learner: moving statistics + freshly calibrated activation range
+    with torch.no_grad():
+      nblk = _bn_blocks(rows, C)
+      partial = g.scratch(nblk * 4 * C)
+      ss = torch.empty((2, C), dtype=torch.float32, device=x.device)
+      mi = torch.empty((2, C), dtype=torch.float32, device=x.device)
+      hip.bn_stats(x, rows, C, partial, nblk)
+      hip.bn_finalize(partial, nblk, rows, C, x, self.gamma.tensor, self.beta.tensor, self.moving_mean.tensor,
+                      self.moving_var.tensor, self.momentum, self.eps, g.training, self.act, ss, mi, slot)
+      hip.bn_act_quant_apply(x, q, rows, C, ss, self.act, slot, bits, True)
+    return q
+
+
+def max_pool_same(x: torch.Tensor, k: int, stride: int) -> torch.Tensor:
+  """tf.layers.max_pooling2d(padding='SAME'): pad with -inf, extra pixel at the end."""
+  ph = _same_pads(x.shape[2], k, stride)
+  pw = _same_pads(x.shape[3], k, stride)
+  if any(ph) or any(pw):
+    x = F.pad(x, (pw[0], pw[1], ph[0], ph[1]), value=float('-inf'))
+  return F.max_pool2d(x, k, stride)
+
+
+def fixed_padding(x: torch.Tensor, k: int) -> torch.Tensor:
+  """resnet_model.fixed_padding (utils/external/resnet_model.py:65-89)."""
+  pad_total = k - 1
+  pb = pad_total // 2
+  pe = pad_total - pb
+  if pad_total == 0:
+    return x
+  return F.pad(x, (pb, pe, pb, pe))
+
+
+def to_device_images(images, graph: Graph) -> torch.Tensor:
+  """NHWC float32 batch (reference tensor contract) -> logical NCHW / physical NHWC compute tensor."""
+  if isinstance(images, np.ndarray):
+    images = torch.from_numpy(images)
+  x = images.to(graph.device, non_blocking=True)
+  if x.dim() == 4:
+    x = x.permute(0, 3, 1, 2)                  # view: logical NCHW over NHWC memory (channels_last)
+  return x.to(graph.compute_dtype)

@@ -1,0 +1,297 @@
+"""ctypes binding of the gfx950 kernel library (include/pocketflow_hip.h).
+
+This is the ONLY way the Python host reaches the device code: raw device pointers
+(``tensor.data_ptr()``), sizes and the current HIP stream go through the C ABI -- no torch types
+cross the boundary.  There is no CPU fallback: if the shared library is missing the import of
+this module raises, and every wrapper raises on a non-zero hipError_t.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_void_p
+
+import numpy as np
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libpocketflow_hip.so')
+
+PF_F32, PF_BF16 = 0, 1
+PF_ACT_NONE, PF_ACT_RELU, PF_ACT_RELU6 = 0, 1, 2
+PF_BUCKET_TENSOR, PF_BUCKET_CHANNEL, PF_BUCKET_SPLIT = 0, 1, 2
+PF_CHUNK = 4096
+
+# numpy mirrors of the C structs (checked against sizeof in tests)
+SEG_DTYPE = np.dtype([('offset', '<i8'), ('len', '<i8'), ('RS', '<i4'), ('layout', '<i4'),
+                      ('I', '<i4'), ('O', '<i4'), ('mode', '<i4'), ('bits', '<i4'),
+                      ('bucket_size', '<i4'), ('n_bucket', '<i4'), ('slot_offset', '<i8'),
+                      ('cb_offset', '<i8')])
+BLOCK_DTYPE = np.dtype([('seg', '<i4'), ('chunk', '<i4'), ('row0', '<i4'), ('nrows', '<i4')])
+assert SEG_DTYPE.itemsize == 64 and BLOCK_DTYPE.itemsize == 16
+
+ACT_CODES = {None: PF_ACT_NONE, 'none': PF_ACT_NONE, 'Relu': PF_ACT_RELU, 'relu': PF_ACT_RELU,
+             'Relu6': PF_ACT_RELU6, 'relu6': PF_ACT_RELU6}
+
+# every symbol include/pocketflow_hip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    'pf_error_string', 'pf_version', 'pf_minmax_slots_init', 'pf_minmax_tensor', 'pf_minmax_decode',
+    'pf_uq_apply', 'pf_act_grad', 'pf_seg_minmax', 'pf_seg_uq_apply', 'pf_seg_nuq_apply',
+    'pf_seg_nuq_codebook_grad', 'pf_seg_normalize', 'pf_ws_bkup_merge_abs', 'pf_kth_largest_nonneg',
+    'pf_ws_mask_apply', 'pf_count_nonzero', 'pf_cp_build_mask', 'pf_cp_mask_grad', 'pf_adam_flat',
+    'pf_momentum_flat', 'pf_ce_distill_fwd_bwd', 'pf_bn_stats', 'pf_bn_finalize',
+    'pf_bn_act_quant_apply', 'pf_bn_bwd_stats', 'pf_bn_bwd_finalize', 'pf_bn_bwd_apply',
+    'pf_bn_eval_scale_shift', 'pf_gemm_bf16_nt', 'pf_gemm_bf16_nn', 'pf_gemm_bf16_tn',
+]
+
+
+class HipLibraryMissing(RuntimeError):
+  pass
+
+
+def lib_path() -> str:
+  return _LIB_PATH
+
+
+def _load() -> ctypes.CDLL:
+  if not os.path.exists(_LIB_PATH):
+    raise HipLibraryMissing(
+        'pocketflow_amd: %s not found -- build it with `python -c "import __graft_entry__ as g; '
+        'g.build()"` or pocketflow_amd/csrc/build.sh.  There is no CPU fallback.' % _LIB_PATH)
+  lib = ctypes.CDLL(_LIB_PATH)
+  lib.pf_error_string.restype = ctypes.c_char_p
+  lib.pf_error_string.argtypes = [c_int]
+  lib.pf_version.restype = c_int
+  for name in SYMBOLS:
+    fn = getattr(lib, name)            # AttributeError here = header/library mismatch
+    if name not in ('pf_error_string',):
+      fn.restype = c_int
+  return lib
+
+
+_lib = _load()
+
+
+def _check(err: int, what: str) -> None:
+  if err != 0:
+    raise RuntimeError('%s failed: hipError %d (%s)' % (what, err, _lib.pf_error_string(err).decode()))
+
+
+def _stream() -> c_void_p:
+  return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t) -> c_void_p:
+  if t is None:
+    return c_void_p(0)
+  return c_void_p(t.data_ptr())
+
+
+def dtype_code(t: torch.Tensor) -> int:
+  if t.dtype == torch.float32:
+    return PF_F32
+  if t.dtype == torch.bfloat16:
+    return PF_BF16
+  raise TypeError('unsupported dtype %s (float32 / bfloat16 only)' % t.dtype)
+
+
+def _dev(t: torch.Tensor) -> None:
+  if not t.is_cuda:
+    raise RuntimeError('pocketflow_amd kernels run on the GPU only (got a %s tensor)' % t.device)
+
+
+def version() -> int:
+  return int(_lib.pf_version())
+
+
+# ------------------------------------------------------------------------------------------------
+# K1 / K2 / K4
+# ------------------------------------------------------------------------------------------------
+
+def minmax_slots_init(slots: torch.Tensor) -> None:
+  _dev(slots)
+  _check(_lib.pf_minmax_slots_init(_ptr(slots), c_int64(slots.numel() // 2), _stream()), 'pf_minmax_slots_init')
+
+
+def minmax_tensor(x: torch.Tensor, slot: torch.Tensor, act=None) -> None:
+  _dev(x)
+  _check(_lib.pf_minmax_tensor(_ptr(x), c_int64(x.numel()), c_int(dtype_code(x)), c_int(ACT_CODES[act]),
+                               _ptr(slot), _stream()), 'pf_minmax_tensor')
+
+
+def minmax_decode(slots: torch.Tensor) -> torch.Tensor:
+  n = slots.numel() // 2
+  out = torch.empty((n, 2), dtype=torch.float32, device=slots.device)
+  _check(_lib.pf_minmax_decode(_ptr(slots), c_int64(n), _ptr(out), _stream()), 'pf_minmax_decode')
+  return out
+
+
+def uq_apply(x: torch.Tensor, y: torch.Tensor, slot: torch.Tensor, bits: int, act=None) -> None:
+  _dev(x)
+  _check(_lib.pf_uq_apply(_ptr(x), _ptr(y), c_int64(x.numel()), c_int(dtype_code(x)), c_int(dtype_code(y)),
+                          c_int(ACT_CODES[act]), _ptr(slot), c_int(int(bits)), _stream()), 'pf_uq_apply')
+
+
+def act_grad(g: torch.Tensor, u: torch.Tensor, dx: torch.Tensor, act) -> None:
+  _dev(g)
+  assert g.dtype == u.dtype == dx.dtype
+  _check(_lib.pf_act_grad(_ptr(g), _ptr(u), _ptr(dx), c_int64(g.numel()), c_int(dtype_code(g)),
+                          c_int(ACT_CODES[act]), _stream()), 'pf_act_grad')
+
+
+# ------------------------------------------------------------------------------------------------
+# segment (all-weights) kernels
+# ------------------------------------------------------------------------------------------------
+
+def seg_minmax(w_flat, segs, blocks, n_blocks, slots) -> None:
+  _check(_lib.pf_seg_minmax(_ptr(w_flat), _ptr(segs), _ptr(blocks), c_int(n_blocks), _ptr(slots), _stream()),
+         'pf_seg_minmax')
+
+
+def seg_uq_apply(w_flat, qw_flat, segs, blocks, n_blocks, slots) -> None:
+  _check(_lib.pf_seg_uq_apply(_ptr(w_flat), _ptr(qw_flat), c_int(dtype_code(qw_flat)), _ptr(segs), _ptr(blocks),
+                              c_int(n_blocks), _ptr(slots), _stream()), 'pf_seg_uq_apply')
+
+
+def seg_nuq_apply(w_flat, qw_flat, idx_flat, codebooks, segs, blocks, n_blocks, slots) -> None:
+  _check(_lib.pf_seg_nuq_apply(_ptr(w_flat), _ptr(qw_flat), c_int(dtype_code(qw_flat)), _ptr(idx_flat),
+                               _ptr(codebooks), _ptr(segs), _ptr(blocks), c_int(n_blocks), _ptr(slots),
+                               _stream()), 'pf_seg_nuq_apply')
+
+
+def seg_nuq_codebook_grad(g_flat, idx_flat, dcodebooks, segs, blocks, n_blocks, slots) -> None:
+  _check(_lib.pf_seg_nuq_codebook_grad(_ptr(g_flat), c_int(dtype_code(g_flat)), _ptr(idx_flat), _ptr(dcodebooks),
+                                       _ptr(segs), _ptr(blocks), c_int(n_blocks), _ptr(slots), _stream()),
+         'pf_seg_nuq_codebook_grad')
+
+
+def seg_normalize(w_flat, xn_out, segs, seg_index, slots) -> None:
+  _check(_lib.pf_seg_normalize(_ptr(w_flat), _ptr(xn_out), _ptr(segs), c_int(seg_index), _ptr(slots), _stream()),
+         'pf_seg_normalize')
+
+
+# ------------------------------------------------------------------------------------------------
+# weight sparsification / channel pruning
+# ------------------------------------------------------------------------------------------------
+
+def ws_bkup_merge_abs(var, bkup, mask, abs_out) -> None:
+  _check(_lib.pf_ws_bkup_merge_abs(_ptr(var), _ptr(bkup), _ptr(mask), _ptr(abs_out), c_int64(var.numel()),
+                                   _stream()), 'pf_ws_bkup_merge_abs')
+
+
+def kth_largest_nonneg(a, k_desc_index: int, out, workspace) -> None:
+  _check(_lib.pf_kth_largest_nonneg(_ptr(a), c_int64(a.numel()), c_int64(int(k_desc_index)), _ptr(out),
+                                    _ptr(workspace), _stream()), 'pf_kth_largest_nonneg')
+
+
+def ws_mask_apply(var, bkup, mask, thr) -> None:
+  _check(_lib.pf_ws_mask_apply(_ptr(var), _ptr(bkup), _ptr(mask), _ptr(thr), c_int64(var.numel()), _stream()),
+         'pf_ws_mask_apply')
+
+
+def count_nonzero(x, out_u64) -> None:
+  _check(_lib.pf_count_nonzero(_ptr(x), c_int64(x.numel()), _ptr(out_u64), _stream()), 'pf_count_nonzero')
+
+
+def cp_build_mask(mask, keep_in, keep_out, O: int, RS: int, I: int) -> None:
+  _check(_lib.pf_cp_build_mask(_ptr(mask), _ptr(keep_in), _ptr(keep_out), c_int(O), c_int(RS), c_int(I),
+                               _stream()), 'pf_cp_build_mask')
+
+
+def cp_mask_grad(g, keep_in, keep_out, O: int, RS: int, I: int) -> None:
+  _check(_lib.pf_cp_mask_grad(_ptr(g), _ptr(keep_in), _ptr(keep_out), c_int(O), c_int(RS), c_int(I), _stream()),
+         'pf_cp_mask_grad')
+
+
+# ------------------------------------------------------------------------------------------------
+# optimisers
+# ------------------------------------------------------------------------------------------------
+
+def adam_flat(p, g, m, v, mask, n_decay: int, wd: float, g_scale: float, lr: float, beta1: float,
+              beta2: float, eps: float, beta1_power: float, beta2_power: float) -> None:
+  _check(_lib.pf_adam_flat(_ptr(p), _ptr(g), c_int(dtype_code(g)), _ptr(m), _ptr(v), _ptr(mask),
+                           c_int64(p.numel()), c_int64(int(n_decay)), c_float(wd), c_float(g_scale), c_float(lr),
+                           c_float(beta1), c_float(beta2), c_float(eps), c_float(beta1_power),
+                           c_float(beta2_power), _stream()), 'pf_adam_flat')
+
+
+def momentum_flat(p, g, acc, mask, n_decay: int, wd: float, g_scale: float, lr: float,
+                  momentum: float) -> None:
+  _check(_lib.pf_momentum_flat(_ptr(p), _ptr(g), c_int(dtype_code(g)), _ptr(acc), _ptr(mask), c_int64(p.numel()),
+                               c_int64(int(n_decay)), c_float(wd), c_float(g_scale), c_float(lr),
+                               c_float(momentum), _stream()), 'pf_momentum_flat')
+
+
+# ------------------------------------------------------------------------------------------------
+# losses
+# ------------------------------------------------------------------------------------------------
+
+def ce_distill_fwd_bwd(z_s, labels, z_t, tempr: float, loss_w: float, losses, dz_s, row_ws) -> None:
+  B, C = z_s.shape
+  _check(_lib.pf_ce_distill_fwd_bwd(_ptr(z_s), c_int(dtype_code(z_s)), _ptr(labels), _ptr(z_t),
+                                    c_int(dtype_code(z_t) if z_t is not None else 0), c_int(B), c_int(C),
+                                    c_float(tempr), c_float(loss_w), _ptr(losses), _ptr(dz_s),
+                                    c_int(dtype_code(dz_s)), _ptr(row_ws), _stream()), 'pf_ce_distill_fwd_bwd')
+
+
+# ------------------------------------------------------------------------------------------------
+# fused BN + act + fake-quant
+# ------------------------------------------------------------------------------------------------
+
+def bn_stats(x, rows: int, C: int, partial, n_blocks: int) -> None:
+  _check(_lib.pf_bn_stats(_ptr(x), c_int(dtype_code(x)), c_int64(rows), c_int(C), _ptr(partial), c_int(n_blocks),
+                          _stream()), 'pf_bn_stats')
+
+
+def bn_finalize(partial, n_blocks, rows, C, x, gamma, beta, moving_mean, moving_var, momentum, eps,
+                training: bool, act, scale_shift, mean_invstd, slot) -> None:
+  _check(_lib.pf_bn_finalize(_ptr(partial), c_int(n_blocks), c_int64(rows), c_int(C), _ptr(x),
+                             c_int(dtype_code(x)), _ptr(gamma), _ptr(beta), _ptr(moving_mean), _ptr(moving_var),
+                             c_float(momentum), c_float(eps), c_int(1 if training else 0), c_int(ACT_CODES[act]),
+                             _ptr(scale_shift), _ptr(mean_invstd), _ptr(slot), _stream()), 'pf_bn_finalize')
+
+
+def bn_act_quant_apply(x, q, rows, C, scale_shift, act, slot, bits: int, quantize: bool) -> None:
+  _check(_lib.pf_bn_act_quant_apply(_ptr(x), _ptr(q), c_int(dtype_code(x)), c_int64(rows), c_int(C),
+                                    _ptr(scale_shift), c_int(ACT_CODES[act]), _ptr(slot), c_int(int(bits)),
+                                    c_int(1 if quantize else 0), _stream()), 'pf_bn_act_quant_apply')
+
+
+def bn_bwd_stats(dq, x, rows, C, scale_shift, mean_invstd, act, partial, n_blocks) -> None:
+  _check(_lib.pf_bn_bwd_stats(_ptr(dq), _ptr(x), c_int(dtype_code(x)), c_int64(rows), c_int(C), _ptr(scale_shift),
+                              _ptr(mean_invstd), c_int(ACT_CODES[act]), _ptr(partial), c_int(n_blocks),
+                              _stream()), 'pf_bn_bwd_stats')
+
+
+def bn_bwd_finalize(partial, n_blocks, C, dgamma, dbeta) -> None:
+  _check(_lib.pf_bn_bwd_finalize(_ptr(partial), c_int(n_blocks), c_int(C), _ptr(dgamma), _ptr(dbeta), _stream()),
+         'pf_bn_bwd_finalize')
+
+
+def bn_bwd_apply(dq, x, dx, rows, C, scale_shift, mean_invstd, dgamma, dbeta, act) -> None:
+  _check(_lib.pf_bn_bwd_apply(_ptr(dq), _ptr(x), _ptr(dx), c_int(dtype_code(x)), c_int64(rows), c_int(C),
+                              _ptr(scale_shift), _ptr(mean_invstd), _ptr(dgamma), _ptr(dbeta),
+                              c_int(ACT_CODES[act]), _stream()), 'pf_bn_bwd_apply')
+
+
+def bn_eval_scale_shift(gamma, beta, moving_mean, moving_var, eps: float, scale_shift) -> None:
+  _check(_lib.pf_bn_eval_scale_shift(_ptr(gamma), _ptr(beta), _ptr(moving_mean), _ptr(moving_var), c_float(eps),
+                                     c_int(gamma.numel()), _ptr(scale_shift), _stream()), 'pf_bn_eval_scale_shift')
+
+
+# ------------------------------------------------------------------------------------------------
+# MFMA GEMM
+# ------------------------------------------------------------------------------------------------
+
+def gemm_bf16_nt(A, B, C, M: int, N: int, K: int) -> None:
+  _check(_lib.pf_gemm_bf16_nt(_ptr(A), _ptr(B), _ptr(C), c_int(M), c_int(N), c_int(K), c_int(dtype_code(C)),
+                              _stream()), 'pf_gemm_bf16_nt')
+
+
+def gemm_bf16_nn(A, B, C, M: int, N: int, K: int) -> None:
+  _check(_lib.pf_gemm_bf16_nn(_ptr(A), _ptr(B), _ptr(C), c_int(M), c_int(N), c_int(K), c_int(dtype_code(C)),
+                              _stream()), 'pf_gemm_bf16_nn')
+
+
+def gemm_bf16_tn(A, B, C, M: int, N: int, K: int) -> None:
+  _check(_lib.pf_gemm_bf16_tn(_ptr(A), _ptr(B), _ptr(C), c_int(M), c_int(N), c_int(K), c_int(dtype_code(C)),
+                              _stream()), 'pf_gemm_bf16_tn')

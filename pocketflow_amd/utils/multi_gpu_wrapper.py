@@ -1,0 +1,74 @@
+"""RCCL-backed replacement of the reference's Horovod / TF-Plus shim.
+
+Same seven-method surface as `MultiGpuWrapper` (utils/multi_gpu_wrapper.py:30-98): init, size, rank,
+local_size, local_rank, DistributedOptimizer, broadcast_global_variables.  One process per GPU,
+`torch.distributed` with backend "nccl" (= RCCL over xGMI on ROCm); on a CPU-only host (tests) the
+backend is gloo.  Gradient exchange is ONE all-reduce per flat gradient buffer (two per model), not
+one message per tensor: an MI355X node is a point-to-point xGMI mesh, so few
+large messages (tens of MB) is what keeps every link busy.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class MultiGpuWrapper(object):
+  _initialized = False
+
+  @classmethod
+  def init(cls, *args):
+    if cls._initialized or dist.is_initialized():
+      cls._initialized = True
+      return
+    if 'RANK' not in os.environ or 'WORLD_SIZE' not in os.environ:
+      raise NameError('module <mgw> not imported: launch with torchrun / torch.distributed.run '
+                      '(RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT)')
+    backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend == 'nccl':
+      torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group(backend=backend)
+    cls._initialized = True
+
+  @classmethod
+  def size(cls, *args):
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+  @classmethod
+  def rank(cls, *args):
+    return dist.get_rank() if dist.is_initialized() else 0
+
+  @classmethod
+  def local_size(cls, *args):
+    return int(os.environ.get('LOCAL_WORLD_SIZE', cls.size()))
+
+  @classmethod
+  def local_rank(cls, *args):
+    return int(os.environ.get('LOCAL_RANK', cls.rank()))
+
+  @classmethod
+  def DistributedOptimizer(cls, optimizer):
+    """Wrap a FlatOptimizer: gradients are summed across ranks before apply (Horovod averages;
+    the 1/size factor is folded into the optimiser kernel's g_scale)."""
+    from pocketflow_amd.optim import DistributedFlatOptimizer
+    return DistributedFlatOptimizer(optimizer)
+
+  @classmethod
+  def broadcast_global_variables(cls, root_rank, stores=(), optimizers=()):
+    """Returns a callable ("bcast op") that broadcasts every global variable from `root_rank`:
+    parameters, BN moving statistics, optimiser slots (learners/*/learner.py `ops['bcast']`)."""
+    def bcast_op():
+      if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+      for st in stores:
+        dist.broadcast(st.w_master, root_rank)
+        dist.broadcast(st.o_master, root_rank)
+        dist.broadcast(st.state, root_rank)
+        st.sync_compute()
+      for opt in optimizers:
+        for t in opt.state_tensors():
+          dist.broadcast(t, root_rank)
+    return bcast_op
