@@ -1,0 +1,146 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of the ResNet-50 8-bit UniformQuantLearner fine-tune step with
+distillation (BASELINE.json configs[2]) on N MI355X GPUs of one node, synthetic 224x224x3 batches.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full pass of the hot path over one batch per GPU: teacher forward, weight fake-quant
+of all 54 kernels, student forward with fused BN+ReLU+activation fake-quant, CE + coupled L2 +
+distillation loss, backward with straight-through estimators, [RCCL all-reduce], fused Adam.
+Rank 0 prints ONE JSON line (contract in the task description).
+"""
+import argparse
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+R50_FLOPS_PER_IMAGE_STEP_DST = 32.71e9    # fwd + bwd-data + bwd-filter + teacher fwd
+MFMA_BF16_PEAK = 2.5e15                   # dense bf16, MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12                         # B/s, MI355X_MICROARCH.md
+
+
+def parse_args():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=20)
+  ap.add_argument('--warmup', type=int, default=5)
+  ap.add_argument('--batch', type=int, default=256, help='per-GPU batch (north star: 256)')
+  ap.add_argument('--resnet_size', type=int, default=50)
+  ap.add_argument('--image_size', type=int, default=224)
+  ap.add_argument('--dtype', default='bfloat16')
+  ap.add_argument('--act_bits', type=int, default=8)
+  ap.add_argument('--weight_bits', type=int, default=8)
+  ap.add_argument('--roofline_kernel', default='bn_bwd_apply')
+  ap.add_argument('--no_cpu_baseline', action='store_true')
+  ap.add_argument('--cpu_batch', type=int, default=8)
+  ap.add_argument('--cpu_steps', type=int, default=2)
+  return ap.parse_args()
+
+
+def main():
+  args = parse_args()
+  import torch
+  import torch.distributed as dist
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  if world != args.gpus:
+    if world == 1 and args.gpus > 1:
+      raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+  from pocketflow_amd.flags import FLAGS
+  from pocketflow_amd import profiling
+  from pocketflow_amd.nets.resnet_at_ilsvrc12 import ModelHelper
+  from pocketflow_amd.learners.uniform_quantization.learner import UniformQuantLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  from pocketflow_amd.utils.multi_gpu_wrapper import MultiGpuWrapper as mgw
+
+  tmp = tempfile.mkdtemp(prefix='pf_bench_r%d_' % rank)
+  FLAGS.enbl_multi_gpu = world > 1
+  FLAGS.resnet_size = args.resnet_size
+  FLAGS.nb_classes = 1001
+  FLAGS.image_size = args.image_size
+  FLAGS.batch_size = args.batch
+  FLAGS.compute_dtype = args.dtype
+  FLAGS.enbl_dst = True
+  FLAGS.dst_eval_teacher = False            # the teacher's one-off evaluation is not part of a step
+  FLAGS.uql_weight_bits = args.weight_bits
+  FLAGS.uql_activation_bits = args.act_bits
+  FLAGS.synthetic_pool = 2
+  FLAGS.save_path = os.path.join(tmp, 'models', 'model.ckpt')
+  FLAGS.save_path_dst = os.path.join(tmp, 'models_dst', 'model.ckpt')
+  FLAGS.uql_save_quant_model_path = os.path.join(tmp, 'uql', 'model.ckpt')
+  if world > 1:
+    mgw.init()
+  torch.backends.cudnn.benchmark = True
+
+  mh = ModelHelper()
+  create_synthetic_checkpoint(mh)
+  learner = UniformQuantLearner(None, mh)
+  if world > 1:
+    learner.ops['bcast']()
+
+  def sync():
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  for _ in range(args.warmup):
+    learner.train_step()
+  profiling.enable(args.roofline_kernel)
+  sync()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    learner.train_step()
+  sync()
+  dt = time.perf_counter() - t0
+  if world > 1:
+    t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+  n_launch, ms, work = profiling.summary(args.roofline_kernel)
+
+  if rank == 0:
+    images = args.batch * world * args.steps
+    value = images / dt
+    per_gpu = value / world
+    ach = (work / (ms * 1e-3)) if ms > 0 else 0.0
+    roofline = {'bound': 'hbm', 'kernel': 'k_' + args.roofline_kernel, 'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9,
+                'unit': 'GB/s', 'frac': ach / HBM_PEAK, 'traffic': None, 'launches': n_launch,
+                'avg_launch_ms': (ms / n_launch) if n_launch else None,
+                'step_mfma_frac': per_gpu * R50_FLOPS_PER_IMAGE_STEP_DST / MFMA_BF16_PEAK}
+    cpu_baseline = None
+    if world == 1 and not args.no_cpu_baseline:
+      try:
+        from oracle.learner_oracle import time_cpu_baseline
+        cpu_baseline = time_cpu_baseline(args.resnet_size, args.image_size, args.cpu_batch, args.cpu_steps,
+                                         args.weight_bits, args.act_bits)
+      except ImportError:
+        cpu_baseline = None
+    line = {
+        'metric': 'images/sec ResNet-50 INT8 quant-aware fine-tune (whole job; per GPU = value / n_gpus)',
+        'value': value, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'bf16' if args.dtype.startswith('bf') else 'f32', 'data': 'synthetic',
+        'value_per_gpu': per_gpu,
+        'config': {'workload': 'ResNet-v2-%d@ILSVRC-12-synthetic %dx%dx3, UniformQuantLearner w%d/a%d + distillation, '
+                               'Adam, batch %d/GPU (BASELINE.json configs[2])'
+                               % (args.resnet_size, args.image_size, args.image_size, args.weight_bits,
+                                  args.act_bits, args.batch),
+                   'global_batch': args.batch * world, 'parallelism': 'dp%d' % world},
+        'roofline': roofline, 'cpu_baseline': cpu_baseline}
+    print(json.dumps(line))
+  shutil.rmtree(tmp, ignore_errors=True)
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

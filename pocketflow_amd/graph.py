@@ -35,6 +35,7 @@ import torch.nn.functional as F
 
 from pocketflow_amd import hip
 from pocketflow_amd.plan import WeightDesc
+from pocketflow_amd.profiling import region
 
 ALIGN = 64  # elements; keeps every tensor 256-byte aligned inside the flat buffers
 
@@ -391,12 +392,15 @@ class _BnActQuant(torch.autograd.Function):
     scale_shift = torch.empty((2, C), dtype=torch.float32, device=x.device)
     mean_invstd = torch.empty((2, C), dtype=torch.float32, device=x.device)
     quantize = bits is not None
-    hip.bn_stats(x, rows, C, partial, nblk)
+    nbytes = float(x.numel() * x.element_size())
+    with region('bn_stats', nbytes):                 # algorithmic bytes: 1 read of x
+      hip.bn_stats(x, rows, C, partial, nblk)
     hip.bn_finalize(partial, nblk, rows, C, x, gamma, beta, layer.moving_mean.tensor, layer.moving_var.tensor,
                     layer.momentum, layer.eps, training, layer.act, scale_shift, mean_invstd,
                     slot if quantize else None)
     q = torch.empty_like(x)
-    hip.bn_act_quant_apply(x, q, rows, C, scale_shift, layer.act, slot, bits if quantize else 8, quantize)
+    with region('bn_act_quant_apply', 2 * nbytes):   # 1 read of x + 1 write of q
+      hip.bn_act_quant_apply(x, q, rows, C, scale_shift, layer.act, slot, bits if quantize else 8, quantize)
     ctx.save_for_backward(x, scale_shift, mean_invstd)
     ctx.meta = (layer.act, graph, rows, C, nblk)
     return q
@@ -409,12 +413,15 @@ class _BnActQuant(torch.autograd.Function):
     if dq.dtype != x.dtype:
       dq = dq.to(x.dtype)
     partial = graph.scratch(nblk * 2 * C)
-    hip.bn_bwd_stats(dq, x, rows, C, scale_shift, mean_invstd, act, partial, nblk)
+    nbytes = float(x.numel() * x.element_size())
+    with region('bn_bwd_stats', 2 * nbytes):         # reads dq and x
+      hip.bn_bwd_stats(dq, x, rows, C, scale_shift, mean_invstd, act, partial, nblk)
     dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
     dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
     hip.bn_bwd_finalize(partial, nblk, C, dgamma, dbeta)
     dx = torch.empty_like(x)
-    hip.bn_bwd_apply(dq, x, dx, rows, C, scale_shift, mean_invstd, dgamma, dbeta, act)
+    with region('bn_bwd_apply', 3 * nbytes):         # reads dq and x, writes dx
+      hip.bn_bwd_apply(dq, x, dx, rows, C, scale_shift, mean_invstd, dgamma, dbeta, act)
     return dx, dgamma, dbeta, None, None, None, None, None
 
 

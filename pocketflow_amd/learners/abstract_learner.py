@@ -56,6 +56,15 @@ def require_gpu() -> torch.device:
   return torch.device('cuda', idx)
 
 
+def input_spec(model_helper):
+  """A `meta` tensor with the shape of one training batch [B, H, W, C] (build-mode input)."""
+  ds = getattr(model_helper, 'dataset_train', None)
+  if ds is not None and hasattr(ds, 'image_shape'):
+    return torch.empty((ds.batch_size,) + tuple(ds.image_shape), device='meta')
+  images, __ = model_helper.build_dataset_train().get_next()
+  return torch.empty(tuple(images.shape), device='meta')
+
+
 class AbstractLearner(ABC):  # pylint: disable=too-many-instance-attributes
   """Abstract class for learners: takes a ModelHelper (data pipeline + network definition) and
   either trains (periodically saving checkpoints) or restores and evaluates a model."""
@@ -140,9 +149,7 @@ class AbstractLearner(ABC):  # pylint: disable=too-many-instance-attributes
   def build_graph(self, scope, separate_compute=False, requires_grad=True):
     """Declare the model's variables & ops on a new Graph by running forward_train in build mode."""
     graph = Graph(scope, self.device, compute_dtype())
-    iterator = self.build_dataset_train()
-    images, __ = iterator.get_next()
-    spec = torch.empty(tuple(images.shape), device='meta')
+    spec = input_spec(self.model_helper)
     with graph.as_default():
       self.forward_train(spec)
     graph.finalize(separate_compute=separate_compute, seed=FLAGS.init_seed, requires_grad=requires_grad)

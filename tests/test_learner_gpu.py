@@ -1,0 +1,75 @@
+"""End-to-end learner steps on the GPU (smoke + invariants); step-level parity against the CPU
+oracle learner lives in tests/test_parity_gpu.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(tmp_path, **kw):
+  from pocketflow_amd.flags import FLAGS
+  import pocketflow_amd.learners.learner_utils  # noqa: F401  (defines flags)
+  import pocketflow_amd.learners.abstract_learner  # noqa: F401
+  FLAGS.save_path = str(tmp_path / 'models' / 'model.ckpt')
+  FLAGS.save_path_eval = str(tmp_path / 'models_eval' / 'model.ckpt')
+  FLAGS.synthetic_pool = 2
+  for k, v in kw.items():
+    setattr(FLAGS, k, v)
+  return FLAGS
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+def test_uq_lenet_steps(tmp_path, dtype):
+  from pocketflow_amd.nets.lenet_at_cifar10 import ModelHelper
+  from pocketflow_amd.learners.uniform_quantization.learner import UniformQuantLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  FLAGS = _setup(tmp_path, batch_size=32, uql_weight_bits=8, uql_activation_bits=8, compute_dtype=dtype,
+                 uql_save_quant_model_path=str(tmp_path / 'uql' / 'm.ckpt'), nb_eval_batches_override=2)
+  mh = ModelHelper()
+  create_synthetic_checkpoint(mh)
+  learner = UniformQuantLearner(None, mh)
+  assert learner.statistics['nb_matmuls'] == 2 and learner.statistics['nb_activations'] == 3
+  w0 = learner.graph.store.w_master.clone()
+  for _ in range(3):
+    out = learner.train_step()
+    assert np.isfinite(float(out['loss']))
+  assert not torch.equal(w0, learner.graph.store.w_master)
+  # quantised compute copy of conv2 holds at most 256 distinct values; conv1 (first layer) is a plain cast
+  st = learner.graph.store
+  v = st.by_name['model/conv2/kernel']
+  assert torch.unique(st.w_compute[v.offset:v.offset + v.numel].float()).numel() <= 256
+  v1 = st.by_name['model/conv1/kernel']
+  torch.testing.assert_close(st.w_compute[v1.offset:v1.offset + v1.numel].float(),
+                             st.w_master[v1.offset:v1.offset + v1.numel], rtol=1e-2, atol=1e-2)
+
+
+def test_uq_resnet20_with_distillation_and_eval(tmp_path):
+  from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
+  from pocketflow_amd.learners.uniform_quantization.learner import UniformQuantLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  FLAGS = _setup(tmp_path, batch_size=16, batch_size_eval=16, uql_weight_bits=8, uql_activation_bits=8,
+                 enbl_dst=True, save_path_dst=str(tmp_path / 'models_dst' / 'model.ckpt'),
+                 uql_save_quant_model_path=str(tmp_path / 'uql' / 'm.ckpt'), nb_eval_batches_override=2,
+                 nb_iters_override=4, summ_step=2, resnet_size=20, nb_classes=10)
+  mh = ModelHelper()
+  create_synthetic_checkpoint(mh)
+  learner = UniformQuantLearner(None, mh)
+  assert learner.statistics['nb_matmuls'] == 21 and learner.statistics['nb_activations'] == 19
+  rslt = learner.train()
+  assert np.isfinite(rslt['loss'])
+  # teacher == initial student, so at step 0 the distillation gradient is ~0 only through quant noise
+  assert os.path.exists(str(tmp_path / 'uql' / 'checkpoint'))
+
+
+def test_full_prec_resnet20_two_steps(tmp_path):
+  from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
+  from pocketflow_amd.learners.full_precision.learner import FullPrecLearner
+  FLAGS = _setup(tmp_path, batch_size=16, resnet_size=20, nb_classes=10)
+  learner = FullPrecLearner(None, ModelHelper())
+  l0 = float(learner.train_step()[1])
+  for _ in range(5):
+    l = float(learner.train_step()[1])
+  assert np.isfinite(l) and l < l0 * 1.5
