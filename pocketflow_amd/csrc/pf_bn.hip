@@ -22,27 +22,68 @@
 static inline bool bn_fast_ok(int C) {
   if (C % 8) return false;
   const int G = C / 8;
-  return G <= 256 && (256 % G) == 0;
+  if (G < 8) return (8 % G) == 0;                        // C = 8, 16, 32: a single slab
+  return (C % 64) == 0 && G <= 256 && (256 % G) == 0;    // streaming kernels keep the (256 % G) map
 }
 
 // ---------------------------------------------------------------------------------------------
 // forward pass 1
 // ---------------------------------------------------------------------------------------------
+// 2-D decomposition: a 1024-thread workgroup (16 wavefronts) owns a SLAB of up to 64 channels
+// (CG = min(C/8, 8) groups of 8 channels, 16 B per lane) and one of `nsplit` interleaved row ranges;
+// 1024/CG row-lanes walk the rows.  Per-workgroup partials are only 4 x 64 floats, so the partial
+// buffer [nsplit][4][C] stays ~1000x smaller than the tensor and the finalize pass is a few us.
+#define BN_BIG 1024
+__device__ __forceinline__ int bn_cg_of(int C) { return (C >> 3) < 8 ? (C >> 3) : 8; }
+
+// KIND per statistic: 0 = sum, 1 = min, 2 = max
+template <int KIND> __device__ __forceinline__ float bn_comb(float a, float b) {
+  return KIND == 0 ? (a + b) : (KIND == 1 ? fminf(a, b) : fmaxf(a, b));
+}
+template <int KIND>
+__device__ __forceinline__ void bn_wave_reduce8(float (&a)[8], int CG) {
+  // lanes with equal (lane % CG) hold the same channel group: butterfly over the other lane bits
+  for (int m = CG; m < 64; m <<= 1) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = bn_comb<KIND>(a[j], __shfl_xor(a[j], m, 64));
+  }
+}
+template <int KIND>
+__device__ __forceinline__ void bn_lds_put(const float (&a)[8], int st, int NS, int CG, float* lds) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < CG) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lds[(wave * NS + st) * 64 + lane * 8 + j] = a[j];
+  }
+}
+template <int KIND>
+__device__ __forceinline__ void bn_lds_finish(int st, int NS, int slabC, const float* lds, float* out) {
+  // threads [st*slabC, (st+1)*slabC) combine the 16 per-wave partials of statistic `st`
+  const int t = (int)threadIdx.x - st * slabC;
+  if (t >= 0 && t < slabC) {
+    float a = lds[st * 64 + t];
+    for (int w = 1; w < BN_BIG / 64; ++w) a = bn_comb<KIND>(a, lds[(w * NS + st) * 64 + t]);
+    out[t] = a;
+  }
+}
+
 template <typename T>
-__global__ __launch_bounds__(PF_THREADS) void k_bn_stats_fast(const T* __restrict__ x, int64_t rows, int C,
-                                                              float* __restrict__ partial) {
-  extern __shared__ float lds[];                 // [256/G][4][C] staged in 4 rounds of [256][8]
-  const int G = C >> 3;
-  const int RPS = PF_THREADS / G;                // rows per slab
-  const int cg = threadIdx.x % G, rsub = threadIdx.x / G;
+__global__ __launch_bounds__(BN_BIG) void k_bn_stats_fast(const T* __restrict__ x, int64_t rows, int C,
+                                                          float* __restrict__ partial, int nslab, int nsplit) {
+  __shared__ float lds[(BN_BIG / 64) * 4 * 64];
+  const int CG = bn_cg_of(C), slabC = CG * 8, RL = BN_BIG / CG;
+  const int slab = blockIdx.x % nslab, split = blockIdx.x / nslab;
+  const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
+  const int c0 = slab * slabC + cg * 8;
   float piv[8];
-  load8<T>(x + (cg << 3), piv);                  // pivot = row 0 (shifted sums: no cancellation)
+  load8<T>(x + c0, piv);                          // pivot = row 0 (shifted sums: no cancellation)
   float s[8], ss[8], mn[8], mx[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s[j] = 0.f; ss[j] = 0.f; mn[j] = INFINITY; mx[j] = -INFINITY; }
-  for (int64_t r = (int64_t)blockIdx.x * RPS + rsub; r < rows; r += (int64_t)gridDim.x * RPS) {
+#pragma unroll 2
+  for (int64_t r = (int64_t)split * RL + rl; r < rows; r += (int64_t)nsplit * RL) {
     float v[8];
-    load8<T>(x + r * C + (cg << 3), v);
+    load8<T>(x + r * C + c0, v);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float d = v[j] - piv[j];
@@ -52,26 +93,15 @@ __global__ __launch_bounds__(PF_THREADS) void k_bn_stats_fast(const T* __restric
       mx[j] = fmaxf(mx[j], v[j]);
     }
   }
-  // cross-thread (same cg, different rsub) reduction through LDS, one statistic at a time
-  float* out = partial + (int64_t)blockIdx.x * 4 * C;
-#pragma unroll
-  for (int st = 0; st < 4; ++st) {
-    float* a = (st == 0) ? s : (st == 1) ? ss : (st == 2) ? mn : mx;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) lds[threadIdx.x * 8 + j] = a[j];
-    __syncthreads();
-    if (rsub == 0) {
-      for (int j = 0; j < 8; ++j) {
-        float acc = lds[cg * 8 + j];
-        for (int q = 1; q < RPS; ++q) {
-          const float o = lds[(q * G + cg) * 8 + j];
-          acc = (st < 2) ? (acc + o) : (st == 2 ? fminf(acc, o) : fmaxf(acc, o));
-        }
-        out[st * C + (cg << 3) + j] = acc;
-      }
-    }
-    __syncthreads();
-  }
+  bn_wave_reduce8<0>(s, CG); bn_wave_reduce8<0>(ss, CG); bn_wave_reduce8<1>(mn, CG); bn_wave_reduce8<2>(mx, CG);
+  bn_lds_put<0>(s, 0, 4, CG, lds); bn_lds_put<0>(ss, 1, 4, CG, lds);
+  bn_lds_put<1>(mn, 2, 4, CG, lds); bn_lds_put<2>(mx, 3, 4, CG, lds);
+  __syncthreads();
+  float* out = partial + (int64_t)split * 4 * C + slab * slabC;
+  bn_lds_finish<0>(0, 4, slabC, lds, out);
+  bn_lds_finish<0>(1, 4, slabC, lds, out + C);
+  bn_lds_finish<1>(2, 4, slabC, lds, out + 2 * C);
+  bn_lds_finish<2>(3, 4, slabC, lds, out + 3 * C);
 }
 
 template <typename T>
@@ -97,9 +127,10 @@ extern "C" int pf_bn_stats(const void* x, int dtype, int64_t rows, int C, float*
   if (rows <= 0 || C <= 0 || n_blocks <= 0) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   if (bn_fast_ok(C) && pf_aligned16(x)) {
-    const size_t shm = PF_THREADS * 8 * sizeof(float);
-    if (dtype == PF_F32) k_bn_stats_fast<float><<<n_blocks, PF_THREADS, shm, st>>>((const float*)x, rows, C, partial);
-    else if (dtype == PF_BF16) k_bn_stats_fast<bf16_t><<<n_blocks, PF_THREADS, shm, st>>>((const bf16_t*)x, rows, C, partial);
+    const int CG = (C / 8) < 8 ? (C / 8) : 8;
+    const int nslab = C / (CG * 8);
+    if (dtype == PF_F32) k_bn_stats_fast<float><<<nslab * n_blocks, BN_BIG, 0, st>>>((const float*)x, rows, C, partial, nslab, n_blocks);
+    else if (dtype == PF_BF16) k_bn_stats_fast<bf16_t><<<nslab * n_blocks, BN_BIG, 0, st>>>((const bf16_t*)x, rows, C, partial, nslab, n_blocks);
     else return (int)hipErrorInvalidValue;
   } else {
     dim3 grid((C + PF_THREADS - 1) / PF_THREADS, n_blocks);
@@ -293,25 +324,28 @@ extern "C" int pf_bn_act_quant_apply(const void* x, void* q, int dtype, int64_t 
 // backward pass 1: per-channel sum(dy), sum(dy * xhat),  dy = dq * act'(scale*x+shift)
 // ---------------------------------------------------------------------------------------------
 template <typename T, int ACT>
-__global__ __launch_bounds__(PF_THREADS) void k_bn_bwd_stats_fast(const T* __restrict__ dq, const T* __restrict__ x,
-                                                                  int64_t rows, int C,
-                                                                  const float* __restrict__ scale_shift,
-                                                                  const float* __restrict__ mean_invstd,
-                                                                  float* __restrict__ partial) {
-  extern __shared__ float lds[];
-  const int G = C >> 3, RPS = PF_THREADS / G;
-  const int cg = threadIdx.x % G, rsub = threadIdx.x / G;
+__global__ __launch_bounds__(BN_BIG) void k_bn_bwd_stats_fast(const T* __restrict__ dq, const T* __restrict__ x,
+                                                              int64_t rows, int C,
+                                                              const float* __restrict__ scale_shift,
+                                                              const float* __restrict__ mean_invstd,
+                                                              float* __restrict__ partial, int nslab, int nsplit) {
+  __shared__ float lds[(BN_BIG / 64) * 2 * 64];
+  const int CG = bn_cg_of(C), slabC = CG * 8, RL = BN_BIG / CG;
+  const int slab = blockIdx.x % nslab, split = blockIdx.x / nslab;
+  const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
+  const int c0 = slab * slabC + cg * 8;
   float sc[8], sh[8], mu[8], is[8], s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int c = (cg << 3) + j;
+    const int c = c0 + j;
     sc[j] = scale_shift[c]; sh[j] = scale_shift[C + c];
     mu[j] = mean_invstd[c]; is[j] = mean_invstd[C + c];
     s1[j] = 0.f; s2[j] = 0.f;
   }
-  for (int64_t r = (int64_t)blockIdx.x * RPS + rsub; r < rows; r += (int64_t)gridDim.x * RPS) {
+#pragma unroll 2
+  for (int64_t r = (int64_t)split * RL + rl; r < rows; r += (int64_t)nsplit * RL) {
     float g[8], v[8];
-    const int64_t off = r * C + (cg << 3);
+    const int64_t off = r * C + c0;
     load8<T>(dq + off, g);
     load8<T>(x + off, v);
 #pragma unroll
@@ -321,22 +355,12 @@ __global__ __launch_bounds__(PF_THREADS) void k_bn_bwd_stats_fast(const T* __res
       s2[j] = fmaf(dy, (v[j] - mu[j]) * is[j], s2[j]);
     }
   }
-  float* out = partial + (int64_t)blockIdx.x * 2 * C;
-#pragma unroll
-  for (int st = 0; st < 2; ++st) {
-    float* a = (st == 0) ? s1 : s2;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) lds[threadIdx.x * 8 + j] = a[j];
-    __syncthreads();
-    if (rsub == 0) {
-      for (int j = 0; j < 8; ++j) {
-        float acc = lds[cg * 8 + j];
-        for (int q = 1; q < RPS; ++q) acc += lds[(q * G + cg) * 8 + j];
-        out[st * C + (cg << 3) + j] = acc;
-      }
-    }
-    __syncthreads();
-  }
+  bn_wave_reduce8<0>(s1, CG); bn_wave_reduce8<0>(s2, CG);
+  bn_lds_put<0>(s1, 0, 2, CG, lds); bn_lds_put<0>(s2, 1, 2, CG, lds);
+  __syncthreads();
+  float* out = partial + (int64_t)split * 2 * C + slab * slabC;
+  bn_lds_finish<0>(0, 2, slabC, lds, out);
+  bn_lds_finish<0>(1, 2, slabC, lds, out + C);
 }
 
 template <typename T, int ACT>
@@ -363,12 +387,13 @@ template <typename T>
 static int launch_bn_bwd_stats(const T* dq, const T* x, int64_t rows, int C, const float* ss,
                                const float* mi, int act, float* partial, int n_blocks, hipStream_t st) {
   const bool fast = bn_fast_ok(C) && pf_aligned16(x) && pf_aligned16(dq);
-  const size_t shm = PF_THREADS * 8 * sizeof(float);
+  const int CG = (C / 8) < 8 ? (C / 8) : 8;
+  const int nslab = fast ? C / (CG * 8) : 1;
   dim3 ggrid((C + PF_THREADS - 1) / PF_THREADS, n_blocks);
-#define PF_BS(ACTV)                                                                                             \
-  do {                                                                                                          \
-    if (fast) k_bn_bwd_stats_fast<T, ACTV><<<n_blocks, PF_THREADS, shm, st>>>(dq, x, rows, C, ss, mi, partial);  \
-    else k_bn_bwd_stats_generic<T, ACTV><<<ggrid, PF_THREADS, 0, st>>>(dq, x, rows, C, ss, mi, partial);         \
+#define PF_BS(ACTV)                                                                                                       \
+  do {                                                                                                                    \
+    if (fast) k_bn_bwd_stats_fast<T, ACTV><<<nslab * n_blocks, BN_BIG, 0, st>>>(dq, x, rows, C, ss, mi, partial, nslab, n_blocks);  \
+    else k_bn_bwd_stats_generic<T, ACTV><<<ggrid, PF_THREADS, 0, st>>>(dq, x, rows, C, ss, mi, partial);                  \
   } while (0)
   if (act == PF_ACT_RELU) PF_BS(PF_ACT_RELU);
   else if (act == PF_ACT_RELU6) PF_BS(PF_ACT_RELU6);

@@ -372,10 +372,24 @@ def _nhwc(x: torch.Tensor) -> torch.Tensor:
   return x.contiguous()
 
 
+def _bn_fast_ok(C: int) -> bool:
+  """Mirror of bn_fast_ok() in csrc/pf_bn.hip."""
+  if C % 8:
+    return False
+  G = C // 8
+  if G < 8:
+    return 8 % G == 0
+  return C % 64 == 0 and G <= 256 and 256 % G == 0
+
+
 def _bn_blocks(rows: int, C: int) -> int:
-  if C % 8 == 0 and (C // 8) <= 256 and 256 % (C // 8) == 0:
-    rps = 256 // (C // 8)
-    return int(min(1024, max(1, rows // (rps * 8))))
+  """Number of row splits of the BN statistics passes (= entries per channel the finalize kernel
+  reduces).  Fast path: 1024-thread workgroups over (channel slab x row split); ~256 workgroups."""
+  if _bn_fast_ok(C):
+    cg = min(C // 8, 8)
+    nslab = C // (cg * 8)
+    row_lanes = 1024 // cg
+    return int(max(1, min(256 // nslab, rows // (row_lanes * 2))))
   return int(min(256, max(1, rows // 64)))
 
 
@@ -505,7 +519,9 @@ class Conv2D:
     w = self.kernel.tensor
     b = self.bias.tensor.to(x.dtype) if self.bias is not None else None
     pad = 0
-    if self.padding == 'SAME' and self.k > 1:
+    if isinstance(self.padding, int):
+      pad = self.padding
+    elif self.padding == 'SAME' and self.k > 1:
       ph = _same_pads(x.shape[2], self.k, self.stride)
       pw = _same_pads(x.shape[3], self.k, self.stride)
       if ph[0] == ph[1] and pw[0] == pw[1]:
@@ -625,6 +641,9 @@ def max_pool_same(x: torch.Tensor, k: int, stride: int) -> torch.Tensor:
   """tf.layers.max_pooling2d(padding='SAME'): pad with -inf, extra pixel at the end."""
   ph = _same_pads(x.shape[2], k, stride)
   pw = _same_pads(x.shape[3], k, stride)
+  if ph[0] == 0 and pw[0] == 0:
+    # padding only at the end: identical to a ceil-mode pool (clipped last window), no padded copy
+    return F.max_pool2d(x, k, stride, ceil_mode=True)
   if any(ph) or any(pw):
     x = F.pad(x, (pw[0], pw[1], ph[0], ph[1]), value=float('-inf'))
   return F.max_pool2d(x, k, stride)
