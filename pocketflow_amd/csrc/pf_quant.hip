@@ -510,6 +510,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_seg_nuq_cbgrad(const TG* __restr
   __shared__ float bins[256];
   const PfBlock b = blocks[blockIdx.x];
   const PfSeg sg = segs[b.seg];
+  if (sg.bits <= 0) return;                   // tensor is not quantised: it has no codebook
   const TG* __restrict__ gb = g + sg.offset;
   const uint8_t* __restrict__ ib = idx + sg.offset;
   const uint32_t* __restrict__ sl = slots + 2 * sg.slot_offset;

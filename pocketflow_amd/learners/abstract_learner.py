@@ -146,12 +146,15 @@ class AbstractLearner(ABC):  # pylint: disable=too-many-instance-attributes
   # ---------------------------------------------------------------------------------------------
   # shared machinery (no reference counterpart: replaces tf.Graph / tf.Session plumbing)
   # ---------------------------------------------------------------------------------------------
-  def build_graph(self, scope, separate_compute=False, requires_grad=True):
-    """Declare the model's variables & ops on a new Graph by running forward_train in build mode."""
+  def build_graph(self, scope, separate_compute=False, requires_grad=True, before_finalize=None):
+    """Declare the model's variables & ops on a new Graph by running forward_train in build mode.
+    `before_finalize(graph)` may declare further variables (e.g. NUQ codebooks)."""
     graph = Graph(scope, self.device, compute_dtype())
     spec = input_spec(self.model_helper)
     with graph.as_default():
       self.forward_train(spec)
+    if before_finalize is not None:
+      before_finalize(graph)
     graph.finalize(separate_compute=separate_compute, seed=FLAGS.init_seed, requires_grad=requires_grad)
     return graph
 

@@ -57,6 +57,7 @@ class FullPrecLearner(AbstractLearner):  # pylint: disable=too-many-instance-att
   def train_step(self):
     """One `sess.run(train_op)`: data -> [teacher fwd] -> fwd -> loss -> bwd -> [all-reduce] -> Momentum."""
     g = self.graph
+    g.store.sync_compute()                       # bf16 mode: compute copy <- fp32 master (one cast launch)
     images, labels = self.iter_train.get_next()
     x, y = self.to_device(images, labels)
     g.begin_step()

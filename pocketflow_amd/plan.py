@@ -36,7 +36,8 @@ class QuantPlan:
   """Segment table + block maps + slot/codebook offsets for one set of weight tensors."""
 
   def __init__(self, weights: Sequence[WeightDesc], bits: Sequence[int], use_buckets: bool,
-               bucket_type: str, bucket_size: int, device, nuq: bool = False):
+               bucket_type: str, bucket_size: int, device, nuq: bool = False,
+               cb_offsets: Optional[Sequence[int]] = None):
     assert len(weights) == len(bits)
     self.weights = list(weights)
     self.device = device
@@ -61,6 +62,8 @@ class QuantPlan:
         mode, n_bucket = hip.PF_BUCKET_SPLIT, -(-length // bucket_size)
       else:
         raise ValueError("Unrecognized bucket type, must be 'split' or 'channel'.")
+      if cb_offsets is not None:
+        cb_off = int(cb_offsets[s])              # codebooks live in an external buffer (the VarStore)
       segs[s] = (w.offset, length, w.RS, w.layout, w.I, w.O, mode, int(b), bucket_size, n_bucket,
                  slot_off, cb_off)
       self.slot_offsets.append(slot_off)
@@ -123,8 +126,9 @@ class QuantPlan:
     hip.seg_nuq_apply(w_flat, qw_flat, idx_flat, codebooks, self.segs, self.ap_blocks, self.n_ap_blocks,
                       self.slots)
 
-  def codebook_grad(self, g_flat, idx_flat, dcodebooks) -> None:
-    dcodebooks.zero_()
+  def codebook_grad(self, g_flat, idx_flat, dcodebooks, zero: bool = True) -> None:
+    if zero:
+      dcodebooks.zero_()
     hip.seg_nuq_codebook_grad(g_flat, idx_flat, dcodebooks, self.segs, self.ap_blocks, self.n_ap_blocks,
                               self.slots)
 
