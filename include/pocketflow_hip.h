@@ -204,6 +204,35 @@ int pf_gemm_bf16_nn(const void* A, const void* B, void* C, int M, int N, int K, 
 int pf_gemm_bf16_tn(const void* A, const void* B, void* C, int M, int N, int K, int out_dtype,
                     void* stream);
 
+/* ---- K12 fused with K13/K4: 1x1 convolutions with BN/ReLU/fake-quant prologue and residual-add /
+ * BN-statistics epilogue (bf16 NHWC, fp32 accumulate) -------------------------------------------
+ * replaces, per bottleneck block, the chain  tf.layers.batch_normalization -> tf.nn.relu ->
+ * __uniform_quantize(activation) -> tf.nn.conv2d(1x1) [-> + shortcut] of
+ * utils/external/resnet_model.py:257-314 + learners/uniform_quantization/utils.py:51-79,92-103 and the
+ * Conv2DBackpropInput / Conv2DBackpropFilter gradients of that convolution.
+ *
+ * pf_conv1x1_fwd:  Y[m][n] = sum_k Q(X)[row(m)][k] * W[n][k]  (+ R[m][n])
+ *   X [rows_in][K], W [N][K], Y / R [M][N], all bf16.  Prologue (scale_shift != NULL):
+ *   Q(x) = fake_quant(act(scale[k]*x + shift[k])) with scale_shift = {scale[K], shift[K]} as written by
+ *   pf_bn_finalize / pf_bn_eval_scale_shift and the activation range in `slot` (NULL: no fake-quant).
+ *   Epilogue: R != NULL adds the residual; partial != NULL receives per-channel {sum, sumsq, min, max} of
+ *   the stored Y values as [G][4][N] floats, G = pf_conv1x1_stats_groups(M, N), in the layout
+ *   pf_bn_finalize consumes (pivot 0).  stride > 1: output pixel (img, ho, wo) of an [.., Ho, Wo] grid
+ *   reads input pixel (img, ho*stride, wo*stride) of an [.., H, Wd] grid; ymap != 0 maps the OUTPUT rows
+ *   instead (backward-data of a strided conv: X = dY dense, Y = dX pre-zeroed).
+ *   Backward-data of a stride-1 conv is the same call with W = the transposed kernel [K][N].
+ * pf_conv1x1_wrw:  dW[n][k] = sum_m dY[m][n] * Q(X)[row(m)][k], dW float32 or bf16 [N][K];
+ *   workspace: (pf_conv1x1_wrw_splits(M, N, K) + 32) * N * K floats (deterministic staged reduction).
+ * Requirements: K % 8 == 0, N % 8 == 0, 16-byte aligned pointers; hipErrorInvalidValue otherwise.     */
+int pf_conv1x1_stats_groups(int M, int N);
+int pf_conv1x1_fwd(const void* X, const void* W, void* Y, const void* R, const float* scale_shift,
+                   int act, const uint32_t* slot, int bits, float* partial, int M, int N, int K,
+                   int Ho, int Wo, int H, int Wd, int stride, int ymap, void* stream);
+int pf_conv1x1_wrw_splits(int M, int N, int K);
+int pf_conv1x1_wrw(const void* dY, const void* X, void* dW, int dw_dtype, float* workspace,
+                   const float* scale_shift, int act, const uint32_t* slot, int bits, int M, int N,
+                   int K, int Ho, int Wo, int H, int Wd, int stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

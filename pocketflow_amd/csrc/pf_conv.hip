@@ -1,0 +1,569 @@
+// K12 fused with K13/K4: 1x1 convolutions of the student / teacher as MFMA GEMMs over NHWC
+// activations, with the batch-norm + ReLU + activation-fake-quant of the PRODUCER layer applied while
+// the input tile is staged (prologue) and the residual add + batch-norm statistics of the CONSUMER
+// layer computed while the output tile is written (epilogue).
+//
+//   reference chain per bottleneck block (utils/external/resnet_model.py:257-314 +
+//   learners/uniform_quantization/utils.py:51-79), each arrow a separate TF kernel with a full HBM
+//   round trip:  x -> BN -> ReLU -> min/max -> quantise -> conv1x1 -> ... -> conv1x1 -> + shortcut
+//
+//   here:   Y = conv1x1( Q(x) ) [+ R],   Q(x) = fake_quant(act(scale*x + shift))  applied on the fly,
+//           partial[g] = per-channel {sum, sumsq, min, max} of the (bf16-rounded) Y tile rows
+//   so the activated / quantised tensor Q(x) is never written to HBM and the consumer BN needs no
+//   statistics pass:  2 passes over the 256-channel tensors of a block instead of 8.
+//
+// MI355X mapping: 64-lane wavefronts, v_mfma_f32_16x16x32_bf16 with the WEIGHT tile as the A operand
+// and the PIXEL tile as the B operand, so that a lane's 4 accumulator values are 4 consecutive output
+// channels of one pixel (8-byte LDS writes when the tile is staged for the coalesced 16-byte row
+// stores); persistent workgroups (<= 2 per CU) walk row tiles with the next input tile prefetched into
+// registers; tiles of one row panel are placed on one XCD (blockIdx % 8) so the panel is read from HBM
+// once and shared through that XCD's L2.
+//
+//   pf_conv1x1_fwd   : forward (student + teacher), also backward-data with the transposed weights
+//   pf_conv1x1_wrw   : backward-filter, same prologue on the input operand, split over pixels,
+//                      deterministic two-stage reduction (no float atomics)
+#include "pf_common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define CV_BM 128
+#define CV_BK 64
+#define CV_LDK (CV_BK + 8)
+
+// bf16 packing without the NaN branch of f32_to_bf16 (activations / gradients are finite; an Inf
+// stays an Inf, a NaN stays a NaN because the mantissa carry cannot clear all mantissa bits of 0x7FC0)
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
+  ua += 0x7FFFu + ((ua >> 16) & 1u);
+  ub += 0x7FFFu + ((ub >> 16) & 1u);
+  return (ua >> 16) | (ub & 0xFFFF0000u);
+}
+__device__ __forceinline__ void unpack8(const uint4& v, float* o) {
+  o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xFFFF0000u);
+  o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xFFFF0000u);
+  o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xFFFF0000u);
+  o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xFFFF0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float* o) {
+  return make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]),
+                    pack_bf16x2(o[6], o[7]));
+}
+
+// Everything the kernels need, passed by value.
+struct ConvArgs {
+  const bf16_t* X;      // [rows_in][K]   pre-BN producer output (or any NHWC tensor)
+  const bf16_t* W;      // fwd: [N][K]    wrw: dY [M][N]
+  bf16_t* Y;            // fwd: [M][N]
+  const bf16_t* R;      // residual [M][N] or null
+  const float* ss;      // prologue scale[K] | shift[K], or null
+  const uint32_t* slot; // activation min/max slot (null: no fake-quant in the prologue)
+  float* partial;       // fwd: stats [G][4][N] or null;  wrw: [S][N][K] fp32
+  float kq, act_lo, act_hi;
+  int M, N, K;          // output pixels, output channels, input channels
+  int tiles_m, tiles_n, G;
+  // strided 1x1: output pixel (n, ho, wo) reads input pixel (n, ho*stride, wo*stride); stride == 1: identity
+  int Ho, Wo, H, Wd, stride;
+  int ymap;             // fwd as backward-data of a strided conv: map the OUTPUT rows instead of the input rows
+  int rows_per_split;   // wrw
+};
+
+__device__ __forceinline__ int64_t map_row(const ConvArgs& a, int m) {
+  if (a.stride == 1) return m;
+  const int hw = a.Ho * a.Wo;
+  const int n = m / hw, rem = m - n * hw;
+  const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+  return ((int64_t)n * a.H + (int64_t)ho * a.stride) * a.Wd + (int64_t)wo * a.stride;
+}
+
+// prologue on one 16-byte vector (8 consecutive input channels of one pixel)
+struct Pro {
+  float sc[8], sh[8];
+  float lo, hi, beta, c1, c2;
+  int quant;
+};
+__device__ __forceinline__ uint4 pro_apply(const Pro& p, const uint4& v) {
+  float f[8];
+  unpack8(v, f);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float y = fminf(fmaxf(fmaf(p.sc[j], f[j], p.sh[j]), p.lo), p.hi);
+    // fake-quant with the per-tensor constants folded: rint((y - beta) * k/alpha) * alpha/k + beta.
+    // Differs from the five-rounding chain of uq_point() only on exact rounding ties (bf16 throughput
+    // mode; the float32 parity mode never takes this path).
+    if (p.quant) y = fmaf(rintf((y - p.beta) * p.c1), p.c2, p.beta);
+    f[j] = y;
+  }
+  return pack8(f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward:  Y[m][n] = sum_k Q(X)[row(m)][k] * W[n][k]  (+ R[m][n]),  optional per-channel stats
+// ---------------------------------------------------------------------------------------------
+template <int BN_T, bool PRO>
+__global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a) {
+  constexpr int WM = (BN_T == 128) ? 64 : 32;       // pixel rows per wavefront
+  constexpr int JM = WM / 16;
+  constexpr int CS_LD = BN_T + 8;
+  constexpr int VPR = BN_T / 8;                     // 16-byte vectors per output row
+  constexpr int RPP = PF_THREADS / VPR;             // rows per write pass
+  constexpr int NBV = BN_T * 8 / PF_THREADS;        // weight-tile vectors per thread
+  constexpr int A_EL = CV_BM * CV_LDK, B_EL = BN_T * CV_LDK;
+  constexpr int C_EL = CV_BM * CS_LD;
+  constexpr int RED_FL = 4 * RPP * BN_T;            // stats reduction scratch (floats)
+  constexpr int SM_BYTES_AB = (A_EL + B_EL) * 2;
+  constexpr int SM_BYTES = SM_BYTES_AB > RED_FL * 4 ? (SM_BYTES_AB > C_EL * 2 ? SM_BYTES_AB : C_EL * 2)
+                                                    : RED_FL * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SM_BYTES];
+  bf16_t* As = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* Bs = As + A_EL;
+  bf16_t* Cs = reinterpret_cast<bf16_t*>(smem);
+  float* red = reinterpret_cast<float*>(smem);
+
+  // workgroup -> (row-tile group g, column tile tn): the tiles_n column tiles of one row panel sit on
+  // one XCD with consecutive dispatch slots
+  const int xcd = blockIdx.x & 7, L = blockIdx.x >> 3;
+  const int g = xcd + 8 * (L / a.tiles_n), tn = L % a.tiles_n;
+  const int n0 = tn * BN_T;
+  const int nk = (a.K + CV_BK - 1) / CV_BK;
+  const int ntl = (g < a.tiles_m) ? (a.tiles_m - g + a.G - 1) / a.G : 0;
+  const int total = ntl * nk;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = (BN_T == 128) ? (wave >> 1) : wave, wn = (BN_T == 128) ? (wave & 1) : 0;
+  const int frow = lane & 15, fk = (lane >> 4) * 8;
+  const int lrow = tid >> 3, kp = tid & 7;          // staging: 8 lanes cover 128 contiguous bytes of a row
+
+  Pro pro;
+  pro.lo = a.act_lo; pro.hi = a.act_hi; pro.quant = 0; pro.beta = 0.f; pro.c1 = 1.f; pro.c2 = 1.f;
+  if (PRO && a.slot != nullptr) {
+    float alpha, beta;
+    slot_alpha_beta(a.slot, alpha, beta);
+    pro.quant = 1; pro.beta = beta; pro.c1 = a.kq / alpha; pro.c2 = alpha / a.kq;
+  }
+
+  f32x4 acc[4][JM];
+  uint4 ra[4], rb[NBV];
+  int64_t arow[4];                                  // input row of each staged vector (or -1)
+
+  auto gload = [&](int it) {
+    const int ti = it / nk, ks = it - ti * nk;
+    const int m0 = (g + ti * a.G) * CV_BM;
+    const int k = ks * CV_BK + kp * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + lrow + i * 32;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      arow[i] = -1;
+      if (m < a.M && k < a.K) {
+        const int64_t r = a.ymap ? (int64_t)m : map_row(a, m);
+        arow[i] = r;
+        v = *reinterpret_cast<const uint4*>(a.X + r * a.K + k);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NBV; ++i) {
+      const int n = n0 + lrow + i * 32;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (n < a.N && k < a.K) v = *reinterpret_cast<const uint4*>(a.W + (int64_t)n * a.K + k);
+      rb[i] = v;
+    }
+    if (PRO) {
+      if (k < a.K) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { pro.sc[j] = a.ss[k + j]; pro.sh[j] = a.ss[a.K + k + j]; }
+      }
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint4 v = ra[i];
+      if (PRO) v = (arow[i] >= 0) ? pro_apply(pro, v) : make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(As + (lrow + i * 32) * CV_LDK + kp * 8) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NBV; ++i)
+      *reinterpret_cast<uint4*>(Bs + (lrow + i * 32) * CV_LDK + kp * 8) = rb[i];
+  };
+
+  // running per-thread statistics of the columns this thread writes (8 channels x {sum, sumsq, min, max})
+  float st_s[8], st_q[8], st_mn[8], st_mx[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; st_mn[j] = INFINITY; st_mx[j] = -INFINITY; }
+  const int wvec = tid % VPR, wrow = tid / VPR;
+
+  if (total > 0) gload(0);
+  for (int it = 0; it < total; ++it) {
+    const int ti = it / nk, ks = it - ti * nk;
+    if (ks == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < JM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    sstore();
+    __syncthreads();
+    if (it + 1 < total) gload(it + 1);
+#pragma unroll
+    for (int kk = 0; kk < CV_BK / 32; ++kk) {
+      bf16x8 wf[4], xf[JM];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        wf[i] = *reinterpret_cast<const bf16x8*>(Bs + (wn * 64 + i * 16 + frow) * CV_LDK + kk * 32 + fk);
+#pragma unroll
+      for (int j = 0; j < JM; ++j)
+        xf[j] = *reinterpret_cast<const bf16x8*>(As + (wm * WM + j * 16 + frow) * CV_LDK + kk * 32 + fk);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < JM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (ks != nk - 1) continue;
+
+    // ---- epilogue of one [128][BN_T] tile ---------------------------------------------------------
+    // accumulators: D row = channel (lane >> 4) * 4 + r of block i, D col = pixel (lane & 15) of block j
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < JM; ++j) {
+        const uint2 v = make_uint2(pack_bf16x2(acc[i][j][0], acc[i][j][1]), pack_bf16x2(acc[i][j][2], acc[i][j][3]));
+        *reinterpret_cast<uint2*>(Cs + (wm * WM + j * 16 + frow) * CS_LD + wn * 64 + i * 16 + (lane >> 4) * 4) = v;
+      }
+    // residual vectors of this thread's 8 (or 4) output rows: all loads in flight before the LDS hand-off
+    const int m0 = (g + ti * a.G) * CV_BM;
+    uint4 rres[CV_BM / RPP];
+    if (a.R != nullptr) {
+#pragma unroll
+      for (int p = 0; p < CV_BM / RPP; ++p) {
+        const int m = m0 + wrow + p * RPP, n = n0 + wvec * 8;
+        rres[p] = make_uint4(0, 0, 0, 0);
+        if (m < a.M && n < a.N) {
+          const int64_t orow = a.ymap ? map_row(a, m) : (int64_t)m;
+          rres[p] = *reinterpret_cast<const uint4*>(a.R + orow * a.N + n);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < CV_BM / RPP; ++p) {
+      const int rl = wrow + p * RPP;
+      const int m = m0 + rl, n = n0 + wvec * 8;
+      if (m < a.M && n < a.N) {
+        uint4 c = *reinterpret_cast<const uint4*>(Cs + rl * CS_LD + wvec * 8);
+        const int64_t orow = a.ymap ? map_row(a, m) : (int64_t)m;
+        if (a.R != nullptr || a.partial != nullptr) {
+          float f[8];
+          unpack8(c, f);
+          if (a.R != nullptr) {
+            float r[8];
+            unpack8(rres[p], r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] += r[j];
+            c = pack8(f);
+            unpack8(c, f);                           // statistics see the stored (bf16) values
+          }
+          if (a.partial != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              st_s[j] += f[j];
+              st_q[j] = fmaf(f[j], f[j], st_q[j]);
+              st_mn[j] = fminf(st_mn[j], f[j]);
+              st_mx[j] = fmaxf(st_mx[j], f[j]);
+            }
+          }
+        }
+        *reinterpret_cast<uint4*>(a.Y + orow * a.N + n) = c;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- per-workgroup statistics -> partial[g][4][N] (fixed order: deterministic) ------------------
+  if (a.partial != nullptr) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[(0 * RPP + wrow) * BN_T + wvec * 8 + j] = st_s[j];
+      red[(1 * RPP + wrow) * BN_T + wvec * 8 + j] = st_q[j];
+      red[(2 * RPP + wrow) * BN_T + wvec * 8 + j] = st_mn[j];
+      red[(3 * RPP + wrow) * BN_T + wvec * 8 + j] = st_mx[j];
+    }
+    __syncthreads();
+    for (int t = tid; t < 4 * BN_T; t += PF_THREADS) {
+      const int stat = t / BN_T, c = t - stat * BN_T;
+      float v = red[(stat * RPP) * BN_T + c];
+      for (int r = 1; r < RPP; ++r) {
+        const float w = red[(stat * RPP + r) * BN_T + c];
+        v = (stat < 2) ? (v + w) : (stat == 2 ? fminf(v, w) : fmaxf(v, w));
+      }
+      if (n0 + c < a.N) a.partial[((int64_t)g * 4 + stat) * a.N + n0 + c] = v;
+    }
+  }
+}
+
+static int conv_fwd_grid(int tiles_m, int tiles_n, int* G_out) {
+  // ~2 workgroups per CU (256 CUs); G is a multiple of 8 so that a row panel's column tiles share an XCD
+  int G = 512 / tiles_n;
+  G = (G / 8) * 8;
+  if (G < 8) G = 8;
+  const int need = ((tiles_m + 7) / 8) * 8;
+  if (G > need) G = need;
+  *G_out = G;
+  return G * tiles_n;
+}
+
+extern "C" int pf_conv1x1_stats_groups(int M, int N) {
+  const int bn = (N % 128 == 0) ? 128 : 64;
+  int G;
+  conv_fwd_grid((M + CV_BM - 1) / CV_BM, (N + bn - 1) / bn, &G);
+  return G;
+}
+
+extern "C" int pf_conv1x1_fwd(const void* X, const void* W, void* Y, const void* R, const float* scale_shift,
+                              int act, const uint32_t* slot, int bits, float* partial, int M, int N, int K,
+                              int Ho, int Wo, int H, int Wd, int stride, int ymap, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || (K % 8) || (N % 8)) return (int)hipErrorInvalidValue;
+  if (!pf_aligned16(X) || !pf_aligned16(W) || !pf_aligned16(Y) || (R && !pf_aligned16(R)))
+    return (int)hipErrorInvalidValue;
+  if (slot != nullptr && (bits < 1 || bits > 32 || scale_shift == nullptr)) return (int)hipErrorInvalidValue;
+  if (stride < 1 || (stride > 1 && (Ho <= 0 || Wo <= 0 || H <= 0 || Wd <= 0))) return (int)hipErrorInvalidValue;
+  ConvArgs a;
+  a.X = (const bf16_t*)X; a.W = (const bf16_t*)W; a.Y = (bf16_t*)Y; a.R = (const bf16_t*)R;
+  a.ss = scale_shift; a.slot = slot; a.partial = partial;
+  a.kq = uq_k_of_bits(slot ? bits : 8);
+  a.act_lo = (act == PF_ACT_NONE) ? -INFINITY : 0.0f;
+  a.act_hi = (act == PF_ACT_RELU6) ? 6.0f : INFINITY;
+  a.M = M; a.N = N; a.K = K;
+  a.Ho = Ho; a.Wo = Wo; a.H = H; a.Wd = Wd; a.stride = stride; a.ymap = ymap; a.rows_per_split = 0;
+  const int bn = (N % 128 == 0) ? 128 : 64;
+  a.tiles_m = (M + CV_BM - 1) / CV_BM;
+  a.tiles_n = (N + bn - 1) / bn;
+  const int grid = conv_fwd_grid(a.tiles_m, a.tiles_n, &a.G);
+  hipStream_t st = (hipStream_t)stream;
+  const bool pro = scale_shift != nullptr;
+  if (bn == 128) {
+    if (pro) k_conv1x1_fwd<128, true><<<grid, PF_THREADS, 0, st>>>(a);
+    else k_conv1x1_fwd<128, false><<<grid, PF_THREADS, 0, st>>>(a);
+  } else {
+    if (pro) k_conv1x1_fwd<64, true><<<grid, PF_THREADS, 0, st>>>(a);
+    else k_conv1x1_fwd<64, false><<<grid, PF_THREADS, 0, st>>>(a);
+  }
+  PF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward-filter:  dW[n][k] = sum_m dY[m][n] * Q(X)[row(m)][k]
+// Output tile 128 (n) x 64 (k) per workgroup and pixel split; both operands are contracted over the
+// pixel index, which is the SLOW index of both NHWC tensors, so the tiles are transposed while they
+// are staged: LDS image [channel][pixel] with the 16-byte pixel groups XOR-swizzled by the channel
+// group (2-way instead of 16-way bank conflicts on the scattered 2-byte writes; fragment reads stay
+// single aligned 16-byte reads).
+// ---------------------------------------------------------------------------------------------
+#define WR_TN 128
+#define WR_TK 64
+#define WR_BM 64
+#define WR_LDM (WR_BM + 8)
+
+__device__ __forceinline__ void st_transposed(bf16_t* S, int c0, int m, const uint4& v) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  const int mg = m >> 3, ml = m & 7;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = c0 + j;
+    S[c * WR_LDM + (((mg ^ ((c >> 3) & 7)) << 3) | ml)] = (bf16_t)((w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu);
+  }
+}
+
+template <bool PRO>
+__global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_wrw(const ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_t Ds[WR_TN * WR_LDM];   // dY tile, [n][m]
+  __shared__ __attribute__((aligned(16))) bf16_t Qs[WR_TK * WR_LDM];   // Q tile,  [k][m]
+  const int tn = blockIdx.x % a.tiles_n, tk = blockIdx.x / a.tiles_n;
+  const int n0 = tn * WR_TN, k0 = tk * WR_TK;
+  const int mbeg = blockIdx.y * a.rows_per_split;
+  const int mend = (mbeg + a.rows_per_split < a.M) ? (mbeg + a.rows_per_split) : a.M;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int frow = lane & 15, fm = lane >> 4;               // fragment: channel row, 8-pixel group
+
+  Pro pro;
+  pro.lo = a.act_lo; pro.hi = a.act_hi; pro.quant = 0; pro.beta = 0.f; pro.c1 = 1.f; pro.c2 = 1.f;
+  if (PRO && a.slot != nullptr) {
+    float alpha, beta;
+    slot_alpha_beta(a.slot, alpha, beta);
+    pro.quant = 1; pro.beta = beta; pro.c1 = a.kq / alpha; pro.c2 = alpha / a.kq;
+  }
+  // staging maps: dY tile 64 x 128 = 1024 vectors (4 / thread): pixel = p >> 4, channel group = p & 15
+  //               X  tile 64 x 64  =  512 vectors (2 / thread): pixel = p >> 3, channel group = p & 7
+  const int qkp = tid & 7;
+  if (PRO) {
+    const int k = k0 + qkp * 8;
+    if (k < a.K) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { pro.sc[j] = a.ss[k + j]; pro.sh[j] = a.ss[a.K + k + j]; }
+    }
+  }
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  uint4 rd[4], rq[2];
+  bool vq[2];
+  auto gload = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = tid + i * PF_THREADS;
+      const int m = mb + (p >> 4), n = n0 + (p & 15) * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (m < mend && n < a.N) v = *reinterpret_cast<const uint4*>(a.W + (int64_t)m * a.N + n);
+      rd[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int p = tid + i * PF_THREADS;
+      const int m = mb + (p >> 3), k = k0 + (p & 7) * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      vq[i] = (m < mend && k < a.K);
+      if (vq[i]) v = *reinterpret_cast<const uint4*>(a.X + map_row(a, m) * a.K + k);
+      rq[i] = v;
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = tid + i * PF_THREADS;
+      st_transposed(Ds, (p & 15) * 8, p >> 4, rd[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int p = tid + i * PF_THREADS;
+      uint4 v = rq[i];
+      if (PRO) v = vq[i] ? pro_apply(pro, v) : make_uint4(0, 0, 0, 0);
+      st_transposed(Qs, (p & 7) * 8, p >> 3, v);
+    }
+  };
+
+  if (mbeg < mend) gload(mbeg);
+  for (int mb = mbeg; mb < mend; mb += WR_BM) {
+    sstore();
+    __syncthreads();
+    if (mb + WR_BM < mend) gload(mb + WR_BM);
+#pragma unroll
+    for (int kk = 0; kk < WR_BM / 32; ++kk) {
+      bf16x8 df[2], qf[4];
+      const int mg = kk * 4 + fm;                           // 8-pixel group of this lane's fragment
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = wave * 32 + i * 16 + frow;
+        df[i] = *reinterpret_cast<const bf16x8*>(Ds + c * WR_LDM + ((mg ^ ((c >> 3) & 7)) << 3));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = j * 16 + frow;
+        qf[j] = *reinterpret_cast<const bf16x8*>(Qs + c * WR_LDM + ((mg ^ ((c >> 3) & 7)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[i], qf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D row = n (lane >> 4) * 4 + r of block i, D col = k (lane & 15) of block j
+  float* out = a.partial + (int64_t)blockIdx.y * a.N * a.K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + j * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wave * 32 + i * 16 + (lane >> 4) * 4 + r;
+        if (n < a.N && k < a.K) out[(int64_t)n * a.K + k] = acc[i][j][r];
+      }
+    }
+}
+
+// dW = sum over splits, written as float32 or bf16.  One workgroup owns 64 consecutive outputs and one
+// of gridDim.y split ranges; its 4 wavefronts take interleaved splits (256-byte coalesced rows) and are
+// combined through LDS in a fixed order; a second launch folds the gridDim.y range sums.  Deterministic.
+template <typename TO>
+__global__ __launch_bounds__(PF_THREADS) void k_wrw_reduce(const float* __restrict__ partial, int splits,
+                                                           int64_t n, TO* __restrict__ out, int64_t out_stride) {
+  __shared__ float l[4][64];
+  const int e_l = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + e_l;
+  const int per = (splits + gridDim.y - 1) / gridDim.y;
+  const int s0 = blockIdx.y * per, s1 = (s0 + per < splits) ? (s0 + per) : splits;
+  float acc = 0.f;
+  if (e < n)
+    for (int s = s0 + sg; s < s1; s += 4) acc += partial[(int64_t)s * n + e];
+  l[sg][e_l] = acc;
+  __syncthreads();
+  if (sg == 0 && e < n) store_one<TO>(out + (int64_t)blockIdx.y * out_stride + e, (l[0][e_l] + l[1][e_l]) + (l[2][e_l] + l[3][e_l]));
+}
+
+// number of pixel splits; the workspace must hold (splits + 32) * N * K floats
+extern "C" int pf_conv1x1_wrw_splits(int M, int N, int K) {
+  const int tiles = ((N + WR_TN - 1) / WR_TN) * ((K + WR_TK - 1) / WR_TK);
+  int S = (768 + tiles - 1) / tiles;
+  const int maxS = (M + 4 * WR_BM - 1) / (4 * WR_BM);       // at least 4 pixel steps per workgroup
+  if (S > maxS) S = maxS;
+  if (S < 1) S = 1;
+  int rows = (M + S - 1) / S;
+  rows = ((rows + WR_BM - 1) / WR_BM) * WR_BM;
+  return (M + rows - 1) / rows;
+}
+
+extern "C" int pf_conv1x1_wrw(const void* dY, const void* X, void* dW, int dw_dtype, float* workspace,
+                              const float* scale_shift, int act, const uint32_t* slot, int bits, int M, int N,
+                              int K, int Ho, int Wo, int H, int Wd, int stride, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || (K % 8) || (N % 8) || ((int64_t)N * K) % 4) return (int)hipErrorInvalidValue;
+  if (!pf_aligned16(dY) || !pf_aligned16(X) || !pf_aligned16(workspace) || !pf_aligned16(dW))
+    return (int)hipErrorInvalidValue;
+  if (slot != nullptr && (bits < 1 || bits > 32 || scale_shift == nullptr)) return (int)hipErrorInvalidValue;
+  ConvArgs a;
+  a.X = (const bf16_t*)X; a.W = (const bf16_t*)dY; a.Y = nullptr; a.R = nullptr;
+  a.ss = scale_shift; a.slot = slot; a.partial = workspace;
+  a.kq = uq_k_of_bits(slot ? bits : 8);
+  a.act_lo = (act == PF_ACT_NONE) ? -INFINITY : 0.0f;
+  a.act_hi = (act == PF_ACT_RELU6) ? 6.0f : INFINITY;
+  a.M = M; a.N = N; a.K = K;
+  a.Ho = Ho; a.Wo = Wo; a.H = H; a.Wd = Wd; a.stride = stride < 1 ? 1 : stride; a.ymap = 0;
+  a.tiles_m = 0; a.G = 0;
+  a.tiles_n = (N + WR_TN - 1) / WR_TN;
+  const int tiles_k = (K + WR_TK - 1) / WR_TK;
+  const int S = pf_conv1x1_wrw_splits(M, N, K);
+  int rows = (M + S - 1) / S;
+  rows = ((rows + WR_BM - 1) / WR_BM) * WR_BM;
+  a.rows_per_split = rows;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(a.tiles_n * tiles_k, S);
+  if (scale_shift != nullptr) k_conv1x1_wrw<true><<<grid, PF_THREADS, 0, st>>>(a);
+  else k_conv1x1_wrw<false><<<grid, PF_THREADS, 0, st>>>(a);
+  PF_LAUNCH_CHECK();
+  const int64_t n = (int64_t)N * K;
+  const int gx = (int)((n + 63) / 64);
+  int ry = 1;                                           // split ranges of the first reduction stage
+  while (ry < 32 && gx * ry < 1024 && ry * 8 <= S) ry *= 2;
+  float* stage = workspace + (int64_t)S * n;            // [ry][n] floats behind the split slabs
+  if (ry > 1) {
+    k_wrw_reduce<float><<<dim3(gx, ry), PF_THREADS, 0, st>>>(workspace, S, n, stage, n);
+    if (dw_dtype == PF_F32) k_wrw_reduce<float><<<dim3(gx, 1), PF_THREADS, 0, st>>>(stage, ry, n, (float*)dW, 0);
+    else if (dw_dtype == PF_BF16) k_wrw_reduce<bf16_t><<<dim3(gx, 1), PF_THREADS, 0, st>>>(stage, ry, n, (bf16_t*)dW, 0);
+    else return (int)hipErrorInvalidValue;
+  } else {
+    if (dw_dtype == PF_F32) k_wrw_reduce<float><<<dim3(gx, 1), PF_THREADS, 0, st>>>(workspace, S, n, (float*)dW, 0);
+    else if (dw_dtype == PF_BF16) k_wrw_reduce<bf16_t><<<dim3(gx, 1), PF_THREADS, 0, st>>>(workspace, S, n, (bf16_t*)dW, 0);
+    else return (int)hipErrorInvalidValue;
+  }
+  PF_LAUNCH_CHECK();
+  return 0;
+}

@@ -312,6 +312,11 @@ class Graph:
     self.frozen = False                        # teacher: BN scale/shift cached
     self.act_slots: Optional[torch.Tensor] = None
     self._scratch: Optional[torch.Tensor] = None
+    self._zero_row: Optional[torch.Tensor] = None
+    self.fuse_conv1x1 = True                   # bf16 mode: defer BN/act/quant into 1x1 convolutions (pf_conv.hip)
+    # channel pruning (host side): when `taps` is a dict, Conv2D / DepthwiseConv2D layers record
+    # {layer: (input, output, producer-of-input)}; BN / activation / pooling layers pass the producer tag on
+    self.taps: Optional[Dict[object, tuple]] = None
     self._names: Dict[str, int] = {}
 
   # -- naming like tf.layers (conv2d, conv2d_1, ...) ---------------------------------------------
@@ -361,6 +366,12 @@ class Graph:
   def act_alpha_beta(self) -> torch.Tensor:
     return hip.minmax_decode(self.act_slots)
 
+  def zero_row(self, C: int) -> torch.Tensor:
+    """A float32 zero vector: the pivot row of BN statistics that were accumulated un-shifted."""
+    if self._zero_row is None or self._zero_row.numel() < C:
+      self._zero_row = torch.zeros(max(C, 4096), dtype=torch.float32, device=self.device)
+    return self._zero_row
+
 
 # =================================================================================================
 # autograd functions over the HIP kernels
@@ -397,46 +408,31 @@ class _BnActQuant(torch.autograd.Function):
   """BN (batch stats) -> act -> activation fake-quant, fused (pf_bn_* kernels)."""
 
   @staticmethod
-  def forward(ctx, x, gamma, beta, layer, graph, training, slot, bits):
+  def forward(ctx, x, gamma, beta, layer, graph, training, slot, bits, stats=None):
     x = _nhwc(x)
     C = gamma.numel()
     rows = x.numel() // C
-    nblk = _bn_blocks(rows, C)
-    partial = graph.scratch(nblk * 4 * C)
     scale_shift = torch.empty((2, C), dtype=torch.float32, device=x.device)
     mean_invstd = torch.empty((2, C), dtype=torch.float32, device=x.device)
     quantize = bits is not None
     nbytes = float(x.numel() * x.element_size())
-    with region('bn_stats', nbytes):                 # algorithmic bytes: 1 read of x
-      hip.bn_stats(x, rows, C, partial, nblk)
-    hip.bn_finalize(partial, nblk, rows, C, x, gamma, beta, layer.moving_mean.tensor, layer.moving_var.tensor,
+    partial, nblk, piv = _bn_statistics(x, rows, C, graph, stats)
+    hip.bn_finalize(partial, nblk, rows, C, piv, gamma, beta, layer.moving_mean.tensor, layer.moving_var.tensor,
                     layer.momentum, layer.eps, training, layer.act, scale_shift, mean_invstd,
                     slot if quantize else None)
     q = torch.empty_like(x)
     with region('bn_act_quant_apply', 2 * nbytes):   # 1 read of x + 1 write of q
       hip.bn_act_quant_apply(x, q, rows, C, scale_shift, layer.act, slot, bits if quantize else 8, quantize)
     ctx.save_for_backward(x, scale_shift, mean_invstd)
-    ctx.meta = (layer.act, graph, rows, C, nblk)
+    ctx.meta = (layer.act, graph, rows, C)
     return q
 
   @staticmethod
   def backward(ctx, dq):
     x, scale_shift, mean_invstd = ctx.saved_tensors
-    act, graph, rows, C, nblk = ctx.meta
-    dq = _nhwc(dq)
-    if dq.dtype != x.dtype:
-      dq = dq.to(x.dtype)
-    partial = graph.scratch(nblk * 2 * C)
-    nbytes = float(x.numel() * x.element_size())
-    with region('bn_bwd_stats', 2 * nbytes):         # reads dq and x
-      hip.bn_bwd_stats(dq, x, rows, C, scale_shift, mean_invstd, act, partial, nblk)
-    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
-    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
-    hip.bn_bwd_finalize(partial, nblk, C, dgamma, dbeta)
-    dx = torch.empty_like(x)
-    with region('bn_bwd_apply', 3 * nbytes):         # reads dq and x, writes dx
-      hip.bn_bwd_apply(dq, x, dx, rows, C, scale_shift, mean_invstd, dgamma, dbeta, act)
-    return dx, dgamma, dbeta, None, None, None, None, None
+    act, graph, rows, C = ctx.meta
+    dx, dgamma, dbeta = _bn_backward(dq, x, scale_shift, mean_invstd, act, graph, rows, C)
+    return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
 class _ActQuant(torch.autograd.Function):
@@ -461,6 +457,195 @@ class _ActQuant(torch.autograd.Function):
     dx = torch.empty_like(u)
     hip.act_grad(g, u, dx, ctx.act)
     return dx, None, None, None
+
+
+# =================================================================================================
+# BN -> act -> fake-quant deferred into the consuming 1x1 convolution (pf_conv.hip)
+# =================================================================================================
+
+class LazyAct(object):
+  """The output of a BatchNormAct that has NOT been written to HBM.
+
+  `x` is the raw (pre-BN) tensor; a consumer computes q = fake_quant(act(scale * x + shift)) itself:
+  the fused 1x1 convolutions do it while staging their input tile (prologue of pf_conv1x1_fwd /
+  pf_conv1x1_wrw), anything else calls `materialize()` (one pf_bn_act_quant_apply launch, cached).
+  Gradients with respect to q flow into `x`'s autograd node (_BnLazy), which runs the BN backward once.
+  """
+
+  def __init__(self, x, scale_shift, act, slot, bits, rows, C):
+    self.x, self.scale_shift, self.act, self.slot, self.bits = x, scale_shift, act, slot, bits
+    self.rows, self.C = rows, C
+    self._q = None
+
+  @property
+  def shape(self):
+    return self.x.shape
+
+  @property
+  def dtype(self):
+    return self.x.dtype
+
+  @property
+  def device(self):
+    return self.x.device
+
+  def materialize(self) -> torch.Tensor:
+    if self._q is None:
+      self._q = _Materialize.apply(self.x, self)
+    return self._q
+
+
+def materialize(x):
+  return x.materialize() if isinstance(x, LazyAct) else x
+
+
+class _Materialize(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x, lazy):
+    q = torch.empty_like(x)
+    quant = lazy.bits is not None
+    hip.bn_act_quant_apply(x, q, lazy.rows, lazy.C, lazy.scale_shift, lazy.act, lazy.slot if quant else None,
+                           lazy.bits if quant else 8, quant)
+    return q
+
+  @staticmethod
+  def backward(ctx, dq):
+    return dq, None
+
+
+def _bn_statistics(x, rows, C, graph, st=None):
+  """(partial, n_blocks, pivot_row): from the producing convolution's epilogue when it left them
+  (`st` = the tensor's `_pf_stats`), otherwise one pf_bn_stats pass over x."""
+  if st is not None:
+    partial, nblk = st
+    return partial, nblk, graph.zero_row(C)
+  nblk = _bn_blocks(rows, C)
+  partial = graph.scratch(nblk * 4 * C)
+  with region('bn_stats', float(x.numel() * x.element_size())):
+    hip.bn_stats(x, rows, C, partial, nblk)
+  return partial, nblk, x
+
+
+class _BnLazy(torch.autograd.Function):
+  """BN statistics + finalize only; returns an alias of x that stands for q (see LazyAct)."""
+
+  @staticmethod
+  def forward(ctx, x, gamma, beta, layer, graph, slot, bits, box, stats):
+    C = gamma.numel()
+    rows = x.numel() // C
+    partial, nblk, piv = _bn_statistics(x, rows, C, graph, stats)
+    scale_shift = torch.empty((2, C), dtype=torch.float32, device=x.device)
+    mean_invstd = torch.empty((2, C), dtype=torch.float32, device=x.device)
+    hip.bn_finalize(partial, nblk, rows, C, piv, gamma, beta, layer.moving_mean.tensor, layer.moving_var.tensor,
+                    layer.momentum, layer.eps, True, layer.act, scale_shift, mean_invstd,
+                    slot if bits is not None else None)
+    ctx.save_for_backward(x, scale_shift, mean_invstd)
+    ctx.meta = (layer.act, graph, rows, C)
+    box.append(scale_shift)
+    return x.view_as(x)
+
+  @staticmethod
+  def backward(ctx, dq):
+    x, scale_shift, mean_invstd = ctx.saved_tensors
+    act, graph, rows, C = ctx.meta
+    dx, dgamma, dbeta = _bn_backward(dq, x, scale_shift, mean_invstd, act, graph, rows, C)
+    return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def _bn_backward(dq, x, scale_shift, mean_invstd, act, graph, rows, C):
+  dq = _nhwc(dq)
+  if dq.dtype != x.dtype:
+    dq = dq.to(x.dtype)
+  nblk = _bn_blocks(rows, C)
+  partial = graph.scratch(nblk * 2 * C)
+  nbytes = float(x.numel() * x.element_size())
+  with region('bn_bwd_stats', 2 * nbytes):         # reads dq and x
+    hip.bn_bwd_stats(dq, x, rows, C, scale_shift, mean_invstd, act, partial, nblk)
+  dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+  dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+  hip.bn_bwd_finalize(partial, nblk, C, dgamma, dbeta)
+  dx = torch.empty_like(x)
+  with region('bn_bwd_apply', 3 * nbytes):         # reads dq and x, writes dx
+    hip.bn_bwd_apply(dq, x, dx, rows, C, scale_shift, mean_invstd, dgamma, dbeta, act)
+  return dx, dgamma, dbeta
+
+
+def _conv1x1_geom(x_shape, stride):
+  """(M, geom) of a 1x1 convolution over a logical-NCHW / physical-NHWC input."""
+  n, _, h, w = x_shape
+  if stride == 1:
+    return n * h * w, None, (h, w)
+  ho, wo = -(-h // stride), -(-w // stride)
+  return n * ho * wo, (ho, wo, h, w, stride), (ho, wo)
+
+
+def _run_conv1x1(x, w2d, lazy, residual, want_stats, stride):
+  N, K = w2d.shape
+  M, geom, (ho, wo) = _conv1x1_geom(x.shape, stride)
+  y = torch.empty((x.shape[0], N, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+  partial, G = None, 0
+  if want_stats:
+    G = hip.conv1x1_stats_groups(M, N)
+    partial = torch.empty((G, 4, N), dtype=torch.float32, device=x.device)
+  ss = lazy.scale_shift if lazy is not None else None
+  quant = lazy is not None and lazy.bits is not None
+  nbytes = float((M * K + M * N * (2 if residual is not None else 1)) * 2)
+  with region('conv1x1_fwd', nbytes):
+    hip.conv1x1_fwd(x, w2d, y, M, N, K, R=residual, scale_shift=ss, act=lazy.act if lazy is not None else None,
+                    slot=lazy.slot if quant else None, bits=lazy.bits if quant else 8, partial=partial, geom=geom)
+  if want_stats:
+    y._pf_stats = (partial, G)
+  return y
+
+
+class _FusedConv1x1(torch.autograd.Function):
+  """y = conv1x1(Q(x), W) [+ residual], Q = the producer BN's normalise/act/fake-quant (prologue)."""
+
+  @staticmethod
+  def forward(ctx, x, w, residual, lazy, want_stats, stride, graph, box):
+    w2d = w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], w.shape[1])      # [N][K] (KRSC, R=S=1)
+    res = _nhwc(residual) if residual is not None else None
+    y = _run_conv1x1(x, w2d, lazy, res, want_stats, stride)
+    ctx.save_for_backward(x, w2d)
+    ctx.meta = (lazy, stride, graph, residual is not None, w.shape)
+    box.append(getattr(y, '_pf_stats', None))
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    x, w2d = ctx.saved_tensors
+    lazy, stride, graph, has_res, w_shape = ctx.meta
+    dy = _nhwc(dy)
+    N, K = w2d.shape
+    M, geom, _ = _conv1x1_geom(x.shape, stride)
+    ss = lazy.scale_shift if lazy is not None else None
+    quant = lazy is not None and lazy.bits is not None
+    act = lazy.act if lazy is not None else None
+    dx = dw = None
+    if ctx.needs_input_grad[1]:
+      S = hip.conv1x1_wrw_splits(M, N, K)
+      ws = graph.scratch((S + 32) * N * K)
+      dw2d = torch.empty((N, K), dtype=w2d.dtype, device=x.device)
+      with region('conv1x1_wrw', float((M * K + M * N) * 2)):
+        hip.conv1x1_wrw(dy, x, dw2d, ws, M, N, K, scale_shift=ss, act=act, slot=lazy.slot if quant else None,
+                        bits=lazy.bits if quant else 8, geom=geom)
+      dw = dw2d.view(N, 1, 1, K).permute(0, 3, 1, 2)                            # logical OIHW over KRSC memory
+    if ctx.needs_input_grad[0]:
+      wt = w2d.t().contiguous()                                                # [K][N]
+      if geom is None:
+        dx = torch.empty_like(x)
+      else:
+        dx = torch.zeros_like(x)
+      with region('conv1x1_bwd_data', float((M * K + M * N) * 2)):
+        hip.conv1x1_fwd(dy, wt, dx, M, K, N, geom=geom, ymap=geom is not None)
+    return dx, dw, (dy if has_res else None), None, None, None, None, None
+
+
+def fused_conv1x1_ok(x, conv) -> bool:
+  t = x.x if isinstance(x, LazyAct) else x
+  return (conv.k == 1 and conv.bias is None and t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 4
+          and conv.kernel.ref_shape[2] % 8 == 0 and conv.kernel.ref_shape[3] % 8 == 0
+          and conv.padding in ('SAME', 'VALID', 0) and conv.graph.fuse_conv1x1)
 
 
 # =================================================================================================
@@ -515,8 +700,25 @@ class Conv2D:
                  if use_bias else None)
     self.op = graph.add_matmul_op('Conv2D', name + '/Conv2D', self.kernel)
 
-  def __call__(self, x: torch.Tensor) -> torch.Tensor:
+  def __call__(self, x, residual: Optional[torch.Tensor] = None, want_stats: bool = False) -> torch.Tensor:
+    """`residual`: tensor added to the output (the block's shortcut); `want_stats`: the consumer is a
+    BatchNormAct -- leave per-channel statistics of the output on the tensor (1x1 fused path only)."""
     w = self.kernel.tensor
+    if self.graph.taps is not None:
+      return _tapped(self, materialize(x), residual)
+    if fused_conv1x1_ok(x, self):
+      lazy = x if isinstance(x, LazyAct) else None
+      xin = lazy.x if lazy is not None else _nhwc(x)
+      if torch.is_grad_enabled() and (xin.requires_grad or w.requires_grad):
+        box = []
+        y = _FusedConv1x1.apply(xin, w, residual, lazy, want_stats, self.stride, self.graph, box)
+        if box and box[0] is not None:
+          y._pf_stats = box[0]
+        return y
+      w2d = w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], w.shape[1])
+      return _run_conv1x1(xin, w2d, lazy, _nhwc(residual) if residual is not None else None, want_stats,
+                          self.stride)
+    x = materialize(x)
     b = self.bias.tensor.to(x.dtype) if self.bias is not None else None
     pad = 0
     if isinstance(self.padding, int):
@@ -528,7 +730,32 @@ class Conv2D:
         pad = (ph[0], pw[0])
       else:
         x = F.pad(x, (pw[0], pw[1], ph[0], ph[1]))
-    return F.conv2d(x, w, b, stride=self.stride, padding=pad)
+    y = F.conv2d(x, w, b, stride=self.stride, padding=pad)
+    return y if residual is None else y + residual
+
+  def plain(self, x: torch.Tensor) -> torch.Tensor:
+    """The convolution alone on a materialised tensor (tracing / channel pruning)."""
+    taps, self.graph.taps = self.graph.taps, None
+    fuse, self.graph.fuse_conv1x1 = self.graph.fuse_conv1x1, False
+    try:
+      return self(x)
+    finally:
+      self.graph.taps, self.graph.fuse_conv1x1 = taps, fuse
+
+
+def _tapped(layer, x, residual=None):
+  g = layer.graph
+  y = layer.plain(x)
+  g.taps[layer] = (x, y, getattr(x, '_pf_src', None))
+  y._pf_src = layer
+  return y if residual is None else y + residual     # a residual sum has no single producer: tag dropped
+
+
+def _pass_tag(x, y):
+  src = getattr(x, '_pf_src', None)
+  if src is not None:
+    y._pf_src = src
+  return y
 
 
 class DepthwiseConv2D:
@@ -542,7 +769,17 @@ class DepthwiseConv2D:
     self.kernel = graph.store.add(name + '/' + kernel_name, ref_shape, 'depthwise', True, l2, init)
     self.op = graph.add_matmul_op('DepthwiseConv2dNative', name + '/depthwise', self.kernel)
 
-  def __call__(self, x: torch.Tensor) -> torch.Tensor:
+  def plain(self, x):
+    taps, self.graph.taps = self.graph.taps, None
+    try:
+      return self(x)
+    finally:
+      self.graph.taps = taps
+
+  def __call__(self, x) -> torch.Tensor:
+    x = materialize(x)
+    if self.graph.taps is not None:
+      return _tapped(self, x)
     ph = _same_pads(x.shape[2], self.k, self.stride)
     pw = _same_pads(x.shape[3], self.k, self.stride)
     pad = 0
@@ -563,8 +800,8 @@ class Dense:
     self.bias = graph.store.add(name + '/bias', (cout,), 'bias', True, l2, constant_init((cout,), 0.0))
     self.op = graph.add_matmul_op('MatMul', name + '/MatMul', self.kernel)
 
-  def __call__(self, x: torch.Tensor) -> torch.Tensor:
-    return F.linear(x, self.kernel.tensor, self.bias.tensor.to(x.dtype))
+  def __call__(self, x) -> torch.Tensor:
+    return F.linear(materialize(x), self.kernel.tensor, self.bias.tensor.to(x.dtype))
 
 
 class Activation:
@@ -577,7 +814,8 @@ class Activation:
   def __call__(self, x: torch.Tensor) -> torch.Tensor:
     g = self.graph
     if self.op.bits is None:
-      return F.relu(x) if self.act == 'Relu' else F.relu6(x)
+      y = F.relu(x) if self.act == 'Relu' else F.relu6(x)
+      return _pass_tag(x, y) if g.taps is not None else y
     return _ActQuant.apply(x, self.act, g.act_slots[self.op.index], self.op.bits)
 
 
@@ -590,8 +828,9 @@ class BatchNormAct:
 
   def __init__(self, graph: Graph, name: str, channels: int, act: Optional[str], momentum: float, eps: float,
                l2: bool = False, act_name: Optional[str] = None, names=('gamma', 'beta', 'moving_mean',
-                                                                       'moving_variance')):
+                                                                       'moving_variance'), lazy_ok: bool = False):
     self.graph, self.act, self.momentum, self.eps, self.C = graph, act, momentum, eps, channels
+    self.lazy_ok = lazy_ok                    # every consumer is a Conv2D: the output may stay un-materialised
     st = graph.store
     self.gamma = st.add(name + '/' + names[0], (channels,), 'bn_gamma', True, l2, constant_init((channels,), 1.0))
     self.beta = st.add(name + '/' + names[1], (channels,), 'bn_beta', True, l2, constant_init((channels,), 0.0))
@@ -606,23 +845,23 @@ class BatchNormAct:
     g = self.graph
     bits = self.op.bits if self.op is not None else None
     slot = g.act_slots[self.op.index] if (self.op is not None and bits is not None) else None
+    lazy = self.lazy_ok and g.fuse_conv1x1 and x.dtype == torch.bfloat16 and x.is_cuda
     if g.training and torch.is_grad_enabled():
-      return _BnActQuant.apply(x, self.gamma.tensor, self.beta.tensor, self, g, True, slot, bits)
+      stats = getattr(x, '_pf_stats', None)      # left by the fused convolution that produced x
+      if lazy:
+        box = []
+        alias = _BnLazy.apply(_nhwc(x), self.gamma.tensor, self.beta.tensor, self, g, slot, bits, box, stats)
+        return LazyAct(alias, box[0], self.act, slot, bits, x.numel() // self.C, self.C)
+      return _BnActQuant.apply(x, self.gamma.tensor, self.beta.tensor, self, g, True, slot, bits, stats)
     x = _nhwc(x)
     C = self.C
     rows = x.numel() // C
+    if bits is None and lazy:
+      return LazyAct(x, self._eval_scale_shift(x), self.act, None, None, rows, C)
     q = torch.empty_like(x)
     if bits is None:
       # inference BN + act only: y = act(scale*x + shift); the teacher's (frozen) scale/shift is cached
-      if g.frozen and self._frozen_ss is not None:
-        ss = self._frozen_ss
-      else:
-        ss = torch.empty((2, C), dtype=torch.float32, device=x.device)
-        hip.bn_eval_scale_shift(self.gamma.tensor, self.beta.tensor, self.moving_mean.tensor,
-                                self.moving_var.tensor, self.eps, ss)
-        if g.frozen:
-          self._frozen_ss = ss
-      hip.bn_act_quant_apply(x, q, rows, C, ss, self.act, None, 8, False)
+      hip.bn_act_quant_apply(x, q, rows, C, self._eval_scale_shift(x), self.act, None, 8, False)
       return q
     # eval graph of a quantising learner: moving statistics + freshly calibrated activation range
     with torch.no_grad():
@@ -635,6 +874,31 @@ class BatchNormAct:
                       self.moving_var.tensor, self.momentum, self.eps, g.training, self.act, ss, mi, slot)
       hip.bn_act_quant_apply(x, q, rows, C, ss, self.act, slot, bits, True)
     return q
+
+
+def _bn_eval_scale_shift(self, x):
+  """Inference BN folded to scale/shift; the teacher's (frozen) pair is cached."""
+  g = self.graph
+  if g.frozen and self._frozen_ss is not None:
+    return self._frozen_ss
+  ss = torch.empty((2, self.C), dtype=torch.float32, device=x.device)
+  hip.bn_eval_scale_shift(self.gamma.tensor, self.beta.tensor, self.moving_mean.tensor, self.moving_var.tensor,
+                          self.eps, ss)
+  if g.frozen:
+    self._frozen_ss = ss
+  return ss
+
+
+BatchNormAct._eval_scale_shift = _bn_eval_scale_shift
+_bn_call = BatchNormAct.__call__
+
+
+def _bn_call_tagged(self, x):
+  y = _bn_call(self, x)
+  return _pass_tag(x, y) if (self.graph.taps is not None and isinstance(y, torch.Tensor)) else y
+
+
+BatchNormAct.__call__ = _bn_call_tagged
 
 
 def max_pool_same(x: torch.Tensor, k: int, stride: int) -> torch.Tensor:

@@ -41,6 +41,7 @@ SYMBOLS = [
     'pf_momentum_flat', 'pf_ce_distill_fwd_bwd', 'pf_bn_stats', 'pf_bn_finalize',
     'pf_bn_act_quant_apply', 'pf_bn_bwd_stats', 'pf_bn_bwd_finalize', 'pf_bn_bwd_apply',
     'pf_bn_eval_scale_shift', 'pf_gemm_bf16_nt', 'pf_gemm_bf16_nn', 'pf_gemm_bf16_tn',
+    'pf_conv1x1_stats_groups', 'pf_conv1x1_fwd', 'pf_conv1x1_wrw_splits', 'pf_conv1x1_wrw',
 ]
 
 
@@ -295,3 +296,35 @@ def gemm_bf16_nn(A, B, C, M: int, N: int, K: int) -> None:
 def gemm_bf16_tn(A, B, C, M: int, N: int, K: int) -> None:
   _check(_lib.pf_gemm_bf16_tn(_ptr(A), _ptr(B), _ptr(C), c_int(M), c_int(N), c_int(K), c_int(dtype_code(C)),
                               _stream()), 'pf_gemm_bf16_tn')
+
+
+# ------------------------------------------------------------------------------------------------
+# fused 1x1 convolutions
+# ------------------------------------------------------------------------------------------------
+
+def conv1x1_stats_groups(M: int, N: int) -> int:
+  return int(_lib.pf_conv1x1_stats_groups(c_int(M), c_int(N)))
+
+
+def conv1x1_wrw_splits(M: int, N: int, K: int) -> int:
+  return int(_lib.pf_conv1x1_wrw_splits(c_int(M), c_int(N), c_int(K)))
+
+
+def conv1x1_fwd(X, W, Y, M: int, N: int, K: int, R=None, scale_shift=None, act=None, slot=None, bits: int = 8,
+                partial=None, geom=None, ymap: bool = False) -> None:
+  """geom = (Ho, Wo, H, Wd, stride) for a strided 1x1 convolution, None for stride 1."""
+  _dev(X)
+  Ho, Wo, H, Wd, stride = geom if geom is not None else (0, 0, 0, 0, 1)
+  _check(_lib.pf_conv1x1_fwd(_ptr(X), _ptr(W), _ptr(Y), _ptr(R), _ptr(scale_shift), c_int(ACT_CODES[act]),
+                             _ptr(slot), c_int(int(bits)), _ptr(partial), c_int(M), c_int(N), c_int(K), c_int(Ho),
+                             c_int(Wo), c_int(H), c_int(Wd), c_int(stride), c_int(1 if ymap else 0), _stream()),
+         'pf_conv1x1_fwd')
+
+
+def conv1x1_wrw(dY, X, dW, workspace, M: int, N: int, K: int, scale_shift=None, act=None, slot=None,
+                bits: int = 8, geom=None) -> None:
+  _dev(X)
+  Ho, Wo, H, Wd, stride = geom if geom is not None else (0, 0, 0, 0, 1)
+  _check(_lib.pf_conv1x1_wrw(_ptr(dY), _ptr(X), _ptr(dW), c_int(dtype_code(dW)), _ptr(workspace), _ptr(scale_shift),
+                             c_int(ACT_CODES[act]), _ptr(slot), c_int(int(bits)), c_int(M), c_int(N), c_int(K),
+                             c_int(Ho), c_int(Wo), c_int(H), c_int(Wd), c_int(stride), _stream()), 'pf_conv1x1_wrw')

@@ -34,6 +34,8 @@ flags.DEFINE_boolean('enbl_warm_start', False, 'enable warm start for training')
 # --- flags with no reference counterpart (the reference is fp32 TF on whatever device TF picks) ---
 flags.DEFINE_string('compute_dtype', 'float32', 'activation / matmul dtype: float32 (parity) | bfloat16 (MFMA)')
 flags.DEFINE_integer('init_seed', 42, 'seed of the variable initialisers')
+flags.DEFINE_boolean('fuse_conv1x1', True, 'bf16 mode: apply BN/ReLU/fake-quant inside the consuming 1x1 convolutions '
+                     '(pf_conv.hip) instead of writing the activated tensor to HBM')
 flags.DEFINE_integer('nb_iters_override', 0, 'if > 0, train() stops after this many iterations')
 flags.DEFINE_integer('nb_eval_batches_override', 0, 'if > 0, evaluate() uses this many batches')
 
@@ -150,6 +152,7 @@ class AbstractLearner(ABC):  # pylint: disable=too-many-instance-attributes
     """Declare the model's variables & ops on a new Graph by running forward_train in build mode.
     `before_finalize(graph)` may declare further variables (e.g. NUQ codebooks)."""
     graph = Graph(scope, self.device, compute_dtype())
+    graph.fuse_conv1x1 = bool(FLAGS.fuse_conv1x1)
     spec = input_spec(self.model_helper)
     with graph.as_default():
       self.forward_train(spec)

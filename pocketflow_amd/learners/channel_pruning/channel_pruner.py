@@ -1,0 +1,320 @@
+"""Channel pruner (reference learners/channel_pruning/channel_pruner.py:52-808, He et al. 2017).
+
+Host-side, rank 0 only, exactly as in the reference: feature maps are sampled at random spatial points
+over `cp_nb_batches` batches, the input channels of each convolution are selected by a LASSO
+(scikit-learn LassoLars with an alpha bisection, :456-577) and the kernel is re-fitted by least squares
+(:443-454); pruning is "fake" -- tensors keep their shape, pruned channels are zeroed and recorded in
+`fake_pruning_dict[op] = [keep_in, keep_out]` (:665-725) for the masked fine-tune.
+
+What runs on the MI355X: the `cp_nb_batches` x (1 + #layers) forward passes that produce the sampled
+feature maps and convolution inputs (the executor's tap mode, graph.Graph.taps); the LASSO / least
+squares stay in scikit-learn on the host like in the reference.
+
+Supported topologies: chains of Conv2D / DepthwiseConv2dNative with BN / ReLU(6) between them
+(MobileNet-v1 = BASELINE config 3, LeNet-like nets).  Networks with residual additions need the
+reference's `residual_branch_diff` correction (:579-586), which is not implemented: such convolutions
+are reported as not prunable.  The RL mode (`cp_prune_option auto`) is out of scope.
+"""
+from __future__ import annotations
+
+import logging
+from collections import OrderedDict
+from timeit import default_timer as timer
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from pocketflow_amd.flags import FLAGS, flags
+from pocketflow_amd.graph import Conv2D, DepthwiseConv2D, Graph, to_device_images
+
+flags.DEFINE_boolean('cp_lasso', True, 'If True use lasso and reconstruction otherwise prune according to weight magnitude')
+flags.DEFINE_boolean('cp_quadruple', False, 'Restric the channels after pruning is a mutiple of 4')
+flags.DEFINE_string('cp_reward_policy', 'accuracy', 'reward policy of the RL mode (unused: RL mode is out of scope)')
+flags.DEFINE_integer('cp_nb_points_per_layer', 10, 'Sample how many point for each layer')
+flags.DEFINE_integer('cp_nb_batches', 30, 'Input how many bathes data into a model')
+flags.DEFINE_integer('cp_seed', 2018, 'seed of the host-side sampling (the reference never seeds np.random)')
+
+log = logging.getLogger('pocketflow_amd')
+
+
+def compute_pruned_kernel(X, W2, Y, c_new, rng, alpha=1e-4, tolerance=0.02, quadruple=False):
+  """LASSO channel selection + least-squares reconstruction (reference :456-577).
+
+  X [n, kh, kw, cin] sampled input patches, W2 [kh, kw, cin, cout] (HWIO), Y [n, cout] target outputs.
+  Returns (idxs bool[cin], newW2 [cout, kh*kw*c_kept] = LinearRegression.coef_)."""
+  from sklearn.linear_model import LassoLars, LinearRegression
+  nb_samples, c_in, c_out = X.shape[0], X.shape[-1], W2.shape[-1]
+  samples = rng.randint(0, nb_samples, min(400, nb_samples // 20))
+  reshape_X = np.rollaxis(np.transpose(X, (0, 3, 1, 2)).reshape((nb_samples, c_in, -1))[samples], 1, 0)
+  reshape_W2 = np.transpose(np.transpose(W2, (3, 2, 0, 1)).reshape((c_out, c_in, -1)), [1, 2, 0])
+  product = np.matmul(reshape_X, reshape_W2).reshape((c_in, -1)).T
+  reshape_Y = Y[samples].reshape(-1)
+  solver = LassoLars(alpha=alpha, fit_intercept=False, max_iter=3000)
+
+  def solve(a):
+    solver.alpha = a
+    solver.fit(product, reshape_Y)
+    idx = solver.coef_ != 0.
+    return idx, int(sum(idx)), solver.coef_
+
+  if c_new == c_in:
+    idxs = np.array([True] * c_new)
+  else:
+    left, right = 0, alpha
+    lbound = c_new - tolerance * c_in / 2
+    rbound = c_new + tolerance * c_in / 2
+    while True:
+      _, tmp, _ = solve(right)
+      if tmp < c_new:
+        break
+      right *= 2
+    while True:
+      if lbound < 0:
+        lbound = 1
+      idxs, tmp, _ = solve(alpha)
+      if quadruple and tmp % 4 == 0 and abs(tmp - lbound) <= 2:
+        break
+      if lbound <= tmp <= rbound:
+        if quadruple:
+          if tmp % 4 == 0:
+            break
+          elif tmp % 4 <= 2:
+            rbound = tmp - 1
+            lbound = lbound - 2
+          else:
+            lbound = tmp + 1
+            rbound = rbound + 2
+        else:
+          break
+      elif abs(left - right) <= right * 0.1:
+        if lbound > 1:
+          lbound = lbound - 1
+        if rbound < c_in:
+          rbound = rbound + 1
+        left = left / 1.2
+        right = right * 1.2
+      elif tmp > rbound:
+        left = left + (alpha - left) / 2
+      else:
+        right = right - (right - alpha) / 2
+      if alpha < 1e-10:
+        break
+      alpha = (left + right) / 2
+  reg = LinearRegression(n_jobs=-1, copy_X=True, fit_intercept=False)
+  reg.fit(X[:, :, :, idxs].reshape((nb_samples, -1)), Y)
+  return idxs, reg.coef_
+
+
+class ChannelPruner(object):  # pylint: disable=too-many-instance-attributes
+  """Prunes the convolutions of one Graph in creation order; `compress(ratio)` handles one layer."""
+
+  def __init__(self, graph: Graph, forward_eval, batches, sm_writer=None):
+    self.graph = graph
+    self.forward_eval = forward_eval
+    self.batches = batches                       # list of (images NHWC float32 device tensor, labels)
+    self.sm_writer = sm_writer
+    self.rng = np.random.RandomState(FLAGS.cp_seed)
+    self.state = 0
+    self.points: Dict = {}
+    self.feats_dict: Dict[object, np.ndarray] = {}
+    self.__trace()
+    self.fake_pruning_dict = {}
+    self.max_strategy_dict = {}
+    for conv in self.thisconvs:
+      cin, cout = conv.kernel.ref_shape[2], conv.kernel.ref_shape[3]
+      self.fake_pruning_dict[conv.op.name] = [[True] * cin, [True] * cout]
+      self.max_strategy_dict[conv.op.name] = [1.0, 1.0]
+    self.model_flops = self.compute_model_flops(fake=False)
+    log.info('The original model flops is {}'.format(self.model_flops))
+
+  # -- topology ------------------------------------------------------------------------------------
+  def __run(self, images):
+    """One eval-mode forward in tap mode; returns {layer: (input, output, producer)}."""
+    g = self.graph
+    g.taps = OrderedDict()
+    try:
+      with torch.no_grad(), g.as_default():
+        self.forward_eval(to_device_images(images, g))
+      return g.taps
+    finally:
+      g.taps = None
+
+  def __trace(self):
+    taps = self.__run(self.batches[0][0])
+    self.layers = list(taps.keys())
+    self.thisconvs: List[Conv2D] = [l for l in self.layers if isinstance(l, Conv2D)]
+    self.fathers: Dict[object, Optional[object]] = {l: taps[l][2] for l in self.layers}
+    self.out_hw = {l: (taps[l][1].shape[2], taps[l][1].shape[3]) for l in self.layers}
+    self.names = [c.op.name for c in self.thisconvs]
+
+  def is_W1_prunable(self, conv) -> bool:
+    """The input reaches `conv` from another convolution through BN / ReLU / pooling only (:343-370)."""
+    return self.fathers.get(conv) is not None
+
+  def finallayer(self, offset=1):
+    return len(self.thisconvs) - offset == self.state
+
+  # -- flops -----------------------------------------------------------------------------------------
+  def compute_layer_flops(self, conv) -> float:
+    kh, kw, cin, cout = conv.kernel.ref_shape
+    ho, wo = self.out_hw[conv]
+    return 2.0 * ho * wo * kh * kw * cin * cout
+
+  def compute_model_flops(self, fake=False) -> float:
+    flops = 0.0
+    for conv in self.thisconvs:
+      f = self.compute_layer_flops(conv)
+      if fake:
+        keep_in, keep_out = self.fake_pruning_dict[conv.op.name]
+        f *= (sum(keep_in) / float(len(keep_in))) * (sum(keep_out) / float(len(keep_out)))
+      flops += f
+    for l in self.layers:
+      if isinstance(l, DepthwiseConv2D):
+        kh, kw, c, _ = l.kernel.ref_shape
+        ho, wo = self.out_hw[l]
+        flops += 2.0 * ho * wo * kh * kw * c
+    return flops
+
+  # -- sampling ----------------------------------------------------------------------------------------
+  def extract_features(self):
+    """Outputs of every convolution of the ORIGINAL model at cp_nb_points_per_layer random points per
+    batch (the same points for every image of a batch), over cp_nb_batches batches (:263-341)."""
+    npts = FLAGS.cp_nb_points_per_layer
+    nb_batches = min(FLAGS.cp_nb_batches, len(self.batches))
+    feats = {c: [] for c in self.thisconvs}
+    self.points = {}
+    for b in range(nb_batches):
+      taps = self.__run(self.batches[b][0])
+      for conv in self.thisconvs:
+        h, w = self.out_hw[conv]
+        xs = self.rng.randint(0, h, npts)
+        ys = self.rng.randint(0, w, npts)
+        self.points[(b, conv)] = (xs.copy(), ys.copy())
+        y = taps[conv][1]                                   # logical NCHW
+        sel = y[:, :, torch.as_tensor(xs, device=y.device), torch.as_tensor(ys, device=y.device)]
+        feats[conv].append(sel.permute(0, 2, 1).reshape(-1, y.shape[1]).float().cpu().numpy().astype(np.float64))
+    self.feats_dict = {c: np.vstack(v) for c, v in feats.items()}
+    self.nb_batches = nb_batches
+
+  def __extract_input(self, conv) -> np.ndarray:
+    """Input patches [n, kh, kw, cin] of `conv` at its sampled output points, from the CURRENT
+    (partially pruned) model (:391-412)."""
+    kh, kw, cin, _ = conv.kernel.ref_shape
+    Xs = []
+    for b in range(self.nb_batches):
+      x = self.__run(self.batches[b][0])[conv][0]          # logical NCHW, materialised
+      xs, ys = self.points[(b, conv)]
+      if kh == 1 and kw == 1:
+        ix = torch.as_tensor(xs * conv.stride, device=x.device)
+        iy = torch.as_tensor(ys * conv.stride, device=x.device)
+        p = x[:, :, ix, iy].permute(0, 2, 1).reshape(-1, 1, 1, cin)
+      else:
+        from pocketflow_amd.graph import _same_pads
+        if conv.padding == 'SAME':
+          ph, pw = _same_pads(x.shape[2], kh, conv.stride), _same_pads(x.shape[3], kw, conv.stride)
+        elif isinstance(conv.padding, int):
+          ph = pw = (conv.padding, conv.padding)
+        else:
+          ph = pw = (0, 0)
+        xp = torch.nn.functional.pad(x, (pw[0], pw[1], ph[0], ph[1]))
+        pts = []
+        for px, py in zip(xs, ys):
+          h0, w0 = int(px) * conv.stride, int(py) * conv.stride
+          pts.append(xp[:, :, h0:h0 + kh, w0:w0 + kw].permute(0, 2, 3, 1))     # [B, kh, kw, cin]
+        p = torch.stack(pts, dim=1).reshape(-1, kh, kw, cin)
+      Xs.append(p.float().cpu().numpy().astype(np.float64))
+    return np.vstack(Xs)
+
+  # -- one layer ------------------------------------------------------------------------------------------
+  def prune_kernel(self, conv, ratio):
+    """Select the input channels of `conv` to keep and re-fit its kernel (:588-640)."""
+    kh, kw, c, _ = conv.kernel.ref_shape
+    nb_channel_new = max(int(np.around(c * ratio)), 1)
+    newX = self.__extract_input(conv)
+    Y = self.feats_dict[conv]
+    W2 = conv.kernel.to_ref(conv.kernel.master.detach().float().cpu().numpy()).astype(np.float64)
+    if FLAGS.cp_lasso:
+      idxs, newW2 = compute_pruned_kernel(newX, W2, Y, nb_channel_new, self.rng, quadruple=FLAGS.cp_quadruple)
+    else:
+      from sklearn.linear_model import LinearRegression
+      order = np.argsort(-np.abs(W2).sum((0, 1, 3)))
+      idxs = np.zeros(len(order), bool)
+      idxs[order[:nb_channel_new]] = True
+      reg = LinearRegression(fit_intercept=False)
+      reg.fit(newX[:, :, :, idxs].reshape(newX.shape[0], -1), Y)
+      newW2 = reg.coef_
+    rel = lambda A, B: np.mean((A - B) ** 2) ** .5 / np.mean(A ** 2) ** .5
+    log.info('Prune {} c_in from {} to {} | feature map rmse {:.4f}'.format(
+        conv.op.name, newX.shape[-1], int(sum(idxs)),
+        rel(newX[:, :, :, idxs].reshape(newX.shape[0], -1).dot(newW2.T), Y)))
+    kept = int(sum(idxs))
+    newW2 = np.transpose(newW2.reshape(-1, kh, kw, kept), (1, 2, 3, 0))      # [kh, kw, kept, cout]
+    return idxs, newW2, kept / float(len(idxs))
+
+  def __assign(self, var, ref_value):
+    var.master.copy_(torch.from_numpy(var.to_storage(ref_value.astype(np.float32))).to(var.master.device))
+
+  def prune_W1(self, father, idxs):
+    """Zero the pruned OUTPUT channels (and bias entries) of the producing convolution (:665-697)."""
+    name = father.op.name
+    if name not in self.fake_pruning_dict:              # a depthwise producer that is not W1-prunable itself
+      c = father.kernel.ref_shape[2]
+      self.fake_pruning_dict[name] = [[True] * c, [True] * c]
+      self.max_strategy_dict[name] = [1.0, 1.0]
+    self.max_strategy_dict[name][1] = sum(idxs) / float(len(idxs))
+    self.fake_pruning_dict[name][1] = list(idxs)
+    w = father.kernel.to_ref(father.kernel.master.detach().cpu().numpy())
+    not_idxs = np.invert(np.asarray(idxs, dtype=bool))
+    if isinstance(father, DepthwiseConv2D):
+      w[:, :, not_idxs, :] = 0
+    else:
+      w[:, :, :, not_idxs] = 0
+    self.__assign(father.kernel, w)
+    bias = getattr(father, 'bias', None)
+    if bias is not None:
+      b = bias.master.detach().cpu().numpy().copy()
+      b[not_idxs] = 0
+      bias.master.copy_(torch.from_numpy(b).to(bias.master.device))
+
+  def prune_W2(self, conv, idxs, W2=None):
+    """Write the reconstructed kernel, zero the pruned INPUT channels (:699-725)."""
+    name = conv.op.name
+    self.max_strategy_dict[name][0] = sum(idxs) / float(len(idxs))
+    self.fake_pruning_dict[name][0] = list(idxs)
+    w = conv.kernel.to_ref(conv.kernel.master.detach().cpu().numpy())
+    idxs = np.asarray(idxs, dtype=bool)
+    if W2 is not None:
+      w[:, :, idxs, :] = W2
+    w[:, :, np.invert(idxs), :] = 0
+    self.__assign(conv.kernel, w)
+
+  def compress(self, c_ratio):
+    """Prune the layer at `self.state` with preserve ratio `c_ratio`; returns done (:727-799)."""
+    if self.state == 0:
+      c_ratio = 1.0                                        # first layer is not prunable
+    if self.finallayer():
+      c_ratio = 1                                          # final layer is not prunable
+    conv = self.thisconvs[self.state]
+    if c_ratio != 1:
+      idxs, W2, c_ratio = self.prune_kernel(conv, c_ratio)
+      if self.is_W1_prunable(conv):
+        father = self.fathers[conv]
+        while isinstance(father, DepthwiseConv2D):
+          if self.is_W1_prunable(father):
+            father = self.fathers[father]
+          else:
+            break
+        log.info('father conv {}'.format(father.op.name))
+        self.prune_W1(father, idxs)
+      self.prune_W2(conv, idxs, W2)
+      self.graph.store.sync_compute()
+    log.info('Channel pruning the {} layer, the pruning rate is {}'.format(conv.op.name, c_ratio))
+    if self.finallayer():
+      pruned_flops = self.compute_model_flops(fake=True)
+      log.info('The pruned flops is {} | the speedup ratio is {}'.format(pruned_flops, pruned_flops / self.model_flops))
+      log.info('The max strategy dict is {}'.format(self.max_strategy_dict))
+      self.preserve_ratio = pruned_flops / self.model_flops
+      return True
+    self.state += 1
+    return False

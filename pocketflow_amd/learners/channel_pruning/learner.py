@@ -1,0 +1,250 @@
+"""Channel-pruned learner (reference learners/channel_pruning/learner.py:82-695).
+
+Flow: rank 0 prunes the pre-trained model layer by layer on the host (ChannelPruner:
+sampled feature maps from MI355X forward passes, LASSO + least squares in scikit-learn), saves the
+"fake-pruned" checkpoint and broadcasts the keep-masks; then every rank fine-tunes the full-size
+network with per-channel gradient masks (`__calc_grads_pruned`, :381-421: mask = ones(HWIO) with the
+pruned cin rows and cout columns zeroed) -- here the masks live in one flat buffer parallel to the
+kernel buffer and are applied inside the fused optimiser kernel (pf_adam_flat / pf_momentum_flat).
+
+`cp_prune_option`: 'uniform' (every layer at cp_uniform_preserve_ratio) and 'list' (ratios from
+cp_prune_list_file, optionally fine-tuning between groups of cp_list_group layers).  'auto' (DDPG
+search, :623-695) is outside the hot path and raises.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from collections import deque
+from timeit import default_timer as timer
+
+import numpy as np
+import torch
+
+from pocketflow_amd import hip
+from pocketflow_amd.flags import FLAGS, flags
+from pocketflow_amd.graph import Conv2D
+from pocketflow_amd.learners.abstract_learner import AbstractLearner
+from pocketflow_amd.learners.channel_pruning.channel_pruner import ChannelPruner
+from pocketflow_amd.learners.distillation_helper import DistillationHelper
+from pocketflow_amd.optim import FlatOptimizer
+from pocketflow_amd.utils import checkpoint
+from pocketflow_amd.utils.multi_gpu_wrapper import MultiGpuWrapper as mgw
+
+flags.DEFINE_string('cp_prune_option', 'auto', "'uniform': one ratio for every layer | 'list': ratios from a file | 'auto': RL (out of scope)")
+flags.DEFINE_string('cp_prune_list_file', 'ratio.list', 'the prune list file which contains the compression ratio of each convolution layers')
+flags.DEFINE_string('cp_channel_pruned_path', './models/pruned_model.ckpt', 'channel pruned model\'s save path')
+flags.DEFINE_string('cp_best_path', './models/best_model.ckpt', 'channel pruned model\'s temporary save path')
+flags.DEFINE_string('cp_original_path', './models/original_model.ckpt', 'channel pruned model\'s temporary save path')
+flags.DEFINE_float('cp_preserve_ratio', 0.5, 'How much computation cost desired to be preserved after pruning')
+flags.DEFINE_float('cp_uniform_preserve_ratio', 0.6, 'How much computation cost desired to be preserved each layer')
+flags.DEFINE_float('cp_noise_tolerance', 0.15, 'noise tolerance of the RL reward (unused)')
+flags.DEFINE_float('cp_lrn_rate_ft', 1e-4, 'CP: learning rate for global fine-tuning')
+flags.DEFINE_float('cp_nb_iters_ft_ratio', 0.2, 'CP: the ratio of total iterations for global fine-tuning')
+flags.DEFINE_boolean('cp_finetune', False, 'CP: whether finetuning between each list group')
+flags.DEFINE_boolean('cp_retrain', False, 'CP: whether retraining between each list group')
+flags.DEFINE_integer('cp_list_group', 1000, 'CP: # of layers pruned between two fine-tuning phases')
+flags.DEFINE_integer('cp_nb_rlouts', 200, 'CP: # of roll-outs for the RL agent (unused)')
+flags.DEFINE_integer('cp_nb_rlouts_min', 50, 'CP: # of roll-outs for the RL agent (unused)')
+
+log = logging.getLogger('pocketflow_amd')
+
+
+class ChannelPrunedLearner(AbstractLearner):  # pylint: disable=too-many-instance-attributes
+  """Learner with channel/filter pruning."""
+
+  def __init__(self, sm_writer, model_helper):
+    super(ChannelPrunedLearner, self).__init__(sm_writer, model_helper)
+    self.learner_dst = DistillationHelper(sm_writer, model_helper, self.mpi_comm) if FLAGS.enbl_dst else None
+    self.graph = self.build_graph(self.model_scope, separate_compute=False)
+    self.iter_train = self.build_dataset_train().to(self.device)
+    self.iter_eval = self.build_dataset_eval().to(self.device)
+    self.pruner = None
+    self.fake_pruning_dict = {}
+    self.max_eval_acc = 0.0
+    self.global_step = 0
+    self.w_mask = torch.ones_like(self.graph.store.w_master)
+    self.last_speed = None
+    self.last_eval = None
+
+  # -- reference surface ------------------------------------------------------------------------------
+  def train(self):
+    """Prune (rank 0) and fine-tune (all ranks)."""
+    if self.is_primary_worker('global'):
+      self.download_model()
+      self.restore_vars(checkpoint.latest_checkpoint(os.path.dirname(FLAGS.save_path)))
+      self.save_vars(FLAGS.cp_original_path)
+      self.create_pruner()
+    self.auto_barrier()
+    if FLAGS.cp_prune_option == 'uniform':
+      self.__prune_and_finetune_uniform()
+    elif FLAGS.cp_prune_option == 'list':
+      self.__prune_and_finetune_list()
+    elif FLAGS.cp_prune_option == 'auto':
+      raise ValueError("cp_prune_option 'auto' (DDPG search) is outside the MI355X hot path (SURVEY section 8f)")
+    else:
+      raise ValueError('unrecognized cp_prune_option: ' + str(FLAGS.cp_prune_option))
+    return self.last_eval
+
+  def create_pruner(self):
+    nb = FLAGS.cp_nb_batches
+    batches = [self.iter_train.get_next() for _ in range(nb)]
+    self.iter_train.reset()
+    self.pruner = ChannelPruner(self.graph, self.forward_eval, batches, self.sm_writer)
+
+  def evaluate(self):
+    """Restore the latest checkpoint and evaluate it (:181-206)."""
+    path = checkpoint.latest_checkpoint(os.path.dirname(FLAGS.save_path))
+    self.restore_vars(path)
+    return self.run_eval()
+
+  def run_eval(self):
+    nb_iters = FLAGS.nb_eval_batches_override or int(np.ceil(float(FLAGS.nb_smpls_eval) / FLAGS.batch_size_eval))
+    g = self.graph
+    g.store.sync_compute()
+    self.iter_eval.reset()
+    rows, names = [], None
+    with torch.no_grad():
+      for _ in range(nb_iters):
+        images, labels = self.iter_eval.get_next()
+        x, y = self.to_device(images, labels)
+        g.begin_step()
+        with g.as_default():
+          logits = self.forward_eval(x)
+          loss, metrics = self.calc_loss(y, logits, self.trainable_vars)
+        names = ['loss'] + list(metrics.keys())
+        rows.append([float(loss)] + [float(v) for v in metrics.values()])
+    means = np.mean(np.array(rows), axis=0)
+    out = dict(zip(names, [float(m) for m in means]))
+    for k, v in out.items():
+      log.info('%s = %.4e', k, v)
+    acc = out.get('acc_top1', out.get('accuracy', 0.0))
+    self.max_eval_acc = max(self.max_eval_acc, acc)
+    self.last_eval = out
+    return out
+
+  # -- pruning protocols ----------------------------------------------------------------------------------
+  def __prune_and_finetune_uniform(self):
+    if self.is_primary_worker('global'):
+      self.pruner.extract_features()
+      start = timer()
+      done = False
+      while not done:
+        done = self.pruner.compress(FLAGS.cp_uniform_preserve_ratio)
+      log.info('uniform channl pruning time cost: {}s'.format(timer() - start))
+      self.save_vars(FLAGS.cp_channel_pruned_path)
+    self.auto_barrier()
+    self.__finetune_pruned_model(path=FLAGS.cp_channel_pruned_path)
+
+  def __prune_and_finetune_list(self):
+    try:
+      ratio_list = list(np.atleast_1d(np.loadtxt(FLAGS.cp_prune_list_file, delimiter=',')))
+    except IOError as err:
+      log.error('The prune list file format is not correct: a float list delimited by commas is expected')
+      raise err
+    ratio_list.reverse()
+    queue = deque(ratio_list)
+    done = False
+    while not done:
+      done = self.__prune_n_layers(FLAGS.cp_list_group, queue)
+
+  def __prune_n_layers(self, n, queue):
+    done = False
+    if self.is_primary_worker('global'):
+      self.pruner.extract_features()
+      i = 0
+      while not done and i < n:
+        ratio = queue.pop() if queue else 1
+        done = self.pruner.compress(ratio)
+        i += 1
+      self.save_vars(FLAGS.cp_channel_pruned_path)
+    if FLAGS.enbl_multi_gpu:
+      self.auto_barrier()
+      done = self.mpi_comm.bcast(done, root=0)
+    self.__finetune_pruned_model(path=FLAGS.cp_channel_pruned_path, finetune=False if done else FLAGS.cp_finetune)
+    return done
+
+  # -- masked fine-tune ------------------------------------------------------------------------------------
+  def __calc_grads_pruned(self):
+    """Broadcast rank 0's keep-masks and build the flat gradient mask (:381-421)."""
+    fake_pruning_dict = self.pruner.fake_pruning_dict if self.is_primary_worker('global') else {}
+    if FLAGS.enbl_multi_gpu:
+      fake_pruning_dict = self.mpi_comm.bcast(fake_pruning_dict, root=0)
+    self.fake_pruning_dict = fake_pruning_dict
+    self.w_mask.fill_(1.0)
+    by_op = {op.name: op.var for op in self.graph.matmul_ops}
+    for op_name, (keep_in, keep_out) in fake_pruning_dict.items():
+      var = by_op[op_name]
+      if var.kind != 'conv':
+        continue                                          # depthwise kernels are never masked
+      kh, kw, cin, cout = var.ref_shape
+      ki = torch.tensor(np.asarray(keep_in, dtype=np.uint8), device=self.device)
+      ko = torch.tensor(np.asarray(keep_out, dtype=np.uint8), device=self.device)
+      hip.cp_build_mask(self.w_mask[var.offset:var.offset + var.numel], ki, ko, cout, kh * kw, cin)
+
+  def __finetune_pruned_model(self, path=None, finetune=False):
+    start = timer()
+    self.restore_vars(path)                               # every rank starts from the pruned checkpoint
+    self.__calc_grads_pruned()
+    self.global_step = 0
+    self.lrn_rate, self.nb_iters_train = self.setup_lrn_rate(self.global_step)
+    st = self.graph.store
+    if finetune and not FLAGS.cp_retrain:
+      base = FlatOptimizer(st, 'adam')
+      self.lrn_rate = lambda step: FLAGS.cp_lrn_rate_ft
+    else:
+      base = FlatOptimizer(st, 'momentum', momentum=FLAGS.momentum)
+    base.w_mask = self.w_mask
+    self.optimizer = mgw.DistributedOptimizer(base) if FLAGS.enbl_multi_gpu else base
+    if FLAGS.enbl_multi_gpu:
+      mgw.broadcast_global_variables(0, [st], [self.optimizer])()
+    self.__train_pruned_model(finetune=finetune)
+    log.info('fintuning time cost: {}s'.format(timer() - start))
+
+  def train_step(self):
+    g = self.graph
+    g.store.sync_compute()
+    images, labels = self.iter_train.get_next()
+    x, y = self.to_device(images, labels)
+    g.begin_step()
+    with g.as_default():
+      logits_dst = self.learner_dst.calc_logits(None, x) if FLAGS.enbl_dst else None
+      logits = self.forward_train(x)
+      loss, metrics = self.calc_loss(y, logits, self.trainable_vars)
+      if FLAGS.enbl_dst:
+        loss = loss + self.learner_dst.calc_loss(logits, logits_dst)
+    loss.backward()
+    lr = self.lrn_rate(self.global_step)
+    self.optimizer.weight_decay = g.store.weight_decay
+    self.optimizer.compute_gradients()
+    self.optimizer.apply_gradients(lr)
+    self.global_step += 1
+    return lr, loss, metrics
+
+  def __train_pruned_model(self, finetune=False):
+    nb_iters = int(FLAGS.cp_nb_iters_ft_ratio * self.nb_iters_train) \
+        if finetune and not FLAGS.cp_retrain else self.nb_iters_train
+    nb_iters = FLAGS.nb_iters_override or nb_iters
+    time_prev = timer()
+    for idx_iter in range(nb_iters):
+      lr, loss, metrics = self.train_step()
+      if (idx_iter + 1) % FLAGS.summ_step == 0 and self.is_primary_worker('global'):
+        torch.cuda.synchronize()
+        speed = FLAGS.batch_size * FLAGS.summ_step / (timer() - time_prev)
+        if FLAGS.enbl_multi_gpu:
+          speed *= mgw.size()
+        log.info('iter #%d: lr = %e | loss = %e | speed = %.2f pics / sec' % (idx_iter + 1, lr, float(loss), speed))
+        for k, v in metrics.items():
+          log.info('{} = {}'.format(k, float(v)))
+        self.last_speed = speed
+        time_prev = timer()
+      if (idx_iter + 1) % FLAGS.save_step == 0:
+        if self.is_primary_worker('global'):
+          self.save_vars(FLAGS.save_path, self.global_step)
+          self.evaluate()
+        self.auto_barrier()
+    if self.is_primary_worker('global'):
+      self.save_vars(FLAGS.save_path, self.global_step)
+      self.evaluate()
+      self.save_vars(FLAGS.cp_best_path)                  # __save_in_progress_pruned_model
+    self.auto_barrier()

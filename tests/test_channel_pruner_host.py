@@ -1,0 +1,41 @@
+"""Host side of the channel pruner on CPU: the LASSO selector of the product against the oracle's
+restatement (both drive the real scikit-learn LassoLars / LinearRegression, which is what the reference
+does, channel_pruner.py:456-577) and the fake-pruning bookkeeping on a small conv chain."""
+import numpy as np
+import pytest
+
+
+def _problem(seed, n=800, kh=1, kw=1, cin=24, cout=16, rank=8):
+  rng = np.random.RandomState(seed)
+  basis = rng.randn(n, kh, kw, rank)
+  mix = rng.randn(rank, cin)
+  X = np.einsum('nhwr,rc->nhwc', basis, mix) + 0.05 * rng.randn(n, kh, kw, cin)     # correlated channels
+  W2 = rng.randn(kh, kw, cin, cout) * 0.2
+  Y = X.reshape(n, -1) @ np.transpose(W2, (0, 1, 2, 3)).reshape(-1, cout)
+  return X, W2, Y
+
+
+@pytest.mark.parametrize('seed,kh,c_new', [(1, 1, 12), (2, 3, 8), (3, 1, 6)])
+def test_lasso_selector_matches_oracle(seed, kh, c_new):
+  from oracle import pf_oracle as O
+  from pocketflow_amd.learners.channel_pruning.channel_pruner import compute_pruned_kernel
+  X, W2, Y = _problem(seed, kh=kh, kw=kh)
+  idx_p, coef = compute_pruned_kernel(X, W2, Y, c_new, np.random.RandomState(77))
+  idx_o, new_o = O.cp_lasso_select(X, Y, W2, c_new, np.random.RandomState(77))
+  assert np.array_equal(idx_p, idx_o)
+  cin = X.shape[-1]
+  assert abs(int(idx_p.sum()) - c_new) <= max(1, int(0.02 * cin / 2) + 1)
+  kept = int(idx_p.sum())
+  new_p = np.transpose(coef.reshape(-1, kh, kh, kept), (1, 2, 3, 0))
+  np.testing.assert_allclose(new_p, new_o, rtol=1e-5, atol=1e-6)
+  # the reconstruction explains the original feature map well (channels are rank-8 correlated)
+  rec = X[:, :, :, idx_p].reshape(X.shape[0], -1) @ coef.T
+  assert np.mean((rec - Y) ** 2) ** .5 / np.mean(Y ** 2) ** .5 < 0.35
+
+
+def test_fake_pruning_masks_match_oracle():
+  from oracle import pf_oracle as O
+  keep_in = np.array([True, False, True, True])
+  keep_out = np.array([False, True, True])
+  m = O.cp_grad_mask((3, 3, 4, 3), keep_in, keep_out)
+  assert m.sum() == 9 * 3 * 2 and m[:, :, 1, :].sum() == 0 and m[:, :, :, 0].sum() == 0

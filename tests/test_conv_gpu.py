@@ -1,0 +1,200 @@
+"""Fused 1x1-convolution kernels (pf_conv1x1_fwd / pf_conv1x1_wrw) against float32 torch references
+built from the SAME bf16 inputs; the prologue is checked against the stand-alone BN+ReLU+fake-quant
+kernel (pf_bn_act_quant_apply), which is itself bit-exact against the oracle (test_kernels_gpu.py)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+  from pocketflow_amd import hip as h
+  return h
+
+
+def _bf(x):
+  return x.to(torch.bfloat16)
+
+
+def _close_bf16(got, ref, frac_tol=0.0, what='', scale=None):
+  """Equal up to one bf16 ulp of the reference (different fp32 accumulation order); `scale`: magnitude
+  the ulp refers to when the reference is a sum of larger terms."""
+  got, ref = got.float(), ref.float()
+  err = (got - ref).abs()
+  mag = ref.abs() if scale is None else torch.maximum(ref.abs(), scale.float().abs())
+  tol = mag * 2 ** -7 + 1e-3
+  bad = float((err > tol).float().mean())
+  assert bad <= frac_tol, '%s: %.3e of the elements differ by more than a bf16 ulp (max err %.3e)' % (
+      what, bad, float(err.max()))
+
+
+@pytest.mark.parametrize('M,N,K', [(1000, 64, 64), (3000, 128, 96), (777, 192, 256), (4096, 256, 64), (130, 512, 128)])
+def test_conv1x1_fwd_plain_and_residual_and_stats(hip, M, N, K):
+  g = torch.Generator(device='cuda').manual_seed(M + N + K)
+  X = _bf(torch.randn(M, K, device='cuda', generator=g))
+  W = _bf(torch.randn(N, K, device='cuda', generator=g) * 0.1)
+  R = _bf(torch.randn(M, N, device='cuda', generator=g))
+  Y = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+  hip.conv1x1_fwd(X, W, Y, M, N, K)
+  ref = X.float() @ W.float().t()
+  _close_bf16(Y, _bf(ref), what='plain')
+  # residual + statistics
+  G = hip.conv1x1_stats_groups(M, N)
+  partial = torch.full((G, 4, N), float('nan'), device='cuda')
+  Y2 = torch.empty_like(Y)
+  hip.conv1x1_fwd(X, W, Y2, M, N, K, R=R, partial=partial)
+  ref2 = _bf(_bf(ref).float() + R.float())
+  _close_bf16(Y2, ref2, what='residual', scale=ref)
+  y = Y2.float()
+  assert not torch.isnan(partial).any()
+  s, q = partial[:, 0].sum(0), partial[:, 1].sum(0)
+  torch.testing.assert_close(s, y.sum(0), rtol=1e-4, atol=1e-2)
+  torch.testing.assert_close(q, (y * y).sum(0), rtol=1e-4, atol=1e-2)
+  assert torch.equal(partial[:, 2].min(0).values, y.min(0).values)
+  assert torch.equal(partial[:, 3].max(0).values, y.max(0).values)
+
+
+@pytest.mark.parametrize('act,bits', [('Relu', 8), ('Relu6', 4), ('Relu', None), (None, None)])
+def test_conv1x1_fwd_prologue_matches_standalone_bn_act_quant(hip, act, bits):
+  M, N, K = 2500, 128, 192
+  g = torch.Generator(device='cuda').manual_seed(7)
+  X = _bf(torch.randn(M, K, device='cuda', generator=g) * 2)
+  W = _bf(torch.randn(N, K, device='cuda', generator=g) * 0.1)
+  ss = torch.stack([torch.rand(K, device='cuda', generator=g) + 0.5, torch.randn(K, device='cuda', generator=g)])
+  slot = torch.empty(2, dtype=torch.int32, device='cuda')
+  hip.minmax_slots_init(slot)
+  Q = torch.empty_like(X)
+  if bits is not None:
+    # activation range of act(scale*x+shift), written the way pf_bn_finalize does (atomicMin on the slot)
+    y = X.float() * ss[0] + ss[1]
+    y = torch.relu(y) if act == 'Relu' else torch.clamp(y, 0, 6)
+    hip.minmax_tensor(y.contiguous(), slot)
+  hip.bn_act_quant_apply(X, Q, M, K, ss, act, slot if bits is not None else None, bits or 8, bits is not None)
+  Y = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+  hip.conv1x1_fwd(X, W, Y, M, N, K, scale_shift=ss, act=act, slot=slot if bits is not None else None, bits=bits or 8)
+  ref = _bf(Q.float() @ W.float().t())
+  # the folded-constant fake-quant of the prologue may differ from the five-rounding chain on exact ties
+  _close_bf16(Y, ref, frac_tol=2e-3 if bits is not None else 0.0, what='prologue %s/%s' % (act, bits))
+
+
+def test_conv1x1_fwd_strided_and_ymap(hip):
+  n, H, Wd, K, N, s = 3, 14, 10, 64, 128, 2
+  Ho, Wo = H // s, Wd // s
+  g = torch.Generator(device='cuda').manual_seed(3)
+  X = _bf(torch.randn(n, H, Wd, K, device='cuda', generator=g))
+  W = _bf(torch.randn(N, K, device='cuda', generator=g) * 0.1)
+  M = n * Ho * Wo
+  Y = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+  hip.conv1x1_fwd(X, W, Y, M, N, K, geom=(Ho, Wo, H, Wd, s))
+  ref = X[:, ::s, ::s, :].reshape(M, K).float() @ W.float().t()
+  _close_bf16(Y, _bf(ref), what='strided')
+  # backward-data of that conv: dX[img, ho*s, wo*s, :] = dY @ W, zero elsewhere
+  dY = _bf(torch.randn(M, N, device='cuda', generator=g))
+  Wt = W.t().contiguous()                      # [K][N] -> acts as the [N'][K'] weight of the NT kernel
+  dX = torch.zeros(n, H, Wd, K, device='cuda', dtype=torch.bfloat16)
+  hip.conv1x1_fwd(dY, Wt, dX, M, K, N, geom=(Ho, Wo, H, Wd, s), ymap=True)
+  refd = torch.zeros(n, H, Wd, K, device='cuda')
+  refd[:, ::s, ::s, :] = (dY.float() @ W.float()).reshape(n, Ho, Wo, K)
+  _close_bf16(dX, _bf(refd), what='ymap')
+
+
+@pytest.mark.parametrize('M,N,K,dw_dtype', [(1000, 64, 64, torch.float32), (5000, 128, 96, torch.bfloat16),
+                                            (20000, 256, 64, torch.float32), (333, 192, 512, torch.float32)])
+def test_conv1x1_wrw(hip, M, N, K, dw_dtype):
+  g = torch.Generator(device='cuda').manual_seed(M)
+  X = _bf(torch.randn(M, K, device='cuda', generator=g))
+  dY = _bf(torch.randn(M, N, device='cuda', generator=g) * 0.1)
+  ss = torch.stack([torch.rand(K, device='cuda', generator=g) + 0.5, torch.randn(K, device='cuda', generator=g)])
+  ws = torch.empty((hip.conv1x1_wrw_splits(M, N, K) + 32) * N * K, device='cuda')
+  dW = torch.empty(N, K, device='cuda', dtype=dw_dtype)
+  hip.conv1x1_wrw(dY, X, dW, ws, M, N, K)
+  ref = dY.float().t() @ X.float()
+  torch.testing.assert_close(dW.float(), ref, rtol=2e-2 if dw_dtype == torch.bfloat16 else 1e-3, atol=2e-2)
+  # with the prologue: Q = relu(scale*x+shift), no quantisation
+  Q = torch.empty_like(X)
+  hip.bn_act_quant_apply(X, Q, M, K, ss, 'Relu', None, 8, False)
+  hip.conv1x1_wrw(dY, X, dW, ws, M, N, K, scale_shift=ss, act='Relu')
+  ref = dY.float().t() @ Q.float()
+  torch.testing.assert_close(dW.float(), ref, rtol=2e-2 if dw_dtype == torch.bfloat16 else 1e-3, atol=2e-2)
+  # bit-reproducible (two-stage reduction, no atomics)
+  dW2 = torch.empty_like(dW)
+  hip.conv1x1_wrw(dY, X, dW2, ws, M, N, K, scale_shift=ss, act='Relu')
+  assert torch.equal(dW, dW2)
+
+
+def test_conv1x1_wrw_strided(hip):
+  n, H, Wd, K, N, s = 2, 8, 12, 64, 64, 2
+  Ho, Wo = H // s, Wd // s
+  M = n * Ho * Wo
+  g = torch.Generator(device='cuda').manual_seed(5)
+  X = _bf(torch.randn(n, H, Wd, K, device='cuda', generator=g))
+  dY = _bf(torch.randn(M, N, device='cuda', generator=g))
+  ws = torch.empty((hip.conv1x1_wrw_splits(M, N, K) + 32) * N * K, device='cuda')
+  dW = torch.empty(N, K, device='cuda')
+  hip.conv1x1_wrw(dY, X, dW, ws, M, N, K, geom=(Ho, Wo, H, Wd, s))
+  ref = dY.float().t() @ X[:, ::s, ::s, :].reshape(M, K).float()
+  torch.testing.assert_close(dW, ref, rtol=1e-3, atol=2e-2)
+
+
+def _r50_learner(tmp_path, fuse, tag, a_bits=8):
+  from pocketflow_amd.flags import FLAGS
+  import pocketflow_amd.learners.learner_utils  # noqa: F401
+  import pocketflow_amd.learners.abstract_learner  # noqa: F401
+  import pocketflow_amd.learners.distillation_helper  # noqa: F401
+  from pocketflow_amd.nets.resnet_at_ilsvrc12 import ModelHelper
+  from pocketflow_amd.learners.uniform_quantization.learner import UniformQuantLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  FLAGS.reset()
+  d = tmp_path / tag
+  FLAGS.save_path = str(tmp_path / 'models' / 'model.ckpt')          # shared: identical initial weights
+  FLAGS.save_path_dst = str(d / 'models_dst' / 'model.ckpt')
+  FLAGS.uql_save_quant_model_path = str(d / 'uql' / 'm.ckpt')
+  FLAGS.synthetic_pool = 2
+  FLAGS.compute_dtype = 'bfloat16'
+  FLAGS.resnet_size, FLAGS.nb_classes, FLAGS.image_size, FLAGS.batch_size = 50, 1001, 64, 8
+  FLAGS.uql_weight_bits, FLAGS.uql_activation_bits = 8, a_bits
+  FLAGS.enbl_dst, FLAGS.dst_eval_teacher = True, False
+  FLAGS.fuse_conv1x1 = fuse
+  mh = ModelHelper()
+  create_synthetic_checkpoint(mh)
+  return UniformQuantLearner(None, mh)
+
+
+@pytest.mark.parametrize('a_bits,cos_min', [(32, 0.999), (8, 0.95)])
+def test_fused_path_matches_unfused_learner_step(tmp_path, a_bits, cos_min):
+  """ResNet-50 (bottleneck blocks, strided projections) UQ w8/a8 + distillation, bf16: one step with the
+  BN/act/quant prologue + residual/statistics epilogue fused into the 1x1 convolutions vs the same step
+  with every activation materialised (pf_bn_* kernels + MIOpen).  Both are bf16 computations with
+  different accumulation orders, so the comparison is statistical: tight with 32-bit activation "quantisers"
+  (continuous), looser with 8-bit ones (a step function of bf16 noise, see tests/test_parity_gpu.py)."""
+  outs = {}
+  for fuse in (False, True):
+    lrn = _r50_learner(tmp_path, fuse, 'fuse%d' % int(fuse), a_bits)
+    st = lrn.graph.store
+    # one forward/backward without the optimiser step: compare loss and raw gradients
+    g = lrn.graph
+    images, labels = lrn.iter_train.get_next()
+    x, y = lrn.to_device(images, labels)
+    g.begin_step()
+    lrn.uni_quant.quantize_weights()
+    with g.as_default():
+      logits_dst = lrn.helper_dst.calc_logits(None, x)
+      logits = lrn.forward_train(x)
+      loss, _ = lrn.calc_loss(y, logits, lrn.trainable_vars)
+      loss = loss + lrn.helper_dst.calc_loss(logits, logits_dst)
+    loss.backward()
+    outs[fuse] = (float(loss.detach()), logits.detach().float().clone(), logits_dst.float().clone(),
+                  st.w_grad.float().clone(), st.o_grad.float().clone(), st.state.clone())
+    assert np.isfinite(outs[fuse][0])
+  l0, z0, t0, gw0, go0, s0 = outs[False]
+  l1, z1, t1, gw1, go1, s1 = outs[True]
+  assert abs(l0 - l1) <= 2e-2 * max(1.0, abs(l0)), (l0, l1)
+  cos = lambda a, b: float(torch.dot(a.flatten(), b.flatten()) / (a.norm() * b.norm() + 1e-30))
+  assert cos(t0, t1) > 0.999, 'teacher logits'
+  assert cos(z0, z1) > cos_min, ('student logits', cos(z0, z1))
+  assert cos(gw0, gw1) > min(cos_min, 0.99) - 0.04, ('kernel gradients', cos(gw0, gw1))
+  assert cos(go0, go1) > min(cos_min, 0.99) - 0.04, ('BN gradients', cos(go0, go1))
+  assert cos(s0, s1) > 0.999, 'BN moving statistics'
+  assert 0.5 < float(gw1.norm() / gw0.norm()) < 2.0

@@ -112,3 +112,36 @@ def test_ws_resnet20_masks_and_sparsity(tmp_path):
     sparsity = float((w == 0).float().mean())
     assert abs(sparsity - 0.5) < 2.0 / v.numel + 1e-3, (v.name, sparsity)
   assert abs(rslt['pr_msk'] - 0.5) < 1e-2
+
+
+def test_channel_pruned_mobilenet_uniform(tmp_path):
+  """ChannelPrunedLearner on MobileNet-v1 (BASELINE config 3, shrunk): LASSO pruning on rank 0, then the
+  masked fine-tune -- pruned input / output channels stay exactly zero, FLOPs drop as requested."""
+  from pocketflow_amd.nets.mobilenet_at_ilsvrc12 import ModelHelper
+  from pocketflow_amd.learners.channel_pruning.learner import ChannelPrunedLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  FLAGS = _setup(tmp_path, batch_size=8, batch_size_eval=8, image_size=64, nb_classes=17, mobilenet_depth_mult=0.25,
+                 cp_prune_option='uniform', cp_uniform_preserve_ratio=0.5, cp_nb_batches=4, cp_nb_points_per_layer=10,
+                 cp_channel_pruned_path=str(tmp_path / 'models' / 'pruned_model.ckpt'),
+                 cp_best_path=str(tmp_path / 'models' / 'best_model.ckpt'),
+                 cp_original_path=str(tmp_path / 'models' / 'original_model.ckpt'),
+                 nb_eval_batches_override=2, nb_iters_override=3, summ_step=2, synthetic_pool=4)
+  mh = ModelHelper()
+  create_synthetic_checkpoint(mh)
+  learner = ChannelPrunedLearner(None, mh)
+  rslt = learner.train()
+  assert np.isfinite(rslt['loss'])
+  pr = learner.pruner
+  assert 0.2 < pr.preserve_ratio < 0.6                                  # ~0.5^2 on the pointwise convs + unpruned ends
+  st = learner.graph.store
+  n_masked = 0
+  for op in learner.graph.matmul_ops:
+    if op.name not in learner.fake_pruning_dict or op.var.kind != 'conv':
+      continue
+    keep_in, keep_out = [np.asarray(k, bool) for k in learner.fake_pruning_dict[op.name]]
+    w = op.var.to_ref(op.var.master.detach().cpu().numpy())
+    assert np.all(w[:, :, ~keep_in, :] == 0) and np.all(w[:, :, :, ~keep_out] == 0), op.name
+    n_masked += int((~keep_in).sum() + (~keep_out).sum())
+  assert n_masked > 0
+  first, last = learner.pruner.thisconvs[0], learner.pruner.thisconvs[-1]
+  assert all(learner.fake_pruning_dict[first.op.name][0]) and all(learner.fake_pruning_dict[last.op.name][1])
