@@ -7,7 +7,7 @@ distillation (BASELINE.json configs[2]) on N MI355X GPUs of one node, synthetic 
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one full pass of the hot path over one batch per GPU: teacher forward, weight fake-quant
-of all 54 kernels, student forward with fused BN+ReLU+activation fake-quant, CE + coupled L2 +
+of all 54 kernels, student forward (BN+ReLU+activation fake-quant applied inside the 1x1 convolutions), CE + coupled L2 +
 distillation loss, backward with straight-through estimators, [RCCL all-reduce], fused Adam.
 Rank 0 prints ONE JSON line (contract in the task description).
 """
@@ -22,6 +22,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
+
+# MIOpen's one-off solver search otherwise times its naive reference convolutions (~60 s of warm-up)
+for _k in ('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD', 'MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_BWD',
+           'MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_WRW'):
+  os.environ.setdefault(_k, '0')
 
 R50_FLOPS_PER_IMAGE_STEP_DST = 32.71e9    # fwd + bwd-data + bwd-filter + teacher fwd
 MFMA_BF16_PEAK = 2.5e15                   # dense bf16, MI355X_MICROARCH.md
@@ -39,11 +44,46 @@ def parse_args():
   ap.add_argument('--dtype', default='bfloat16')
   ap.add_argument('--act_bits', type=int, default=8)
   ap.add_argument('--weight_bits', type=int, default=8)
-  ap.add_argument('--roofline_kernel', default='bn_bwd_apply')
+  ap.add_argument('--roofline_kernel', default='conv1x1_fwd',
+                  help='profiling region whose launches are timed with HIP events: conv1x1_fwd | conv1x1_wrw | '
+                       'conv1x1_bwd_data | bn_bwd_apply | bn_bwd_stats | bn_act_quant_apply | bn_stats')
   ap.add_argument('--no_cpu_baseline', action='store_true')
   ap.add_argument('--cpu_batch', type=int, default=8)
   ap.add_argument('--cpu_steps', type=int, default=2)
   return ap.parse_args()
+
+
+# profiling region -> kernel-name prefix in the rocprofv3 PMC summaries under profiles/
+REGION_KERNELS = {'conv1x1_fwd': 'k_conv1x1_fwd<', 'conv1x1_wrw': 'k_conv1x1_wrw<', 'conv1x1_bwd_data': 'k_conv1x1_fwd<',
+                  'bn_bwd_apply': 'k_bn_bwd_apply<', 'bn_bwd_stats': 'k_bn_bwd_stats', 'bn_act_quant_apply': 'k_bn_apply<',
+                  'bn_stats': 'k_bn_stats'}
+
+
+def pmc_traffic_per_launch(region, tag='r01'):
+  """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes of THIS command
+  (profiles/<tag>_pmc_FETCH_SIZE.csv / _WRITE_SIZE.csv; separate --pmc passes, values in KiB).  Per
+  MI355X_MICROARCH.md (HBM section) FETCH_SIZE counts wide coalesced reads at half their size on gfx950
+  (x2 correction); WRITE_SIZE needs none (calibrated here on k_bn_apply, whose writes are exactly one
+  tensor).  Returns None when the summaries are absent."""
+  import csv
+  prefix = REGION_KERNELS.get(region)
+  if region == 'conv1x1_bwd_data':
+    return None                                   # shares its kernel name with the forward: not separable
+  tot, n = 0.0, 0
+  for counter, mult in (('FETCH_SIZE', 2.0), ('WRITE_SIZE', 1.0)):
+    path = os.path.join(ROOT, 'profiles', '%s_pmc_%s.csv' % (tag, counter))
+    if prefix is None or not os.path.exists(path):
+      return None
+    disp, kib = 0, 0.0
+    with open(path) as f:
+      for r in csv.DictReader(f):
+        if r['kernel'].startswith(prefix) and (region != 'conv1x1_fwd' or 'true>' in r['kernel']):
+          disp += int(r['dispatches'])
+          kib += float(r['mean_' + counter]) * int(r['dispatches'])
+    if disp == 0:
+      return None
+    tot += mult * kib / disp * 1024.0
+  return tot
 
 
 def main():
@@ -112,8 +152,10 @@ def main():
     value = images / dt
     per_gpu = value / world
     ach = (work / (ms * 1e-3)) if ms > 0 else 0.0
-    roofline = {'bound': 'hbm', 'kernel': 'k_' + args.roofline_kernel, 'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9,
-                'unit': 'GB/s', 'frac': ach / HBM_PEAK, 'traffic': None, 'launches': n_launch,
+    roofline = {'bound': 'hbm', 'kernel': REGION_KERNELS.get(args.roofline_kernel, args.roofline_kernel).rstrip('<'),
+                'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9,
+                'unit': 'GB/s', 'frac': ach / HBM_PEAK, 'traffic': pmc_traffic_per_launch(args.roofline_kernel),
+                'algorithmic_bytes_per_launch': (work / n_launch) if n_launch else None, 'launches': n_launch,
                 'avg_launch_ms': (ms / n_launch) if n_launch else None,
                 'step_mfma_frac': per_gpu * R50_FLOPS_PER_IMAGE_STEP_DST / MFMA_BF16_PEAK}
     cpu_baseline = None

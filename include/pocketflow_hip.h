@@ -182,6 +182,12 @@ int pf_bn_bwd_apply(const void* dq, const void* x, void* dx, int dtype, int64_t 
                     const float* scale_shift, const float* mean_invstd,
                     const float* dgamma, const float* dbeta, int act, void* stream);
 /* inference-mode BN + act (teacher forward, eval graphs): y = act(scale*x+shift) */
+/* pf_bn_bwd_apply + the gradient that reaches the same tensor through an identity shortcut:
+ * dx = bn_backward(dq, x) + addend  (replaces the AddN of the two gradient paths TF inserts for a tensor
+ * with two consumers, utils/external/resnet_model.py:257-314 `inputs + shortcut`).  addend may be NULL. */
+int pf_bn_bwd_apply_add(const void* dq, const void* x, const void* addend, void* dx, int dtype,
+                        int64_t rows, int C, const float* scale_shift, const float* mean_invstd,
+                        const float* dgamma, const float* dbeta, int act, void* stream);
 int pf_bn_eval_scale_shift(const float* gamma, const float* beta, const float* moving_mean,
                            const float* moving_var, float eps, int C, float* scale_shift,
                            void* stream);

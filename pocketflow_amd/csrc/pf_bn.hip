@@ -447,7 +447,10 @@ __global__ __launch_bounds__(PF_THREADS) void k_bn_bwd_apply(const T* __restrict
                                                              const float* __restrict__ scale_shift,
                                                              const float* __restrict__ mean_invstd,
                                                              const float* __restrict__ dgamma,
-                                                             const float* __restrict__ dbeta) {
+                                                             const float* __restrict__ dbeta,
+                                                             const T* __restrict__ addend) {
+  // addend (optional): the gradient arriving through the block's identity shortcut, which shares x with
+  // this BN -- dx_total = dx_bn + addend in the same pass (autograd would add them in a separate kernel)
   const float inv_n = 1.0f / (float)rows;
   if (FAST) {
     const int G = C >> 3, RPS = PF_THREADS / G;
@@ -472,6 +475,12 @@ __global__ __launch_bounds__(PF_THREADS) void k_bn_bwd_apply(const T* __restrict
         const float xh = (v[j] - mu[j]) * is[j];
         g[j] = sc[j] * (dy - a[j] - xh * b[j]);
       }
+      if (addend != nullptr) {
+        float ad[8];
+        load8<T>(addend + off, ad);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] += ad[j];
+      }
       store8<T>(dx + off, g);
     }
   } else {
@@ -483,7 +492,9 @@ __global__ __launch_bounds__(PF_THREADS) void k_bn_bwd_apply(const T* __restrict
       const float sc = scale_shift[c];
       const float dy = load_one<T>(dq + e) * act_mask<ACT>(fmaf(sc, v, scale_shift[C + c]));
       const float xh = (v - mean_invstd[c]) * mean_invstd[C + c];
-      store_one<T>(dx + e, sc * (dy - dbeta[c] * inv_n - xh * (dgamma[c] * inv_n)));
+      float o = sc * (dy - dbeta[c] * inv_n - xh * (dgamma[c] * inv_n));
+      if (addend != nullptr) o += load_one<T>(addend + e);
+      store_one<T>(dx + e, o);
     }
   }
 }
@@ -491,13 +502,13 @@ __global__ __launch_bounds__(PF_THREADS) void k_bn_bwd_apply(const T* __restrict
 template <typename T>
 static int launch_bn_bwd_apply(const T* dq, const T* x, T* dx, int64_t rows, int C, const float* ss,
                                const float* mi, const float* dgamma, const float* dbeta, int act,
-                               hipStream_t st) {
-  const bool fast = bn_fast_ok(C) && pf_aligned16(x) && pf_aligned16(dq) && pf_aligned16(dx);
+                               const T* addend, hipStream_t st) {
+  const bool fast = bn_fast_ok(C) && pf_aligned16(x) && pf_aligned16(dq) && pf_aligned16(dx) && pf_aligned16(addend);
   const int grid = fast ? pf_grid_for(rows, (PF_THREADS / (C / 8)) * 2) : pf_grid_for(rows * C, PF_THREADS * 4);
 #define PF_BB(ACTV)                                                                                                    \
   do {                                                                                                                 \
-    if (fast) k_bn_bwd_apply<T, ACTV, true><<<grid, PF_THREADS, 0, st>>>(dq, x, dx, rows, C, ss, mi, dgamma, dbeta);    \
-    else k_bn_bwd_apply<T, ACTV, false><<<grid, PF_THREADS, 0, st>>>(dq, x, dx, rows, C, ss, mi, dgamma, dbeta);        \
+    if (fast) k_bn_bwd_apply<T, ACTV, true><<<grid, PF_THREADS, 0, st>>>(dq, x, dx, rows, C, ss, mi, dgamma, dbeta, addend);    \
+    else k_bn_bwd_apply<T, ACTV, false><<<grid, PF_THREADS, 0, st>>>(dq, x, dx, rows, C, ss, mi, dgamma, dbeta, addend);        \
   } while (0)
   if (act == PF_ACT_RELU) PF_BB(PF_ACT_RELU);
   else if (act == PF_ACT_RELU6) PF_BB(PF_ACT_RELU6);
@@ -507,11 +518,17 @@ static int launch_bn_bwd_apply(const T* dq, const T* x, T* dx, int64_t rows, int
   return 0;
 }
 
+extern "C" int pf_bn_bwd_apply_add(const void* dq, const void* x, const void* addend, void* dx, int dtype,
+                                   int64_t rows, int C, const float* scale_shift, const float* mean_invstd,
+                                   const float* dgamma, const float* dbeta, int act, void* stream) {
+  if (rows <= 0 || C <= 0) return (int)hipErrorInvalidValue;
+  if (dtype == PF_F32) return launch_bn_bwd_apply<float>((const float*)dq, (const float*)x, (float*)dx, rows, C, scale_shift, mean_invstd, dgamma, dbeta, act, (const float*)addend, (hipStream_t)stream);
+  if (dtype == PF_BF16) return launch_bn_bwd_apply<bf16_t>((const bf16_t*)dq, (const bf16_t*)x, (bf16_t*)dx, rows, C, scale_shift, mean_invstd, dgamma, dbeta, act, (const bf16_t*)addend, (hipStream_t)stream);
+  return (int)hipErrorInvalidValue;
+}
+
 extern "C" int pf_bn_bwd_apply(const void* dq, const void* x, void* dx, int dtype, int64_t rows, int C,
                                const float* scale_shift, const float* mean_invstd, const float* dgamma,
                                const float* dbeta, int act, void* stream) {
-  if (rows <= 0 || C <= 0) return (int)hipErrorInvalidValue;
-  if (dtype == PF_F32) return launch_bn_bwd_apply<float>((const float*)dq, (const float*)x, (float*)dx, rows, C, scale_shift, mean_invstd, dgamma, dbeta, act, (hipStream_t)stream);
-  if (dtype == PF_BF16) return launch_bn_bwd_apply<bf16_t>((const bf16_t*)dq, (const bf16_t*)x, (bf16_t*)dx, rows, C, scale_shift, mean_invstd, dgamma, dbeta, act, (hipStream_t)stream);
-  return (int)hipErrorInvalidValue;
+  return pf_bn_bwd_apply_add(dq, x, nullptr, dx, dtype, rows, C, scale_shift, mean_invstd, dgamma, dbeta, act, stream);
 }

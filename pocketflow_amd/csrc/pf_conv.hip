@@ -30,14 +30,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define CV_BM 128
 #define CV_BK 64
 #define CV_LDK (CV_BK + 8)
+#define CV_MAXK 2048     // largest input-channel count the prologue can stage in LDS
 
-// bf16 packing without the NaN branch of f32_to_bf16 (activations / gradients are finite; an Inf
-// stays an Inf, a NaN stays a NaN because the mantissa carry cannot clear all mantissa bits of 0x7FC0)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
-  uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
-  ua += 0x7FFFu + ((ua >> 16) & 1u);
-  ub += 0x7FFFu + ((ub >> 16) & 1u);
-  return (ua >> 16) | (ub & 0xFFFF0000u);
+  // one v_cvt_pk_bf16_f32 (round-to-nearest-even, same as f32_to_bf16)
+  const f32x2_t v = {a, b};
+  const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+  return *reinterpret_cast<const uint32_t*>(&r);
 }
 __device__ __forceinline__ void unpack8(const uint4& v, float* o) {
   o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xFFFF0000u);
@@ -114,7 +115,9 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a)
   constexpr int SM_BYTES_AB = (A_EL + B_EL) * 2;
   constexpr int SM_BYTES = SM_BYTES_AB > RED_FL * 4 ? (SM_BYTES_AB > C_EL * 2 ? SM_BYTES_AB : C_EL * 2)
                                                     : RED_FL * 4;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SM_BYTES];
+  constexpr int SS_BYTES = PRO ? 2 * CV_MAXK * 4 : 0;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SM_BYTES + SS_BYTES];
+  float* ssl = reinterpret_cast<float*>(smem + SM_BYTES);     // prologue scale | shift (PRO only)
   bf16_t* As = reinterpret_cast<bf16_t*>(smem);
   bf16_t* Bs = As + A_EL;
   bf16_t* Cs = reinterpret_cast<bf16_t*>(smem);
@@ -143,25 +146,32 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a)
   }
 
   f32x4 acc[4][JM];
-  uint4 ra[4], rb[NBV];
-  int64_t arow[4];                                  // input row of each staged vector (or -1)
+  // input tiles are prefetched TWO k-steps ahead in two register sets (ra0 / ra1, used alternately): with
+  // ~2 workgroups per CU one 16 KiB tile in flight per workgroup covers only half of the bandwidth-latency
+  // product of this chip's HBM; the (L2-resident) weight tile stays one step ahead
+  uint4 ra0[4], ra1[4], rb[NBV];
+  uint32_t av0 = 0, av1 = 0;                        // validity bits of the staged vectors
 
-  auto gload = [&](int it) {
+  auto gloadA = [&](int it, uint4 (&ra)[4], uint32_t& av) {
     const int ti = it / nk, ks = it - ti * nk;
     const int m0 = (g + ti * a.G) * CV_BM;
     const int k = ks * CV_BK + kp * 8;
+    av = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + lrow + i * 32;
       uint4 v = make_uint4(0, 0, 0, 0);
-      arow[i] = -1;
       if (m < a.M && k < a.K) {
         const int64_t r = a.ymap ? (int64_t)m : map_row(a, m);
-        arow[i] = r;
+        av |= 1u << i;
         v = *reinterpret_cast<const uint4*>(a.X + r * a.K + k);
       }
       ra[i] = v;
     }
+  };
+  auto gloadB = [&](int it) {
+    const int ti = it / nk, ks = it - ti * nk;
+    const int k = ks * CV_BK + kp * 8;
 #pragma unroll
     for (int i = 0; i < NBV; ++i) {
       const int n = n0 + lrow + i * 32;
@@ -169,18 +179,24 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a)
       if (n < a.N && k < a.K) v = *reinterpret_cast<const uint4*>(a.W + (int64_t)n * a.K + k);
       rb[i] = v;
     }
+  };
+  auto sstore = [&](int it, const uint4 (&ra)[4], uint32_t av) {
     if (PRO) {
+      const int ti = it / nk, ks = it - ti * nk;
+      const int k = ks * CV_BK + kp * 8;
       if (k < a.K) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { pro.sc[j] = a.ss[k + j]; pro.sh[j] = a.ss[a.K + k + j]; }
+        const float4 s0 = *reinterpret_cast<const float4*>(ssl + k), s1 = *reinterpret_cast<const float4*>(ssl + k + 4);
+        const float4 h0 = *reinterpret_cast<const float4*>(ssl + a.K + k), h1 = *reinterpret_cast<const float4*>(ssl + a.K + k + 4);
+        pro.sc[0] = s0.x; pro.sc[1] = s0.y; pro.sc[2] = s0.z; pro.sc[3] = s0.w;
+        pro.sc[4] = s1.x; pro.sc[5] = s1.y; pro.sc[6] = s1.z; pro.sc[7] = s1.w;
+        pro.sh[0] = h0.x; pro.sh[1] = h0.y; pro.sh[2] = h0.z; pro.sh[3] = h0.w;
+        pro.sh[4] = h1.x; pro.sh[5] = h1.y; pro.sh[6] = h1.z; pro.sh[7] = h1.w;
       }
     }
-  };
-  auto sstore = [&]() {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       uint4 v = ra[i];
-      if (PRO) v = (arow[i] >= 0) ? pro_apply(pro, v) : make_uint4(0, 0, 0, 0);
+      if (PRO) v = ((av >> i) & 1u) ? pro_apply(pro, v) : make_uint4(0, 0, 0, 0);
       *reinterpret_cast<uint4*>(As + (lrow + i * 32) * CV_LDK + kp * 8) = v;
     }
 #pragma unroll
@@ -194,8 +210,14 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a)
   for (int j = 0; j < 8; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; st_mn[j] = INFINITY; st_mx[j] = -INFINITY; }
   const int wvec = tid % VPR, wrow = tid / VPR;
 
-  if (total > 0) gload(0);
-  for (int it = 0; it < total; ++it) {
+  if (PRO) {                                        // scale | shift of all K input channels, once per workgroup
+    for (int i = tid; i < 2 * a.K; i += PF_THREADS) ssl[i] = a.ss[i];
+  }
+  if (total > 0) { gloadA(0, ra0, av0); gloadB(0); }
+  if (total > 1) gloadA(1, ra1, av1);
+  if (PRO) __syncthreads();
+
+  auto body = [&](int it, uint4 (&ra)[4], uint32_t& av) {
     const int ti = it / nk, ks = it - ti * nk;
     if (ks == 0) {
 #pragma unroll
@@ -203,9 +225,10 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a)
 #pragma unroll
         for (int j = 0; j < JM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    sstore();
+    sstore(it, ra, av);
     __syncthreads();
-    if (it + 1 < total) gload(it + 1);
+    if (it + 2 < total) gloadA(it + 2, ra, av);
+    if (it + 1 < total) gloadB(it + 1);
 #pragma unroll
     for (int kk = 0; kk < CV_BK / 32; ++kk) {
       bf16x8 wf[4], xf[JM];
@@ -222,7 +245,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
-    if (ks != nk - 1) continue;
+    if (ks != nk - 1) return;
 
     // ---- epilogue of one [128][BN_T] tile ---------------------------------------------------------
     // accumulators: D row = channel (lane >> 4) * 4 + r of block i, D col = pixel (lane & 15) of block j
@@ -280,6 +303,11 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a)
       }
     }
     __syncthreads();
+  };
+
+  for (int it = 0; it < total; it += 2) {
+    body(it, ra0, av0);
+    if (it + 1 < total) body(it + 1, ra1, av1);
   }
 
   // ---- per-workgroup statistics -> partial[g][4][N] (fixed order: deterministic) ------------------
@@ -330,6 +358,7 @@ extern "C" int pf_conv1x1_fwd(const void* X, const void* W, void* Y, const void*
   if (!pf_aligned16(X) || !pf_aligned16(W) || !pf_aligned16(Y) || (R && !pf_aligned16(R)))
     return (int)hipErrorInvalidValue;
   if (slot != nullptr && (bits < 1 || bits > 32 || scale_shift == nullptr)) return (int)hipErrorInvalidValue;
+  if (scale_shift != nullptr && K > CV_MAXK) return (int)hipErrorInvalidValue;
   if (stride < 1 || (stride > 1 && (Ho <= 0 || Wo <= 0 || H <= 0 || Wd <= 0))) return (int)hipErrorInvalidValue;
   ConvArgs a;
   a.X = (const bf16_t*)X; a.W = (const bf16_t*)W; a.Y = (bf16_t*)Y; a.R = (const bf16_t*)R;

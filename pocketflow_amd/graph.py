@@ -541,21 +541,31 @@ class _BnLazy(torch.autograd.Function):
                     slot if bits is not None else None)
     ctx.save_for_backward(x, scale_shift, mean_invstd)
     ctx.meta = (layer.act, graph, rows, C)
+    ctx.set_materialize_grads(False)          # an unused shortcut alias must arrive as None, not as a zeros tensor
     box.append(scale_shift)
-    return x.view_as(x)
+    # two aliases of x: the first stands for q (consumed by the fused convolutions), the second is x
+    # itself for the block's identity shortcut -- routing the shortcut through this node lets the
+    # backward add its gradient inside pf_bn_bwd_apply_add instead of a separate accumulation kernel
+    return x.view_as(x), x.view_as(x)
 
   @staticmethod
-  def backward(ctx, dq):
+  def backward(ctx, dq, dskip):
     x, scale_shift, mean_invstd = ctx.saved_tensors
     act, graph, rows, C = ctx.meta
-    dx, dgamma, dbeta = _bn_backward(dq, x, scale_shift, mean_invstd, act, graph, rows, C)
+    if dq is None:
+      return dskip, None, None, None, None, None, None, None, None
+    dx, dgamma, dbeta = _bn_backward(dq, x, scale_shift, mean_invstd, act, graph, rows, C, addend=dskip)
     return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
-def _bn_backward(dq, x, scale_shift, mean_invstd, act, graph, rows, C):
+def _bn_backward(dq, x, scale_shift, mean_invstd, act, graph, rows, C, addend=None):
   dq = _nhwc(dq)
   if dq.dtype != x.dtype:
     dq = dq.to(x.dtype)
+  if addend is not None:
+    addend = _nhwc(addend)
+    if addend.dtype != x.dtype:
+      addend = addend.to(x.dtype)
   nblk = _bn_blocks(rows, C)
   partial = graph.scratch(nblk * 2 * C)
   nbytes = float(x.numel() * x.element_size())
@@ -565,8 +575,8 @@ def _bn_backward(dq, x, scale_shift, mean_invstd, act, graph, rows, C):
   dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
   hip.bn_bwd_finalize(partial, nblk, C, dgamma, dbeta)
   dx = torch.empty_like(x)
-  with region('bn_bwd_apply', 3 * nbytes):         # reads dq and x, writes dx
-    hip.bn_bwd_apply(dq, x, dx, rows, C, scale_shift, mean_invstd, dgamma, dbeta, act)
+  with region('bn_bwd_apply', (4 if addend is not None else 3) * nbytes):   # reads dq, x [, addend], writes dx
+    hip.bn_bwd_apply(dq, x, dx, rows, C, scale_shift, mean_invstd, dgamma, dbeta, act, addend)
   return dx, dgamma, dbeta
 
 
@@ -850,8 +860,9 @@ class BatchNormAct:
       stats = getattr(x, '_pf_stats', None)      # left by the fused convolution that produced x
       if lazy:
         box = []
-        alias = _BnLazy.apply(_nhwc(x), self.gamma.tensor, self.beta.tensor, self, g, slot, bits, box, stats)
-        return LazyAct(alias, box[0], self.act, slot, bits, x.numel() // self.C, self.C)
+        alias, skip = _BnLazy.apply(_nhwc(x), self.gamma.tensor, self.beta.tensor, self, g, slot, bits, box, stats)
+        lazy_out = LazyAct(alias, box[0], self.act, slot, bits, x.numel() // self.C, self.C)
+        return (lazy_out, skip) if getattr(self, '_want_skip', False) else lazy_out
       return _BnActQuant.apply(x, self.gamma.tensor, self.beta.tensor, self, g, True, slot, bits, stats)
     x = _nhwc(x)
     C = self.C
@@ -893,9 +904,16 @@ BatchNormAct._eval_scale_shift = _bn_eval_scale_shift
 _bn_call = BatchNormAct.__call__
 
 
-def _bn_call_tagged(self, x):
+def _bn_call_tagged(self, x, with_skip: bool = False):
+  """`with_skip`: also return x for the block's identity shortcut (see _BnLazy)."""
+  self._want_skip = with_skip
   y = _bn_call(self, x)
-  return _pass_tag(x, y) if (self.graph.taps is not None and isinstance(y, torch.Tensor)) else y
+  skip = x
+  if isinstance(y, tuple):
+    y, skip = y
+  if self.graph.taps is not None and isinstance(y, torch.Tensor):
+    y = _pass_tag(x, y)
+  return (y, skip) if with_skip else y
 
 
 BatchNormAct.__call__ = _bn_call_tagged

@@ -39,7 +39,7 @@ SYMBOLS = [
     'pf_seg_nuq_codebook_grad', 'pf_seg_normalize', 'pf_ws_bkup_merge_abs', 'pf_kth_largest_nonneg',
     'pf_ws_mask_apply', 'pf_count_nonzero', 'pf_cp_build_mask', 'pf_cp_mask_grad', 'pf_adam_flat',
     'pf_momentum_flat', 'pf_ce_distill_fwd_bwd', 'pf_bn_stats', 'pf_bn_finalize',
-    'pf_bn_act_quant_apply', 'pf_bn_bwd_stats', 'pf_bn_bwd_finalize', 'pf_bn_bwd_apply',
+    'pf_bn_act_quant_apply', 'pf_bn_bwd_stats', 'pf_bn_bwd_finalize', 'pf_bn_bwd_apply', 'pf_bn_bwd_apply_add',
     'pf_bn_eval_scale_shift', 'pf_gemm_bf16_nt', 'pf_gemm_bf16_nn', 'pf_gemm_bf16_tn',
     'pf_conv1x1_stats_groups', 'pf_conv1x1_fwd', 'pf_conv1x1_wrw_splits', 'pf_conv1x1_wrw',
 ]
@@ -268,10 +268,10 @@ def bn_bwd_finalize(partial, n_blocks, C, dgamma, dbeta) -> None:
          'pf_bn_bwd_finalize')
 
 
-def bn_bwd_apply(dq, x, dx, rows, C, scale_shift, mean_invstd, dgamma, dbeta, act) -> None:
-  _check(_lib.pf_bn_bwd_apply(_ptr(dq), _ptr(x), _ptr(dx), c_int(dtype_code(x)), c_int64(rows), c_int(C),
-                              _ptr(scale_shift), _ptr(mean_invstd), _ptr(dgamma), _ptr(dbeta),
-                              c_int(ACT_CODES[act]), _stream()), 'pf_bn_bwd_apply')
+def bn_bwd_apply(dq, x, dx, rows, C, scale_shift, mean_invstd, dgamma, dbeta, act, addend=None) -> None:
+  _check(_lib.pf_bn_bwd_apply_add(_ptr(dq), _ptr(x), _ptr(addend), _ptr(dx), c_int(dtype_code(x)), c_int64(rows),
+                                  c_int(C), _ptr(scale_shift), _ptr(mean_invstd), _ptr(dgamma), _ptr(dbeta),
+                                  c_int(ACT_CODES[act]), _stream()), 'pf_bn_bwd_apply_add')
 
 
 def bn_eval_scale_shift(gamma, beta, moving_mean, moving_var, eps: float, scale_shift) -> None:

@@ -101,6 +101,12 @@ def compute_pruned_kernel(X, W2, Y, c_new, rng, alpha=1e-4, tolerance=0.02, quad
       if alpha < 1e-10:
         break
       alpha = (left + right) / 2
+  if not np.any(idxs):
+    # degenerate LASSO (every coefficient shrunk to zero: tiny sample or dead layer).  The reference would
+    # crash in LinearRegression; keep the c_new channels with the largest kernel magnitude instead.
+    order = np.argsort(-np.abs(W2).sum((0, 1, 3)))
+    idxs = np.zeros(c_in, bool)
+    idxs[order[:max(int(c_new), 1)]] = True
   reg = LinearRegression(n_jobs=-1, copy_X=True, fit_intercept=False)
   reg.fit(X[:, :, :, idxs].reshape((nb_samples, -1)), Y)
   return idxs, reg.coef_

@@ -138,7 +138,7 @@ def test_conv1x1_wrw_strided(hip):
   torch.testing.assert_close(dW, ref, rtol=1e-3, atol=2e-2)
 
 
-def _r50_learner(tmp_path, fuse, tag, a_bits=8):
+def _r50_learner(tmp_path, fuse, tag, a_bits=8, dtype='bfloat16'):
   from pocketflow_amd.flags import FLAGS
   import pocketflow_amd.learners.learner_utils  # noqa: F401
   import pocketflow_amd.learners.abstract_learner  # noqa: F401
@@ -152,8 +152,8 @@ def _r50_learner(tmp_path, fuse, tag, a_bits=8):
   FLAGS.save_path_dst = str(d / 'models_dst' / 'model.ckpt')
   FLAGS.uql_save_quant_model_path = str(d / 'uql' / 'm.ckpt')
   FLAGS.synthetic_pool = 2
-  FLAGS.compute_dtype = 'bfloat16'
-  FLAGS.resnet_size, FLAGS.nb_classes, FLAGS.image_size, FLAGS.batch_size = 50, 1001, 64, 8
+  FLAGS.compute_dtype = dtype
+  FLAGS.resnet_size, FLAGS.nb_classes, FLAGS.image_size, FLAGS.batch_size = 50, 1001, 96, 16
   FLAGS.uql_weight_bits, FLAGS.uql_activation_bits = 8, a_bits
   FLAGS.enbl_dst, FLAGS.dst_eval_teacher = True, False
   FLAGS.fuse_conv1x1 = fuse
@@ -162,39 +162,45 @@ def _r50_learner(tmp_path, fuse, tag, a_bits=8):
   return UniformQuantLearner(None, mh)
 
 
-@pytest.mark.parametrize('a_bits,cos_min', [(32, 0.999), (8, 0.95)])
-def test_fused_path_matches_unfused_learner_step(tmp_path, a_bits, cos_min):
-  """ResNet-50 (bottleneck blocks, strided projections) UQ w8/a8 + distillation, bf16: one step with the
-  BN/act/quant prologue + residual/statistics epilogue fused into the 1x1 convolutions vs the same step
-  with every activation materialised (pf_bn_* kernels + MIOpen).  Both are bf16 computations with
-  different accumulation orders, so the comparison is statistical: tight with 32-bit activation "quantisers"
-  (continuous), looser with 8-bit ones (a step function of bf16 noise, see tests/test_parity_gpu.py)."""
-  outs = {}
-  for fuse in (False, True):
-    lrn = _r50_learner(tmp_path, fuse, 'fuse%d' % int(fuse), a_bits)
-    st = lrn.graph.store
-    # one forward/backward without the optimiser step: compare loss and raw gradients
-    g = lrn.graph
-    images, labels = lrn.iter_train.get_next()
-    x, y = lrn.to_device(images, labels)
-    g.begin_step()
-    lrn.uni_quant.quantize_weights()
-    with g.as_default():
-      logits_dst = lrn.helper_dst.calc_logits(None, x)
-      logits = lrn.forward_train(x)
-      loss, _ = lrn.calc_loss(y, logits, lrn.trainable_vars)
-      loss = loss + lrn.helper_dst.calc_loss(logits, logits_dst)
-    loss.backward()
-    outs[fuse] = (float(loss.detach()), logits.detach().float().clone(), logits_dst.float().clone(),
-                  st.w_grad.float().clone(), st.o_grad.float().clone(), st.state.clone())
-    assert np.isfinite(outs[fuse][0])
-  l0, z0, t0, gw0, go0, s0 = outs[False]
-  l1, z1, t1, gw1, go1, s1 = outs[True]
-  assert abs(l0 - l1) <= 2e-2 * max(1.0, abs(l0)), (l0, l1)
+def _one_fwd_bwd(lrn):
+  st, g = lrn.graph.store, lrn.graph
+  images, labels = lrn.iter_train.get_next()
+  x, y = lrn.to_device(images, labels)
+  g.begin_step()
+  lrn.uni_quant.quantize_weights()
+  with g.as_default():
+    logits_dst = lrn.helper_dst.calc_logits(None, x)
+    logits = lrn.forward_train(x)
+    loss, _ = lrn.calc_loss(y, logits, lrn.trainable_vars)
+    loss = loss + lrn.helper_dst.calc_loss(logits, logits_dst)
+  loss.backward()
+  return dict(loss=float(loss.detach()), student=logits.detach().float().flatten().clone(),
+              teacher=logits_dst.float().flatten().clone(), kernel_grads=st.w_grad.float().clone(),
+              bn_grads=st.o_grad.float().clone(), bn_state=st.state.clone())
+
+
+@pytest.mark.parametrize('a_bits', [32, 8])
+def test_fused_path_is_as_accurate_as_unfused(tmp_path, a_bits):
+  """ResNet-50 (bottleneck blocks, strided projections) UQ w8 + distillation: one forward/backward in
+  float32 (the parity-checked mode, MIOpen convolutions) is the ground truth; the bf16 run with every
+  activation materialised (pf_bn_* + MIOpen) and the bf16 run with the BN/act/quant prologue and the
+  residual/statistics epilogue fused into the 1x1 convolutions (pf_conv.hip) must agree with it EQUALLY
+  well.  A deep randomly initialised BN network amplifies bf16 rounding noise layer by layer, so neither
+  bf16 run reproduces the float32 gradients closely -- what is asserted is that fusion adds no error."""
+  ref = _one_fwd_bwd(_r50_learner(tmp_path, False, 'fp32', a_bits, 'float32'))
+  unf = _one_fwd_bwd(_r50_learner(tmp_path, False, 'bf16u', a_bits))
+  fus = _one_fwd_bwd(_r50_learner(tmp_path, True, 'bf16f', a_bits))
   cos = lambda a, b: float(torch.dot(a.flatten(), b.flatten()) / (a.norm() * b.norm() + 1e-30))
-  assert cos(t0, t1) > 0.999, 'teacher logits'
-  assert cos(z0, z1) > cos_min, ('student logits', cos(z0, z1))
-  assert cos(gw0, gw1) > min(cos_min, 0.99) - 0.04, ('kernel gradients', cos(gw0, gw1))
-  assert cos(go0, go1) > min(cos_min, 0.99) - 0.04, ('BN gradients', cos(go0, go1))
-  assert cos(s0, s1) > 0.999, 'BN moving statistics'
-  assert 0.5 < float(gw1.norm() / gw0.norm()) < 2.0
+  report = {}
+  for k in ('teacher', 'student', 'kernel_grads', 'bn_grads', 'bn_state'):
+    report[k] = (round(cos(unf[k], ref[k]), 4), round(cos(fus[k], ref[k]), 4))
+  report['loss'] = (ref['loss'], unf['loss'], fus['loss'])
+  report['grad_norm'] = (float(ref['kernel_grads'].norm()), float(unf['kernel_grads'].norm()),
+                         float(fus['kernel_grads'].norm()))
+  print('a_bits=%d (cos vs float32: unfused, fused): %s' % (a_bits, report))
+  assert np.isfinite(fus['loss']) and abs(fus['loss'] - ref['loss']) <= 2e-2 * abs(ref['loss']), report
+  assert report['teacher'][1] > 0.999 and report['bn_state'][1] > 0.999, report
+  for k in ('student', 'kernel_grads', 'bn_grads'):
+    u, f = report[k]
+    assert f >= u - 0.05, (k, report)
+  assert 0.7 < report['grad_norm'][2] / report['grad_norm'][0] < 1.4, report

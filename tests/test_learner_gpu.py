@@ -120,12 +120,12 @@ def test_channel_pruned_mobilenet_uniform(tmp_path):
   from pocketflow_amd.nets.mobilenet_at_ilsvrc12 import ModelHelper
   from pocketflow_amd.learners.channel_pruning.learner import ChannelPrunedLearner
   from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
-  FLAGS = _setup(tmp_path, batch_size=8, batch_size_eval=8, image_size=64, nb_classes=17, mobilenet_depth_mult=0.25,
-                 cp_prune_option='uniform', cp_uniform_preserve_ratio=0.5, cp_nb_batches=4, cp_nb_points_per_layer=10,
+  FLAGS = _setup(tmp_path, batch_size=16, batch_size_eval=16, image_size=64, nb_classes=17, mobilenet_depth_mult=0.5,
+                 cp_prune_option='uniform', cp_uniform_preserve_ratio=0.5, cp_nb_batches=8, cp_nb_points_per_layer=10,
                  cp_channel_pruned_path=str(tmp_path / 'models' / 'pruned_model.ckpt'),
                  cp_best_path=str(tmp_path / 'models' / 'best_model.ckpt'),
                  cp_original_path=str(tmp_path / 'models' / 'original_model.ckpt'),
-                 nb_eval_batches_override=2, nb_iters_override=3, summ_step=2, synthetic_pool=4)
+                 nb_eval_batches_override=2, nb_iters_override=3, summ_step=2, synthetic_pool=8)
   mh = ModelHelper()
   create_synthetic_checkpoint(mh)
   learner = ChannelPrunedLearner(None, mh)
