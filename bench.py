@@ -102,7 +102,13 @@ def main():
   from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
   from pocketflow_amd.utils.multi_gpu_wrapper import MultiGpuWrapper as mgw
 
-  tmp = tempfile.mkdtemp(prefix='pf_bench_r%d_' % rank)
+  # one scratch directory for ALL ranks (rank 0 writes the synthetic "pre-trained" checkpoint and the teacher's
+  # renamed copy, the other ranks restore from them after a barrier -- exactly the reference's file-based hand-off)
+  if world > 1:
+    tag = '%s_%s' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'run'))
+    tmp = os.path.join(tempfile.gettempdir(), 'pf_bench_' + ''.join(c if c.isalnum() else '_' for c in tag))
+  else:
+    tmp = tempfile.mkdtemp(prefix='pf_bench_')
   FLAGS.enbl_multi_gpu = world > 1
   FLAGS.resnet_size = args.resnet_size
   FLAGS.nb_classes = 1001
@@ -119,10 +125,17 @@ def main():
   FLAGS.uql_save_quant_model_path = os.path.join(tmp, 'uql', 'model.ckpt')
   if world > 1:
     mgw.init()
+    if rank == 0:
+      shutil.rmtree(tmp, ignore_errors=True)
+      os.makedirs(tmp, exist_ok=True)
+    dist.barrier()
   torch.backends.cudnn.benchmark = True
 
   mh = ModelHelper()
-  create_synthetic_checkpoint(mh)
+  if rank == 0:
+    create_synthetic_checkpoint(mh)
+  if world > 1:
+    dist.barrier()
   learner = UniformQuantLearner(None, mh)
   if world > 1:
     learner.ops['bcast']()
@@ -179,7 +192,10 @@ def main():
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world},
         'roofline': roofline, 'cpu_baseline': cpu_baseline}
     print(json.dumps(line))
-  shutil.rmtree(tmp, ignore_errors=True)
+  if world > 1:
+    dist.barrier()
+  if rank == 0:
+    shutil.rmtree(tmp, ignore_errors=True)
   if world > 1:
     dist.destroy_process_group()
 

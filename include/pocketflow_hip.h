@@ -234,6 +234,14 @@ int pf_conv1x1_stats_groups(int M, int N);
 int pf_conv1x1_fwd(const void* X, const void* W, void* Y, const void* R, const float* scale_shift,
                    int act, const uint32_t* slot, int bits, float* partial, int M, int N, int K,
                    int Ho, int Wo, int H, int Wd, int stride, int ymap, void* stream);
+/* backward-data of a stride-1 1x1 convolution, dQ[M][K] = dY[M][N] * W[N][K] (Wt = transposed kernel [K][N]),
+ * with the statistics pass of the BN backward of the layer that produced Q fused into the epilogue
+ * (replaces FusedBatchNormGrad's reduction over dy, utils/external/resnet_model.py:55-62):
+ * partial[G][2][K] = {sum dy, sum dy*xhat}, dy = dQ * act'(scale*x+shift), G = pf_conv1x1_stats_groups(M, K),
+ * in the layout pf_bn_bwd_finalize consumes.                                                              */
+int pf_conv1x1_bwd_data_bnstats(const void* dY, const void* Wt, void* dQ, const void* bn_x,
+                                const float* bn_scale_shift, const float* bn_mean_invstd, int bn_act,
+                                float* partial, int M, int N, int K, void* stream);
 int pf_conv1x1_wrw_splits(int M, int N, int K);
 int pf_conv1x1_wrw(const void* dY, const void* X, void* dW, int dw_dtype, float* workspace,
                    const float* scale_shift, int act, const uint32_t* slot, int bits, int M, int N,

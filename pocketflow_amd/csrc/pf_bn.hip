@@ -144,7 +144,7 @@ extern "C" int pf_bn_stats(const void* x, int dtype, int64_t rows, int C, float*
 
 // ---------------------------------------------------------------------------------------------
 // finalize: 64 channels per block; thread (cl = t & 63, part = t >> 6) sums partial blocks
-// part, part+4, ... in a fixed order, then 4-way LDS combine.  Deterministic.
+// part, part+16, ... in a fixed order, then a 16-way LDS combine.  Deterministic.
 // ---------------------------------------------------------------------------------------------
 template <int ACT>
 __device__ __forceinline__ void y_range(float scale, float shift, float xmin, float xmax, float& ymin,
@@ -154,18 +154,20 @@ __device__ __forceinline__ void y_range(float scale, float shift, float xmin, fl
   ymax = apply_act<ACT>(fmaxf(a, b));
 }
 
-__global__ __launch_bounds__(PF_THREADS) void k_bn_finalize(
+#define BN_FIN_P 16                      // row-partial groups per channel (1024 threads: 16 x 64 channels)
+#define BN_FIN_T (BN_FIN_P * 64)
+__global__ __launch_bounds__(BN_FIN_T) void k_bn_finalize(
     const float* __restrict__ partial, int n_blocks, int64_t rows, int C, const void* __restrict__ x_row0,
     int dtype, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ moving_mean, float* __restrict__ moving_var, float momentum, float eps,
     int training, int act, float* __restrict__ scale_shift, float* __restrict__ mean_invstd,
     uint32_t* __restrict__ slot) {
-  __shared__ float l_s[4][64], l_ss[4][64], l_mn[4][64], l_mx[4][64];
+  __shared__ float l_s[BN_FIN_P][64], l_ss[BN_FIN_P][64], l_mn[BN_FIN_P][64], l_mx[BN_FIN_P][64];
   const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   float s = 0.f, ss = 0.f, mn = INFINITY, mx = -INFINITY;
   if (c < C) {
-    for (int b = part; b < n_blocks; b += 4) {
+    for (int b = part; b < n_blocks; b += BN_FIN_P) {
       const float* p = partial + (int64_t)b * 4 * C;
       s += p[c]; ss += p[C + c];
       mn = fminf(mn, p[2 * C + c]); mx = fmaxf(mx, p[3 * C + c]);
@@ -175,10 +177,12 @@ __global__ __launch_bounds__(PF_THREADS) void k_bn_finalize(
   __syncthreads();
   float ymin = INFINITY, ymax = -INFINITY;
   if (part == 0 && c < C) {
-    s = (l_s[0][cl] + l_s[1][cl]) + (l_s[2][cl] + l_s[3][cl]);
-    ss = (l_ss[0][cl] + l_ss[1][cl]) + (l_ss[2][cl] + l_ss[3][cl]);
-    mn = fminf(fminf(l_mn[0][cl], l_mn[1][cl]), fminf(l_mn[2][cl], l_mn[3][cl]));
-    mx = fmaxf(fmaxf(l_mx[0][cl], l_mx[1][cl]), fmaxf(l_mx[2][cl], l_mx[3][cl]));
+    s = l_s[0][cl]; ss = l_ss[0][cl]; mn = l_mn[0][cl]; mx = l_mx[0][cl];
+#pragma unroll
+    for (int p = 1; p < BN_FIN_P; ++p) {                 // fixed order: deterministic
+      s += l_s[p][cl]; ss += l_ss[p][cl];
+      mn = fminf(mn, l_mn[p][cl]); mx = fmaxf(mx, l_mx[p][cl]);
+    }
     float mean, var;
     if (training) {
       const float piv = (dtype == PF_F32) ? ((const float*)x_row0)[c] : bf16_to_f32(((const bf16_t*)x_row0)[c]);
@@ -225,7 +229,7 @@ extern "C" int pf_bn_finalize(const float* partial, int n_blocks, int64_t rows, 
                               int training, int act, float* scale_shift, float* mean_invstd,
                               uint32_t* slot, void* stream) {
   if (C <= 0) return (int)hipErrorInvalidValue;
-  k_bn_finalize<<<(C + 63) / 64, PF_THREADS, 0, (hipStream_t)stream>>>(
+  k_bn_finalize<<<(C + 63) / 64, BN_FIN_T, 0, (hipStream_t)stream>>>(
       partial, n_blocks, rows, C, x_row0, dtype, gamma, beta, moving_mean, moving_var, momentum, eps,
       training, act, scale_shift, mean_invstd, slot);
   PF_LAUNCH_CHECK();

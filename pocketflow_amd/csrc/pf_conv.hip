@@ -67,6 +67,12 @@ struct ConvArgs {
   int Ho, Wo, H, Wd, stride;
   int ymap;             // fwd as backward-data of a strided conv: map the OUTPUT rows instead of the input rows
   int rows_per_split;   // wrw
+  // backward-data with the BN-backward statistics of the consumer of dQ in the epilogue (bx != null):
+  // partial[g][2][N] = per-channel {sum dy, sum dy * xhat}, dy = dq * act'(scale*x+shift), xhat = (x-mean)*invstd
+  const bf16_t* bx;     // the BN's input x, [M][N]
+  const float* bss;     // its scale | shift   [2][N]
+  const float* bmi;     // its mean | invstd   [2][N]
+  float b_lo, b_hi;     // activation window of the mask: lo < u < hi  (ReLU: 0, +inf; ReLU6: 0, 6)
 };
 
 __device__ __forceinline__ int64_t map_row(const ConvArgs& a, int m) {
@@ -101,7 +107,7 @@ __device__ __forceinline__ uint4 pro_apply(const Pro& p, const uint4& v) {
 // ---------------------------------------------------------------------------------------------
 // forward:  Y[m][n] = sum_k Q(X)[row(m)][k] * W[n][k]  (+ R[m][n]),  optional per-channel stats
 // ---------------------------------------------------------------------------------------------
-template <int BN_T, bool PRO>
+template <int BN_T, bool PRO, bool BWD>
 __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a) {
   constexpr int WM = (BN_T == 128) ? 64 : 32;       // pixel rows per wavefront
   constexpr int JM = WM / 16;
@@ -118,6 +124,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a)
   constexpr int SS_BYTES = PRO ? 2 * CV_MAXK * 4 : 0;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SM_BYTES + SS_BYTES];
   float* ssl = reinterpret_cast<float*>(smem + SM_BYTES);     // prologue scale | shift (PRO only)
+  __shared__ float bpl[BWD ? 4 * BN_T : 4];                            // bwd-stats mode: scale | shift | mean | invstd of this column tile
   bf16_t* As = reinterpret_cast<bf16_t*>(smem);
   bf16_t* Bs = As + A_EL;
   bf16_t* Cs = reinterpret_cast<bf16_t*>(smem);
@@ -213,9 +220,18 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a)
   if (PRO) {                                        // scale | shift of all K input channels, once per workgroup
     for (int i = tid; i < 2 * a.K; i += PF_THREADS) ssl[i] = a.ss[i];
   }
+  constexpr bool bwd_stats = BWD;                    // backward-data + BN-backward statistics (PRO == false)
+  if (bwd_stats) {
+    for (int i = tid; i < 4 * BN_T; i += PF_THREADS) {
+      const int q = i / BN_T, c = n0 + (i - q * BN_T);
+      float v = 0.f;
+      if (c < a.N) v = (q < 2) ? a.bss[q * a.N + c] : a.bmi[(q - 2) * a.N + c];
+      bpl[i] = v;
+    }
+  }
   if (total > 0) { gloadA(0, ra0, av0); gloadB(0); }
   if (total > 1) gloadA(1, ra1, av1);
-  if (PRO) __syncthreads();
+  if (PRO || bwd_stats) __syncthreads();
 
   auto body = [&](int it, uint4 (&ra)[4], uint32_t& av) {
     const int ti = it / nk, ks = it - ti * nk;
@@ -259,14 +275,15 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a)
     // residual vectors of this thread's 8 (or 4) output rows: all loads in flight before the LDS hand-off
     const int m0 = (g + ti * a.G) * CV_BM;
     uint4 rres[CV_BM / RPP];
-    if (a.R != nullptr) {
+    const bf16_t* __restrict__ side = bwd_stats ? a.bx : a.R;   // second [M][N] operand of the epilogue
+    if (side != nullptr) {
 #pragma unroll
       for (int p = 0; p < CV_BM / RPP; ++p) {
         const int m = m0 + wrow + p * RPP, n = n0 + wvec * 8;
         rres[p] = make_uint4(0, 0, 0, 0);
         if (m < a.M && n < a.N) {
           const int64_t orow = a.ymap ? map_row(a, m) : (int64_t)m;
-          rres[p] = *reinterpret_cast<const uint4*>(a.R + orow * a.N + n);
+          rres[p] = *reinterpret_cast<const uint4*>(side + orow * a.N + n);
         }
       }
     }
@@ -278,7 +295,19 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a)
       if (m < a.M && n < a.N) {
         uint4 c = *reinterpret_cast<const uint4*>(Cs + rl * CS_LD + wvec * 8);
         const int64_t orow = a.ymap ? map_row(a, m) : (int64_t)m;
-        if (a.R != nullptr || a.partial != nullptr) {
+        if (bwd_stats) {
+          float f[8], xv[8];
+          unpack8(c, f);
+          unpack8(rres[p], xv);
+          const float* bp = bpl + wvec * 8;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float u = fmaf(bp[j], xv[j], bp[BN_T + j]);
+            const float dy = (u > a.b_lo && u < a.b_hi) ? f[j] : 0.f;
+            st_s[j] += dy;
+            st_q[j] = fmaf(dy, (xv[j] - bp[2 * BN_T + j]) * bp[3 * BN_T + j], st_q[j]);
+          }
+        } else if (a.R != nullptr || a.partial != nullptr) {
           float f[8];
           unpack8(c, f);
           if (a.R != nullptr) {
@@ -321,16 +350,25 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a)
       red[(3 * RPP + wrow) * BN_T + wvec * 8 + j] = st_mx[j];
     }
     __syncthreads();
-    for (int t = tid; t < 4 * BN_T; t += PF_THREADS) {
+    const int nstat = bwd_stats ? 2 : 4;
+    for (int t = tid; t < nstat * BN_T; t += PF_THREADS) {
       const int stat = t / BN_T, c = t - stat * BN_T;
       float v = red[(stat * RPP) * BN_T + c];
       for (int r = 1; r < RPP; ++r) {
         const float w = red[(stat * RPP + r) * BN_T + c];
         v = (stat < 2) ? (v + w) : (stat == 2 ? fminf(v, w) : fmaxf(v, w));
       }
-      if (n0 + c < a.N) a.partial[((int64_t)g * 4 + stat) * a.N + n0 + c] = v;
+      if (n0 + c < a.N) a.partial[((int64_t)g * nstat + stat) * a.N + n0 + c] = v;
     }
   }
+}
+
+#include <stdlib.h>
+static int conv_bn_of(int N) {
+  static int forced = -1;                           // PF_CONV_BN=64|128: tuning override (experiments only)
+  if (forced < 0) { const char* e = getenv("PF_CONV_BN"); forced = e ? atoi(e) : 0; }
+  if (forced == 64) return 64;
+  return (N % 128 == 0) ? 128 : 64;
 }
 
 static int conv_fwd_grid(int tiles_m, int tiles_n, int* G_out) {
@@ -345,15 +383,16 @@ static int conv_fwd_grid(int tiles_m, int tiles_n, int* G_out) {
 }
 
 extern "C" int pf_conv1x1_stats_groups(int M, int N) {
-  const int bn = (N % 128 == 0) ? 128 : 64;
+  const int bn = conv_bn_of(N);
   int G;
   conv_fwd_grid((M + CV_BM - 1) / CV_BM, (N + bn - 1) / bn, &G);
   return G;
 }
 
-extern "C" int pf_conv1x1_fwd(const void* X, const void* W, void* Y, const void* R, const float* scale_shift,
-                              int act, const uint32_t* slot, int bits, float* partial, int M, int N, int K,
-                              int Ho, int Wo, int H, int Wd, int stride, int ymap, void* stream) {
+static int conv_fwd_launch(const void* X, const void* W, void* Y, const void* R, const float* scale_shift,
+                           int act, const uint32_t* slot, int bits, float* partial, int M, int N, int K,
+                           int Ho, int Wo, int H, int Wd, int stride, int ymap, const void* bx,
+                           const float* bss, const float* bmi, int bact, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (K % 8) || (N % 8)) return (int)hipErrorInvalidValue;
   if (!pf_aligned16(X) || !pf_aligned16(W) || !pf_aligned16(Y) || (R && !pf_aligned16(R)))
     return (int)hipErrorInvalidValue;
@@ -368,21 +407,47 @@ extern "C" int pf_conv1x1_fwd(const void* X, const void* W, void* Y, const void*
   a.act_hi = (act == PF_ACT_RELU6) ? 6.0f : INFINITY;
   a.M = M; a.N = N; a.K = K;
   a.Ho = Ho; a.Wo = Wo; a.H = H; a.Wd = Wd; a.stride = stride; a.ymap = ymap; a.rows_per_split = 0;
-  const int bn = (N % 128 == 0) ? 128 : 64;
+  a.bx = (const bf16_t*)bx; a.bss = bss; a.bmi = bmi;
+  a.b_lo = (bact == PF_ACT_NONE) ? -INFINITY : 0.0f;
+  a.b_hi = (bact == PF_ACT_RELU6) ? 6.0f : INFINITY;
+  if (bx != nullptr && (R != nullptr || partial == nullptr || bss == nullptr || bmi == nullptr || stride != 1 ||
+                        !pf_aligned16(bx)))
+    return (int)hipErrorInvalidValue;
+  const int bn = conv_bn_of(N);
   a.tiles_m = (M + CV_BM - 1) / CV_BM;
   a.tiles_n = (N + bn - 1) / bn;
   const int grid = conv_fwd_grid(a.tiles_m, a.tiles_n, &a.G);
   hipStream_t st = (hipStream_t)stream;
   const bool pro = scale_shift != nullptr;
+  if (bx != nullptr && pro) return (int)hipErrorInvalidValue;
   if (bn == 128) {
-    if (pro) k_conv1x1_fwd<128, true><<<grid, PF_THREADS, 0, st>>>(a);
-    else k_conv1x1_fwd<128, false><<<grid, PF_THREADS, 0, st>>>(a);
+    if (pro) k_conv1x1_fwd<128, true, false><<<grid, PF_THREADS, 0, st>>>(a);
+    else if (bx != nullptr) k_conv1x1_fwd<128, false, true><<<grid, PF_THREADS, 0, st>>>(a);
+    else k_conv1x1_fwd<128, false, false><<<grid, PF_THREADS, 0, st>>>(a);
   } else {
-    if (pro) k_conv1x1_fwd<64, true><<<grid, PF_THREADS, 0, st>>>(a);
-    else k_conv1x1_fwd<64, false><<<grid, PF_THREADS, 0, st>>>(a);
+    if (pro) k_conv1x1_fwd<64, true, false><<<grid, PF_THREADS, 0, st>>>(a);
+    else if (bx != nullptr) k_conv1x1_fwd<64, false, true><<<grid, PF_THREADS, 0, st>>>(a);
+    else k_conv1x1_fwd<64, false, false><<<grid, PF_THREADS, 0, st>>>(a);
   }
   PF_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int pf_conv1x1_fwd(const void* X, const void* W, void* Y, const void* R, const float* scale_shift,
+                              int act, const uint32_t* slot, int bits, float* partial, int M, int N, int K,
+                              int Ho, int Wo, int H, int Wd, int stride, int ymap, void* stream) {
+  return conv_fwd_launch(X, W, Y, R, scale_shift, act, slot, bits, partial, M, N, K, Ho, Wo, H, Wd, stride, ymap,
+                         nullptr, nullptr, nullptr, PF_ACT_NONE, stream);
+}
+
+// backward-data of a stride-1 1x1 convolution, dQ[M][K] = dY[M][N] * W[N][K] (Wt = the transposed kernel
+// [K][N]), with the BN-backward statistics of the layer that produced Q in the epilogue:
+// partial[G][2][K] = {sum dy, sum dy*xhat} over the rows of each workgroup, G = pf_conv1x1_stats_groups(M, K).
+extern "C" int pf_conv1x1_bwd_data_bnstats(const void* dY, const void* Wt, void* dQ, const void* bn_x,
+                                           const float* bn_scale_shift, const float* bn_mean_invstd, int bn_act,
+                                           float* partial, int M, int N, int K, void* stream) {
+  return conv_fwd_launch(dY, Wt, dQ, nullptr, nullptr, PF_ACT_NONE, nullptr, 8, partial, M, K, N, 0, 0, 0, 0, 1, 0,
+                         bn_x, bn_scale_shift, bn_mean_invstd, bn_act, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -566,6 +631,7 @@ extern "C" int pf_conv1x1_wrw(const void* dY, const void* X, void* dW, int dw_dt
   a.act_hi = (act == PF_ACT_RELU6) ? 6.0f : INFINITY;
   a.M = M; a.N = N; a.K = K;
   a.Ho = Ho; a.Wo = Wo; a.H = H; a.Wd = Wd; a.stride = stride < 1 ? 1 : stride; a.ymap = 0;
+  a.bx = nullptr; a.bss = nullptr; a.bmi = nullptr; a.b_lo = 0.f; a.b_hi = INFINITY;
   a.tiles_m = 0; a.G = 0;
   a.tiles_n = (N + WR_TN - 1) / WR_TN;
   const int tiles_k = (K + WR_TK - 1) / WR_TK;

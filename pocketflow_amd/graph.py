@@ -25,6 +25,7 @@ kernels, [in, out] dense) so that checkpoints and the oracle see TF-shaped tenso
 from __future__ import annotations
 
 import math
+import os
 import threading
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
@@ -38,6 +39,8 @@ from pocketflow_amd.plan import WeightDesc
 from pocketflow_amd.profiling import region
 
 ALIGN = 64  # elements; keeps every tensor 256-byte aligned inside the flat buffers
+# reduce the BN-backward statistics inside the backward-data kernel of the single consuming 1x1 convolution
+FUSE_BN_BWD_STATS = os.environ.get('PF_FUSE_BN_BWD_STATS', '1') != '0'
 
 
 def _align(n: int) -> int:
@@ -425,13 +428,14 @@ class _BnActQuant(torch.autograd.Function):
       hip.bn_act_quant_apply(x, q, rows, C, scale_shift, layer.act, slot, bits if quantize else 8, quantize)
     ctx.save_for_backward(x, scale_shift, mean_invstd)
     ctx.meta = (layer.act, graph, rows, C)
+    ctx.params = (gamma, beta)
     return q
 
   @staticmethod
   def backward(ctx, dq):
     x, scale_shift, mean_invstd = ctx.saved_tensors
     act, graph, rows, C = ctx.meta
-    dx, dgamma, dbeta = _bn_backward(dq, x, scale_shift, mean_invstd, act, graph, rows, C)
+    dx, dgamma, dbeta = _bn_backward(dq, x, scale_shift, mean_invstd, act, graph, rows, C, params=ctx.params)
     return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
@@ -472,9 +476,12 @@ class LazyAct(object):
   Gradients with respect to q flow into `x`'s autograd node (_BnLazy), which runs the BN backward once.
   """
 
-  def __init__(self, x, scale_shift, act, slot, bits, rows, C):
+  def __init__(self, x, scale_shift, act, slot, bits, rows, C, mean_invstd=None):
     self.x, self.scale_shift, self.act, self.slot, self.bits = x, scale_shift, act, slot, bits
     self.rows, self.C = rows, C
+    self.mean_invstd = mean_invstd            # training mode only: lets a consumer fuse the BN-backward statistics
+    self.n_consumers = 0                      # fused convolutions that read this activation
+    self.bwd_stats = None                     # (partial, n_blocks, data_ptr of dq) left by the single consumer
     self._q = None
 
   @property
@@ -490,6 +497,7 @@ class LazyAct(object):
     return self.x.device
 
   def materialize(self) -> torch.Tensor:
+    self.n_consumers += 2                     # a materialised consumer: its gradient is summed by autograd
     if self._q is None:
       self._q = _Materialize.apply(self.x, self)
     return self._q
@@ -541,8 +549,11 @@ class _BnLazy(torch.autograd.Function):
                     slot if bits is not None else None)
     ctx.save_for_backward(x, scale_shift, mean_invstd)
     ctx.meta = (layer.act, graph, rows, C)
+    ctx.params = (gamma, beta)
+    ctx.box = box                             # [scale_shift, mean_invstd, LazyAct (appended by the caller)]
     ctx.set_materialize_grads(False)          # an unused shortcut alias must arrive as None, not as a zeros tensor
     box.append(scale_shift)
+    box.append(mean_invstd)
     # two aliases of x: the first stands for q (consumed by the fused convolutions), the second is x
     # itself for the block's identity shortcut -- routing the shortcut through this node lets the
     # backward add its gradient inside pf_bn_bwd_apply_add instead of a separate accumulation kernel
@@ -554,11 +565,27 @@ class _BnLazy(torch.autograd.Function):
     act, graph, rows, C = ctx.meta
     if dq is None:
       return dskip, None, None, None, None, None, None, None, None
-    dx, dgamma, dbeta = _bn_backward(dq, x, scale_shift, mean_invstd, act, graph, rows, C, addend=dskip)
+    pre = None
+    lazy = ctx.box[2] if len(ctx.box) > 2 else None
+    if lazy is not None and lazy.bwd_stats is not None and lazy.bwd_stats[2] == dq.data_ptr():
+      pre = lazy.bwd_stats[:2]                # the single consumer's backward-data kernel already reduced dy
+    dx, dgamma, dbeta = _bn_backward(dq, x, scale_shift, mean_invstd, act, graph, rows, C, addend=dskip,
+                                     params=ctx.params, pre=pre)
     return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
-def _bn_backward(dq, x, scale_shift, mean_invstd, act, graph, rows, C, addend=None):
+def _grad_view(t: Optional[torch.Tensor], n: int):
+  """The pre-allocated flat-buffer gradient view of a leaf (VarStore.finalize), if it can be written directly."""
+  g = getattr(t, 'grad', None) if t is not None else None
+  if g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.numel() == n:
+    return g
+  return None
+
+
+def _bn_backward(dq, x, scale_shift, mean_invstd, act, graph, rows, C, addend=None, params=None, pre=None):
+  """Returns (dx, dgamma, dbeta); when `params` = (gamma leaf, beta leaf) carry flat-buffer gradient views,
+  dgamma / dbeta are written there by pf_bn_bwd_finalize and None is returned for them (no accumulation
+  kernels; every BN layer is applied once per step and the buffers are zeroed by the optimiser)."""
   dq = _nhwc(dq)
   if dq.dtype != x.dtype:
     dq = dq.to(x.dtype)
@@ -566,18 +593,24 @@ def _bn_backward(dq, x, scale_shift, mean_invstd, act, graph, rows, C, addend=No
     addend = _nhwc(addend)
     if addend.dtype != x.dtype:
       addend = addend.to(x.dtype)
-  nblk = _bn_blocks(rows, C)
-  partial = graph.scratch(nblk * 2 * C)
   nbytes = float(x.numel() * x.element_size())
-  with region('bn_bwd_stats', 2 * nbytes):         # reads dq and x
-    hip.bn_bwd_stats(dq, x, rows, C, scale_shift, mean_invstd, act, partial, nblk)
-  dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
-  dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+  if pre is not None:
+    partial, nblk = pre
+  else:
+    nblk = _bn_blocks(rows, C)
+    partial = graph.scratch(nblk * 2 * C)
+    with region('bn_bwd_stats', 2 * nbytes):       # reads dq and x
+      hip.bn_bwd_stats(dq, x, rows, C, scale_shift, mean_invstd, act, partial, nblk)
+  gview = _grad_view(params[0], C) if params is not None else None
+  bview = _grad_view(params[1], C) if params is not None else None
+  direct = gview is not None and bview is not None
+  dgamma = gview if direct else torch.empty(C, dtype=torch.float32, device=x.device)
+  dbeta = bview if direct else torch.empty(C, dtype=torch.float32, device=x.device)
   hip.bn_bwd_finalize(partial, nblk, C, dgamma, dbeta)
   dx = torch.empty_like(x)
   with region('bn_bwd_apply', (4 if addend is not None else 3) * nbytes):   # reads dq, x [, addend], writes dx
     hip.bn_bwd_apply(dq, x, dx, rows, C, scale_shift, mean_invstd, dgamma, dbeta, act, addend)
-  return dx, dgamma, dbeta
+  return (dx, None, None) if direct else (dx, dgamma, dbeta)
 
 
 def _conv1x1_geom(x_shape, stride):
@@ -618,6 +651,7 @@ class _FusedConv1x1(torch.autograd.Function):
     y = _run_conv1x1(x, w2d, lazy, res, want_stats, stride)
     ctx.save_for_backward(x, w2d)
     ctx.meta = (lazy, stride, graph, residual is not None, w.shape)
+    ctx.w_leaf = w
     box.append(getattr(y, '_pf_stats', None))
     return y
 
@@ -635,19 +669,32 @@ class _FusedConv1x1(torch.autograd.Function):
     if ctx.needs_input_grad[1]:
       S = hip.conv1x1_wrw_splits(M, N, K)
       ws = graph.scratch((S + 32) * N * K)
-      dw2d = torch.empty((N, K), dtype=w2d.dtype, device=x.device)
+      # the kernel's gradient view inside the flat gradient buffer ([N][1][1][K] memory = [N][K]): written
+      # directly (each kernel is used once per step; the optimiser zeroes the buffer), no accumulation kernel
+      gw = getattr(ctx.w_leaf, 'grad', None)
+      direct = (gw is not None and gw.dtype == w2d.dtype and gw.shape == ctx.w_leaf.shape
+                and gw.permute(0, 2, 3, 1).is_contiguous())
+      dw2d = gw.permute(0, 2, 3, 1).view(N, K) if direct else torch.empty((N, K), dtype=w2d.dtype, device=x.device)
       with region('conv1x1_wrw', float((M * K + M * N) * 2)):
         hip.conv1x1_wrw(dy, x, dw2d, ws, M, N, K, scale_shift=ss, act=act, slot=lazy.slot if quant else None,
                         bits=lazy.bits if quant else 8, geom=geom)
-      dw = dw2d.view(N, 1, 1, K).permute(0, 3, 1, 2)                            # logical OIHW over KRSC memory
+      dw = None if direct else dw2d.view(N, 1, 1, K).permute(0, 3, 1, 2)       # logical OIHW over KRSC memory
     if ctx.needs_input_grad[0]:
       wt = w2d.t().contiguous()                                                # [K][N]
       if geom is None:
         dx = torch.empty_like(x)
       else:
         dx = torch.zeros_like(x)
-      with region('conv1x1_bwd_data', float((M * K + M * N) * 2)):
-        hip.conv1x1_fwd(dy, wt, dx, M, K, N, geom=geom, ymap=geom is not None)
+      fuse_stats = (FUSE_BN_BWD_STATS and lazy is not None and lazy.n_consumers == 1 and geom is None
+                    and lazy.mean_invstd is not None and lazy.act in ('Relu', 'Relu6'))
+      with region('conv1x1_bwd_data', float((M * K * (2 if fuse_stats else 1) + M * N) * 2)):
+        if fuse_stats:
+          G = hip.conv1x1_stats_groups(M, K)
+          partial = torch.empty((G, 2, K), dtype=torch.float32, device=x.device)
+          hip.conv1x1_bwd_data_bnstats(dy, wt, dx, x, lazy.scale_shift, lazy.mean_invstd, lazy.act, partial, M, N, K)
+          lazy.bwd_stats = (partial, G, dx.data_ptr())
+        else:
+          hip.conv1x1_fwd(dy, wt, dx, M, K, N, geom=geom, ymap=geom is not None)
     return dx, dw, (dy if has_res else None), None, None, None, None, None
 
 
@@ -718,6 +765,8 @@ class Conv2D:
       return _tapped(self, materialize(x), residual)
     if fused_conv1x1_ok(x, self):
       lazy = x if isinstance(x, LazyAct) else None
+      if lazy is not None:
+        lazy.n_consumers += 1
       xin = lazy.x if lazy is not None else _nhwc(x)
       if torch.is_grad_enabled() and (xin.requires_grad or w.requires_grad):
         box = []
@@ -861,7 +910,8 @@ class BatchNormAct:
       if lazy:
         box = []
         alias, skip = _BnLazy.apply(_nhwc(x), self.gamma.tensor, self.beta.tensor, self, g, slot, bits, box, stats)
-        lazy_out = LazyAct(alias, box[0], self.act, slot, bits, x.numel() // self.C, self.C)
+        lazy_out = LazyAct(alias, box[0], self.act, slot, bits, x.numel() // self.C, self.C, mean_invstd=box[1])
+        box.append(lazy_out)
         return (lazy_out, skip) if getattr(self, '_want_skip', False) else lazy_out
       return _BnActQuant.apply(x, self.gamma.tensor, self.beta.tensor, self, g, True, slot, bits, stats)
     x = _nhwc(x)

@@ -41,7 +41,8 @@ SYMBOLS = [
     'pf_momentum_flat', 'pf_ce_distill_fwd_bwd', 'pf_bn_stats', 'pf_bn_finalize',
     'pf_bn_act_quant_apply', 'pf_bn_bwd_stats', 'pf_bn_bwd_finalize', 'pf_bn_bwd_apply', 'pf_bn_bwd_apply_add',
     'pf_bn_eval_scale_shift', 'pf_gemm_bf16_nt', 'pf_gemm_bf16_nn', 'pf_gemm_bf16_tn',
-    'pf_conv1x1_stats_groups', 'pf_conv1x1_fwd', 'pf_conv1x1_wrw_splits', 'pf_conv1x1_wrw',
+    'pf_conv1x1_stats_groups', 'pf_conv1x1_fwd', 'pf_conv1x1_bwd_data_bnstats', 'pf_conv1x1_wrw_splits',
+    'pf_conv1x1_wrw',
 ]
 
 
@@ -328,3 +329,11 @@ def conv1x1_wrw(dY, X, dW, workspace, M: int, N: int, K: int, scale_shift=None, 
   _check(_lib.pf_conv1x1_wrw(_ptr(dY), _ptr(X), _ptr(dW), c_int(dtype_code(dW)), _ptr(workspace), _ptr(scale_shift),
                              c_int(ACT_CODES[act]), _ptr(slot), c_int(int(bits)), c_int(M), c_int(N), c_int(K),
                              c_int(Ho), c_int(Wo), c_int(H), c_int(Wd), c_int(stride), _stream()), 'pf_conv1x1_wrw')
+
+
+def conv1x1_bwd_data_bnstats(dY, Wt, dQ, bn_x, bn_scale_shift, bn_mean_invstd, bn_act, partial, M: int, N: int,
+                             K: int) -> None:
+  _dev(dY)
+  _check(_lib.pf_conv1x1_bwd_data_bnstats(_ptr(dY), _ptr(Wt), _ptr(dQ), _ptr(bn_x), _ptr(bn_scale_shift),
+                                          _ptr(bn_mean_invstd), c_int(ACT_CODES[bn_act]), _ptr(partial), c_int(M),
+                                          c_int(N), c_int(K), _stream()), 'pf_conv1x1_bwd_data_bnstats')

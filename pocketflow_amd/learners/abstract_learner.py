@@ -53,7 +53,7 @@ def require_gpu() -> torch.device:
   if not torch.cuda.is_available():
     raise RuntimeError('pocketflow_amd learners need a ROCm GPU (torch.cuda.is_available() is False); '
                        'the CPU oracle under oracle/ is test infrastructure, not a fallback')
-  idx = mgw.local_rank() if FLAGS.enbl_multi_gpu else 0
+  idx = mgw.device_index() if FLAGS.enbl_multi_gpu else 0
   torch.cuda.set_device(idx)
   return torch.device('cuda', idx)
 

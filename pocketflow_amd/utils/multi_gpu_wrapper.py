@@ -26,9 +26,11 @@ class MultiGpuWrapper(object):
     if 'RANK' not in os.environ or 'WORLD_SIZE' not in os.environ:
       raise NameError('module <mgw> not imported: launch with torchrun / torch.distributed.run '
                       '(RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT)')
-    backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-    if backend == 'nccl':
-      torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+    # PF_DIST_BACKEND=gloo + PF_SINGLE_DEVICE=1: test hooks that let N ranks share ONE GPU (RCCL refuses
+    # duplicate devices), so the whole multi-rank control flow can be exercised on a single-GPU box
+    backend = os.environ.get('PF_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+    if torch.cuda.is_available():
+      torch.cuda.set_device(cls.device_index())
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     dist.init_process_group(backend=backend)
     cls._initialized = True
@@ -48,6 +50,11 @@ class MultiGpuWrapper(object):
   @classmethod
   def local_rank(cls, *args):
     return int(os.environ.get('LOCAL_RANK', cls.rank()))
+
+  @classmethod
+  def device_index(cls):
+    """HIP device of this rank: its local rank (one process per GPU), or 0 under the PF_SINGLE_DEVICE hook."""
+    return 0 if os.environ.get('PF_SINGLE_DEVICE') == '1' else cls.local_rank()
 
   @classmethod
   def DistributedOptimizer(cls, optimizer):

@@ -204,3 +204,29 @@ def test_fused_path_is_as_accurate_as_unfused(tmp_path, a_bits):
     u, f = report[k]
     assert f >= u - 0.05, (k, report)
   assert 0.7 < report['grad_norm'][2] / report['grad_norm'][0] < 1.4, report
+
+
+def test_conv1x1_bwd_data_with_bn_backward_statistics(hip):
+  """dQ = dY @ W with {sum dy, sum dy*xhat} of the producer BN in the epilogue == pf_bn_bwd_stats on (dQ, x)."""
+  M, N, K = 3000, 256, 128
+  g = torch.Generator(device='cuda').manual_seed(11)
+  dY = _bf(torch.randn(M, N, device='cuda', generator=g) * 0.1)
+  W = _bf(torch.randn(N, K, device='cuda', generator=g) * 0.1)
+  x = _bf(torch.randn(M, K, device='cuda', generator=g))
+  ss = torch.stack([torch.rand(K, device='cuda', generator=g) + 0.5, torch.randn(K, device='cuda', generator=g) * 0.3])
+  mi = torch.stack([torch.randn(K, device='cuda', generator=g) * 0.1, torch.rand(K, device='cuda', generator=g) + 0.5])
+  Wt = W.t().contiguous()
+  dQ = torch.empty(M, K, device='cuda', dtype=torch.bfloat16)
+  G = hip.conv1x1_stats_groups(M, K)
+  partial = torch.full((G, 2, K), float('nan'), device='cuda')
+  hip.conv1x1_bwd_data_bnstats(dY, Wt, dQ, x, ss, mi, 'Relu', partial, M, N, K)
+  _close_bf16(dQ, _bf(dY.float() @ W.float()), what='bwd-data')
+  nblk = 32
+  ref_partial = torch.empty(nblk * 2 * K, device='cuda')
+  hip.bn_bwd_stats(dQ, x, M, K, ss, mi, 'Relu', ref_partial, nblk)
+  dgamma, dbeta = torch.empty(K, device='cuda'), torch.empty(K, device='cuda')
+  hip.bn_bwd_finalize(ref_partial, nblk, K, dgamma, dbeta)
+  dg2, db2 = torch.empty(K, device='cuda'), torch.empty(K, device='cuda')
+  hip.bn_bwd_finalize(partial, G, K, dg2, db2)
+  torch.testing.assert_close(db2, dbeta, rtol=1e-4, atol=1e-3)
+  torch.testing.assert_close(dg2, dgamma, rtol=1e-4, atol=1e-3)

@@ -145,3 +145,22 @@ def test_channel_pruned_mobilenet_uniform(tmp_path):
   assert n_masked > 0
   first, last = learner.pruner.thisconvs[0], learner.pruner.thisconvs[-1]
   assert all(learner.fake_pruning_dict[first.op.name][0]) and all(learner.fake_pruning_dict[last.op.name][1])
+
+
+def test_bench_two_ranks_share_one_gpu(tmp_path):
+  """The N > 1 control flow of bench.py end to end on a single-GPU box: two ranks on cuda:0 over gloo
+  (RCCL refuses duplicate devices): shared scratch directory, rank-0 checkpoint + teacher hand-off,
+  broadcast of the flat buffers, gradient all-reduce with the 1/N folded into Adam, max-over-ranks timing."""
+  import json
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, PF_DIST_BACKEND='gloo', PF_SINGLE_DEVICE='1', TMPDIR=str(tmp_path))
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+         '127.0.0.1', '--master-port', '29533', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2',
+         '--warmup', '1', '--batch', '8', '--image_size', '64', '--no_cpu_baseline']
+  out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+  assert out.returncode == 0, out.stderr[-3000:]
+  line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+  rec = json.loads(line)
+  assert rec['n_gpus'] == 2 and rec['config']['global_batch'] == 16 and rec['value'] > 0

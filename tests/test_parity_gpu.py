@@ -112,7 +112,7 @@ def test_uq_lenet_steps_match_oracle(tmp_path, use_buckets, bucket_type, bits):
   assert abs(rs['acc_top1'] - np.mean([e['metrics']['accuracy'] for e in ev])) <= 1e-6
 
 
-@pytest.mark.parametrize('a_bits,loss_tol,bulk_tol', [(32, 2e-4, 1e-5), (8, 1e-2, None)])
+@pytest.mark.parametrize('a_bits,loss_tol,bulk_tol', [(32, 2e-4, 2e-4), (8, 1e-2, None)])
 def test_uq_resnet20_distillation_matches_oracle(tmp_path, a_bits, loss_tol, bulk_tol):
   from oracle.learner_oracle import OracleLearner
   from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
