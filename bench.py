@@ -48,8 +48,8 @@ def parse_args():
                   help='profiling region whose launches are timed with HIP events: conv1x1_fwd | conv1x1_wrw | '
                        'conv1x1_bwd_data | bn_bwd_apply | bn_bwd_stats | bn_act_quant_apply | bn_stats')
   ap.add_argument('--no_cpu_baseline', action='store_true')
-  ap.add_argument('--cpu_batch', type=int, default=8)
-  ap.add_argument('--cpu_steps', type=int, default=2)
+  ap.add_argument('--cpu_batch', type=int, default=4)
+  ap.add_argument('--cpu_steps', type=int, default=3)
   return ap.parse_args()
 
 
@@ -77,7 +77,7 @@ def pmc_traffic_per_launch(region, tag='r01'):
     disp, kib = 0, 0.0
     with open(path) as f:
       for r in csv.DictReader(f):
-        if r['kernel'].startswith(prefix) and (region != 'conv1x1_fwd' or 'true>' in r['kernel']):
+        if r['kernel'].startswith(prefix) and (region != 'conv1x1_fwd' or ', true, ' in r['kernel']):
           disp += int(r['dispatches'])
           kib += float(r['mean_' + counter]) * int(r['dispatches'])
     if disp == 0:
@@ -173,11 +173,19 @@ def main():
                 'step_mfma_frac': per_gpu * R50_FLOPS_PER_IMAGE_STEP_DST / MFMA_BF16_PEAK}
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
+      # the reference path restated on the host cores (oracle/learner_oracle.py), in a child process with a
+      # hard wall-clock limit so that the default run always finishes within minutes
+      import subprocess
+      code = ('import json, sys; sys.path.insert(0, %r); from oracle.learner_oracle import time_cpu_baseline; '
+              'print("CPU_BASELINE " + json.dumps(time_cpu_baseline(%d, %d, %d, %d, %d, %d)))'
+              % (ROOT, args.resnet_size, args.image_size, args.cpu_batch, args.cpu_steps, args.weight_bits,
+                 args.act_bits))
       try:
-        from oracle.learner_oracle import time_cpu_baseline
-        cpu_baseline = time_cpu_baseline(args.resnet_size, args.image_size, args.cpu_batch, args.cpu_steps,
-                                         args.weight_bits, args.act_bits)
-      except ImportError:
+        out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=150)
+        for ln in out.stdout.splitlines():
+          if ln.startswith('CPU_BASELINE '):
+            cpu_baseline = json.loads(ln[len('CPU_BASELINE '):])
+      except subprocess.TimeoutExpired:
         cpu_baseline = None
     line = {
         'metric': 'images/sec ResNet-50 INT8 quant-aware fine-tune (whole job; per GPU = value / n_gpus)',

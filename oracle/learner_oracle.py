@@ -617,12 +617,19 @@ def _random_values_resnet(dataset, resnet_size, nb_classes, image_shape, seed=42
   return values
 
 
-def time_cpu_baseline(resnet_size=50, image_size=224, batch=8, steps=2, weight_bits=8, act_bits=8,
-                      nb_classes=1001, enbl_dst=True, threads: Optional[int] = None) -> Dict:
+def time_cpu_baseline(resnet_size=50, image_size=224, batch=4, steps=3, weight_bits=8, act_bits=8,
+                      nb_classes=1001, enbl_dst=True, threads: Optional[int] = None, budget_s: float = 25.0) -> Dict:
   """Time the oracle UniformQuantLearner step (the reference's TF-CPU path restated; TF itself is
-  unavailable) on the host cores: `steps` timed steps after one warm-up, batch `batch`."""
+  unavailable) on the host cores.  Bounded sample: one warm-up step, then up to `steps` timed steps while
+  the wall-clock budget lasts; if the warm-up alone exhausts the budget it IS the sample.  Threads: the
+  cores this process may run on (sched_getaffinity), capped at 16 -- more only adds contention for a
+  batch-4 ResNet-50 and an unconstrained 256-thread pool on a shared box is 100x slower."""
   import os
-  threads = threads or os.cpu_count() or 1
+  try:
+    avail = len(os.sched_getaffinity(0))
+  except AttributeError:
+    avail = os.cpu_count() or 1
+  threads = threads or max(1, min(avail, 16))
   torch.set_num_threads(threads)
   shape = (image_size, image_size, 3)
   values = _random_values_resnet('ilsvrc_12', resnet_size, nb_classes, shape)
@@ -635,14 +642,46 @@ def time_cpu_baseline(resnet_size=50, image_size=224, batch=8, steps=2, weight_b
   images = rng.randint(0, 256, size=(batch,) + shape).astype(np.float32) - means
   labels = np.zeros((batch, nb_classes), np.float32)
   labels[np.arange(batch), rng.randint(0, nb_classes, batch)] = 1
-  lrn.train_step(images, labels)
   t0 = time.perf_counter()
-  for _ in range(steps):
+  lrn.train_step(images, labels)
+  warm = time.perf_counter() - t0
+  done, dt = 0, 0.0
+  t0 = time.perf_counter()
+  while done < steps and warm + dt + (dt / done if done else warm) <= budget_s:
     lrn.train_step(images, labels)
-  dt = time.perf_counter() - t0
-  return {'value': batch * steps / dt, 'unit': 'images/s', 'cores': threads, 'kind': 'port',
+    done += 1
+    dt = time.perf_counter() - t0
+  if done == 0:
+    done, dt, what = 1, warm, 'the first (warm-up) step only: it exhausted the %.0f s budget' % budget_s
+  else:
+    what = '%d timed steps after 1 warm-up' % done
+  return {'value': batch * done / dt, 'unit': 'images/s', 'cores': threads, 'kind': 'port',
           'sample': 'oracle UniformQuantLearner step (NumPy fake-quant/loss/Adam + torch-CPU fp32 conv/BN), '
-                    'ResNet-v2-%d %dx%d w%d/a%d%s, batch %d x %d timed steps after 1 warm-up; TF-1.x (the '
-                    'reference runtime) is not installable here' % (resnet_size, image_size, image_size, weight_bits,
-                                                                    act_bits, ' + distillation' if enbl_dst else '',
-                                                                    batch, steps)}
+                    'ResNet-v2-%d %dx%d w%d/a%d%s, batch %d, %s; TF-1.x (the reference runtime) is not installable '
+                    'here' % (resnet_size, image_size, image_size, weight_bits, act_bits,
+                              ' + distillation' if enbl_dst else '', batch, what)}
+
+
+def check_uq_step_against_oracle(learner, steps: int = 1, loss_rtol: float = 2e-4) -> float:
+  """__graft_entry__.smoke(): run `steps` fine-tune steps of a freshly constructed (float32)
+  UniformQuantLearner on the GPU and the same steps here, from the same variables and batches; returns
+  the largest relative loss difference and raises if it exceeds `loss_rtol`."""
+  from pocketflow_amd.flags import FLAGS          # the oracle may read the product's flags, never the reverse
+  model = learner.model_name
+  cfg = dict(model='lenet' if model == 'lenet' else 'resnet', dataset=learner.dataset_name,
+             resnet_size=FLAGS.resnet_size if 'resnet_size' in FLAGS else 0, nb_classes=FLAGS.nb_classes,
+             learner='uniform', loss_w_dcy=FLAGS.loss_w_dcy, enbl_dst=False, uql_weight_bits=FLAGS.uql_weight_bits,
+             uql_activation_bits=FLAGS.uql_activation_bits, uql_use_buckets=FLAGS.uql_use_buckets,
+             uql_bucket_type=FLAGS.uql_bucket_type, uql_bucket_size=FLAGS.uql_bucket_size,
+             image_shape=tuple(learner.iter_train.batches[0][0].shape[1:]))
+  ora = OracleLearner(learner.graph.store.export_numpy(), cfg, learner.lrn_rate)
+  pool = [(i.cpu().numpy(), l.cpu().numpy()) for i, l in learner.iter_train.batches]
+  worst = 0.0
+  for step in range(steps):
+    out = learner.train_step()
+    ref = ora.train_step(*pool[step % len(pool)])
+    rel = abs(float(out['loss'].detach()) - ref['loss']) / max(1.0, abs(ref['loss']))
+    worst = max(worst, rel)
+    if rel > loss_rtol:
+      raise AssertionError('step %d: loss %.6f (HIP) vs %.6f (oracle)' % (step, float(out['loss'].detach()), ref['loss']))
+  return worst

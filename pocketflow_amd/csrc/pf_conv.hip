@@ -477,9 +477,20 @@ template <bool PRO>
 __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_wrw(const ConvArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_t Ds[WR_TN * WR_LDM];   // dY tile, [n][m]
   __shared__ __attribute__((aligned(16))) bf16_t Qs[WR_TK * WR_LDM];   // Q tile,  [k][m]
-  const int tn = blockIdx.x % a.tiles_n, tk = blockIdx.x / a.tiles_n;
+  // XCD-aware order: the hardware deals consecutive workgroup ids round-robin over the 8 XCDs; give every
+  // XCD a contiguous run of logical ids so that all (n, k) output tiles of one pixel split -- which read the
+  // same dY / X rows -- share that XCD's L2 instead of re-reading the rows from HBM on 8 different L2s
+  const int ntile = gridDim.x, nwg = gridDim.x * gridDim.y;
+  int wg = blockIdx.y * gridDim.x + blockIdx.x;
+  {
+    const int xcd = wg & 7, idx = wg >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile = wg % ntile, split = wg / ntile;
+  const int tn = tile % a.tiles_n, tk = tile / a.tiles_n;
   const int n0 = tn * WR_TN, k0 = tk * WR_TK;
-  const int mbeg = blockIdx.y * a.rows_per_split;
+  const int mbeg = split * a.rows_per_split;
   const int mend = (mbeg + a.rows_per_split < a.M) ? (mbeg + a.rows_per_split) : a.M;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int frow = lane & 15, fm = lane >> 4;               // fragment: channel row, 8-pixel group
@@ -571,7 +582,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_wrw(const ConvArgs a)
     __syncthreads();
   }
   // D row = n (lane >> 4) * 4 + r of block i, D col = k (lane & 15) of block j
-  float* out = a.partial + (int64_t)blockIdx.y * a.N * a.K;
+  float* out = a.partial + (int64_t)split * a.N * a.K;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll

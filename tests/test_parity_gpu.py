@@ -109,7 +109,8 @@ def test_uq_lenet_steps_match_oracle(tmp_path, use_buckets, bucket_type, bits):
   rs = learner.run_eval()
   ev = [ora.eval_batch(*b) for b in _pool(learner.iter_eval)[:2]]
   assert abs(rs['loss'] - np.mean([e['loss'] for e in ev])) <= 1e-4
-  assert abs(rs['acc_top1'] - np.mean([e['metrics']['accuracy'] for e in ev])) <= 1e-6
+  # top-1 over 2 x 32 samples: with 2-bit weights one borderline sample may flip (1/64 = 0.0156)
+  assert abs(rs['acc_top1'] - np.mean([e['metrics']['accuracy'] for e in ev])) <= (1e-6 if bits > 2 else 2.0 / 64 + 1e-6)
 
 
 @pytest.mark.parametrize('a_bits,loss_tol,bulk_tol', [(32, 2e-4, 2e-4), (8, 1e-2, None)])
