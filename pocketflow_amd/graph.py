@@ -698,9 +698,14 @@ class _FusedConv1x1(torch.autograd.Function):
     return dx, dw, (dy if has_res else None), None, None, None, None, None
 
 
+def fusable_tensor(t: torch.Tensor) -> bool:
+  """pf_conv.hip works on bf16 device tensors (the float32 parity mode keeps every activation materialised)."""
+  return t.is_cuda and t.dtype == torch.bfloat16
+
+
 def fused_conv1x1_ok(x, conv) -> bool:
   t = x.x if isinstance(x, LazyAct) else x
-  return (conv.k == 1 and conv.bias is None and t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 4
+  return (conv.k == 1 and conv.bias is None and fusable_tensor(t) and t.dim() == 4
           and conv.kernel.ref_shape[2] % 8 == 0 and conv.kernel.ref_shape[3] % 8 == 0
           and conv.padding in ('SAME', 'VALID', 0) and conv.graph.fuse_conv1x1)
 
@@ -904,7 +909,7 @@ class BatchNormAct:
     g = self.graph
     bits = self.op.bits if self.op is not None else None
     slot = g.act_slots[self.op.index] if (self.op is not None and bits is not None) else None
-    lazy = self.lazy_ok and g.fuse_conv1x1 and x.dtype == torch.bfloat16 and x.is_cuda
+    lazy = self.lazy_ok and g.fuse_conv1x1 and fusable_tensor(x)
     if g.training and torch.is_grad_enabled():
       stats = getattr(x, '_pf_stats', None)      # left by the fused convolution that produced x
       if lazy:
