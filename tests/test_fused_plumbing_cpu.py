@@ -232,3 +232,35 @@ def test_fused_plumbing_is_exact_on_cpu(monkeypatch, act_bits):
     # ... and the gradients still point the same way
     cos = float(torch.dot(a['w_grad'], b['w_grad']) / (a['w_grad'].norm() * b['w_grad'].norm()))
     assert cos > 0.995, cos
+
+
+def test_mobilenet_pointwise_fusion_is_exact_on_cpu(monkeypatch):
+  """MobileNet-v1: the depthwise BN+ReLU6 is applied inside the pointwise 1x1 convolution, which leaves the
+  statistics for its own BN; same exactness check as above (no quantisers)."""
+  from pocketflow_amd import graph as G
+  from pocketflow_amd.utils.external.mobilenet_v1 import MobilenetV1
+  results = {}
+  for fuse in (False, True):
+    fake = FakeHip()
+    monkeypatch.setattr(G, 'hip', fake)
+    monkeypatch.setattr(G, 'fusable_tensor', lambda t: True)
+    g = G.Graph('model', 'cpu', torch.float32)
+    g.fuse_conv1x1 = fuse
+    net = MobilenetV1(g, num_classes=16, depth_multiplier=0.25, dropout_keep_prob=1.0)   # 16 classes: fusable logits conv
+    g.finalize(seed=5, requires_grad=True)
+    torch.manual_seed(1)
+    x = torch.randn(8, 3, 64, 64).contiguous(memory_format=torch.channels_last)
+    wts = torch.randn(8, 16)
+    fake.minmax_slots_init(g.act_slots)
+    with g.as_default():
+      logits = net(x, True)
+    (logits * wts).sum().backward()
+    st = g.store
+    results[fuse] = dict(logits=logits.detach().clone(), w_grad=st.w_grad.clone(), o_grad=st.o_grad.clone(),
+                         state=st.state.clone(), calls=dict(fake.calls))
+  a, b = results[False], results[True]
+  assert b['calls'].get('conv1x1_fwd', 0) == 13 and a['calls'].get('conv1x1_fwd', 0) == 0     # 13 pointwise convs
+  assert b['calls']['bn_stats'] == a['calls']['bn_stats'] - 13                                # their BNs use the epilogue
+  for k in ('logits', 'w_grad', 'o_grad', 'state'):
+    err = float((a[k] - b[k]).abs().max() / (a[k].abs().max() + 1e-12))
+    assert err <= 5e-4, (k, err)      # 27 BN layers deep; the fused statistics are un-pivoted sums
