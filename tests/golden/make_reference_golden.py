@@ -26,6 +26,8 @@ Lifted (paths relative to /root/reference):
   learners/uniform_quantization/learner.py    setup_bnds_decay_rates
   learners/nonuniform_quantization/learner.py setup_bnds_decay_rates
   utils/lrn_rate_utils.py                     setup_lrn_rate_piecewise_constant / _exponential_decay
+  learners/channel_pruning/channel_pruner.py  ChannelPruner.compute_pruned_kernel + featuremap_reconstruction
+                                              (NumPy + the real scikit-learn LassoLars / LinearRegression)
   utils/get_path_args.py                      run as a script (pure Python)
 """
 import ast
@@ -272,6 +274,33 @@ def gen_ws_host(meta):
                         'out': [[n, float(r)] for n, r in cls._PROptimizer__calc_heurist_prune_ratios(self)]}
 
 
+def gen_channel_pruner(out):
+  """compute_pruned_kernel + featuremap_reconstruction of the reference's ChannelPruner (channel_pruner.py:
+  443-577) executed as they are (NumPy + the real scikit-learn); np.random is seeded because the reference
+  samples with the global generator."""
+  from timeit import default_timer as timer
+  from sklearn.linear_model import LassoLars, LinearRegression
+  ns = lift('learners/channel_pruning/channel_pruner.py',
+            ['ChannelPruner.compute_pruned_kernel', 'ChannelPruner.featuremap_reconstruction'],
+            {'LassoLars': LassoLars, 'LinearRegression': LinearRegression, 'timer': timer})
+  cls = ns['ChannelPruner']
+  cls.featuremap_reconstruction = classmethod(cls.featuremap_reconstruction)
+  FLAGS.debug, FLAGS.cp_quadruple = False, False
+  for name, (seed, n, kh, cin, cout, rank, c_new) in {'pw24': (1, 800, 1, 24, 16, 8, 12), 'k3c16': (2, 800, 3, 16, 12, 6, 8),
+                                                       'pw32': (3, 1200, 1, 32, 20, 10, 10)}.items():
+    rng = np.random.RandomState(seed)
+    basis = rng.randn(n, kh, kh, rank)
+    X = np.einsum('nhwr,rc->nhwc', basis, rng.randn(rank, cin)) + 0.05 * rng.randn(n, kh, kh, cin)
+    W2 = rng.randn(kh, kh, cin, cout) * 0.2
+    Y = X.reshape(n, -1) @ W2.reshape(-1, cout)
+    np.random.seed(77)
+    self = cls.__new__(cls)
+    idxs, newW2 = cls.compute_pruned_kernel(self, X, W2, Y, c_new=c_new)
+    # the inputs are regenerated by the test from this recipe (same NumPy Mersenne stream)
+    out['cp/%s/recipe' % name] = np.array([seed, n, kh, cin, cout, rank, c_new], np.int64)
+    out['cp/%s/idxs' % name], out['cp/%s/newW2' % name] = np.asarray(idxs, bool), np.asarray(newW2)
+
+
 def gen_path_args(meta):
   conf = os.path.join(HERE, 'path.conf.sample')
   rows = []
@@ -292,6 +321,7 @@ def main():
   gen_nonuniform(arrays)
   gen_distill(arrays)
   gen_ws(arrays)
+  gen_channel_pruner(arrays)
   gen_schedules(meta)
   gen_ws_host(meta)
   gen_path_args(meta)

@@ -39,3 +39,28 @@ def test_fake_pruning_masks_match_oracle():
   keep_out = np.array([False, True, True])
   m = O.cp_grad_mask((3, 3, 4, 3), keep_in, keep_out)
   assert m.sum() == 9 * 3 * 2 and m[:, :, 1, :].sum() == 0 and m[:, :, :, 0].sum() == 0
+
+
+@pytest.mark.parametrize('name', ['pw24', 'k3c16', 'pw32'])
+def test_lasso_selector_matches_the_reference_code(name):
+  """Fixtures produced by executing the reference's own ChannelPruner.compute_pruned_kernel
+  (tests/golden/make_reference_golden.py, np.random.seed(77)): the product selector and the oracle must
+  reproduce the kept channels exactly and the reconstructed kernel to round-off."""
+  import os
+  from oracle import pf_oracle as O
+  from pocketflow_amd.learners.channel_pruning.channel_pruner import compute_pruned_kernel
+  with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_arrays.npz')) as z:
+    seed, n, kh, cin, cout, rank, c_new = [int(v) for v in z['cp/%s/recipe' % name]]
+    ref_idxs, ref_new = z['cp/%s/idxs' % name], z['cp/%s/newW2' % name]
+  rng = np.random.RandomState(seed)
+  basis = rng.randn(n, kh, kh, rank)
+  X = np.einsum('nhwr,rc->nhwc', basis, rng.randn(rank, cin)) + 0.05 * rng.randn(n, kh, kh, cin)
+  W2 = rng.randn(kh, kh, cin, cout) * 0.2
+  Y = X.reshape(n, -1) @ W2.reshape(-1, cout)
+  idxs, coef = compute_pruned_kernel(X, W2, Y, c_new, np.random.RandomState(77))
+  assert np.array_equal(idxs, ref_idxs)
+  np.testing.assert_allclose(coef, ref_new, rtol=1e-9, atol=1e-11)
+  idx_o, new_o = O.cp_lasso_select(X, Y, W2, c_new, np.random.RandomState(77))
+  assert np.array_equal(idx_o, ref_idxs)
+  kept = int(ref_idxs.sum())
+  np.testing.assert_allclose(new_o, np.transpose(ref_new.reshape(-1, kh, kh, kept), (1, 2, 3, 0)), rtol=1e-5, atol=1e-6)
