@@ -617,6 +617,36 @@ def _random_values_resnet(dataset, resnet_size, nb_classes, image_shape, seed=42
   return values
 
 
+def net_fixture_recipe(model: str, dataset: str, resnet_size: int, nb_classes: int, image_shape, batch: int = 4,
+                       seed: int = 7):
+  """(values, images) of the network-definition fixtures (tests/golden/make_reference_golden.py executes the
+  reference's own network code on them; tests/test_oracle_golden.py re-creates them with this recipe)."""
+  rng = np.random.RandomState(seed + 1000)
+  if model == 'resnet':
+    vals = _random_values_resnet(dataset, resnet_size, nb_classes, image_shape, seed=seed)
+  elif model == 'lenet':
+    h, w, c = image_shape
+    hh, ww = ((h - 4) // 2 - 4) // 2, ((w - 4) // 2 - 4) // 2
+    vals = {'model/conv1/kernel': rng.randn(5, 5, c, 32) * 0.1, 'model/conv1/bias': rng.randn(32) * 0.1,
+            'model/conv2/kernel': rng.randn(5, 5, 32, 64) * 0.05, 'model/conv2/bias': rng.randn(64) * 0.1,
+            'model/fc3/kernel': rng.randn(hh * ww * 64, 256) * 0.03, 'model/fc3/bias': rng.randn(256) * 0.1,
+            'model/fc4/kernel': rng.randn(256, nb_classes) * 0.1, 'model/fc4/bias': rng.randn(nb_classes) * 0.1}
+    vals = {k: v.astype(np.float32) for k, v in vals.items()}
+  else:
+    raise ValueError(model)
+  for k in sorted(vals):                       # non-trivial BN parameters / statistics / biases
+    if 'moving_mean' in k:
+      vals[k] = (rng.randn(*vals[k].shape) * 0.1).astype(np.float32)
+    elif 'moving_variance' in k:
+      vals[k] = (rng.rand(*vals[k].shape) + 0.5).astype(np.float32)
+    elif k.endswith('gamma'):
+      vals[k] = (rng.rand(*vals[k].shape) + 0.5).astype(np.float32)
+    elif k.endswith('beta') or (k.endswith('bias') and model == 'resnet'):
+      vals[k] = (rng.randn(*vals[k].shape) * 0.1).astype(np.float32)
+  images = rng.randn(batch, *image_shape).astype(np.float32)
+  return vals, images
+
+
 def time_cpu_baseline(resnet_size=50, image_size=224, batch=4, steps=3, weight_bits=8, act_bits=8,
                       nb_classes=1001, enbl_dst=True, threads: Optional[int] = None, budget_s: float = 25.0) -> Dict:
   """Time the oracle UniformQuantLearner step (the reference's TF-CPU path restated; TF itself is

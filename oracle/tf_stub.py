@@ -22,6 +22,12 @@ individual TF primitive remain a restatement of TF's published behaviour [3P]:
     the reference chain are NOT produced by this stub; the STE rules are pinned by hand-derived
     known answers in tests/golden/make_golden.py).
 
+A second group of stand-ins (tf.layers.conv2d / batch_normalization / dense / max_pooling2d, tf.pad,
+tf.squeeze) lets the reference's NETWORK DEFINITIONS (utils/external/resnet_model.py) execute as they are,
+with variables supplied by name (`variable_values`), so that the creation order, the auto-generated layer
+names, the fixed-padding rule, the projection-shortcut placement and the BN constants of the restated
+networks are pinned against the reference's own code.  The dense contractions use torch-CPU float32.
+
 Only what the lifted functions use is implemented; anything else raises AttributeError loudly.
 """
 from __future__ import annotations
@@ -165,7 +171,7 @@ def tile(x, multiples, **kw): return T(np.tile(_raw(x), [int(m) for m in np.asar
 def transpose(x, perm=None, **kw): return T(np.transpose(_raw(x), perm))
 def gather(params, indices, axis=0, **kw): return T(np.take(_raw(params), np.asarray(_raw(indices)), axis=axis))
 def stop_gradient(x, **kw): return T(_raw(x))
-def identity(x, **kw): return T(_raw(x))
+def identity(x, name=None, **kw): return T(_raw(x))
 def sign(x, **kw): return T(np.sign(_raw(x)))
 def abs(x, **kw): return T(np.abs(_raw(x)))                                     # noqa: A001
 def round(x, **kw): return T(np.rint(_raw(x)))                                  # noqa: A001
@@ -173,7 +179,7 @@ def square(x, **kw): return T(_raw(x) * _raw(x))
 def argmin(x, axis=None, **kw): return T(np.argmin(_raw(x), axis=axis).astype(np.int64))
 def reduce_max(x, axis=None, **kw): return T(np.max(_raw(x), axis=axis))
 def reduce_min(x, axis=None, **kw): return T(np.min(_raw(x), axis=axis))
-def reduce_mean(x, axis=None, **kw): return T(np.mean(_raw(x), axis=axis, dtype=np.float32))
+def reduce_mean(x, axis=None, keepdims=False, **kw): return T(np.mean(_raw(x), axis=tuple(axis) if isinstance(axis, (list, tuple)) else axis, dtype=np.float32, keepdims=keepdims))
 def reduce_sum(x, axis=None, **kw): return T(np.sum(_raw(x), axis=axis, dtype=np.asarray(_raw(x)).dtype))
 def minimum(a, b, **kw): return T(np.minimum(T._b(a, np.asarray(_raw(b))), T._b(b, np.asarray(_raw(a)))))
 def maximum(a, b, **kw): return T(np.maximum(T._b(a, np.asarray(_raw(b))), T._b(b, np.asarray(_raw(a)))))
@@ -290,6 +296,106 @@ def _percentile(x, q, axis=None, interpolation=None, keep_dims=False, **kw):
   return T(sorted_y[..., idx])
 
 
+
+# -- tf.layers subset (network definitions) ----------------------------------------------------------------
+float16 = np.float16
+variable_values = {}          # full variable name (without ':0') -> ndarray in the reference layout
+variables_used = []           # creation order of the variables the executed network asked for
+_layer_names = {}
+
+
+def reset_layers(values):
+  variable_values.clear()
+  variable_values.update(values)
+  del variables_used[:]
+  _layer_names.clear()
+
+
+def _layer_scope(base):
+  """tf.layers auto-naming: `<base>`, `<base>_1`, ... unique per enclosing variable scope."""
+  key = '/'.join(_scopes + [base])
+  k = _layer_names.get(key, 0)
+  _layer_names[key] = k + 1
+  return base if k == 0 else '%s_%d' % (base, k)
+
+
+def _var(layer, name):
+  full = '/'.join(_scopes + [layer, name])
+  variables_used.append(full)
+  return np.asarray(variable_values[full], dtype=np.float32)
+
+
+def _same_pad(size, k, s):
+  out = -(-size // s)
+  tot = max((out - 1) * s + k - size, 0)
+  return tot // 2, tot - tot // 2
+
+
+def _conv2d(inputs, filters, kernel_size, strides=1, padding='valid', use_bias=True, data_format='channels_last',
+            kernel_initializer=None, **kw):
+  import torch
+  import torch.nn.functional as F
+  assert data_format == 'channels_last'
+  layer = kw.get('name') or _layer_scope('conv2d')
+  if isinstance(kernel_size, (list, tuple)):
+    kernel_size = kernel_size[0]
+  w = _var(layer, 'kernel')                                        # HWIO
+  x = torch.from_numpy(np.ascontiguousarray(_raw(inputs), dtype=np.float32)).permute(0, 3, 1, 2)
+  k = w.shape[0]
+  assert w.shape[0] == kernel_size and w.shape[3] == filters
+  if str(padding).upper() == 'SAME':
+    ph, pw = _same_pad(x.shape[2], k, strides), _same_pad(x.shape[3], k, strides)
+    x = F.pad(x, (pw[0], pw[1], ph[0], ph[1]))
+  b = torch.from_numpy(_var(layer, 'bias')) if use_bias else None
+  y = F.conv2d(x, torch.from_numpy(w).permute(3, 2, 0, 1).contiguous(), b, stride=strides)
+  return T(y.permute(0, 2, 3, 1).contiguous().numpy())
+
+
+def _batch_normalization(inputs, axis=-1, momentum=0.99, epsilon=1e-3, center=True, scale=True, training=False,
+                         fused=None, **kw):
+  layer = _layer_scope('batch_normalization')
+  x = np.asarray(_raw(inputs), dtype=np.float32)
+  assert axis in (3, -1)
+  gamma, beta = _var(layer, 'gamma'), _var(layer, 'beta')
+  mm, mv = _var(layer, 'moving_mean'), _var(layer, 'moving_variance')
+  if training:
+    xr = x.reshape(-1, x.shape[-1]).astype(np.float64)
+    mean, var = xr.mean(0), xr.var(0)
+  else:
+    mean, var = mm.astype(np.float64), mv.astype(np.float64)
+  y = (x.astype(np.float64) - mean) / np.sqrt(var + epsilon) * gamma + beta
+  return T(y.astype(np.float32))
+
+
+def _dense(inputs, units, **kw):
+  layer = kw.get('name') or _layer_scope('dense')
+  w, b = _var(layer, 'kernel'), _var(layer, 'bias')
+  assert w.shape[1] == units
+  return T((np.asarray(_raw(inputs), np.float32) @ w + b).astype(np.float32))
+
+
+def _max_pooling2d(inputs, pool_size, strides, padding='valid', data_format='channels_last', **kw):
+  import torch
+  import torch.nn.functional as F
+  x = torch.from_numpy(np.ascontiguousarray(_raw(inputs), dtype=np.float32)).permute(0, 3, 1, 2)
+  if isinstance(pool_size, (list, tuple)):
+    pool_size = pool_size[0]
+  if str(padding).upper() == 'SAME':
+    ph, pw = _same_pad(x.shape[2], pool_size, strides), _same_pad(x.shape[3], pool_size, strides)
+    x = F.pad(x, (pw[0], pw[1], ph[0], ph[1]), value=float('-inf'))
+  return T(F.max_pool2d(x, pool_size, strides).permute(0, 2, 3, 1).contiguous().numpy())
+
+
+def _flatten(inputs, **kw):
+  a = np.asarray(_raw(inputs))
+  return T(a.reshape(a.shape[0], -1))
+
+
+def pad(x, paddings, **kw): return T(np.pad(_raw(x), [tuple(p) for p in paddings]))
+def squeeze(x, axis=None, **kw): return T(np.squeeze(_raw(x), axis=tuple(axis) if axis is not None else None))
+def variance_scaling_initializer(*a, **kw): return 'variance_scaling'
+
+
 class _Flags(object):
   """tf.app.flags: DEFINE_* + a FLAGS namespace the generator script fills in."""
 
@@ -322,11 +428,14 @@ def install() -> types.ModuleType:
       setattr(tf, k, getattr(this, k))
   flags = _Flags()
   tf.app = _ns('tensorflow.app', flags=flags, run=lambda *a, **k: None)
-  tf.nn = _ns('tensorflow.nn', softmax=lambda z, **kw: T(_softmax(z)), relu=lambda x, **kw: T(np.maximum(_raw(x), np.float32(0))),
+  tf.nn = _ns('tensorflow.nn', softmax=lambda z, name=None, **kw: T(_softmax(z)), relu=lambda x, name=None, **kw: T(np.maximum(_raw(x), np.float32(0))),
               relu6=lambda x, **kw: T(np.minimum(np.maximum(_raw(x), np.float32(0)), np.float32(6))))
   tf.losses = _ns('tensorflow.losses', softmax_cross_entropy=_softmax_cross_entropy)
   tf.train = _ns('tensorflow.train', piecewise_constant=_piecewise_constant, exponential_decay=_exponential_decay)
   tf.summary = _ns('tensorflow.summary', scalar=lambda *a, **k: None)
+  tf.layers = _ns('tensorflow.layers', conv2d=_conv2d, batch_normalization=_batch_normalization, dense=_dense,
+                  max_pooling2d=_max_pooling2d, flatten=_flatten)
+  tf.test = _ns('tensorflow.test', is_built_with_cuda=lambda: False)
   tf.logging = _ns('tensorflow.logging', info=lambda *a, **k: None, warning=lambda *a, **k: None)
   dist = _ns('tensorflow.contrib.distributions', percentile=_percentile)
   ge = _ns('tensorflow.contrib.graph_editor')

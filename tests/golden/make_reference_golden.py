@@ -28,6 +28,8 @@ Lifted (paths relative to /root/reference):
   utils/lrn_rate_utils.py                     setup_lrn_rate_piecewise_constant / _exponential_decay
   learners/channel_pruning/channel_pruner.py  ChannelPruner.compute_pruned_kernel + featuremap_reconstruction
                                               (NumPy + the real scikit-learn LassoLars / LinearRegression)
+  utils/external/resnet_model.py              the WHOLE module (Model.__call__, blocks, fixed padding, BN constants)
+  nets/lenet_at_cifar10.py                    forward_fn
   utils/get_path_args.py                      run as a script (pure Python)
 """
 import ast
@@ -301,6 +303,41 @@ def gen_channel_pruner(out):
     out['cp/%s/idxs' % name], out['cp/%s/newW2' % name] = np.asarray(idxs, bool), np.asarray(newW2)
 
 
+NET_CASES = [('resnet', 'cifar_10', 20, 10, (32, 32, 3)), ('resnet', 'ilsvrc_12', 50, 11, (64, 64, 3)),
+             ('resnet', 'ilsvrc_12', 18, 7, (64, 64, 3)), ('lenet', 'cifar_10', 0, 10, (32, 32, 3))]
+
+
+def gen_networks(out, meta):
+  """Execute the reference's own NETWORK DEFINITIONS (utils/external/resnet_model.py as a whole module,
+  nets/lenet_at_cifar10.py:forward_fn) over the stub's tf.layers stand-ins on seeded variables; store the logits
+  and the order in which the code asked for its variables (= TF's creation order)."""
+  import importlib.util
+  from oracle.learner_oracle import net_fixture_recipe, resnet_cfg
+  spec = importlib.util.spec_from_file_location('ref_resnet_model', os.path.join(REF, 'utils/external/resnet_model.py'))
+  resnet = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(resnet)
+  lenet = lift('nets/lenet_at_cifar10.py', ['forward_fn'])
+  orders = {}
+  for model, ds, size, ncls, shape in NET_CASES:
+    vals, images = net_fixture_recipe(model, ds, size, ncls, shape)
+    key = '%s_%s_%d' % (model, ds, size)
+    for training in ((True, False) if model == 'resnet' else (False,)):
+      tf_stub.reset_layers(vals)
+      with tf.variable_scope('model'):
+        if model == 'resnet':
+          cfg = resnet_cfg(ds, size)
+          net = resnet.Model(size, cfg['bottleneck'], ncls, cfg['num_filters'], cfg['kernel_size'], cfg['conv_stride'],
+                             cfg['first_pool_size'], cfg['first_pool_stride'], cfg['block_sizes'], cfg['block_strides'],
+                             data_format='channels_last')
+          logits = net(tf_stub.T(images), training)
+        else:
+          FLAGS.nb_classes = ncls
+          logits = lenet['forward_fn'](tf_stub.T(images), 'channels_last')
+      out['net/%s/%s' % (key, 'train' if training else 'eval')] = np.asarray(logits.a, np.float32)
+    orders[key] = [u for u in tf_stub.variables_used if u.endswith('kernel')]
+  meta['net_matmul_order'] = orders
+
+
 def gen_path_args(meta):
   conf = os.path.join(HERE, 'path.conf.sample')
   rows = []
@@ -322,6 +359,7 @@ def main():
   gen_distill(arrays)
   gen_ws(arrays)
   gen_channel_pruner(arrays)
+  gen_networks(arrays, meta)
   gen_schedules(meta)
   gen_ws_host(meta)
   gen_path_args(meta)

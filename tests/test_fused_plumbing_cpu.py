@@ -6,6 +6,8 @@ float32 torch emulations of their documented semantics (include/pocketflow_hip.h
 ResNet is run with fusion on and off -- both must give the same outputs, gradients and BN state to float32
 round-off.  The GPU tests can only compare the bf16 kernels statistically (tests/test_conv_gpu.py); this
 test pins the LOGIC around them."""
+import json
+
 import numpy as np
 import pytest
 import torch
@@ -264,3 +266,66 @@ def test_mobilenet_pointwise_fusion_is_exact_on_cpu(monkeypatch):
   for k in ('logits', 'w_grad', 'o_grad', 'state'):
     err = float((a[k] - b[k]).abs().max() / (a[k].abs().max() + 1e-12))
     assert err <= 5e-4, (k, err)      # 27 BN layers deep; the fused statistics are un-pivoted sums
+
+
+@pytest.mark.parametrize('dataset,size,ncls,shape', [('cifar_10', 20, 10, (32, 32, 3)), ('ilsvrc_12', 50, 11, (64, 64, 3)),
+                                                     ('ilsvrc_12', 18, 7, (64, 64, 3))])
+def test_product_resnet_matches_the_reference_network_code(monkeypatch, dataset, size, ncls, shape):
+  """The PRODUCT's ResNet (pocketflow_amd/utils/external/resnet_model.py on the layer executor, HIP entry
+  points emulated) loaded with reference-named variables reproduces the logits obtained by executing the
+  reference's own utils/external/resnet_model.py (tests/golden fixtures): same variable names (load_numpy is
+  strict), same creation order, same padding / projection / BN rules -- fused and unfused."""
+  import os
+  from oracle import learner_oracle as LO
+  from pocketflow_amd import graph as G
+  from pocketflow_amd.utils.external import resnet_model as R
+  with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_arrays.npz')) as z:
+    ref = {m: z['net/resnet_%s_%d/%s' % (dataset, size, m)] for m in ('train', 'eval')}
+  vals, images = LO.net_fixture_recipe('resnet', dataset, size, ncls, shape)
+  cfg = LO.resnet_cfg(dataset, size)
+  for fuse in (False, True):
+    fake = FakeHip()
+    monkeypatch.setattr(G, 'hip', fake)
+    monkeypatch.setattr(G, 'fusable_tensor', lambda t: True)
+    g = G.Graph('model', 'cpu', torch.float32)
+    g.fuse_conv1x1 = fuse
+    net = R.Model(size, cfg['bottleneck'], ncls, cfg['num_filters'], cfg['kernel_size'], cfg['conv_stride'],
+                  cfg['first_pool_size'], cfg['first_pool_stride'], cfg['block_sizes'], cfg['block_strides'],
+                  data_format='channels_last', graph=g)
+    g.finalize(seed=1, requires_grad=True)
+    g.store.load_numpy(vals, strict=True)                 # every product variable exists under the reference name
+    assert sorted(v.name for v in g.store.vars) == sorted(vals.keys())
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_host.json')) as f:
+      order = json.load(f)['net_matmul_order']['resnet_%s_%d' % (dataset, size)]
+    assert [op.var.name for op in g.matmul_ops] == order  # TF's creation order of the matmul kernels
+    x = torch.from_numpy(images).permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+    for mode in ('eval', 'train'):
+      fake.minmax_slots_init(g.act_slots)
+      with g.as_default():
+        if mode == 'eval':
+          with torch.no_grad():
+            logits = net(x, False)
+        else:
+          logits = net(x, True)
+      got = logits.detach().numpy()
+      assert np.max(np.abs(got - ref[mode])) <= 5e-4 * max(1.0, float(np.max(np.abs(ref[mode])))), (fuse, mode)
+      g.store.load_numpy(vals, strict=True)               # undo the moving-average update of the training pass
+
+
+def test_product_lenet_matches_the_reference_network_code():
+  """Same for LeNet (nets/lenet_at_cifar10.py:forward_fn executed by the golden generator)."""
+  import os
+  from oracle import learner_oracle as LO
+  from pocketflow_amd import graph as G
+  from pocketflow_amd.nets.lenet_at_cifar10 import _LeNet
+  with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_arrays.npz')) as z:
+    ref = z['net/lenet_cifar_10_0/eval']
+  vals, images = LO.net_fixture_recipe('lenet', 'cifar_10', 0, 10, (32, 32, 3))
+  g = G.Graph('model', 'cpu', torch.float32)
+  net = _LeNet(g, (32, 32, 3), 10)
+  g.finalize(seed=1, requires_grad=False)
+  g.store.load_numpy(vals, strict=True)
+  assert sorted(v.name for v in g.store.vars) == sorted(vals.keys())
+  with torch.no_grad(), g.as_default():
+    got = net(torch.from_numpy(images).permute(0, 3, 1, 2), False).numpy()
+  assert np.max(np.abs(got - ref)) <= 1e-5

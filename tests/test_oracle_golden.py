@@ -165,3 +165,29 @@ def test_ws_host_side(host):
   got = O.pr_heurist([n for n, _ in h['out']], [int(np.prod(s)) for s in h['shapes']], h['prune_ratio'])
   for (n, r), (n2, r2) in zip(got, h['out']):
     assert n == n2 and abs(r - r2) <= 1e-15
+
+
+@pytest.mark.parametrize('model,dataset,size,ncls,shape', [
+    ('resnet', 'cifar_10', 20, 10, (32, 32, 3)), ('resnet', 'ilsvrc_12', 50, 11, (64, 64, 3)),
+    ('resnet', 'ilsvrc_12', 18, 7, (64, 64, 3)), ('lenet', 'cifar_10', 0, 10, (32, 32, 3))])
+def test_network_definitions_match_the_reference_code(arrays, host, model, dataset, size, ncls, shape):
+  """Logits of the reference's own network code (executed over oracle/tf_stub.py's tf.layers stand-ins) vs the
+  restated networks of oracle/learner_oracle.py on the same seeded variables, and the creation order of the
+  matmul kernels, which decides the per-layer bit widths (uq utils.py:115-134)."""
+  import torch
+  from oracle import learner_oracle as LO
+  vals, images = LO.net_fixture_recipe(model, dataset, size, ncls, shape)
+  key = '%s_%s_%d' % (model, dataset, size)
+  x = torch.from_numpy(images).permute(0, 3, 1, 2)
+  for mode in (('train', 'eval') if model == 'resnet' else ('eval',)):
+    s = LO.Scope(vals, 'model', trainable=False)
+    s.training = mode == 'train'
+    s._begin()
+    with torch.no_grad():
+      if model == 'resnet':
+        got = LO.resnet_v2_forward(s, x, LO.resnet_cfg(dataset, size)).numpy()
+      else:
+        got = LO.lenet_forward(s, x, ncls).numpy()
+    ref = arrays['net/%s/%s' % (key, mode)]
+    assert np.max(np.abs(got - ref)) <= 2e-4 * max(1.0, float(np.max(np.abs(ref)))), (key, mode)
+    assert s.matmul_names == host['net_matmul_order'][key], key
