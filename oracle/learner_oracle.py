@@ -617,6 +617,36 @@ def _random_values_resnet(dataset, resnet_size, nb_classes, image_shape, seed=42
   return values
 
 
+def _random_values_mobilenet(nb_classes, depth_mult=1.0, min_depth=8, seed=42, in_channels=3):
+  """Seeded variables of MobileNet-v1 in slim's naming (utils/external/mobilenet_v1.py)."""
+  rng = np.random.RandomState(seed)
+  vals: Dict[str, np.ndarray] = {}
+  depth = lambda d: max(int(d * depth_mult), min_depth)
+
+  def bn(prefix, c):
+    vals[prefix + '/BatchNorm/gamma'] = (rng.rand(c) + 0.5).astype(np.float32)
+    vals[prefix + '/BatchNorm/beta'] = (rng.randn(c) * 0.1).astype(np.float32)
+    vals[prefix + '/BatchNorm/moving_mean'] = (rng.randn(c) * 0.1).astype(np.float32)
+    vals[prefix + '/BatchNorm/moving_variance'] = (rng.rand(c) + 0.5).astype(np.float32)
+  cin = in_channels
+  for i, (kind, k, stride, d) in enumerate(_MBV1_DEFS):
+    if kind == 'c':
+      name = 'model/MobilenetV1/Conv2d_%d' % i
+      vals[name + '/weights'] = (rng.randn(k, k, cin, depth(d)) * 0.2).astype(np.float32)
+      bn(name, depth(d))
+    else:
+      name = 'model/MobilenetV1/Conv2d_%d_depthwise' % i
+      vals[name + '/depthwise_weights'] = (rng.randn(k, k, cin, 1) * 0.3).astype(np.float32)
+      bn(name, cin)
+      name = 'model/MobilenetV1/Conv2d_%d_pointwise' % i
+      vals[name + '/weights'] = (rng.randn(1, 1, cin, depth(d)) * (1.5 / np.sqrt(cin))).astype(np.float32)
+      bn(name, depth(d))
+    cin = depth(d)
+  vals['model/MobilenetV1/Logits/Conv2d_1c_1x1/weights'] = (rng.randn(1, 1, cin, nb_classes) * 0.1).astype(np.float32)
+  vals['model/MobilenetV1/Logits/Conv2d_1c_1x1/biases'] = (rng.randn(nb_classes) * 0.1).astype(np.float32)
+  return vals
+
+
 def net_fixture_recipe(model: str, dataset: str, resnet_size: int, nb_classes: int, image_shape, batch: int = 4,
                        seed: int = 7):
   """(values, images) of the network-definition fixtures (tests/golden/make_reference_golden.py executes the
@@ -632,6 +662,10 @@ def net_fixture_recipe(model: str, dataset: str, resnet_size: int, nb_classes: i
             'model/fc3/kernel': rng.randn(hh * ww * 64, 256) * 0.03, 'model/fc3/bias': rng.randn(256) * 0.1,
             'model/fc4/kernel': rng.randn(256, nb_classes) * 0.1, 'model/fc4/bias': rng.randn(nb_classes) * 0.1}
     vals = {k: v.astype(np.float32) for k, v in vals.items()}
+  elif model == 'mobilenet_v1':
+    vals = _random_values_mobilenet(nb_classes, depth_mult=resnet_size / 100.0, seed=seed)
+    images = rng.randn(batch, *image_shape).astype(np.float32)
+    return vals, images
   else:
     raise ValueError(model)
   for k in sorted(vals):                       # non-trivial BN parameters / statistics / biases

@@ -179,7 +179,12 @@ def square(x, **kw): return T(_raw(x) * _raw(x))
 def argmin(x, axis=None, **kw): return T(np.argmin(_raw(x), axis=axis).astype(np.int64))
 def reduce_max(x, axis=None, **kw): return T(np.max(_raw(x), axis=axis))
 def reduce_min(x, axis=None, **kw): return T(np.min(_raw(x), axis=axis))
-def reduce_mean(x, axis=None, keepdims=False, **kw): return T(np.mean(_raw(x), axis=tuple(axis) if isinstance(axis, (list, tuple)) else axis, dtype=np.float32, keepdims=keepdims))
+def reduce_mean(x, axis=None, keepdims=False, keep_dims=False, name=None, **kw):
+  keepdims = keepdims or keep_dims
+  return _reduce_mean(x, axis, keepdims)
+
+
+def _reduce_mean(x, axis=None, keepdims=False): return T(np.mean(_raw(x), axis=tuple(axis) if isinstance(axis, (list, tuple)) else axis, dtype=np.float32, keepdims=keepdims))
 def reduce_sum(x, axis=None, **kw): return T(np.sum(_raw(x), axis=axis, dtype=np.asarray(_raw(x)).dtype))
 def minimum(a, b, **kw): return T(np.minimum(T._b(a, np.asarray(_raw(b))), T._b(b, np.asarray(_raw(a)))))
 def maximum(a, b, **kw): return T(np.maximum(T._b(a, np.asarray(_raw(b))), T._b(b, np.asarray(_raw(a)))))
@@ -201,13 +206,23 @@ def map_fn(fn, elems, dtype=None, **kw):
 _scopes = []
 
 
+class _ScopeObj(str):
+  """What `with tf.variable_scope(...) as scope` yields: the absolute scope path; passing it back to
+  tf.variable_scope re-enters that scope instead of nesting."""
+
+
 @contextlib.contextmanager
-def variable_scope(name, *a, **kw):
-  _scopes.append(str(name))
+def variable_scope(name_or_scope, default_name=None, values=None, *a, **kw):
+  saved = list(_scopes)
+  if isinstance(name_or_scope, _ScopeObj):
+    _scopes[:] = [p for p in str(name_or_scope).split('/') if p]
+  else:
+    name = name_or_scope if name_or_scope is not None else default_name
+    _scopes.append(str(name))
   try:
-    yield
+    yield _ScopeObj('/'.join(_scopes))
   finally:
-    _scopes.pop()
+    _scopes[:] = saved
 
 
 class _Scope(object):
@@ -392,8 +407,123 @@ def _flatten(inputs, **kw):
 
 
 def pad(x, paddings, **kw): return T(np.pad(_raw(x), [tuple(p) for p in paddings]))
-def squeeze(x, axis=None, **kw): return T(np.squeeze(_raw(x), axis=tuple(axis) if axis is not None else None))
+def squeeze(x, axis=None, name=None, **kw): return T(np.squeeze(_raw(x), axis=tuple(axis) if axis is not None else None))
 def variance_scaling_initializer(*a, **kw): return 'variance_scaling'
+
+
+# -- tf.contrib.slim subset (MobileNet-v1 definition) ---------------------------------------------------------
+_arg_stack = [{}]
+
+
+def _slim_fn(fn):
+  def wrapped(*args, **kwargs):
+    merged = dict(_arg_stack[-1].get(wrapped, {}))
+    merged.update(kwargs)
+    return fn(*args, **merged)
+  wrapped.__name__ = fn.__name__
+  return wrapped
+
+
+@contextlib.contextmanager
+def _arg_scope(fns_or_scope, **kwargs):
+  if isinstance(fns_or_scope, dict):                 # re-entering a scope captured with `as sc`
+    new = {k: dict(v) for k, v in fns_or_scope.items()}
+  else:
+    new = {k: dict(v) for k, v in _arg_stack[-1].items()}
+    for f in fns_or_scope:
+      new.setdefault(f, {}).update(kwargs)
+  _arg_stack.append(new)
+  try:
+    yield new
+  finally:
+    _arg_stack.pop()
+
+
+def _nhwc_conv(x, w_oihw, stride, padding, groups=1, bias=None):
+  import torch
+  import torch.nn.functional as F
+  x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).permute(0, 3, 1, 2)
+  k = w_oihw.shape[2]
+  if str(padding).upper() == 'SAME':
+    ph, pw = _same_pad(x.shape[2], k, stride), _same_pad(x.shape[3], k, stride)
+    x = F.pad(x, (pw[0], pw[1], ph[0], ph[1]))
+  y = F.conv2d(x, w_oihw, bias, stride=stride, groups=groups)
+  return y.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+@_slim_fn
+def _slim_batch_norm(inputs, decay=0.999, center=False, scale=False, epsilon=0.001, is_training=True,
+                     updates_collections=None, scope=None, **kw):
+  with variable_scope(scope, 'BatchNorm'):
+    x = np.asarray(_raw(inputs), dtype=np.float32)
+    C = x.shape[-1]
+    beta = _var_here('beta') if center else np.zeros(C, np.float32)
+    gamma = _var_here('gamma') if scale else np.ones(C, np.float32)
+    mm, mv = _var_here('moving_mean'), _var_here('moving_variance')
+    if is_training:
+      xr = x.reshape(-1, C).astype(np.float64)
+      mean, var = xr.mean(0), xr.var(0)
+    else:
+      mean, var = mm.astype(np.float64), mv.astype(np.float64)
+    return T(((x.astype(np.float64) - mean) / np.sqrt(var + epsilon) * gamma + beta).astype(np.float32))
+
+
+def _var_here(name):
+  full = '/'.join(_scopes + [name])
+  variables_used.append(full)
+  return np.asarray(variable_values[full], dtype=np.float32)
+
+
+def _post(y, normalizer_fn, normalizer_params, activation_fn):
+  out = T(y)
+  if normalizer_fn is not None:
+    out = normalizer_fn(out, **(normalizer_params or {}))
+  if activation_fn is not None:
+    out = activation_fn(out)
+  return out
+
+
+@_slim_fn
+def _slim_conv2d(inputs, num_outputs, kernel_size, stride=1, padding='SAME', rate=1, activation_fn=None,
+                 normalizer_fn=None, normalizer_params=None, weights_initializer=None, weights_regularizer=None,
+                 scope=None, **kw):
+  import torch
+  with variable_scope(scope, 'Conv'):
+    w = _var_here('weights')                                           # HWIO
+    assert list(w.shape[:2]) == list(kernel_size) and w.shape[3] == num_outputs and rate == 1
+    bias = torch.from_numpy(_var_here('biases')) if normalizer_fn is None else None
+    y = _nhwc_conv(_raw(inputs), torch.from_numpy(w).permute(3, 2, 0, 1).contiguous(), stride, padding, 1, bias)
+    return _post(y, normalizer_fn, normalizer_params, activation_fn)
+
+
+@_slim_fn
+def _slim_separable_conv2d(inputs, num_outputs, kernel_size, depth_multiplier=1, stride=1, padding='SAME', rate=1,
+                           activation_fn=None, normalizer_fn=None, normalizer_params=None, weights_initializer=None,
+                           weights_regularizer=None, scope=None, **kw):
+  import torch
+  assert num_outputs is None and depth_multiplier == 1 and rate == 1      # depthwise only (mobilenet_v1.py:279-284)
+  with variable_scope(scope, 'SeparableConv2d'):
+    w = _var_here('depthwise_weights')                                 # [kh, kw, C, 1]
+    C = w.shape[2]
+    y = _nhwc_conv(_raw(inputs), torch.from_numpy(w).permute(2, 3, 0, 1).contiguous(), stride, padding, C)
+    return _post(y, normalizer_fn, normalizer_params, activation_fn)
+
+
+@_slim_fn
+def _slim_dropout(inputs, keep_prob=0.5, is_training=True, scope=None, **kw):
+  """Deterministic stand-in: in training mode NOTHING is dropped (the overwhelmingly likely outcome at
+  keep_prob 0.999) and the survivors are scaled by 1/keep_prob, as tf.nn.dropout does."""
+  x = np.asarray(_raw(inputs), dtype=np.float32)
+  return T((x / np.float32(keep_prob)).astype(np.float32) if is_training else x)
+
+
+@_slim_fn
+def _slim_avg_pool2d(inputs, kernel_size, stride=2, padding='VALID', scope=None, **kw):
+  import torch
+  import torch.nn.functional as F
+  x = torch.from_numpy(np.ascontiguousarray(_raw(inputs), dtype=np.float32)).permute(0, 3, 1, 2)
+  assert str(padding).upper() == 'VALID'
+  return T(F.avg_pool2d(x, tuple(kernel_size), stride).permute(0, 2, 3, 1).contiguous().numpy())
 
 
 class _Flags(object):
@@ -429,7 +559,7 @@ def install() -> types.ModuleType:
   flags = _Flags()
   tf.app = _ns('tensorflow.app', flags=flags, run=lambda *a, **k: None)
   tf.nn = _ns('tensorflow.nn', softmax=lambda z, name=None, **kw: T(_softmax(z)), relu=lambda x, name=None, **kw: T(np.maximum(_raw(x), np.float32(0))),
-              relu6=lambda x, **kw: T(np.minimum(np.maximum(_raw(x), np.float32(0)), np.float32(6))))
+              relu6=lambda x, name=None, **kw: T(np.minimum(np.maximum(_raw(x), np.float32(0)), np.float32(6))))
   tf.losses = _ns('tensorflow.losses', softmax_cross_entropy=_softmax_cross_entropy)
   tf.train = _ns('tensorflow.train', piecewise_constant=_piecewise_constant, exponential_decay=_exponential_decay)
   tf.summary = _ns('tensorflow.summary', scalar=lambda *a, **k: None)
@@ -439,7 +569,13 @@ def install() -> types.ModuleType:
   tf.logging = _ns('tensorflow.logging', info=lambda *a, **k: None, warning=lambda *a, **k: None)
   dist = _ns('tensorflow.contrib.distributions', percentile=_percentile)
   ge = _ns('tensorflow.contrib.graph_editor')
-  tf.contrib = _ns('tensorflow.contrib', distributions=dist, graph_editor=ge)
+  slim = _ns('tensorflow.contrib.slim', arg_scope=_arg_scope, conv2d=_slim_conv2d, separable_conv2d=_slim_separable_conv2d,
+             batch_norm=_slim_batch_norm, dropout=_slim_dropout, avg_pool2d=_slim_avg_pool2d)
+  clayers = _ns('tensorflow.contrib.layers', softmax=lambda logits, scope=None: T(_softmax(logits)),
+                l2_regularizer=lambda wd: ('l2', wd))
+  tf.contrib = _ns('tensorflow.contrib', distributions=dist, graph_editor=ge, slim=slim, layers=clayers)
+  tf.truncated_normal_initializer = lambda stddev=1.0, **kw: ('truncated_normal', stddev)
+  tf.GraphKeys = _ns('tensorflow.GraphKeys', UPDATE_OPS='update_ops')
   sys.modules.update({'tensorflow': tf, 'tensorflow.contrib': tf.contrib,
                       'tensorflow.contrib.graph_editor': ge, 'tensorflow.contrib.distributions': dist})
   return tf

@@ -30,6 +30,7 @@ Lifted (paths relative to /root/reference):
                                               (NumPy + the real scikit-learn LassoLars / LinearRegression)
   utils/external/resnet_model.py              the WHOLE module (Model.__call__, blocks, fixed padding, BN constants)
   nets/lenet_at_cifar10.py                    forward_fn
+  utils/external/mobilenet_v1.py              the WHOLE module over tf.contrib.slim stand-ins
   utils/get_path_args.py                      run as a script (pure Python)
 """
 import ast
@@ -307,6 +308,9 @@ NET_CASES = [('resnet', 'cifar_10', 20, 10, (32, 32, 3)), ('resnet', 'ilsvrc_12'
              ('resnet', 'ilsvrc_12', 18, 7, (64, 64, 3)), ('lenet', 'cifar_10', 0, 10, (32, 32, 3))]
 
 
+MOBILENET_CASES = [(50, (64, 64, 3), 16), (100, (96, 96, 3), 8)]      # (depth multiplier in %, input, classes)
+
+
 def gen_networks(out, meta):
   """Execute the reference's own NETWORK DEFINITIONS (utils/external/resnet_model.py as a whole module,
   nets/lenet_at_cifar10.py:forward_fn) over the stub's tf.layers stand-ins on seeded variables; store the logits
@@ -335,6 +339,23 @@ def gen_networks(out, meta):
           logits = lenet['forward_fn'](tf_stub.T(images), 'channels_last')
       out['net/%s/%s' % (key, 'train' if training else 'eval')] = np.asarray(logits.a, np.float32)
     orders[key] = [u for u in tf_stub.variables_used if u.endswith('kernel')]
+  # MobileNet-v1: the whole slim module (mobilenet_v1, mobilenet_v1_base, mobilenet_v1_arg_scope) over the slim stand-ins;
+  # dropout_keep_prob = 1.0 in the training-mode fixture keeps it deterministic for every party
+  spec = importlib.util.spec_from_file_location('ref_mobilenet_v1', os.path.join(REF, 'utils/external/mobilenet_v1.py'))
+  mbv1 = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mbv1)
+  slim = tf.contrib.slim
+  for dm, shape, ncls in MOBILENET_CASES:
+    vals, images = net_fixture_recipe('mobilenet_v1', 'ilsvrc_12', dm, ncls, shape)
+    key = 'mobilenet_v1_%d' % dm
+    for training in (True, False):
+      tf_stub.reset_layers(vals)
+      with tf.variable_scope('model'):
+        with slim.arg_scope(mbv1.mobilenet_v1_arg_scope(is_training=training)):
+          logits, _ = mbv1.mobilenet_v1(tf_stub.T(images), is_training=training, num_classes=ncls,
+                                        depth_multiplier=dm / 100.0, dropout_keep_prob=1.0)
+      out['net/%s/%s' % (key, 'train' if training else 'eval')] = np.asarray(logits.a, np.float32)
+    orders[key] = [u for u in tf_stub.variables_used if u.endswith('weights')]
   meta['net_matmul_order'] = orders
 
 

@@ -329,3 +329,42 @@ def test_product_lenet_matches_the_reference_network_code():
   with torch.no_grad(), g.as_default():
     got = net(torch.from_numpy(images).permute(0, 3, 1, 2), False).numpy()
   assert np.max(np.abs(got - ref)) <= 1e-5
+
+
+@pytest.mark.parametrize('dm,shape,ncls', [(50, (64, 64, 3), 16), (100, (96, 96, 3), 8)])
+def test_product_mobilenet_matches_the_reference_network_code(monkeypatch, dm, shape, ncls):
+  """The product's MobileNet-v1 (slim naming, SAME padding, ReLU6, BN 0.9997/1e-3, biased logits conv) against the
+  logits of the reference's own slim module, fused (depthwise BN inside the pointwise convolutions) and unfused."""
+  import os
+  from oracle import learner_oracle as LO
+  from pocketflow_amd import graph as G
+  from pocketflow_amd.utils.external.mobilenet_v1 import MobilenetV1
+  here = os.path.dirname(os.path.abspath(__file__))
+  with np.load(os.path.join(here, 'golden', 'reference_arrays.npz')) as z:
+    ref = {m: z['net/mobilenet_v1_%d/%s' % (dm, m)] for m in ('train', 'eval')}
+  with open(os.path.join(here, 'golden', 'reference_host.json')) as f:
+    order = json.load(f)['net_matmul_order']['mobilenet_v1_%d' % dm]
+  vals, images = LO.net_fixture_recipe('mobilenet_v1', 'ilsvrc_12', dm, ncls, shape)
+  for fuse in (False, True):
+    fake = FakeHip()
+    monkeypatch.setattr(G, 'hip', fake)
+    monkeypatch.setattr(G, 'fusable_tensor', lambda t: True)
+    g = G.Graph('model', 'cpu', torch.float32)
+    g.fuse_conv1x1 = fuse
+    net = MobilenetV1(g, num_classes=ncls, depth_multiplier=dm / 100.0, dropout_keep_prob=1.0)
+    g.finalize(seed=1, requires_grad=True)
+    g.store.load_numpy(vals, strict=True)
+    assert sorted(v.name for v in g.store.vars) == sorted(vals.keys())
+    assert [op.var.name for op in g.matmul_ops] == order
+    x = torch.from_numpy(images).permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+    for mode in ('eval', 'train'):
+      fake.minmax_slots_init(g.act_slots)
+      with g.as_default():
+        if mode == 'eval':
+          with torch.no_grad():
+            logits = net(x, False)
+        else:
+          logits = net(x, True)
+      got = logits.detach().numpy()
+      assert np.max(np.abs(got - ref[mode])) <= 1e-3 * max(1.0, float(np.max(np.abs(ref[mode])))), (fuse, mode)
+      g.store.load_numpy(vals, strict=True)

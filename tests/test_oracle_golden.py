@@ -191,3 +191,20 @@ def test_network_definitions_match_the_reference_code(arrays, host, model, datas
     ref = arrays['net/%s/%s' % (key, mode)]
     assert np.max(np.abs(got - ref)) <= 2e-4 * max(1.0, float(np.max(np.abs(ref)))), (key, mode)
     assert s.matmul_names == host['net_matmul_order'][key], key
+
+
+@pytest.mark.parametrize('dm,shape,ncls', [(50, (64, 64, 3), 16), (100, (96, 96, 3), 8)])
+def test_mobilenet_definition_matches_the_reference_code(arrays, host, dm, shape, ncls):
+  import torch
+  from oracle import learner_oracle as LO
+  vals, images = LO.net_fixture_recipe('mobilenet_v1', 'ilsvrc_12', dm, ncls, shape)
+  x = torch.from_numpy(images).permute(0, 3, 1, 2)
+  for mode in ('train', 'eval'):
+    s = LO.Scope(vals, 'model', trainable=False)
+    s.training = mode == 'train'
+    s._begin()
+    with torch.no_grad():
+      got = LO.mobilenet_v1_forward(s, x, {}).numpy()
+    ref = arrays['net/mobilenet_v1_%d/%s' % (dm, mode)]
+    assert np.max(np.abs(got - ref)) <= 2e-4 * max(1.0, float(np.max(np.abs(ref)))), (dm, mode)
+    assert s.matmul_names == host['net_matmul_order']['mobilenet_v1_%d' % dm]
