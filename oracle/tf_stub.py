@@ -189,6 +189,15 @@ def reduce_sum(x, axis=None, **kw): return T(np.sum(_raw(x), axis=axis, dtype=np
 def minimum(a, b, **kw): return T(np.minimum(T._b(a, np.asarray(_raw(b))), T._b(b, np.asarray(_raw(a)))))
 def maximum(a, b, **kw): return T(np.maximum(T._b(a, np.asarray(_raw(b))), T._b(b, np.asarray(_raw(a)))))
 def pow(x, y, **kw): return T(np.power(_raw(x), T._b(y, np.asarray(_raw(x)))))  # noqa: A001
+def add_n(xs, **kw):
+  out = np.asarray(_raw(xs[0]))
+  for x in xs[1:]:
+    out = out + np.asarray(_raw(x))
+  return T(out)
+
+
+def argmax(x, axis=None, **kw): return T(np.argmax(_raw(x), axis=axis).astype(np.int64))
+def equal(a, b, **kw): return T(np.equal(_raw(a), _raw(b)))
 def where(c, x, y, **kw): return T(np.where(_raw(c), _raw(x), _raw(y)))
 def range(*args, **kw):                                                         # noqa: A001
   vals = [np.asarray(_raw(a)) for a in args]
@@ -561,6 +570,14 @@ def install() -> types.ModuleType:
   tf.nn = _ns('tensorflow.nn', softmax=lambda z, name=None, **kw: T(_softmax(z)), relu=lambda x, name=None, **kw: T(np.maximum(_raw(x), np.float32(0))),
               relu6=lambda x, name=None, **kw: T(np.minimum(np.maximum(_raw(x), np.float32(0)), np.float32(6))))
   tf.losses = _ns('tensorflow.losses', softmax_cross_entropy=_softmax_cross_entropy)
+  tf.nn.l2_loss = lambda v, **kw: T(np.float32(np.sum(np.square(np.asarray(_raw(v), np.float32)), dtype=np.float32) / np.float32(2)))
+
+  def _in_top_k(predictions, targets, k, **kw):
+    p = np.asarray(_raw(predictions), np.float32)
+    t = np.asarray(_raw(targets)).astype(np.int64)
+    tv = p[np.arange(p.shape[0]), t][:, None]
+    return T(np.sum(p > tv, axis=1) < k)            # ties count in favour (TF in_top_k)
+  tf.nn.in_top_k = _in_top_k
   tf.train = _ns('tensorflow.train', piecewise_constant=_piecewise_constant, exponential_decay=_exponential_decay)
   tf.summary = _ns('tensorflow.summary', scalar=lambda *a, **k: None)
   tf.layers = _ns('tensorflow.layers', conv2d=_conv2d, batch_normalization=_batch_normalization, dense=_dense,

@@ -31,6 +31,7 @@ Lifted (paths relative to /root/reference):
   utils/external/resnet_model.py              the WHOLE module (Model.__call__, blocks, fixed padding, BN constants)
   nets/lenet_at_cifar10.py                    forward_fn
   utils/external/mobilenet_v1.py              the WHOLE module over tf.contrib.slim stand-ins
+  nets/{resnet_at_ilsvrc12,resnet_at_cifar10,mobilenet_at_ilsvrc12,lenet_at_cifar10}.py   ModelHelper.calc_loss
   utils/get_path_args.py                      run as a script (pure Python)
 """
 import ast
@@ -359,6 +360,34 @@ def gen_networks(out, meta):
   meta['net_matmul_order'] = orders
 
 
+def gen_model_losses(out):
+  """ModelHelper.calc_loss of the four configured nets (CE + loss_w_dcy * L2 over the filtered trainables, metrics)."""
+  rng = np.random.RandomState(20240605)
+  names = ['model/resnet_model/conv2d/kernel', 'model/resnet_model/batch_normalization/gamma',
+           'model/resnet_model/batch_normalization/beta', 'model/resnet_model/dense/kernel', 'model/resnet_model/dense/bias',
+           'model/MobilenetV1/Conv2d_0/BatchNorm/gamma', 'model/MobilenetV1/Conv2d_1_depthwise/depthwise_weights']
+  shapes = [(3, 3, 4, 8), (8,), (8,), (8, 5), (5,), (8,), (3, 3, 8, 1)]
+  tvars = []
+  for n, sh in zip(names, shapes):
+    v = tf_stub.T((rng.randn(*sh) * 0.5).astype(np.float32), name=n + ':0')
+    out['loss/var/%s' % n.replace('/', '|')] = v.a
+    tvars.append(v)
+  for key, path, ncls in (('resnet_ilsvrc12', 'nets/resnet_at_ilsvrc12.py', 12), ('resnet_cifar10', 'nets/resnet_at_cifar10.py', 10),
+                          ('mobilenet_ilsvrc12', 'nets/mobilenet_at_ilsvrc12.py', 12), ('lenet_cifar10', 'nets/lenet_at_cifar10.py', 10)):
+    ns = lift(path, ['ModelHelper.calc_loss'])
+    FLAGS.loss_w_dcy = 3e-3
+    B = 16
+    logits = (rng.randn(B, ncls) * 2).astype(np.float32)
+    logits[0, :3] = logits[0, 0]                                  # ties for in_top_k
+    labels = np.eye(ncls, dtype=np.float32)[rng.randint(0, ncls, B)]
+    labels[0] = np.eye(ncls, dtype=np.float32)[1]
+    loss, metrics = ns['ModelHelper'].calc_loss(None, tf_stub.T(labels), tf_stub.T(logits), tvars)
+    out['loss/%s/logits' % key], out['loss/%s/labels' % key] = logits, labels
+    out['loss/%s/loss' % key] = np.float32(loss.a)
+    for mk, mv in metrics.items():
+      out['loss/%s/metric/%s' % (key, mk)] = np.float32(mv.a)
+
+
 def gen_path_args(meta):
   conf = os.path.join(HERE, 'path.conf.sample')
   rows = []
@@ -381,6 +410,7 @@ def main():
   gen_ws(arrays)
   gen_channel_pruner(arrays)
   gen_networks(arrays, meta)
+  gen_model_losses(arrays)
   gen_schedules(meta)
   gen_ws_host(meta)
   gen_path_args(meta)

@@ -208,3 +208,21 @@ def test_mobilenet_definition_matches_the_reference_code(arrays, host, dm, shape
     ref = arrays['net/mobilenet_v1_%d/%s' % (dm, mode)]
     assert np.max(np.abs(got - ref)) <= 2e-4 * max(1.0, float(np.max(np.abs(ref)))), (dm, mode)
     assert s.matmul_names == host['net_matmul_order']['mobilenet_v1_%d' % dm]
+
+
+@pytest.mark.parametrize('key,bn_filter,ilsvrc', [('resnet_ilsvrc12', True, True), ('resnet_cifar10', True, False),
+                                                  ('mobilenet_ilsvrc12', True, True), ('lenet_cifar10', False, False)])
+def test_model_loss_and_metrics_match_the_reference_code(arrays, key, bn_filter, ilsvrc):
+  """ModelHelper.calc_loss of the reference, executed: CE + loss_w_dcy * sum l2_loss(v) over the trainables whose
+  name lacks 'batch_normalization' (slim's `BatchNorm/...` names therefore ARE regularised), top-k
+  metrics with ties counted in favour, 'accuracy' == top-5 on ILSVRC-12."""
+  names = [k[len('loss/var/'):].replace('|', '/') for k in arrays if k.startswith('loss/var/')]
+  l2_vars = [arrays['loss/var/' + n.replace('/', '|')] for n in names if not (bn_filter and 'batch_normalization' in n)]
+  loss, _, _ = O.model_loss(arrays['loss/%s/labels' % key], arrays['loss/%s/logits' % key], l2_vars, 3e-3)
+  ref = arrays['loss/%s/loss' % key]
+  assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref)), (float(loss), float(ref))
+  m = (O.metrics_ilsvrc if ilsvrc else O.metrics_cifar)(arrays['loss/%s/labels' % key], arrays['loss/%s/logits' % key])
+  got_keys = sorted(k.split('/')[-1] for k in arrays if k.startswith('loss/%s/metric/' % key))
+  assert got_keys == sorted(m.keys())
+  for k in got_keys:
+    assert float(m[k]) == float(arrays['loss/%s/metric/%s' % (key, k)]), k
