@@ -34,6 +34,8 @@ flags.DEFINE_boolean('enbl_warm_start', False, 'enable warm start for training')
 # --- flags with no reference counterpart (the reference is fp32 TF on whatever device TF picks) ---
 flags.DEFINE_string('compute_dtype', 'float32', 'activation / matmul dtype: float32 (parity) | bfloat16 (MFMA)')
 flags.DEFINE_integer('init_seed', 42, 'seed of the variable initialisers')
+flags.DEFINE_string('ckpt_format', 'npz', "checkpoint files written by the learners: 'npz' | 'tf' (TensorFlow Saver-V2 "
+                    "bundle, readable by the reference's tools); both are read transparently")
 flags.DEFINE_boolean('fuse_conv1x1', True, 'bf16 mode: apply BN/ReLU/fake-quant inside the consuming 1x1 convolutions '
                      '(pf_conv.hip) instead of writing the activated tensor to HBM')
 flags.DEFINE_integer('nb_iters_override', 0, 'if > 0, train() stops after this many iterations')
@@ -167,7 +169,7 @@ class AbstractLearner(ABC):  # pylint: disable=too-many-instance-attributes
     return x, y
 
   def save_vars(self, save_path, global_step=None):
-    return checkpoint.save(self.graph.store.export_numpy(), save_path, global_step)
+    return checkpoint.save(self.graph.store.export_numpy(), save_path, global_step, fmt=FLAGS.ckpt_format)
 
   def restore_vars(self, prefix, store=None, rename_scope=None, strict=True):
     (store or self.graph.store).load_numpy(checkpoint.load(prefix), strict=strict, rename_scope=rename_scope)
