@@ -14,6 +14,7 @@ import numpy as np
 import torch
 
 from pocketflow_amd.flags import FLAGS, flags
+from pocketflow_amd.utils import misc_utils  # noqa: F401  (defines --enbl_multi_gpu, read by build())
 
 flags.DEFINE_string('data_disk', 'local', 'data disk\'s location (\'local\' / \'hdfs\')')
 flags.DEFINE_string('data_hdfs_host', None, 'HDFS host for data files')
