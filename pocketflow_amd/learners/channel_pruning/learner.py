@@ -233,7 +233,7 @@ class ChannelPrunedLearner(AbstractLearner):  # pylint: disable=too-many-instanc
         speed = FLAGS.batch_size * FLAGS.summ_step / (timer() - time_prev)
         if FLAGS.enbl_multi_gpu:
           speed *= mgw.size()
-        log.info('iter #%d: lr = %e | loss = %e | speed = %.2f pics / sec' % (idx_iter + 1, lr, float(loss), speed))
+        log.info('iter #%d: lr = %e | loss = %e | speed = %.2f pics / sec' % (idx_iter + 1, lr, float(loss.detach()), speed))
         for k, v in metrics.items():
           log.info('{} = {}'.format(k, float(v)))
         self.last_speed = speed

@@ -148,7 +148,7 @@ class FullPrecLearner(AbstractLearner):  # pylint: disable=too-many-instance-att
     if FLAGS.enbl_multi_gpu:
       speed *= mgw.size()
     names = ['lr', 'loss'] + list(metrics.keys())
-    vals = [lr, float(loss)] + [float(v) for v in metrics.values()]
+    vals = [lr, float(loss.detach())] + [float(v) for v in metrics.values()]
     if self.sm_writer is not None:
       self.sm_writer.add_summary(dict(zip(names, vals)), idx_iter)
     log_str = ' | '.join(['%s = %.4e' % (n, v) for n, v in zip(names, vals)])

@@ -236,7 +236,7 @@ class WeightSparseLearner(AbstractLearner):  # pylint: disable=too-many-instance
     pr_trn = calc_prune_ratio(self.trainable_vars, self.device)
     pr_msk = calc_prune_ratio(self.maskable_vars, self.device)
     names = ['lr', 'loss', 'pr_trn', 'pr_msk'] + list(metrics.keys())
-    vals = [lr, float(loss), pr_trn, pr_msk] + [float(v) for v in metrics.values()]
+    vals = [lr, float(loss.detach()), pr_trn, pr_msk] + [float(v) for v in metrics.values()]
     if self.sm_writer is not None:
       self.sm_writer.add_summary(dict(zip(names, vals)), idx_iter)
     log_str = ' | '.join(['%s = %.4e' % (n, v) for n, v in zip(names, vals)])

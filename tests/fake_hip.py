@@ -1,0 +1,375 @@
+"""float32 torch / NumPy emulation of the HIP entry points (include/pocketflow_hip.h) for CPU-side tests.
+
+`FakeHip` replaces the `hip` module object inside pocketflow_amd.graph / plan / losses / optim / learners
+(monkeypatch), so that the HOST logic around the kernels -- autograd plumbing, launch plans, learner loops,
+schedules, mask refreshes -- can be executed and checked exactly on a machine without a GPU.  The emulations
+follow the documented semantics of each entry point; the segment (all-weights) kernels, the losses and the
+optimisers delegate to the CPU oracle (oracle/pf_oracle.py), which is allowed here because this file is
+test infrastructure.  Nothing under pocketflow_amd/ imports it.
+"""
+import numpy as np
+import torch
+
+from oracle import pf_oracle as O
+
+
+def _rows(t, C):
+  """[rows][C] view of a logical-NCHW / physical-NHWC tensor (or a flat [rows][C] one)."""
+  if t.dim() == 4:
+    return t.permute(0, 2, 3, 1).reshape(-1, C)
+  return t.reshape(-1, C)
+
+
+def _act(y, act):
+  if act in ('Relu', 'relu'):
+    return torch.relu(y)
+  if act in ('Relu6', 'relu6'):
+    return torch.clamp(y, 0, 6)
+  return y
+
+
+def _mask(u, act):
+  if act in ('Relu', 'relu'):
+    return (u > 0).float()
+  if act in ('Relu6', 'relu6'):
+    return ((u > 0) & (u < 6)).float()
+  return torch.ones_like(u)
+
+
+class FakeHip(object):
+  """float32 torch emulation of the entry points graph.py calls; min/max slots hold two float32 bit patterns."""
+
+  def __init__(self):
+    self.calls = {}
+
+  def _n(self, name):
+    self.calls[name] = self.calls.get(name, 0) + 1
+
+  # -- slots ----------------------------------------------------------------------------------------
+  def minmax_slots_init(self, slots):
+    slots.view(-1).copy_(torch.tensor([float('inf'), float('-inf')] * (slots.numel() // 2)).view(torch.int32))
+
+  @staticmethod
+  def _slot_get(slot):
+    v = slot.view(torch.float32)
+    return float(v[0]), float(v[1])
+
+  @staticmethod
+  def _quant(y, slot, bits):
+    mn, mx = FakeHip._slot_get(slot)
+    alpha, beta = (mx - mn) + 1e-10, mn
+    k = float(2 ** bits - 1)
+    return alpha * (torch.round((y - beta) / alpha * k) / k) + beta
+
+  # -- BN forward --------------------------------------------------------------------------------------
+  def bn_stats(self, x, rows, C, partial, nblk):
+    self._n('bn_stats')
+    xr = _rows(x, C).float()
+    p = partial[:nblk * 4 * C].view(nblk, 4, C)
+    p[:, 0:2] = 0
+    p[:, 2] = float('inf')
+    p[:, 3] = float('-inf')
+    d = xr - xr[0:1]
+    p[0, 0], p[0, 1], p[0, 2], p[0, 3] = d.sum(0), (d * d).sum(0), xr.min(0).values, xr.max(0).values
+
+  def bn_finalize(self, partial, nblk, rows, C, piv, gamma, beta, mm, mv, momentum, eps, training, act, ss, mi, slot):
+    self._n('bn_finalize')
+    p = partial.reshape(-1)[:nblk * 4 * C].view(nblk, 4, C).double()
+    pivot = _rows(piv, C)[0].double() if piv.numel() >= C and piv.dim() != 1 else piv.reshape(-1)[:C].double()
+    s, q = p[:, 0].sum(0), p[:, 1].sum(0)
+    mn, mx = p[:, 2].min(0).values.float(), p[:, 3].max(0).values.float()
+    if training:
+      m1 = s / rows
+      var = (q / rows - m1 * m1).clamp_min(0)
+      mean = (pivot + m1).float()
+      unbiased = (var * (rows / max(rows - 1, 1))).float()
+      mm.sub_((mm - mean) * (1 - momentum))
+      mv.sub_((mv - unbiased) * (1 - momentum))
+      var = var.float()
+    else:
+      mean, var = mm.clone(), mv.clone()
+    invstd = 1.0 / torch.sqrt(var + eps)
+    sc = gamma.detach() * invstd
+    ss[0], ss[1] = sc, beta.detach() - mean * sc
+    mi[0], mi[1] = mean, invstd
+    if slot is not None:
+      a, b = sc * mn + ss[1], sc * mx + ss[1]
+      ymin, ymax = _act(torch.minimum(a, b), act).min(), _act(torch.maximum(a, b), act).max()
+      cur = slot.view(torch.float32)
+      cur[0], cur[1] = min(float(cur[0]), float(ymin)), max(float(cur[1]), float(ymax))
+
+  def bn_eval_scale_shift(self, gamma, beta, mm, mv, eps, ss):
+    sc = gamma.detach() / torch.sqrt(mv + eps)
+    ss[0], ss[1] = sc, beta.detach() - mm * sc
+
+  def _q_of(self, xr, ss, act, slot, bits, quantize):
+    y = _act(xr * ss[0] + ss[1], act)
+    return self._quant(y, slot, bits) if quantize else y
+
+  def bn_act_quant_apply(self, x, q, rows, C, ss, act, slot, bits, quantize):
+    self._n('bn_apply')
+    _rows(q, C).copy_(self._q_of(_rows(x, C).float(), ss, act, slot, bits, quantize))
+
+  # -- BN backward -------------------------------------------------------------------------------------------
+  def bn_bwd_stats(self, dq, x, rows, C, ss, mi, act, partial, nblk):
+    self._n('bn_bwd_stats')
+    xr, g = _rows(x, C).float(), _rows(dq, C).float()
+    dy = g * _mask(xr * ss[0] + ss[1], act)
+    p = partial[:nblk * 2 * C].view(nblk, 2, C)
+    p.zero_()
+    p[0, 0], p[0, 1] = dy.sum(0), (dy * (xr - mi[0]) * mi[1]).sum(0)
+
+  def bn_bwd_finalize(self, partial, nblk, C, dgamma, dbeta):
+    p = partial.reshape(-1)[:nblk * 2 * C].view(nblk, 2, C)
+    dbeta.copy_(p[:, 0].sum(0))
+    dgamma.copy_(p[:, 1].sum(0))
+
+  def bn_bwd_apply(self, dq, x, dx, rows, C, ss, mi, dgamma, dbeta, act, addend=None):
+    self._n('bn_bwd_apply_add' if addend is not None else 'bn_bwd_apply')
+    xr, g = _rows(x, C).float(), _rows(dq, C).float()
+    dy = g * _mask(xr * ss[0] + ss[1], act)
+    out = ss[0] * (dy - dbeta / rows - (xr - mi[0]) * mi[1] * dgamma / rows)
+    if addend is not None:
+      out = out + _rows(addend, C).float()
+    _rows(dx, C).copy_(out)
+
+  # -- fused 1x1 convolutions -------------------------------------------------------------------------------------
+  def conv1x1_stats_groups(self, M, N):
+    return 3
+
+  def conv1x1_wrw_splits(self, M, N, K):
+    return 2
+
+  @staticmethod
+  def _gather(x, K, geom):
+    if geom is None:
+      return _rows(x, K).float()
+    ho, wo, h, w, s = geom
+    return x.permute(0, 2, 3, 1)[:, ::s, ::s, :][:, :ho, :wo, :].reshape(-1, K).float()
+
+  def conv1x1_fwd(self, X, W, Y, M, N, K, R=None, scale_shift=None, act=None, slot=None, bits=8, partial=None,
+                  geom=None, ymap=False):
+    self._n('conv1x1_fwd' if scale_shift is not None else 'conv1x1_plain')
+    if ymap:                                   # backward-data of a strided conv: scatter rows
+      ho, wo, h, w, s = geom
+      out = _rows(X, K).float() @ W.float().t()
+      Y.permute(0, 2, 3, 1)[:, ::s, ::s, :][:, :ho, :wo, :] = out.view(Y.shape[0], ho, wo, N)
+      return
+    xr = self._gather(X, K, geom)
+    if scale_shift is not None:
+      xr = self._q_of(xr, scale_shift, act, slot, bits, slot is not None)
+    y = xr @ W.float().t()
+    if R is not None:
+      y = y + _rows(R, N).float()
+    _rows(Y, N).copy_(y)
+    if partial is not None:
+      partial[:, 0:2] = 0
+      partial[:, 2] = float('inf')
+      partial[:, 3] = float('-inf')
+      partial[1, 0], partial[1, 1], partial[1, 2], partial[1, 3] = y.sum(0), (y * y).sum(0), y.min(0).values, y.max(0).values
+
+  def conv1x1_bwd_data_bnstats(self, dY, Wt, dQ, bn_x, bn_ss, bn_mi, bn_act, partial, M, N, K):
+    self._n('conv1x1_bwd_data_bnstats')
+    dq = _rows(dY, N).float() @ Wt.float().t()
+    _rows(dQ, K).copy_(dq)
+    xr = _rows(bn_x, K).float()
+    dy = dq * _mask(xr * bn_ss[0] + bn_ss[1], bn_act)
+    partial.zero_()
+    partial[2, 0], partial[2, 1] = dy.sum(0), (dy * (xr - bn_mi[0]) * bn_mi[1]).sum(0)
+
+  def conv1x1_wrw(self, dY, X, dW, workspace, M, N, K, scale_shift=None, act=None, slot=None, bits=8, geom=None):
+    self._n('conv1x1_wrw')
+    xr = self._gather(X, K, geom)
+    if scale_shift is not None:
+      xr = self._q_of(xr, scale_shift, act, slot, bits, slot is not None)
+    dW.copy_(_rows(dY, N).float().t() @ xr)
+
+
+
+
+# =================================================================================================
+# learner-level entry points (segment kernels, losses, optimisers, sparsification) on top of FakeHip
+# =================================================================================================
+
+def _real_constants():
+  from pocketflow_amd import hip as real
+  return {k: getattr(real, k) for k in ('PF_F32', 'PF_BF16', 'PF_ACT_NONE', 'PF_ACT_RELU', 'PF_ACT_RELU6',
+                                        'PF_BUCKET_TENSOR', 'PF_BUCKET_CHANNEL', 'PF_BUCKET_SPLIT', 'PF_CHUNK',
+                                        'SEG_DTYPE', 'BLOCK_DTYPE', 'ACT_CODES')}
+
+
+class FakeHipFull(FakeHip):
+  def __init__(self):
+    super(FakeHipFull, self).__init__()
+    for k, v in _real_constants().items():
+      setattr(self, k, v)
+    self._nuq_info = {}
+
+  # -- stand-alone activations (LeNet, ResNet-v1) ---------------------------------------------------------
+  def minmax_tensor(self, x, slot, act=None):
+    t = _act(x.float(), act)
+    cur = slot.view(torch.float32)
+    cur[0], cur[1] = min(float(cur[0]), float(t.min())), max(float(cur[1]), float(t.max()))
+
+  def minmax_decode(self, slots):
+    v = slots.view(torch.float32).view(-1, 2)
+    return torch.stack([(v[:, 1] - v[:, 0]) + 1e-10, v[:, 0]], dim=1)
+
+  def uq_apply(self, x, y, slot, bits, act=None):
+    y.copy_(self._quant(_act(x.float(), act), slot, bits).to(y.dtype))
+
+  def act_grad(self, g, u, dx, act):
+    dx.copy_(g * _mask(u.float(), act))
+
+  # -- segment (all-weights) kernels: delegate to the oracle, tensor by tensor ------------------------------------
+  def _segs(self, segs):
+    return np.frombuffer(segs.cpu().numpy().tobytes(), dtype=self.SEG_DTYPE)
+
+  @staticmethod
+  def _to_hwio(flat, sg):
+    RS, I, Oc = int(sg['RS']), int(sg['I']), int(sg['O'])
+    if int(sg['layout']) == 1:                       # depthwise: storage [C][RS] -> [RS][C][1]
+      return flat.reshape(I, RS).T.reshape(RS, I, 1)
+    return flat.reshape(Oc, RS, I).transpose(1, 2, 0)            # KRSC [O][RS][I] -> [RS][I][O]
+
+  @staticmethod
+  def _to_storage(hwio, sg):
+    RS, I, Oc = int(sg['RS']), int(sg['I']), int(sg['O'])
+    if int(sg['layout']) == 1:
+      return np.ascontiguousarray(hwio.reshape(RS, I).T).reshape(-1)
+    return np.ascontiguousarray(hwio.reshape(RS, I, Oc).transpose(2, 0, 1)).reshape(-1)
+
+  def _bucket_args(self, sg):
+    mode = int(sg['mode'])
+    if mode == self.PF_BUCKET_TENSOR:
+      return False, 'channel', 0
+    if mode == self.PF_BUCKET_CHANNEL:
+      return True, 'channel', 0
+    return True, 'split', int(sg['bucket_size'])
+
+  def seg_minmax(self, w_flat, segs, blocks, n_blocks, slots):
+    pass                                             # ranges are recomputed by the apply emulations
+
+  def seg_uq_apply(self, w_flat, qw_flat, segs, blocks, n_blocks, slots):
+    w = w_flat.detach().numpy()
+    out = qw_flat.detach().numpy() if qw_flat.dtype == torch.float32 else None
+    for sg in self._segs(segs):
+      off, n, bits = int(sg['offset']), int(sg['len']), int(sg['bits'])
+      src = w[off:off + n]
+      if bits > 0:
+        ub, bt, bs = self._bucket_args(sg)
+        q, _ = O.uniform_quantize(self._to_hwio(src, sg), bits, 'weight', ub, bt, bs)
+        res = self._to_storage(q, sg)
+      else:
+        res = src
+      if out is not None:
+        out[off:off + n] = res
+      else:
+        qw_flat[off:off + n] = torch.from_numpy(np.ascontiguousarray(res)).to(qw_flat.dtype)
+
+  def _codebook(self, codebooks, sg, ub):
+    k, nb, cb = 2 ** int(sg['bits']), int(sg['n_bucket']), int(sg['cb_offset'])
+    c = codebooks.detach().numpy()[cb:cb + k * nb]
+    return c.reshape(k, nb) if ub else c.reshape(k)
+
+  def seg_nuq_apply(self, w_flat, qw_flat, idx_flat, codebooks, segs, blocks, n_blocks, slots):
+    w = w_flat.detach().numpy()
+    self._nuq_info = {}
+    for s, sg in enumerate(self._segs(segs)):
+      off, n, bits = int(sg['offset']), int(sg['len']), int(sg['bits'])
+      src = w[off:off + n]
+      if bits > 0:
+        ub, bt, bs = self._bucket_args(sg)
+        q, info = O.nuq_quantize(self._to_hwio(src, sg), bits, self._codebook(codebooks, sg, ub), ub, bt, bs)
+        self._nuq_info[s] = (info, ub, bt, bs)
+        res = self._to_storage(q, sg)
+      else:
+        res = src
+      qw_flat[off:off + n] = torch.from_numpy(np.ascontiguousarray(res)).to(qw_flat.dtype)
+
+  def seg_nuq_codebook_grad(self, g_flat, idx_flat, dcodebooks, segs, blocks, n_blocks, slots):
+    g = g_flat.detach().float().numpy()
+    dc_all = dcodebooks.detach().numpy()
+    for s, sg in enumerate(self._segs(segs)):
+      if s not in self._nuq_info:
+        continue
+      info, ub, bt, bs = self._nuq_info[s]
+      off, n = int(sg['offset']), int(sg['len'])
+      _, dc = O.nuq_backward(self._to_hwio(g[off:off + n], sg), info, ub, bt, bs)
+      k, nb, cb = 2 ** int(sg['bits']), int(sg['n_bucket']), int(sg['cb_offset'])
+      dc_all[cb:cb + k * nb] += np.asarray(dc, np.float32).reshape(-1)
+
+  def seg_normalize(self, w_flat, xn_out, segs, seg_index, slots):
+    sg = self._segs(segs)[seg_index]
+    off, n = int(sg['offset']), int(sg['len'])
+    hw = self._to_hwio(w_flat.detach().numpy()[off:off + n], sg)
+    ub, bt, bs = self._bucket_args(sg)
+    if not ub:
+      xn, _, _ = O.scale(hw, None)
+    elif bt == 'channel':
+      xb, _, _ = O.channel_bucket(hw)
+      xn, _, _ = O.scale(xb, 0)
+      xn = xn.reshape(hw.shape)
+    else:
+      xb, _, pad = O.split_bucket(hw, bs)
+      xn, _, _ = O.scale(xb, 0)
+      xn = xn.reshape(-1)
+      xn = (xn[:-pad] if pad else xn).reshape(hw.shape)
+    xn_out.copy_(torch.from_numpy(self._to_storage(np.asarray(xn, np.float32), sg)))
+
+  # -- losses ----------------------------------------------------------------------------------------------------------
+  def ce_distill_fwd_bwd(self, z_s, labels, z_t, tempr, loss_w, losses, dz_s, row_ws):
+    zs = z_s.detach().float().numpy()
+    ce, dz = O.softmax_cross_entropy(labels.detach().numpy(), zs)
+    dl = np.float32(0)
+    if z_t is not None:
+      dl, ddz = O.distill_loss(zs, z_t.detach().float().numpy(), tempr, loss_w)
+      dz = dz + ddz
+    losses[0], losses[1] = float(ce), float(dl)
+    dz_s.copy_(torch.from_numpy(np.asarray(dz, np.float32)).to(dz_s.dtype))
+
+  # -- optimisers ----------------------------------------------------------------------------------------------------------
+  @staticmethod
+  def _eff_grad(p, g, mask, n_decay, wd, g_scale):
+    ge = g.detach().float().numpy() * np.float32(g_scale)
+    pn = p.detach().numpy()
+    ge[:n_decay] = ge[:n_decay] + np.float32(wd) * pn[:n_decay]
+    if mask is not None:
+      ge = ge * mask.detach().numpy()
+    return ge.astype(np.float32), pn
+
+  def adam_flat(self, p, g, m, v, mask, n_decay, wd, g_scale, lr, beta1, beta2, eps, beta1_power, beta2_power):
+    ge, pn = self._eff_grad(p, g, mask, n_decay, wd, g_scale)
+    one = np.float32(1)
+    alpha_t = np.float32(np.float32(lr) * np.sqrt(one - np.float32(beta2_power)) / (one - np.float32(beta1_power)))
+    mn, vn = m.numpy(), v.numpy()
+    mn += (ge - mn) * (one - np.float32(beta1))
+    vn += (ge * ge - vn) * (one - np.float32(beta2))
+    pn -= (mn * alpha_t) / (np.sqrt(vn) + np.float32(eps))
+
+  def momentum_flat(self, p, g, acc, mask, n_decay, wd, g_scale, lr, momentum):
+    ge, pn = self._eff_grad(p, g, mask, n_decay, wd, g_scale)
+    an = acc.numpy()
+    an[:] = np.float32(momentum) * an + ge
+    pn -= np.float32(lr) * an
+
+  # -- weight sparsification / channel pruning ---------------------------------------------------------------------------------
+  def ws_bkup_merge_abs(self, var, bkup, mask, abs_out):
+    bkup.copy_(torch.where(mask > 0.5, var, bkup))
+    abs_out.copy_(bkup.abs())
+
+  def kth_largest_nonneg(self, a, k_desc_index, out, workspace):
+    out[0] = torch.sort(a, descending=True).values[int(k_desc_index)]
+
+  def ws_mask_apply(self, var, bkup, mask, thr):
+    mask.copy_((bkup.abs() > thr[0]).float())
+    var.copy_(bkup * mask)
+
+  def count_nonzero(self, x, out_u64):
+    out_u64 += int(torch.count_nonzero(x))
+
+  def cp_build_mask(self, mask, keep_in, keep_out, Oc, RS, I):
+    m = mask.view(Oc, RS, I)
+    m.fill_(1.0)
+    m[:, :, ~keep_in.bool()] = 0
+    m[~keep_out.bool()] = 0

@@ -14,176 +14,7 @@ import torch
 import torch.nn.functional as F
 
 
-def _rows(t, C):
-  """[rows][C] view of a logical-NCHW / physical-NHWC tensor (or a flat [rows][C] one)."""
-  if t.dim() == 4:
-    return t.permute(0, 2, 3, 1).reshape(-1, C)
-  return t.reshape(-1, C)
-
-
-def _act(y, act):
-  if act in ('Relu', 'relu'):
-    return torch.relu(y)
-  if act in ('Relu6', 'relu6'):
-    return torch.clamp(y, 0, 6)
-  return y
-
-
-def _mask(u, act):
-  if act in ('Relu', 'relu'):
-    return (u > 0).float()
-  if act in ('Relu6', 'relu6'):
-    return ((u > 0) & (u < 6)).float()
-  return torch.ones_like(u)
-
-
-class FakeHip(object):
-  """float32 torch emulation of the entry points graph.py calls; min/max slots hold two float32 bit patterns."""
-
-  def __init__(self):
-    self.calls = {}
-
-  def _n(self, name):
-    self.calls[name] = self.calls.get(name, 0) + 1
-
-  # -- slots ----------------------------------------------------------------------------------------
-  def minmax_slots_init(self, slots):
-    slots.view(-1).copy_(torch.tensor([float('inf'), float('-inf')] * (slots.numel() // 2)).view(torch.int32))
-
-  @staticmethod
-  def _slot_get(slot):
-    v = slot.view(torch.float32)
-    return float(v[0]), float(v[1])
-
-  @staticmethod
-  def _quant(y, slot, bits):
-    mn, mx = FakeHip._slot_get(slot)
-    alpha, beta = (mx - mn) + 1e-10, mn
-    k = float(2 ** bits - 1)
-    return alpha * (torch.round((y - beta) / alpha * k) / k) + beta
-
-  # -- BN forward --------------------------------------------------------------------------------------
-  def bn_stats(self, x, rows, C, partial, nblk):
-    self._n('bn_stats')
-    xr = _rows(x, C).float()
-    p = partial[:nblk * 4 * C].view(nblk, 4, C)
-    p[:, 0:2] = 0
-    p[:, 2] = float('inf')
-    p[:, 3] = float('-inf')
-    d = xr - xr[0:1]
-    p[0, 0], p[0, 1], p[0, 2], p[0, 3] = d.sum(0), (d * d).sum(0), xr.min(0).values, xr.max(0).values
-
-  def bn_finalize(self, partial, nblk, rows, C, piv, gamma, beta, mm, mv, momentum, eps, training, act, ss, mi, slot):
-    self._n('bn_finalize')
-    p = partial.reshape(-1)[:nblk * 4 * C].view(nblk, 4, C).double()
-    pivot = _rows(piv, C)[0].double() if piv.numel() >= C and piv.dim() != 1 else piv.reshape(-1)[:C].double()
-    s, q = p[:, 0].sum(0), p[:, 1].sum(0)
-    mn, mx = p[:, 2].min(0).values.float(), p[:, 3].max(0).values.float()
-    if training:
-      m1 = s / rows
-      var = (q / rows - m1 * m1).clamp_min(0)
-      mean = (pivot + m1).float()
-      unbiased = (var * (rows / max(rows - 1, 1))).float()
-      mm.sub_((mm - mean) * (1 - momentum))
-      mv.sub_((mv - unbiased) * (1 - momentum))
-      var = var.float()
-    else:
-      mean, var = mm.clone(), mv.clone()
-    invstd = 1.0 / torch.sqrt(var + eps)
-    sc = gamma.detach() * invstd
-    ss[0], ss[1] = sc, beta.detach() - mean * sc
-    mi[0], mi[1] = mean, invstd
-    if slot is not None:
-      a, b = sc * mn + ss[1], sc * mx + ss[1]
-      ymin, ymax = _act(torch.minimum(a, b), act).min(), _act(torch.maximum(a, b), act).max()
-      cur = slot.view(torch.float32)
-      cur[0], cur[1] = min(float(cur[0]), float(ymin)), max(float(cur[1]), float(ymax))
-
-  def bn_eval_scale_shift(self, gamma, beta, mm, mv, eps, ss):
-    sc = gamma.detach() / torch.sqrt(mv + eps)
-    ss[0], ss[1] = sc, beta.detach() - mm * sc
-
-  def _q_of(self, xr, ss, act, slot, bits, quantize):
-    y = _act(xr * ss[0] + ss[1], act)
-    return self._quant(y, slot, bits) if quantize else y
-
-  def bn_act_quant_apply(self, x, q, rows, C, ss, act, slot, bits, quantize):
-    self._n('bn_apply')
-    _rows(q, C).copy_(self._q_of(_rows(x, C).float(), ss, act, slot, bits, quantize))
-
-  # -- BN backward -------------------------------------------------------------------------------------------
-  def bn_bwd_stats(self, dq, x, rows, C, ss, mi, act, partial, nblk):
-    self._n('bn_bwd_stats')
-    xr, g = _rows(x, C).float(), _rows(dq, C).float()
-    dy = g * _mask(xr * ss[0] + ss[1], act)
-    p = partial[:nblk * 2 * C].view(nblk, 2, C)
-    p.zero_()
-    p[0, 0], p[0, 1] = dy.sum(0), (dy * (xr - mi[0]) * mi[1]).sum(0)
-
-  def bn_bwd_finalize(self, partial, nblk, C, dgamma, dbeta):
-    p = partial.reshape(-1)[:nblk * 2 * C].view(nblk, 2, C)
-    dbeta.copy_(p[:, 0].sum(0))
-    dgamma.copy_(p[:, 1].sum(0))
-
-  def bn_bwd_apply(self, dq, x, dx, rows, C, ss, mi, dgamma, dbeta, act, addend=None):
-    self._n('bn_bwd_apply_add' if addend is not None else 'bn_bwd_apply')
-    xr, g = _rows(x, C).float(), _rows(dq, C).float()
-    dy = g * _mask(xr * ss[0] + ss[1], act)
-    out = ss[0] * (dy - dbeta / rows - (xr - mi[0]) * mi[1] * dgamma / rows)
-    if addend is not None:
-      out = out + _rows(addend, C).float()
-    _rows(dx, C).copy_(out)
-
-  # -- fused 1x1 convolutions -------------------------------------------------------------------------------------
-  def conv1x1_stats_groups(self, M, N):
-    return 3
-
-  def conv1x1_wrw_splits(self, M, N, K):
-    return 2
-
-  @staticmethod
-  def _gather(x, K, geom):
-    if geom is None:
-      return _rows(x, K).float()
-    ho, wo, h, w, s = geom
-    return x.permute(0, 2, 3, 1)[:, ::s, ::s, :][:, :ho, :wo, :].reshape(-1, K).float()
-
-  def conv1x1_fwd(self, X, W, Y, M, N, K, R=None, scale_shift=None, act=None, slot=None, bits=8, partial=None,
-                  geom=None, ymap=False):
-    self._n('conv1x1_fwd' if scale_shift is not None else 'conv1x1_plain')
-    if ymap:                                   # backward-data of a strided conv: scatter rows
-      ho, wo, h, w, s = geom
-      out = _rows(X, K).float() @ W.float().t()
-      Y.permute(0, 2, 3, 1)[:, ::s, ::s, :][:, :ho, :wo, :] = out.view(Y.shape[0], ho, wo, N)
-      return
-    xr = self._gather(X, K, geom)
-    if scale_shift is not None:
-      xr = self._q_of(xr, scale_shift, act, slot, bits, slot is not None)
-    y = xr @ W.float().t()
-    if R is not None:
-      y = y + _rows(R, N).float()
-    _rows(Y, N).copy_(y)
-    if partial is not None:
-      partial[:, 0:2] = 0
-      partial[:, 2] = float('inf')
-      partial[:, 3] = float('-inf')
-      partial[1, 0], partial[1, 1], partial[1, 2], partial[1, 3] = y.sum(0), (y * y).sum(0), y.min(0).values, y.max(0).values
-
-  def conv1x1_bwd_data_bnstats(self, dY, Wt, dQ, bn_x, bn_ss, bn_mi, bn_act, partial, M, N, K):
-    self._n('conv1x1_bwd_data_bnstats')
-    dq = _rows(dY, N).float() @ Wt.float().t()
-    _rows(dQ, K).copy_(dq)
-    xr = _rows(bn_x, K).float()
-    dy = dq * _mask(xr * bn_ss[0] + bn_ss[1], bn_act)
-    partial.zero_()
-    partial[2, 0], partial[2, 1] = dy.sum(0), (dy * (xr - bn_mi[0]) * bn_mi[1]).sum(0)
-
-  def conv1x1_wrw(self, dY, X, dW, workspace, M, N, K, scale_shift=None, act=None, slot=None, bits=8, geom=None):
-    self._n('conv1x1_wrw')
-    xr = self._gather(X, K, geom)
-    if scale_shift is not None:
-      xr = self._q_of(xr, scale_shift, act, slot, bits, slot is not None)
-    dW.copy_(_rows(dY, N).float().t() @ xr)
+from fake_hip import FakeHip  # noqa: E402  (tests/fake_hip.py: float32 torch emulation of the HIP entry points)
 
 
 def _build(fuse, fake, act_bits):

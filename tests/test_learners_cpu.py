@@ -1,0 +1,235 @@
+"""The learners' HOST logic executed on the CPU against the CPU oracle learner, exactly.
+
+The HIP entry points are replaced by float32 emulations (tests/fake_hip.py); everything else is the product
+code: graph rewrite (which ops get which bit widths), launch plans over the flat buffers, KRSC <-> HWIO index
+arithmetic, bucket modes, codebook variables in the variable store, loss wiring (CE + coupled L2 + distillation),
+optimiser masks and slots, learning-rate schedules, the mask-refresh schedule.  Both sides use float32; the
+convolutions differ in summation order (torch CPU kernels vs the oracle's), so the bars are the same kind as in
+tests/test_parity_gpu.py (loss within 1e-4 .. 2e-3, weights within the Adam bound)."""
+import numpy as np
+import pytest
+import torch
+
+from fake_hip import FakeHipFull
+
+
+@pytest.fixture
+def cpu_learners(monkeypatch, tmp_path):
+  import pocketflow_amd.graph as G
+  import pocketflow_amd.plan as P
+  import pocketflow_amd.losses as L
+  import pocketflow_amd.optim as Opt
+  import pocketflow_amd.learners.abstract_learner as AL
+  import pocketflow_amd.learners.weight_sparsification.learner as WS
+  import pocketflow_amd.learners.nonuniform_quantization.utils as NU
+  import pocketflow_amd.learners.distillation_helper  # noqa: F401
+  import pocketflow_amd.learners.learner_utils  # noqa: F401
+  import pocketflow_amd.nets.lenet_at_cifar10  # noqa: F401  (flag definitions)
+  import pocketflow_amd.nets.resnet_at_cifar10  # noqa: F401
+  import pocketflow_amd.learners.uniform_quantization.learner  # noqa: F401
+  import pocketflow_amd.learners.nonuniform_quantization.learner  # noqa: F401
+  from pocketflow_amd.flags import FLAGS
+  fake = FakeHipFull()
+  for mod in (G, P, L, Opt, WS, NU):
+    monkeypatch.setattr(mod, 'hip', fake)
+  monkeypatch.setattr(AL, 'require_gpu', lambda: torch.device('cpu'))
+  FLAGS.save_path = str(tmp_path / 'models' / 'model.ckpt')
+  FLAGS.save_path_eval = str(tmp_path / 'models_eval' / 'model.ckpt')
+  FLAGS.enbl_dst = False
+  FLAGS.nb_eval_batches_override = 2
+  FLAGS.save_path_dst = str(tmp_path / 'models_dst' / 'model.ckpt')
+  FLAGS.synthetic_pool = 2
+  FLAGS.compute_dtype = 'float32'
+  return FLAGS, fake, tmp_path
+
+
+def _pool(it):
+  return [(i.numpy(), l.numpy()) for i, l in it.batches]
+
+
+def _cfg(FLAGS, model, dataset, shape, **kw):
+  c = dict(model=model, dataset=dataset, resnet_size=FLAGS.resnet_size if 'resnet_size' in FLAGS else 0,
+           nb_classes=FLAGS.nb_classes, loss_w_dcy=FLAGS.loss_w_dcy, enbl_dst=FLAGS.enbl_dst,
+           loss_w_dst=FLAGS.loss_w_dst, tempr_dst=FLAGS.tempr_dst, momentum=FLAGS.momentum, image_shape=shape)
+  c.update(kw)
+  return c
+
+
+def _max_rel(a, b):
+  worst = 0.0
+  for k, ref in b.items():
+    worst = max(worst, float(np.max(np.abs(a[k] - ref) / np.maximum(1.0, np.abs(ref)))) if ref.size else 0.0)
+  return worst
+
+
+@pytest.mark.parametrize('use_buckets,bucket_type,bits', [(False, 'channel', 8), (True, 'channel', 4), (True, 'split', 3)])
+def test_uq_lenet_on_cpu(cpu_learners, use_buckets, bucket_type, bits):
+  FLAGS, fake, tmp = cpu_learners
+  from oracle.learner_oracle import OracleLearner
+  from pocketflow_amd.nets.lenet_at_cifar10 import ModelHelper
+  from pocketflow_amd.learners.uniform_quantization.learner import UniformQuantLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  FLAGS.batch_size, FLAGS.batch_size_eval, FLAGS.nb_classes = 16, 16, 10
+  FLAGS.uql_weight_bits, FLAGS.uql_activation_bits = bits, 8
+  FLAGS.uql_use_buckets, FLAGS.uql_bucket_type, FLAGS.uql_bucket_size = use_buckets, bucket_type, 64
+  FLAGS.uql_save_quant_model_path = str(tmp / 'uql' / 'm.ckpt')
+  FLAGS.nb_eval_batches_override = 2
+  mh = ModelHelper()
+  create_synthetic_checkpoint(mh)
+  lrn = UniformQuantLearner(None, mh)
+  ora = OracleLearner(lrn.graph.store.export_numpy(),
+                      _cfg(FLAGS, 'lenet', 'cifar_10', (32, 32, 3), learner='uniform', uql_weight_bits=bits,
+                           uql_activation_bits=8, uql_use_buckets=use_buckets, uql_bucket_type=bucket_type,
+                           uql_bucket_size=64), lrn.lrn_rate)
+  pool = _pool(lrn.iter_train)
+  for step in range(3):
+    out = lrn.train_step()
+    ref = ora.train_step(*pool[step % 2])
+    assert abs(float(out['loss'].detach()) - ref['loss']) <= 1e-4 * max(1.0, abs(ref['loss'])), step
+  assert _max_rel(lrn.graph.store.export_numpy(), ora.export()) <= 2 * 3 * lrn.lrn_rate(0) + 1e-6
+  lrn.graph.training = False
+  rs = lrn.run_eval()
+  ev = [ora.eval_batch(*b) for b in _pool(lrn.iter_eval)[:2]]
+  assert abs(rs['loss'] - np.mean([e['loss'] for e in ev])) <= 2e-4
+  assert abs(rs['acc_top1'] - np.mean([e['metrics']['accuracy'] for e in ev])) <= 1.0 / 32 + 1e-6   # one near-tie sample of 32
+
+
+def test_uq_resnet20_distillation_on_cpu(cpu_learners):
+  FLAGS, fake, tmp = cpu_learners
+  from oracle.learner_oracle import OracleLearner
+  from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
+  from pocketflow_amd.learners.uniform_quantization.learner import UniformQuantLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  FLAGS.batch_size, FLAGS.batch_size_eval, FLAGS.nb_classes, FLAGS.resnet_size = 8, 8, 10, 20
+  FLAGS.uql_weight_bits, FLAGS.uql_activation_bits, FLAGS.uql_use_buckets, FLAGS.uql_bucket_type = 8, 8, True, 'channel'
+  FLAGS.enbl_dst, FLAGS.dst_eval_teacher = True, False
+  FLAGS.uql_save_quant_model_path = str(tmp / 'uql' / 'm.ckpt')
+  mh = ModelHelper()
+  create_synthetic_checkpoint(mh)
+  lrn = UniformQuantLearner(None, mh)
+  ora = OracleLearner(lrn.graph.store.export_numpy(),
+                      _cfg(FLAGS, 'resnet', 'cifar_10', (32, 32, 3), learner='uniform', uql_weight_bits=8,
+                           uql_activation_bits=8, uql_use_buckets=True, uql_bucket_type='channel'), lrn.lrn_rate)
+  pool = _pool(lrn.iter_train)
+  for step in range(2):
+    out = lrn.train_step()
+    ref = ora.train_step(*pool[step % 2])
+    # 8-bit activation quantisers on both sides, same float32 point function: only BN / conv summation order differs
+    assert abs(float(out['loss'].detach()) - ref['loss']) <= 2e-3 * max(1.0, abs(ref['loss'])), (step, float(out['loss']), ref['loss'])
+    assert abs(float(out['dst_loss'].detach()) - ref['dst_loss']) <= 2e-3 * max(1.0, abs(ref['dst_loss']))
+  assert _max_rel(lrn.graph.store.export_numpy(), ora.export()) <= 2 * 2 * lrn.lrn_rate(0) + 1e-5
+
+
+@pytest.mark.parametrize('use_buckets,bucket_type,opt_mode', [(False, 'split', 'weights'), (True, 'split', 'both'),
+                                                              (True, 'channel', 'cluster')])
+def test_nuq_resnet20_on_cpu(cpu_learners, use_buckets, bucket_type, opt_mode):
+  FLAGS, fake, tmp = cpu_learners
+  from oracle.learner_oracle import OracleLearner
+  from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
+  from pocketflow_amd.learners.nonuniform_quantization.learner import NonUniformQuantLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  FLAGS.batch_size, FLAGS.batch_size_eval, FLAGS.nb_classes, FLAGS.resnet_size = 8, 8, 10, 20
+  FLAGS.nuql_weight_bits, FLAGS.nuql_activation_bits = 3, 32
+  FLAGS.nuql_use_buckets, FLAGS.nuql_bucket_type, FLAGS.nuql_bucket_size, FLAGS.nuql_opt_mode = use_buckets, bucket_type, 128, opt_mode
+  FLAGS.nuql_save_quant_model_path = str(tmp / 'nuql' / 'm.ckpt')
+  mh = ModelHelper()
+  create_synthetic_checkpoint(mh)
+  lrn = NonUniformQuantLearner(None, mh)
+  lrn.init_clusters()
+  init = lrn.graph.store.export_numpy()
+  ora = OracleLearner({k: v for k, v in init.items() if 'clusters' not in k},
+                      _cfg(FLAGS, 'resnet', 'cifar_10', (32, 32, 3), learner='non-uniform', nuql_weight_bits=3,
+                           nuql_use_buckets=use_buckets, nuql_bucket_type=bucket_type, nuql_bucket_size=128,
+                           nuql_opt_mode=opt_mode, nuql_activation_bits=32), lrn.lrn_rate)
+  nq = lrn.nonuni_quant
+  by_var = {op.var.name: nq.cluster_vars[id(op.var)].name for op in nq.matmul_ops}
+  for i, name in enumerate(ora.matmul_var_names):
+    if i in ora.student.quant.codebooks:
+      ref = ora.student.quant.codebooks[i].detach().numpy()
+      assert np.array_equal(init[by_var[name]].reshape(ref.shape), ref), 'cluster_init of %s' % name
+  pool = _pool(lrn.iter_train)
+  for step in range(2):
+    out = lrn.train_step()
+    ref = ora.train_step(*pool[step % 2])
+    assert abs(float(out['loss'].detach()) - ref['loss']) <= 1e-4 * max(1.0, abs(ref['loss'])), (step, float(out['loss']), ref['loss'])
+  vals = lrn.graph.store.export_numpy()
+  tol = 2 * 2 * lrn.lrn_rate(0) + 1e-5
+  assert _max_rel(vals, {k: v for k, v in ora.export().items() if 'moving_' not in k}) <= tol
+  for i, name in enumerate(ora.matmul_var_names):
+    if i in ora.student.quant.codebooks:
+      ref = ora.student.quant.codebooks[i].detach().numpy()
+      assert np.max(np.abs(vals[by_var[name]].reshape(ref.shape) - ref)) <= tol, name
+
+
+def test_ws_resnet20_on_cpu(cpu_learners):
+  FLAGS, fake, tmp = cpu_learners
+  from oracle import pf_oracle as O
+  from oracle.learner_oracle import OracleLearner
+  from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
+  from pocketflow_amd.learners.weight_sparsification.learner import WeightSparseLearner
+  FLAGS.batch_size, FLAGS.batch_size_eval, FLAGS.nb_classes, FLAGS.resnet_size = 8, 8, 10, 20
+  FLAGS.ws_prune_ratio, FLAGS.ws_prune_ratio_prtl, FLAGS.ws_mask_update_step = 0.5, 'uniform', 2
+  FLAGS.ws_save_path = str(tmp / 'ws' / 'm.ckpt')
+  FLAGS.nb_smpls_train, FLAGS.nb_epochs_rat = 8 * 12, 1.0 / 250
+  lrn = WeightSparseLearner(None, ModelHelper())
+  N = lrn.nb_iters_train
+  assert N == 12
+  ora = OracleLearner(lrn.graph.store.export_numpy(),
+                      _cfg(FLAGS, 'resnet', 'cifar_10', (32, 32, 3), learner='weight-sparse', ws_prune_ratio=0.5,
+                           ws_prune_ratio_prtl='uniform'), lrn.lrn_rate)
+  refresh = set(O.ws_refresh_steps(N, 2))
+  pool = _pool(lrn.iter_train)
+  flips = 0
+  for it in range(8):
+    lr, loss, _ = lrn.train_step()
+    ref = ora.train_step(*pool[it % 2])
+    assert abs(float(loss.detach()) - ref['loss']) <= 2e-3 * max(1.0, abs(ref['loss'])), (it, float(loss), ref['loss'])
+    if it in refresh:
+      lrn.prune_step()
+      ora.prune_step(N)
+      for v in lrn.maskable_vars:
+        m = v.to_ref(lrn.masks[v.offset:v.offset + v.numel].numpy())
+        flips += int(np.sum(m != ora.masks[v.name]))
+      # teacher forcing after a refresh (a mask is a step function of |w|; see tests/test_parity_gpu.py)
+      lrn.graph.store.load_numpy(ora.export())
+      for v in lrn.maskable_vars:
+        sl = slice(v.offset, v.offset + v.numel)
+        lrn.masks[sl] = torch.from_numpy(v.to_storage(ora.masks[v.name]).reshape(-1))
+        lrn.var_bkup[sl] = torch.from_numpy(v.to_storage(ora.bkups[v.name]).reshape(-1))
+  assert flips <= 8, flips
+  for v in lrn.maskable_vars:
+    m = lrn.masks[v.offset:v.offset + v.numel]
+    assert abs(float(1 - m.mean()) - 0.5) <= 1.0 / m.numel() + 1e-6
+
+
+def test_channel_pruned_mobilenet_on_cpu(cpu_learners, monkeypatch):
+  """ChannelPrunedLearner end to end on the CPU (same shrunk configuration as tests/test_learner_gpu.py): taps,
+  LASSO channel selection, least-squares reconstruction, mask construction and the masked fine-tune."""
+  FLAGS, fake, tmp = cpu_learners
+  import pocketflow_amd.learners.channel_pruning.learner as CP
+  from pocketflow_amd.nets.mobilenet_at_ilsvrc12 import ModelHelper
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  monkeypatch.setattr(CP, 'hip', fake)
+  monkeypatch.setattr(torch.cuda, 'synchronize', lambda *a, **k: None)
+  FLAGS.batch_size, FLAGS.batch_size_eval, FLAGS.image_size, FLAGS.nb_classes = 8, 8, 32, 17
+  FLAGS.mobilenet_depth_mult = 0.25
+  FLAGS.cp_prune_option, FLAGS.cp_uniform_preserve_ratio, FLAGS.cp_nb_batches, FLAGS.cp_nb_points_per_layer = 'uniform', 0.5, 8, 10
+  FLAGS.cp_channel_pruned_path = str(tmp / 'models' / 'pruned_model.ckpt')
+  FLAGS.cp_best_path = str(tmp / 'models' / 'best_model.ckpt')
+  FLAGS.cp_original_path = str(tmp / 'models' / 'original_model.ckpt')
+  FLAGS.nb_iters_override, FLAGS.summ_step, FLAGS.synthetic_pool = 3, 2, 8
+  mh = ModelHelper()
+  create_synthetic_checkpoint(mh)
+  lrn = CP.ChannelPrunedLearner(None, mh)
+  rslt = lrn.train()
+  assert np.isfinite(rslt['loss'])
+  assert 0.2 < lrn.pruner.preserve_ratio < 0.7
+  n_masked = 0
+  for op in lrn.graph.matmul_ops:
+    if op.name not in lrn.fake_pruning_dict or op.var.kind != 'conv':
+      continue
+    keep_in, keep_out = [np.asarray(k, bool) for k in lrn.fake_pruning_dict[op.name]]
+    w = op.var.to_ref(op.var.master.detach().numpy())
+    assert np.all(w[:, :, ~keep_in, :] == 0) and np.all(w[:, :, :, ~keep_out] == 0), op.name
+    n_masked += int((~keep_in).sum() + (~keep_out).sum())
+  assert n_masked > 0
