@@ -5,10 +5,16 @@ This file is a plain-NumPy restatement of the arithmetic of the reference's hot 
 ``pocketflow_amd/csrc``; nothing under ``pocketflow_amd/`` may import it.  Only ``tests/``,
 ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg use it.
 
-PARITY UNPINNED.  The reference cannot be executed here (TensorFlow 1.x / Horovod / absl are
-absent and un-installable) and its tree holds no golden vectors, known-answer tests or fixtures
-for this path.  The oracle is therefore pinned only by
- (1) hand-computable known-answer vectors (``oracle/make_golden.py`` -> ``tests/golden``),
+PARITY: PINNED BY REFERENCE-EXECUTED FIXTURES (TF primitives restated).  TensorFlow 1.x / Horovod cannot be
+installed here and the reference tree holds no golden vectors for this path (SURVEY.md sections 4, 8c), so
+the reference's OWN Python functions are executed instead: ``tests/golden/make_reference_golden.py`` lifts them
+out of /root/reference with ``ast`` and runs them over ``oracle/tf_stub.py`` (a NumPy-eager stand-in for the
+~40 stock TF ops they call); inputs + outputs are committed as ``tests/golden/reference_arrays.npz`` /
+``reference_host.json`` and ``tests/test_oracle_golden.py`` holds this oracle to them bit for bit.  That pins
+the op order, bucket reshapes, constants and network definitions against the reference's code; what stays a
+restatement is the behaviour of each individual TF primitive (listed in tf_stub.py) and the gradient rules,
+which are pinned by
+ (1) hand-computable known-answer vectors (``tests/test_oracle_kat.py``),
  (2) cross-checks against independent torch-CPU implementations where the published semantics
      coincide (Adam, Momentum-SGD, soft-label cross-entropy, round-half-even), and
  (3) the real scikit-learn LassoLars / LinearRegression for the channel-pruning selector.

@@ -20,7 +20,7 @@ individual TF primitive remain a restatement of TF's published behaviour [3P]:
   * tf.train.piecewise_constant  -> values[0] for x <= b[0], values[i] for b[i-1] < x <= b[i], ...
   * gradient_override_map / variable_scope / summaries -> no-ops (forward values only: gradients of
     the reference chain are NOT produced by this stub; the STE rules are pinned by hand-derived
-    known answers in tests/golden/make_golden.py).
+    known answers in tests/test_oracle_kat.py).
 
 A second group of stand-ins (tf.layers.conv2d / batch_normalization / dense / max_pooling2d, tf.pad,
 tf.squeeze) lets the reference's NETWORK DEFINITIONS (utils/external/resnet_model.py) execute as they are,
@@ -219,6 +219,9 @@ class _ScopeObj(str):
   """What `with tf.variable_scope(...) as scope` yields: the absolute scope path; passing it back to
   tf.variable_scope re-enters that scope instead of nesting."""
 
+  def reuse_variables(self):
+    """Variables are looked up by name in `variable_values`, so reuse needs nothing."""
+
 
 @contextlib.contextmanager
 def variable_scope(name_or_scope, default_name=None, values=None, *a, **kw):
@@ -228,10 +231,15 @@ def variable_scope(name_or_scope, default_name=None, values=None, *a, **kw):
   else:
     name = name_or_scope if name_or_scope is not None else default_name
     _scopes.append(str(name))
+  path = '/'.join(_scopes)
   try:
-    yield _ScopeObj('/'.join(_scopes))
+    yield _ScopeObj(path)
   finally:
     _scopes[:] = saved
+    # TF closes the sub-scope counters of a variable scope on exit (VariableScopeStore.close_variable_subscopes),
+    # so re-entering `path` names its layers dense, dense_1, ... again -- which is what makes `reuse` work
+    for key in [k for k in _layer_names if k.startswith(path + '/')]:
+      del _layer_names[key]
 
 
 class _Scope(object):
@@ -262,6 +270,15 @@ class _Graph(object):
 
 class Session(object):
   graph = _Graph()
+
+  def __init__(self, *a, **kw):
+    pass
+
+  def run(self, fetches, feed_dict=None):
+    """Eager stub: tensors already hold their values."""
+    if isinstance(fetches, (list, tuple)):
+      return [self.run(f) for f in fetches]
+    return np.asarray(_raw(fetches))
 
 
 def get_default_graph(): return _Graph()
@@ -396,6 +413,35 @@ def _dense(inputs, units, **kw):
   w, b = _var(layer, 'kernel'), _var(layer, 'bias')
   assert w.shape[1] == units
   return T((np.asarray(_raw(inputs), np.float32) @ w + b).astype(np.float32))
+
+
+def _layer_norm(inputs, center=True, scale=True, begin_norm_axis=1, begin_params_axis=-1, scope=None, **kw):
+  """tf.contrib.layers.layer_norm [3P]: moments over axes >= begin_norm_axis, then
+  tf.nn.batch_normalization(x, mean, var, beta, gamma, variance_epsilon=1e-12) = x * inv + (beta - mean * inv),
+  inv = rsqrt(var + eps) * gamma; variables `LayerNorm[_k]/{beta,gamma}` over the last axis."""
+  layer = scope or _layer_scope('LayerNorm')
+  x = np.asarray(_raw(inputs), np.float32)
+  axes = tuple(np.arange(x.ndim)[begin_norm_axis:])
+  mean = np.mean(x, axis=axes, keepdims=True, dtype=np.float32)
+  var = np.mean(np.square(x - mean), axis=axes, keepdims=True, dtype=np.float32)
+  inv = (np.float32(1) / np.sqrt(var + np.float32(1e-12))).astype(np.float32)
+  if scale:
+    inv = inv * _var(layer, 'gamma')
+  off = -mean * inv
+  if center:
+    off = _var(layer, 'beta') + off
+  # creation order in TF is beta, gamma; keep `variables_used` in that order
+  if scale and center:
+    variables_used[-2], variables_used[-1] = variables_used[-1], variables_used[-2]
+  return T((x * inv + off).astype(np.float32))
+
+
+def sigmoid(x, **kw):
+  x = np.asarray(_raw(x), np.float32)
+  return T((np.float32(1) / (np.float32(1) + np.exp(-x))).astype(np.float32))
+
+
+def shape(x, **kw): return T(np.array(np.shape(_raw(x)), dtype=np.int32))          # noqa: A001
 
 
 def _max_pooling2d(inputs, pool_size, strides, padding='valid', data_format='channels_last', **kw):
@@ -589,7 +635,7 @@ def install() -> types.ModuleType:
   slim = _ns('tensorflow.contrib.slim', arg_scope=_arg_scope, conv2d=_slim_conv2d, separable_conv2d=_slim_separable_conv2d,
              batch_norm=_slim_batch_norm, dropout=_slim_dropout, avg_pool2d=_slim_avg_pool2d)
   clayers = _ns('tensorflow.contrib.layers', softmax=lambda logits, scope=None: T(_softmax(logits)),
-                l2_regularizer=lambda wd: ('l2', wd))
+                l2_regularizer=lambda wd: ('l2', wd), layer_norm=_layer_norm)
   tf.contrib = _ns('tensorflow.contrib', distributions=dist, graph_editor=ge, slim=slim, layers=clayers)
   tf.truncated_normal_initializer = lambda stddev=1.0, **kw: ('truncated_normal', stddev)
   tf.GraphKeys = _ns('tensorflow.GraphKeys', UPDATE_OPS='update_ops')

@@ -1,0 +1,282 @@
+"""DDPG agent that drives the hyper-parameter searches of the learners (reference rl_agents/ddpg/agent.py:31-418).
+
+Callers (bit allocation of the quantisation learners, pruning ratios of the weight-sparsification learner,
+preserve ratios of the channel-pruning learner) use the same seven entry points as in the reference:
+
+  agent = Agent(sess, s_dims, a_dims, nb_rlouts, buf_size, a_min, a_max)
+  agent.init()                                   # before all roll-outs
+  agent.init_rlout()                             # before each roll-out: redraw the parameter noise
+  a = agent.actions_noisy(state)                 # reference: sess.run(agent.actions_noisy, {agent.states: state})
+  agent.record(s, a, r, terminal, s_next); agent.train(); agent.finalize_rlout(rewards)
+  a = agent.actions_clean(state)                 # deployment
+
+There is no session: `actions_noisy` / `actions_clean` are callables on NumPy rows.  `sess` is accepted for
+signature compatibility and may carry a seed (int) or a np.random.RandomState for reproducible searches (the
+reference is unseeded).
+
+One `train()` = one sample of `ddpg_batch_size` transitions, rewards minus the EMA baseline, then
+  target_q    = r + (1 - terminal) * gamma * Q'(s', mu'(s'))
+  actor_loss  = -mean Q(s, mu(s))            (+ ddpg_loss_w_dcy * sum l2)     -> Adam on the actor
+  critic_loss = l2_loss(Q(s, a) - target_q)  (+ ddpg_loss_w_dcy * sum l2)     -> Adam on the critic
+both gradients taken at the pre-update values (one `sess.run` of both update ops in the reference, :236-243),
+followed by the soft target update  theta' <- (1 - tau) theta' + tau theta.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from pocketflow_amd.flags import FLAGS, flags
+from pocketflow_amd.rl_agents.ddpg.actor_critic import Actor, Critic
+from pocketflow_amd.rl_agents.ddpg.noise import AdaptiveNoiseSpec, TimeDecayNoiseSpec
+from pocketflow_amd.rl_agents.ddpg.replay_buffer import ReplayBuffer
+from pocketflow_amd.rl_agents.ddpg.running_mean_std import RunningMeanStd
+
+flags.DEFINE_float('ddpg_tau', 0.01, 'DDPG: target networks\' update coefficient')
+flags.DEFINE_float('ddpg_gamma', 0.9, 'DDPG: reward discounting factor')
+flags.DEFINE_float('ddpg_lrn_rate', 1e-3, 'DDPG: actor & critic networks\' learning rate')
+flags.DEFINE_float('ddpg_loss_w_dcy', 0.0, 'DDPG: weight decaying coefficient')
+flags.DEFINE_integer('ddpg_record_step', 1, 'DDPG: recording step size')
+flags.DEFINE_integer('ddpg_batch_size', 64, 'DDPG: batch size')
+flags.DEFINE_boolean('ddpg_enbl_bsln_func', True, 'DDPG: enable baseline function')
+flags.DEFINE_float('ddpg_bsln_decy_rate', 0.95, 'DDPG: baseline function\'s decaying rate')
+
+
+def normalize(smpl_mat, rms):
+  return smpl_mat if rms is None else (smpl_mat - torch.as_tensor(rms.mean)) / torch.as_tensor(rms.std)
+
+
+def denormalize(smpl_mat, rms):
+  return smpl_mat if rms is None else (smpl_mat * torch.as_tensor(rms.std) + torch.as_tensor(rms.mean))
+
+
+def calc_loss_dcy(trainable_vars):
+  return sum((v * v).sum() / 2 for v in trainable_vars)
+
+
+class TfAdam(object):
+  """tf.train.AdamOptimizer on a list of tensors: lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t);
+  p -= lr_t * m / (sqrt(v) + eps)  (epsilon outside the bias correction, unlike torch.optim.Adam)."""
+
+  def __init__(self, params, lrn_rate, beta1=0.9, beta2=0.999, eps=1e-8):
+    self.params, self.lr, self.b1, self.b2, self.eps = list(params), lrn_rate, beta1, beta2, eps
+    self.reset()
+
+  def reset(self):
+    self.m = [torch.zeros_like(p) for p in self.params]
+    self.v = [torch.zeros_like(p) for p in self.params]
+    self.b1p, self.b2p = 1.0, 1.0
+
+  @torch.no_grad()
+  def apply_gradients(self, grads):
+    self.b1p *= self.b1
+    self.b2p *= self.b2
+    lr_t = np.float32(self.lr * np.sqrt(1.0 - self.b2p) / (1.0 - self.b1p))
+    for p, g, m, v in zip(self.params, grads, self.m, self.v):
+      m.mul_(self.b1).add_(g, alpha=1.0 - self.b1)
+      v.mul_(self.b2).addcmul_(g, g, value=1.0 - self.b2)
+      p.sub_(float(lr_t) * m / (v.sqrt() + self.eps))
+
+
+def _make_rng(sess):
+  if isinstance(sess, np.random.RandomState):
+    return sess
+  if isinstance(sess, (int, np.integer)):
+    return np.random.RandomState(int(sess))
+  return np.random.RandomState()
+
+
+class Agent(object):  # pylint: disable=too-many-instance-attributes
+  """DDPG (Deep Deterministic Policy Gradient) agent."""
+
+  def __init__(self, sess, s_dims, a_dims, nb_rlouts, buf_size, a_min=0.0, a_max=1.0):
+    self.sess = sess
+    self.scope = 'agent'
+    self.rng = _make_rng(sess)
+    self.reward_ema = None  # exponential moving average of rewards
+    self.in_explore = True
+    self.s_dims, self.a_dims, self.a_min, self.a_max = s_dims, a_dims, float(a_min), float(a_max)
+    self.__build(s_dims, a_dims, nb_rlouts, buf_size, a_min, a_max)
+
+  # -- life cycle -----------------------------------------------------------------------------------------
+  def init(self):
+    """Before all roll-outs: fresh networks and optimiser slots, empty replay buffer, initial noise."""
+    for net in (self.actor, self.critic):
+      net.reinitialize()
+    self.actor_opt.reset()
+    self.critic_opt.reset()
+    self.__copy(self.actor, self.actor_tr)
+    self.__copy(self.critic, self.critic_tr)
+    if FLAGS.ddpg_noise_type == 'param':
+      self.actor_np.reinitialize()
+      self.actor_ns.reinitialize()
+    self.action_noise_std = 0.0
+    self.memory.reset()
+    self.noise_spec.reset()
+    self.in_explore = True
+
+  def init_rlout(self):
+    """Before each roll-out: adapt the time-decayed noise scale, redraw the parameter noise."""
+    if FLAGS.ddpg_noise_prtl == 'tdecy' and not self.in_explore:
+      self.noise_spec.adapt()
+    if FLAGS.ddpg_noise_type == 'action':
+      self.action_noise_std = self.noise_spec.stdev_curr
+    elif FLAGS.ddpg_noise_type == 'param':
+      self.__perturb(self.actor_np, self.noise_spec.stdev_curr)
+    else:
+      raise ValueError('unrecognized noise type: ' + FLAGS.ddpg_noise_type)
+
+  def finalize_rlout(self, rewards):
+    """After each roll-out: update the EMA baseline of the rewards."""
+    if not FLAGS.ddpg_enbl_bsln_func:
+      return
+    if self.reward_ema is None:
+      self.reward_ema = np.mean(rewards)
+    else:
+      self.reward_ema = FLAGS.ddpg_bsln_decy_rate * self.reward_ema \
+          + (1.0 - FLAGS.ddpg_bsln_decy_rate) * np.mean(rewards)
+
+  def record(self, states, actions, rewards, terminals, states_next):
+    """Append transitions (every ddpg_record_step-th row) to the replay buffer."""
+    step = FLAGS.ddpg_record_step
+    states, states_next = np.asarray(states)[::step], np.asarray(states_next)[::step]
+    n = states.shape[0]
+    self.memory.append(states, np.asarray(actions)[::step], np.asarray(rewards)[::step].reshape(n, 1),
+                       np.asarray(terminals)[::step].reshape(n, 1), states_next)
+    if self.state_rms is not None:
+      self.state_rms.updt(states)
+
+  # -- acting ------------------------------------------------------------------------------------------------
+  def __rows(self, states):
+    return torch.as_tensor(np.asarray(states, np.float32).reshape(-1, self.s_dims), device=self.actor.device)
+
+  @torch.no_grad()
+  def actions_clean(self, states):
+    return self.actor(normalize(self.__rows(states), self.state_rms)).cpu().numpy()
+
+  @torch.no_grad()
+  def actions_noisy(self, states):
+    s = normalize(self.__rows(states), self.state_rms)
+    if FLAGS.ddpg_noise_type == 'action':
+      a = self.actor(s).cpu().numpy()
+      a = a + self.rng.normal(0.0, 1.0, a.shape).astype(np.float32) * np.float32(self.action_noise_std)
+      return np.clip(a, self.a_min, self.a_max).astype(np.float32)
+    return self.actor_np(s).cpu().numpy()
+
+  # -- learning -----------------------------------------------------------------------------------------------
+  def train(self):
+    """One actor + critic update from a replay mini-batch; returns (actor_loss, critic_loss, noise stdev)."""
+    if not self.memory.is_ready():
+      return 0.0, 0.0, self.noise_spec.stdev_curr
+
+    self.in_explore = False
+    if FLAGS.ddpg_noise_prtl == 'adapt':
+      mbatch = self.memory.sample(FLAGS.ddpg_batch_size)
+      self.__perturb(self.actor_ns, self.noise_spec.stdev_curr)
+      with torch.no_grad():
+        s = normalize(self.__rows(mbatch['states']), self.state_rms)
+        action_dist = float((self.actor(s) - self.actor_ns(s)).abs().mean())
+      self.noise_spec.adapt(action_dist)
+
+    mbatch = self.memory.sample(FLAGS.ddpg_batch_size)
+    if FLAGS.ddpg_enbl_bsln_func:
+      mbatch['rewards'] -= np.float32(self.reward_ema)
+    target_q, actor_loss, critic_loss = self.train_on_batch(mbatch)
+    if self.return_rms is not None:
+      self.return_rms.updt(target_q)
+    return actor_loss, critic_loss, self.noise_spec.stdev_curr
+
+  def train_on_batch(self, mbatch):
+    """The `sess.run(monitor + [actor_updt, critic_updt])` + `target_updt` of the reference on a given batch."""
+    dev = self.actor.device
+    t = lambda k: torch.as_tensor(np.asarray(mbatch[k], np.float32), device=dev)
+    s = normalize(t('states'), self.state_rms)
+    s_next = normalize(t('states_next'), self.state_rms)
+    a, r, term = t('actions'), t('rewards'), t('terminals')
+    with torch.no_grad():
+      q_next = denormalize(self.critic_tr(s_next, self.actor_tr(s_next)), self.return_rms)
+      target_q = r + (1.0 - term) * FLAGS.ddpg_gamma * q_next
+    actor_loss = -denormalize(self.critic(s, self.actor(s)), self.return_rms).mean()
+    critic_loss = ((self.critic(s, a) - normalize(target_q, self.return_rms)) ** 2).sum() / 2
+    if FLAGS.ddpg_loss_w_dcy:
+      actor_loss = actor_loss + FLAGS.ddpg_loss_w_dcy * calc_loss_dcy(self.actor.trainable_vars)
+      critic_loss = critic_loss + FLAGS.ddpg_loss_w_dcy * calc_loss_dcy(self.critic.trainable_vars)
+    g_actor = torch.autograd.grad(actor_loss, self.actor.trainable_vars)
+    g_critic = torch.autograd.grad(critic_loss, self.critic.trainable_vars)
+    self.actor_opt.apply_gradients(g_actor)
+    self.critic_opt.apply_gradients(g_critic)
+    self.__soft_update(self.actor, self.actor_tr)
+    self.__soft_update(self.critic, self.critic_tr)
+    return target_q.cpu().numpy(), float(actor_loss.detach()), float(critic_loss.detach())
+
+  # -- construction ------------------------------------------------------------------------------------------------
+  def __build(self, s_dims, a_dims, nb_rlouts, buf_size, a_min, a_max):
+    normalize_state = False          # hard-coded in the reference (agent.py:262-263)
+    normalize_return = False
+    self.state_rms = RunningMeanStd(None, s_dims) if normalize_state else None
+    self.return_rms = RunningMeanStd(None, 1) if normalize_return else None
+
+    mk = lambda cls, name, *a: cls(*a, scope=self.scope + '/' + name, rng=self.rng)
+    self.actor = mk(Actor, 'actor_mn', a_dims, a_min, a_max)
+    self.actor_tr = mk(Actor, 'actor_tr', a_dims, a_min, a_max)
+    self.critic = mk(Critic, 'critic_mn')
+    self.critic_tr = mk(Critic, 'critic_tr')
+    self.memory = ReplayBuffer(s_dims, a_dims, buf_size, rng=self.rng)
+
+    if FLAGS.ddpg_noise_prtl == 'adapt':
+      self.noise_spec = AdaptiveNoiseSpec()
+    elif FLAGS.ddpg_noise_prtl == 'tdecy':
+      self.noise_spec = TimeDecayNoiseSpec(nb_rlouts)
+    else:
+      raise ValueError('unrecognized noise adjustment protocol: ' + FLAGS.ddpg_noise_prtl)
+
+    # create the variables (one dry forward per network, the graph construction of the reference)
+    dev = self.actor.device
+    s0, a0 = torch.zeros((1, s_dims), device=dev), torch.zeros((1, a_dims), device=dev)
+    with torch.no_grad():
+      for net in (self.actor, self.actor_tr):
+        net(s0)
+      for net in (self.critic, self.critic_tr):
+        net(s0, a0)
+      self.action_noise_std = 0.0
+      if FLAGS.ddpg_noise_type == 'param':
+        self.actor_np = mk(Actor, 'actor_np', a_dims, a_min, a_max)     # perturbed copy that acts during roll-outs
+        self.actor_ns = mk(Actor, 'actor_ns', a_dims, a_min, a_max)     # perturbed copy that measures the action distance
+        self.actor_np(s0)
+        self.actor_ns(s0)
+      elif FLAGS.ddpg_noise_type != 'action':
+        raise ValueError('unrecognized noise type: ' + FLAGS.ddpg_noise_type)
+    for net in (self.actor_tr, self.critic_tr):
+      for p in net.vars:
+        p.requires_grad_(False)
+    self.actor_opt = TfAdam(self.actor.trainable_vars, FLAGS.ddpg_lrn_rate)
+    self.critic_opt = TfAdam(self.critic.trainable_vars, FLAGS.ddpg_lrn_rate)
+
+  @staticmethod
+  @torch.no_grad()
+  def __copy(model, model_tr):
+    for var, var_tr in zip(model.vars, model_tr.vars):
+      var_tr.copy_(var)
+
+  @staticmethod
+  @torch.no_grad()
+  def __soft_update(model, model_tr):
+    tau = FLAGS.ddpg_tau
+    for var, var_tr in zip(model.vars, model_tr.vars):
+      var_tr.mul_(1.0 - tau).add_(var, alpha=tau)
+
+  @torch.no_grad()
+  def __perturb(self, model_noisy, param_noise_std):
+    """noisy <- clean + N(0, std^2) on every variable whose name does not contain LayerNorm (:97-117)."""
+    for (name, var_clean), var_noisy in zip(self.actor.params.items(), model_noisy.vars):
+      var_noisy.copy_(var_clean)
+      if 'LayerNorm' not in name:
+        noise = self.rng.normal(0.0, 1.0, tuple(var_clean.shape)).astype(np.float32) * np.float32(param_noise_std)
+        var_noisy.add_(torch.from_numpy(noise).to(var_noisy.device))
+
+  @property
+  def vars(self):
+    nets = [self.actor, self.actor_tr, self.critic, self.critic_tr]
+    if FLAGS.ddpg_noise_type == 'param':
+      nets += [self.actor_np, self.actor_ns]
+    return [v for n in nets for v in n.vars]

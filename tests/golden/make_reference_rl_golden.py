@@ -1,0 +1,251 @@
+#!/usr/bin/env python
+"""Generate tests/golden/reference_rl.npz / reference_rl.json by EXECUTING THE REFERENCE'S OWN hyper-parameter
+search components.  Same method and caveats as make_reference_golden.py: definitions are lifted
+with `ast` from the files under /root/reference and run over oracle/tf_stub.py; build container only.
+
+    python tests/golden/make_reference_rl_golden.py
+
+Lifted (paths relative to /root/reference):
+  rl_agents/ddpg/actor_critic.py                 dense_block, Model, Actor, Critic  (forward values for given variables)
+  rl_agents/ddpg/replay_buffer.py                ReplayBuffer   (pure NumPy)
+  rl_agents/ddpg/noise.py                        AdaptiveNoiseSpec, TimeDecayNoiseSpec
+  rl_agents/ddpg/agent.py                        Agent.finalize_rlout, Agent.record (the two methods without graph code)
+  learners/uniform_quantization/rl_helper.py     RLHelper
+  learners/nonuniform_quantization/rl_helper.py  RLHelper
+  learners/weight_sparsification/rl_helper.py    RLHelper
+  learners/channel_pruning/learner.py            ChannelPrunedLearner.__calc_reward
+Not executable here (TF graph construction / sessions): Agent.__build / train, BitOptimizer, PROptimizer roll-out
+loops; they are restated in oracle/ddpg_oracle.py and pocketflow_amd and anchored on the pieces above.
+"""
+import json
+import os
+import random
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_reference_golden as G  # noqa: E402  (installs the stub, provides lift())
+
+tf, FLAGS, T = G.tf, G.FLAGS, G.tf_stub.T
+
+DDPG_DEFAULTS = dict(ddpg_actor_depth=2, ddpg_actor_width=64, ddpg_critic_depth=2, ddpg_critic_width=64,
+                     ddpg_noise_type='param', ddpg_noise_prtl='tdecy', ddpg_noise_std_init=1e+0, ddpg_noise_dst_finl=1e-2,
+                     ddpg_noise_adpt_rat=1.03, ddpg_noise_std_finl=1e-5, ddpg_record_step=1, ddpg_enbl_bsln_func=True,
+                     ddpg_bsln_decy_rate=0.95)
+
+
+def set_flags(**kw):
+  for k, v in kw.items():
+    setattr(FLAGS, k, v)
+
+
+def net_variables(rng, scope, widths, ln_after):
+  """Random variables of a dense(+LayerNorm) stack: widths = [(in, out), ...]; ln_after[i] -> LayerNorm behind dense i."""
+  vals, k_dense, k_ln = {}, 0, 0
+  for (cin, cout), ln in zip(widths, ln_after):
+    d = 'dense' if k_dense == 0 else 'dense_%d' % k_dense
+    vals['%s/%s/kernel' % (scope, d)] = (rng.randn(cin, cout) / np.sqrt(cin)).astype(np.float32)
+    vals['%s/%s/bias' % (scope, d)] = (0.1 * rng.randn(cout)).astype(np.float32)
+    k_dense += 1
+    if ln:
+      l = 'LayerNorm' if k_ln == 0 else 'LayerNorm_%d' % k_ln
+      vals['%s/%s/beta' % (scope, l)] = (0.1 * rng.randn(cout)).astype(np.float32)
+      vals['%s/%s/gamma' % (scope, l)] = (1.0 + 0.1 * rng.randn(cout)).astype(np.float32)
+      k_ln += 1
+  return vals
+
+
+def gen_actor_critic(out, meta):
+  ns = G.lift('rl_agents/ddpg/actor_critic.py', ['dense_block', 'Model', 'Actor', 'Critic'], {'ENBL_LAYER_NORM': True})
+  rng = np.random.RandomState(31)
+  cases = []
+  for name, s_dims, a_dims, a_min, a_max, width, depth, batch in (
+      ('bits', 9, 1, 0.0, 6.0, 64, 2, 1), ('move', 4, 4, -1.0, 1.0, 64, 2, 7), ('narrow', 6, 2, 0.2, 1.0, 16, 3, 5)):
+    set_flags(ddpg_actor_depth=depth, ddpg_actor_width=width, ddpg_critic_depth=depth, ddpg_critic_width=width)
+    a_scope, c_scope = 'agent/actor_mn', 'agent/critic_mn'
+    a_vals = net_variables(rng, a_scope, [(s_dims, width)] + [(width, width)] * (depth - 1) + [(width, a_dims)],
+                           [True] * depth + [False])
+    c_vals = net_variables(rng, c_scope, [(s_dims, width), (width + a_dims, width)] + [(width, width)] * (depth - 1) + [(width, 1)],
+                           [True] * (depth + 1) + [False])
+    states = rng.randn(batch, s_dims).astype(np.float32)
+    actions = rng.uniform(a_min, a_max, (batch, a_dims)).astype(np.float32)
+    G.tf_stub.reset_layers(dict(a_vals, **c_vals))
+    actor, critic = ns['Actor'](a_dims, a_min, a_max, scope=a_scope), ns['Critic'](scope=c_scope)
+    mu = actor(T(states))
+    a_order = list(G.tf_stub.variables_used)
+    q = critic(T(states), T(actions))
+    c_order = list(G.tf_stub.variables_used)[len(a_order):]
+    q_mu = critic(T(states), mu, reuse=True)                       # second call re-enters the scope: same variables
+    assert list(G.tf_stub.variables_used)[len(a_order) + len(c_order):] == c_order
+    for k, v in dict(a_vals, **c_vals).items():
+      out['ac/%s/var/%s' % (name, k)] = v
+    out['ac/%s/states' % name], out['ac/%s/actions' % name] = states, actions
+    out['ac/%s/mu' % name], out['ac/%s/q' % name], out['ac/%s/q_mu' % name] = mu.numpy(), q.numpy(), q_mu.numpy()
+    cases.append(dict(name=name, s_dims=s_dims, a_dims=a_dims, a_min=a_min, a_max=a_max, width=width, depth=depth,
+                      actor_vars=a_order, critic_vars=c_order))
+  meta['actor_critic'] = cases
+  set_flags(**DDPG_DEFAULTS)
+
+
+def gen_replay(out, meta):
+  RB = G.lift('rl_agents/ddpg/replay_buffer.py', ['ReplayBuffer'])['ReplayBuffer']
+  rng = np.random.RandomState(5)
+  buf = RB(3, 2, 10)
+  trace = []
+  for step, n in enumerate((4, 4, 1, 3, 7, 1)):
+    rows = [rng.randn(n, 3), rng.randn(n, 2), rng.randn(n, 1), (rng.rand(n, 1) > 0.7).astype(np.float64), rng.randn(n, 3)]
+    for j, r in enumerate(rows):
+      out['replay/append%d/%d' % (step, j)] = r
+    buf.append(*rows)
+    trace.append(dict(n=n, idx_smpl=int(buf.idx_smpl), nb_smpls=int(buf.nb_smpls), ready=bool(buf.is_ready())))
+    for k, v in buf.buffers.items():
+      out['replay/after%d/%s' % (step, k)] = v.copy()
+  np.random.seed(7)
+  mb = buf.sample(6)
+  for k, v in mb.items():
+    out['replay/sample_seed7/%s' % k] = v
+  buf.reset()
+  trace.append(dict(n=0, idx_smpl=int(buf.idx_smpl), nb_smpls=int(buf.nb_smpls), ready=bool(buf.is_ready())))
+  meta['replay'] = trace
+
+
+def gen_noise(meta):
+  ns = G.lift('rl_agents/ddpg/noise.py', ['AdaptiveNoiseSpec', 'TimeDecayNoiseSpec'])
+  set_flags(**DDPG_DEFAULTS)
+  td = ns['TimeDecayNoiseSpec'](20)
+  seq = []
+  for _ in range(25):
+    td.adapt()
+    seq.append(td.stdev_curr)
+  td.reset()
+  ad = ns['AdaptiveNoiseSpec']()
+  dists = [0.5, 0.2, 0.005, 0.02, 0.001, 0.0099, 0.0101]
+  aseq = []
+  for d in dists:
+    ad.adapt(d)
+    aseq.append(ad.stdev_curr)
+  meta['noise'] = dict(tdecy_nb_rlouts=20, tdecy=seq, tdecy_rat=td.decy_rat, tdecy_reset=td.stdev_curr, adapt_dists=dists, adapt=aseq)
+
+
+def gen_agent_host(out, meta):
+  """Agent.finalize_rlout / record do not touch the graph: run them on a shell object."""
+  ns = G.lift('rl_agents/ddpg/agent.py', ['Agent.finalize_rlout', 'Agent.record'])
+  RB = G.lift('rl_agents/ddpg/replay_buffer.py', ['ReplayBuffer'])['ReplayBuffer']
+  set_flags(**DDPG_DEFAULTS)
+  ag = ns['Agent']()
+  ag.reward_ema, ag.state_rms = None, None
+  ema = []
+  for rewards in ([0.5] * 4, [0.7, 0.9], [0.1]):
+    ag.finalize_rlout(np.array(rewards))
+    ema.append(float(ag.reward_ema))
+  meta['agent_reward_ema'] = ema
+  # record with (1,1)-shaped rewards / terminals, as every learner calls it
+  ag.memory = RB(3, 1, 4)
+  rng = np.random.RandomState(9)
+  for i in range(3):
+    s, a, r, t, s2 = rng.randn(1, 3), rng.rand(1, 1), 0.25 * (i + 1) * np.ones((1, 1)), np.float64(i == 2) * np.ones((1, 1)), rng.randn(1, 3)
+    for j, x in enumerate((s, a, r, t, s2)):
+      out['agent_record/in%d/%d' % (i, j)] = x
+    ag.record(s, a, r, t, s2)
+  for k, v in ag.memory.buffers.items():
+    out['agent_record/buffers/%s' % k] = v.copy()
+  # record with 1-D rewards over a multi-row roll-out and ddpg_record_step = 2 (rl_agents/unit_tests usage)
+  set_flags(ddpg_record_step=2)
+  ag.memory = RB(3, 1, 4)
+  s, a, r, t, s2 = rng.randn(5, 3), rng.rand(5, 1), rng.randn(5), np.zeros(5), rng.randn(5, 3)
+  for j, x in enumerate((s, a, r, t, s2)):
+    out['agent_record2/in/%d' % j] = x
+  ag.record(s, a, r, t, s2)
+  for k, v in ag.memory.buffers.items():
+    out['agent_record2/buffers/%s' % k] = v.copy()
+  set_flags(ddpg_record_step=1)
+
+
+KERNELS = [(3, 3, 3, 8), (3, 3, 8, 32), (1, 1, 32, 64), (3, 3, 64, 1), (64, 10)]
+
+
+def gen_bit_helpers(out, meta):
+  rows = []
+  for prefix, path in (('uql', 'learners/uniform_quantization/rl_helper.py'), ('nuql', 'learners/nonuniform_quantization/rl_helper.py')):
+    RL = G.lift(path, ['RLHelper'], {'random': random})['RLHelper']
+    set_flags(**{prefix + '_w_bit_min': 2, prefix + '_w_bit_max': 8})
+    vars_ = [T(np.zeros(s, np.float32)) for s in KERNELS]
+    num_weights = [int(np.prod(s)) for s in KERNELS]
+    for eq_bits in (4, 3, 7):
+      total_bits = sum(num_weights) * eq_bits
+      h = RL(tf.Session(), total_bits, num_weights, vars_, random_layers=False)
+      out['%s_helper/eq%d/states' % (prefix, eq_bits)] = h.states.copy()
+      for case, (order, raw) in enumerate((([0, 1, 2, 3, 4], [5.2, 0.4, 2.5, 3.5, 1.0]), ([3, 1, 4, 0, 2], [6.0, 6.0, 6.0, 6.0, 6.0]),
+                                           ([4, 3, 2, 1, 0], [0.0, 1.49, 1.5, 5.9, 0.3]))):
+        h.reset()
+        h.layer_idxs = list(order)
+        bits, used = [], []
+        for idx, a in zip(order, raw):
+          st = h.calc_state(idx)
+          b = h.calc_w(np.array([[a]]), idx)
+          bits.append(float(b[0][0]))
+          used.append(float(h.w_bits_used))
+          assert st.shape == (1, h.s_dims) and b.shape == (1, 1)
+        rows.append(dict(prefix=prefix, eq_bits=eq_bits, case=case, order=list(order), raw=list(raw), bits=bits, used=used,
+                         total_bits=total_bits, s_dims=int(h.s_dims), reward=h.calc_reward(0.625).tolist()))
+  meta['bit_helpers'] = rows
+  meta['kernels'] = [list(k) for k in KERNELS]
+
+
+def gen_ws_helper(out, meta):
+  RL = G.lift('learners/weight_sparsification/rl_helper.py', ['RLHelper'])['RLHelper']
+  rows = []
+  vars_ = [T(np.zeros(s, np.float32)) for s in KERNELS]
+  for ratio in (0.75, 0.5, 0.9):
+    for skip in (True, False):
+      if skip and ratio > 0.8:
+        continue                                   # head & tail dense: the target is unreachable on this small net
+      for reward_type in ('single-obj', 'multi-obj'):
+        set_flags(ws_prune_ratio=ratio, ws_reward_type=reward_type)
+        h = RL(tf.Session(), vars_, skip)
+        tag = 'ws_helper/r%g_skip%d_%s' % (ratio, int(skip), reward_type)
+        out[tag + '/states_static'] = h.states.copy()
+        out[tag + '/normalizer'] = h.state_normalizer.copy()
+        for case, actions in enumerate(([0.5] * 5, [0.0, 1.0, 0.25, 0.75, 0.6], [1.0, 1.0, 1.0, 1.0, 1.0], [0.1, 0.1, 0.0, 0.3, 0.2])):
+          h.prune_ratios[:] = 0
+          states, ratios = [], []
+          for idx, a in enumerate(actions):
+            states.append(h.calc_state(idx)[0])
+            ratios.append(float(h.cvt_action_to_prune_ratio(idx, a)))
+          out['%s/case%d/states' % (tag, case)] = np.stack(states)
+          rows.append(dict(ratio=ratio, skip=skip, reward_type=reward_type, case=case, actions=list(actions), prune_ratios=ratios,
+                           overall=float(h.calc_overall_prune_ratio()), reward=float(h.calc_reward(0.8)), s_dims=int(h.s_dims)))
+  meta['ws_helper'] = rows
+
+
+def gen_cp_reward(meta):
+  ns = G.lift('learners/channel_pruning/learner.py', ['ChannelPrunedLearner.__calc_reward'])
+  fn = getattr(ns['ChannelPrunedLearner'], '_ChannelPrunedLearner__calc_reward')
+  rows = []
+  for policy in ('accuracy', 'flops'):
+    for acc, flops in ((0.9, 0.5), (0.99, 0.25), (0.3, 0.7)):
+      set_flags(cp_reward_policy=policy, cp_noise_tolerance=0.15)
+      rows.append(dict(policy=policy, acc=acc, flops=flops, reward=np.asarray(fn(ns['ChannelPrunedLearner'], acc, flops)).tolist()))
+  meta['cp_reward'] = rows
+
+
+def main():
+  arrays, meta = {}, {}
+  gen_actor_critic(arrays, meta)
+  gen_replay(arrays, meta)
+  gen_noise(meta)
+  gen_agent_host(arrays, meta)
+  gen_bit_helpers(arrays, meta)
+  gen_ws_helper(arrays, meta)
+  gen_cp_reward(meta)
+  np.savez_compressed(os.path.join(HERE, 'reference_rl.npz'), **arrays)
+  with open(os.path.join(HERE, 'reference_rl.json'), 'w') as f:
+    json.dump(meta, f, indent=1, sort_keys=True)
+  print('wrote %d arrays (%.1f KiB) and %d host tables' % (
+      len(arrays), os.path.getsize(os.path.join(HERE, 'reference_rl.npz')) / 1024.0, len(meta)))
+
+
+if __name__ == '__main__':
+  main()
