@@ -77,13 +77,17 @@ class NonUniformQuantLearner(AbstractLearner):
     if self.is_primary_worker('local'):
       self.download_model()  # pre-trained model is required
     self.auto_barrier()
-    bit_optimizer = BitOptimizer(self.dataset_name, self.weights, self.statistics)
-    self.optimal_w_bit_list, self.optimal_a_bit_list = bit_optimizer.run()
-    self.auto_barrier()
     self.clusters_initialized = False
+    bit_optimizer = BitOptimizer(self.dataset_name, self.weights, self.statistics, self.bit_placeholders, self.ops,
+                                 (None, None), self, self, None, None, self.auto_barrier, mpi_comm=self.mpi_comm)
+    self.optimal_w_bit_list, self.optimal_a_bit_list = bit_optimizer.run()
+    self.nonuni_quant.feed_bits(self.optimal_w_bit_list, self.optimal_a_bit_list)
+    self.auto_barrier()
 
   # ---------------------------------------------------------------------------------------------
-  def train_step(self):
+  def train_step(self, optimizer=None):
+    """ops['train'] (Adam) or, with `optimizer=self.optimizer_fintune`, ops['rl_fintune'] (SGD) of the reference."""
+    optimizer = optimizer or self.optimizer
     g = self.graph
     images, labels = self.iter_train.get_next()
     x, y = self.to_device(images, labels)
@@ -101,11 +105,42 @@ class NonUniformQuantLearner(AbstractLearner):
     if FLAGS.nuql_opt_mode in ('cluster', 'both'):
       self.nonuni_quant.codebook_grads()
     lr = self.lrn_rate(self.ft_step)
-    self.optimizer.weight_decay = g.store.weight_decay
-    self.optimizer.compute_gradients()
-    self.optimizer.apply_gradients(lr)
+    optimizer.weight_decay = g.store.weight_decay
+    optimizer.compute_gradients()
+    optimizer.apply_gradients(lr)
     self.ft_step += 1
     return {'lr': lr, 'dst_loss': dst_loss, 'model_loss': model_loss, 'loss': loss, 'metrics': metrics}
+
+  # -- callables handed to the bit optimiser (the reference passes TF ops + sessions) --------------------
+  def __op_non_cluster_init(self):
+    """ops['non_cluster_init']: every variable but the codebooks, optimiser slots, step counter."""
+    self.graph.store.initialize(FLAGS.init_seed)
+    self.optimizer.reset_slots()
+    self.ft_step = 0
+
+  def __op_cluster_init(self, w_bits):
+    """ops['cluster_init'] under a bit-width feed: codebooks of 2**bits points from the CURRENT weights."""
+    self.nonuni_quant.feed_bits(w_bits, [op.bits for op in self.nonuni_quant.activation_ops])
+    self.nonuni_quant.cluster_init()
+    self.clusters_initialized = True
+
+  def __log_row(self, r):
+    acc_top1, acc_top5 = self.__split_metrics(r['metrics'])
+    row = [r['lr']] + ([r['dst_loss']] if FLAGS.enbl_dst else []) + [r['model_loss'], r['loss'], acc_top1, acc_top5]
+    return [float(v.detach()) if torch.is_tensor(v) else float(v) for v in row]
+
+  def __op_train(self, w_bits, a_bits, optimizer=None):
+    self.nonuni_quant.feed_bits(w_bits, a_bits)        # no-op unless the widths changed (then cluster_init is due)
+    return self.__log_row(self.train_step(optimizer))
+
+  def __op_eval(self, w_bits, a_bits):
+    self.nonuni_quant.feed_bits(w_bits, a_bits)
+    with torch.no_grad():
+      self.nonuni_quant.quantize_weights()
+      return list(self.__eval_batch())
+
+  def __op_reset_ft_step(self):
+    self.ft_step = 0
 
   def init_clusters(self):
     """ops['cluster_init'] (+ bcast) -- after the weights are in place."""
@@ -119,6 +154,7 @@ class NonUniformQuantLearner(AbstractLearner):
     if FLAGS.enbl_warm_start:
       self.__restore_model(is_train=True)
     # NOTE: initialize the clusters after restore weights
+    self.nonuni_quant.feed_bits(self.optimal_w_bit_list, self.optimal_a_bit_list)
     self.init_clusters()
     time_prev = timer()
     for idx_iter in range(total_iters):
@@ -142,26 +178,32 @@ class NonUniformQuantLearner(AbstractLearner):
   def run_eval(self):
     losses, acc1, acc5 = [], [], []
     nb_iters = FLAGS.nb_eval_batches_override or int(np.ceil(float(FLAGS.nb_smpls_eval) / FLAGS.batch_size_eval))
-    g = self.graph
     self.iter_eval.reset()
+    self.nonuni_quant.feed_bits(self.optimal_w_bit_list, self.optimal_a_bit_list)
     with torch.no_grad():
       self.nonuni_quant.quantize_weights()
       for _ in range(nb_iters):
-        images, labels = self.iter_eval.get_next()
-        x, y = self.to_device(images, labels)
-        g.begin_step()
-        with g.as_default():
-          logits = self.forward_eval(x)
-          loss, metrics = self.calc_loss(y, logits, self.trainable_vars)
-          if FLAGS.enbl_dst:
-            loss = loss + self.helper_dst.calc_loss(logits, self.helper_dst.calc_logits(None, x))
-        a1, a5 = self.__split_metrics(metrics)
-        losses.append(float(loss)); acc1.append(float(a1)); acc5.append(float(a5))
+        loss, a1, a5 = self.__eval_batch()
+        losses.append(loss); acc1.append(a1); acc5.append(a5)
     log.info('loss: {}'.format(np.mean(np.array(losses))))
     log.info('accuracy: {}'.format(np.mean(np.array(acc1))))
     return {'loss': float(np.mean(losses)), 'acc_top1': float(np.mean(acc1)), 'acc_top5': float(np.mean(acc5))}
 
   # ---------------------------------------------------------------------------------------------
+  def __eval_batch(self):
+    """One run of ops['eval']: quantised forward_eval on the next evaluation batch (weights already quantised)."""
+    g = self.graph
+    images, labels = self.iter_eval.get_next()
+    x, y = self.to_device(images, labels)
+    g.begin_step()
+    with g.as_default():
+      logits = self.forward_eval(x)
+      loss, metrics = self.calc_loss(y, logits, self.trainable_vars)
+      if FLAGS.enbl_dst:
+        loss = loss + self.helper_dst.calc_loss(logits, self.helper_dst.calc_logits(None, x))
+    a1, a5 = self.__split_metrics(metrics)
+    return float(loss), float(a1), float(a5)
+
   def __split_metrics(self, metrics):
     if self.dataset_name == 'cifar_10':
       return metrics['accuracy'], 0.0
@@ -179,7 +221,8 @@ class NonUniformQuantLearner(AbstractLearner):
     self.statistics['nb_activations'] = len(act_ops)
     self._w_bit_dict = {op.name: FLAGS.nuql_weight_bits for op in matmul_ops}
     self._a_bit_dict = {op.name: FLAGS.nuql_activation_bits for op in act_ops}
-    nq.declare_clusters(self._w_bit_dict)
+    # a bit-width search re-sizes the codebooks every roll-out: allocate them for the widest setting
+    nq.declare_clusters(self._w_bit_dict, FLAGS.nuql_w_bit_max if FLAGS.nuql_enbl_rl_agent else 0)
     self.nonuni_quant = nq
 
   def __build_train(self):
@@ -212,10 +255,23 @@ class NonUniformQuantLearner(AbstractLearner):
     elif FLAGS.nuql_opt_mode != 'both':
       raise ValueError("Unknown optimization mode")
     optimizer.o_mask, optimizer.w_mask = o_mask, w_mask
+    # roll-outs of the bit-width search fine-tune with plain SGD when codebooks are optimised (:262-266, 282-285)
+    optimizer_fintune = None
+    if FLAGS.nuql_opt_mode in ('cluster', 'both') and FLAGS.nuql_enbl_rl_agent:
+      optimizer_fintune = FlatOptimizer(st, 'momentum', momentum=0.0)
+      optimizer_fintune.o_mask, optimizer_fintune.w_mask = o_mask, w_mask
     if FLAGS.enbl_multi_gpu:
       optimizer = mgw.DistributedOptimizer(optimizer)
+      if optimizer_fintune is not None:
+        optimizer_fintune = mgw.DistributedOptimizer(optimizer_fintune)
     self.optimizer = optimizer
+    self.optimizer_fintune = optimizer_fintune
     self.ops['bcast'] = mgw.broadcast_global_variables(0, [st], [optimizer]) if FLAGS.enbl_multi_gpu else None
+    self.ops.update({'non_cluster_init': self.__op_non_cluster_init, 'cluster_init': self.__op_cluster_init,
+                     'train': self.__op_train, 'eval': self.__op_eval, 'reset_ft_step': self.__op_reset_ft_step,
+                     'rl_fintune': (lambda w, a: self.__op_train(w, a, self.optimizer_fintune)),
+                     'restore': (lambda path: self.restore_vars(path, strict=False)),
+                     'save': lambda path: self.save_vars(path)})
 
   def __build_eval(self):
     self.iter_eval = self.build_dataset_eval().to(self.device)

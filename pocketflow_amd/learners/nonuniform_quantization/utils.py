@@ -67,11 +67,16 @@ class NonUniformQuantization:
       return 1 if var.kind == 'depthwise' or var.ref_shape[-1] == 1 else var.ref_shape[-1]
     return -(-var.numel // self.bucket_size)
 
-  def declare_clusters(self, w_bit_dict: Dict[str, int]):
+  def declare_clusters(self, w_bit_dict: Dict[str, int], capacity_bits: int = 0):
     """Create the `clusters` variables (must run before the store is finalized).  Shape [k] without
-    buckets, [k, bucket_num] with (:297, :324)."""
+    buckets, [k, bucket_num] with (:297, :324).
+
+    `capacity_bits` > 0 (bit-width search, `nuql_enbl_rl_agent`): the reference declares `clusters` with
+    `validate_shape=False` and re-initialises it with a different k = 2**bits every roll-out (:297, nuq
+    bit_optimizer.py:234-235); here the variable is allocated once for 2**capacity_bits rows, the first
+    2**bits rows are live and the rest stay exactly zero (no gradient, no weight decay, no update)."""
     for op in self.matmul_ops:
-      k = 2 ** int(w_bit_dict[op.name])
+      k = 2 ** max(int(w_bit_dict[op.name]), int(capacity_bits))
       nb = self.n_bucket_of(op.var)
       prefix = '/'.join(op.name.split('/')[1:-1])
       scope = 'nonuniform_bucket_quantize' if self.use_buckets else 'nonuniform_quantize'
@@ -89,9 +94,29 @@ class NonUniformQuantization:
                           self.bucket_size, store.device, nuq=True, cb_offsets=cb_offsets)
     self._all_vars = all_vars
     self._bits = bits
+    self._cb_offsets = cb_offsets
     self.idx_flat = torch.zeros(store.w_master.numel(), dtype=torch.uint8, device=store.device)
     self.quantized_matmul_ops = list(self.matmul_ops)
     self.bucket_storage = self.plan.bucket_storage_bits
+
+  def feed_bits(self, w_bits, a_bits):
+    """Per-layer bit widths changed (the reference feeds them through placeholders, nuq learner.py:128-129):
+    the segment table is rebuilt (host NumPy, a few kB) because codebook sizes follow the bit widths; the
+    caller re-initialises the codebooks (`cluster_init`) afterwards, exactly as the reference must."""
+    store = self.graph.store
+    quant = {id(op.var): int(b) for op, b in zip(self.matmul_ops, w_bits)}
+    bits = [quant.get(id(v), 0) for v in self._all_vars]
+    if bits != self._bits:
+      for v, b in zip(self._all_vars, bits):
+        if b > 0 and (2 ** b) * self.n_bucket_of(v) > self.cluster_vars[id(v)].numel:
+          raise ValueError('%d bits do not fit the codebook declared for %s (%d entries)' % (
+              b, v.name, self.cluster_vars[id(v)].numel))
+      self.plan = QuantPlan(store.weight_descs(self._all_vars), bits, self.use_buckets, self.bucket_type,
+                            self.bucket_size, store.device, nuq=True, cb_offsets=self._cb_offsets)
+      self._bits = bits
+      self.bucket_storage = self.plan.bucket_storage_bits
+    for op, b in zip(self.activation_ops, a_bits):
+      op.bits = int(b)
 
   def insert_quant_op_for_activations(self, act_bit_dict: Dict[str, int]):
     for op in self.activation_ops:
@@ -125,7 +150,7 @@ class NonUniformQuantization:
       if self.init_style == 'uniform':
         if self.use_buckets:
           raise ValueError('Unrecognized Initialization Mode.')   # broken call in the reference (:225 vs :368)
-        cvar.master.copy_(torch.linspace(0., 1., k, device=st.device))
+        self.__write_codebook(cvar, torch.linspace(0., 1., k, device=st.device))
         continue
       if self.init_style != 'quantile':
         raise ValueError('Unrecognized Initialization Mode.')
@@ -156,7 +181,14 @@ class NonUniformQuantization:
         q = np.float64((i + 1) * 100) / np.float64(k + 1)
         rows.append(int(np.clip(np.rint(np.float64(d - 1) * (np.float64(1.0) - q / np.float64(100.0))), 0, d - 1)))
       c = srt[torch.tensor(rows, device=st.device)]               # [k, n_bucket]
-      cvar.master.copy_(c.reshape(cvar.storage_shape))
+      self.__write_codebook(cvar, c)
+
+  @staticmethod
+  def __write_codebook(cvar, c):
+    """The live k rows first, zeros behind them (only a searched codebook is larger than its k rows)."""
+    flat = cvar.master.view(-1)
+    flat.zero_()
+    flat[:c.numel()].copy_(c.reshape(-1))
 
   def __safe_check(self):
     if self.bucket_size < 0:

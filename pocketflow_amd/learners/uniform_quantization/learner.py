@@ -83,9 +83,12 @@ class UniformQuantLearner(AbstractLearner):
       self.download_model()  # pre-trained model is required
     self.auto_barrier()
 
-    bit_optimizer = BitOptimizer(self.dataset_name, self.weights, self.statistics)
+    # determine the optimal policy (constant bit widths, or the DDPG search over the callables in self.ops)
+    bit_optimizer = BitOptimizer(self.dataset_name, self.weights, self.statistics, self.bit_placeholders, self.ops,
+                                 self.layerwise_tune_list, self, self, None, None, self.auto_barrier,
+                                 mpi_comm=self.mpi_comm)
     self.optimal_w_bit_list, self.optimal_a_bit_list = bit_optimizer.run()
-    self.uni_quant.feed_bits(self.optimal_w_bit_list, self.optimal_a_bit_list)
+    self.__feed(self.optimal_w_bit_list, self.optimal_a_bit_list)
     self.auto_barrier()
 
   # ---------------------------------------------------------------------------------------------
@@ -113,6 +116,37 @@ class UniformQuantLearner(AbstractLearner):
     self.ft_step += 1
     return {'lr': lr, 'dst_loss': dst_loss, 'model_loss': model_loss, 'loss': loss, 'metrics': metrics}
 
+  # -- callables handed to the bit optimiser (the reference passes TF ops + sessions) --------------------
+  def __feed(self, w_bits, a_bits):
+    key = (tuple(int(b) for b in w_bits), tuple(int(b) for b in a_bits))
+    if key != getattr(self, '_fed_bits', None):
+      self.uni_quant.feed_bits(*key)
+      self._fed_bits = key
+
+  def __op_init(self):
+    """ops['init'] = tf.global_variables_initializer(): fresh variables, empty Adam slots, step 0."""
+    self.graph.store.initialize(FLAGS.init_seed)
+    self.optimizer.reset_slots()
+    self.ft_step = 0
+
+  def __op_train(self, w_bits, a_bits):
+    """[ops['train'], ops['log']] under a bit-width feed: one quantisation-aware step, returns the log row."""
+    self.__feed(w_bits, a_bits)
+    r = self.train_step()
+    acc_top1, acc_top5 = self.__split_metrics(r['metrics'])
+    row = [r['lr']] + ([r['dst_loss']] if FLAGS.enbl_dst else []) + [r['model_loss'], r['loss'], acc_top1, acc_top5]
+    return [float(v.detach()) if torch.is_tensor(v) else float(v) for v in row]
+
+  def __op_eval(self, w_bits, a_bits):
+    """ops['eval'] under a bit-width feed: [loss, acc_top1, acc_top5] of the next evaluation batch."""
+    self.__feed(w_bits, a_bits)
+    with torch.no_grad():
+      self.uni_quant.quantize_weights()
+      return list(self.__eval_batch())
+
+  def __op_reset_ft_step(self):
+    self.ft_step = 0
+
   def train(self):
     total_iters = FLAGS.nb_iters_override or self.finetune_steps
     if FLAGS.enbl_warm_start:
@@ -121,7 +155,7 @@ class UniformQuantLearner(AbstractLearner):
     if FLAGS.enbl_multi_gpu:
       self.ops['bcast']()
     time_prev = timer()
-    self.uni_quant.feed_bits(self.optimal_w_bit_list, self.optimal_a_bit_list)
+    self.__feed(self.optimal_w_bit_list, self.optimal_a_bit_list)
     for idx_iter in range(total_iters):
       log_rslt = self.train_step()
       if (idx_iter + 1) % FLAGS.summ_step == 0:
@@ -143,22 +177,13 @@ class UniformQuantLearner(AbstractLearner):
     """sess_eval.run(ops['eval']) over the evaluation subset: mean of per-batch [loss, top1, top5]."""
     losses, acc1, acc5 = [], [], []
     nb_iters = FLAGS.nb_eval_batches_override or int(np.ceil(float(FLAGS.nb_smpls_eval) / FLAGS.batch_size_eval))
-    g = self.graph
     self.iter_eval.reset()
-    self.uni_quant.feed_bits(self.optimal_w_bit_list, self.optimal_a_bit_list)
+    self.__feed(self.optimal_w_bit_list, self.optimal_a_bit_list)
     with torch.no_grad():
       self.uni_quant.quantize_weights()          # re-quantise the restored fp32 shadows (App. A.8)
       for _ in range(nb_iters):
-        images, labels = self.iter_eval.get_next()
-        x, y = self.to_device(images, labels)
-        g.begin_step()
-        with g.as_default():
-          logits = self.forward_eval(x)
-          loss, metrics = self.calc_loss(y, logits, self.trainable_vars)
-          if FLAGS.enbl_dst:
-            loss = loss + self.helper_dst.calc_loss(logits, self.helper_dst.calc_logits(None, x))
-        a1, a5 = self.__split_metrics(metrics)
-        losses.append(float(loss)); acc1.append(float(a1)); acc5.append(float(a5))
+        loss, a1, a5 = self.__eval_batch()
+        losses.append(loss); acc1.append(a1); acc5.append(a5)
     log.info('loss: {}'.format(np.mean(np.array(losses))))
     log.info('accuracy: {}'.format(np.mean(np.array(acc1))))
     log.info("Optimal Weight Quantization:{}".format(self.optimal_w_bit_list))
@@ -167,6 +192,20 @@ class UniformQuantLearner(AbstractLearner):
     return {'loss': float(np.mean(losses)), 'acc_top1': float(np.mean(acc1)), 'acc_top5': float(np.mean(acc5))}
 
   # ---------------------------------------------------------------------------------------------
+  def __eval_batch(self):
+    """One run of ops['eval']: quantised forward_eval on the next evaluation batch (weights already quantised)."""
+    g = self.graph
+    images, labels = self.iter_eval.get_next()
+    x, y = self.to_device(images, labels)
+    g.begin_step()
+    with g.as_default():
+      logits = self.forward_eval(x)
+      loss, metrics = self.calc_loss(y, logits, self.trainable_vars)
+      if FLAGS.enbl_dst:
+        loss = loss + self.helper_dst.calc_loss(logits, self.helper_dst.calc_logits(None, x))
+    a1, a5 = self.__split_metrics(metrics)
+    return float(loss), float(a1), float(a5)
+
   def __split_metrics(self, metrics):
     if self.dataset_name == 'cifar_10':
       return metrics['accuracy'], 0.0
@@ -195,6 +234,9 @@ class UniformQuantLearner(AbstractLearner):
     self.optimizer = optimizer
     self.ops['bcast'] = mgw.broadcast_global_variables(0, [self.graph.store], [optimizer]) \
         if FLAGS.enbl_multi_gpu else None
+    self.ops.update({'init': self.__op_init, 'train': self.__op_train, 'eval': self.__op_eval,
+                     'reset_ft_step': self.__op_reset_ft_step, 'restore': self.restore_vars,
+                     'save': lambda path: self.save_vars(path)})
 
   def __build_eval(self):
     self.iter_eval = self.build_dataset_eval().to(self.device)

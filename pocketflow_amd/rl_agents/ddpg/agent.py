@@ -11,8 +11,8 @@ preserve ratios of the channel-pruning learner) use the same seven entry points 
   a = agent.actions_clean(state)                 # deployment
 
 There is no session: `actions_noisy` / `actions_clean` are callables on NumPy rows.  `sess` is accepted for
-signature compatibility and may carry a seed (int) or a np.random.RandomState for reproducible searches (the
-reference is unseeded).
+signature compatibility and may carry a seed (int) or a np.random.RandomState for reproducible searches; with
+`sess=None` the seed comes from `--ddpg_seed` (default: unseeded, as the reference).
 
 One `train()` = one sample of `ddpg_batch_size` transitions, rewards minus the EMA baseline, then
   target_q    = r + (1 - terminal) * gamma * Q'(s', mu'(s'))
@@ -40,6 +40,7 @@ flags.DEFINE_integer('ddpg_record_step', 1, 'DDPG: recording step size')
 flags.DEFINE_integer('ddpg_batch_size', 64, 'DDPG: batch size')
 flags.DEFINE_boolean('ddpg_enbl_bsln_func', True, 'DDPG: enable baseline function')
 flags.DEFINE_float('ddpg_bsln_decy_rate', 0.95, 'DDPG: baseline function\'s decaying rate')
+flags.DEFINE_integer('ddpg_seed', -1, 'DDPG: seed of the agent\'s generator (initialisation, noise, replay sampling); < 0: unseeded as in the reference')
 
 
 def normalize(smpl_mat, rms):
@@ -83,7 +84,7 @@ def _make_rng(sess):
     return sess
   if isinstance(sess, (int, np.integer)):
     return np.random.RandomState(int(sess))
-  return np.random.RandomState()
+  return np.random.RandomState(FLAGS.ddpg_seed if FLAGS.ddpg_seed >= 0 else None)
 
 
 class Agent(object):  # pylint: disable=too-many-instance-attributes

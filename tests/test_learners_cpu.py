@@ -233,3 +233,89 @@ def test_channel_pruned_mobilenet_on_cpu(cpu_learners, monkeypatch):
     assert np.all(w[:, :, ~keep_in, :] == 0) and np.all(w[:, :, :, ~keep_out] == 0), op.name
     n_masked += int((~keep_in).sum() + (~keep_out).sum())
   assert n_masked > 0
+
+
+def test_uq_rl_bit_search_on_cpu(cpu_learners, caplog):
+  """`--uql_enbl_rl_agent`: DDPG roll-outs over per-layer bit widths, each rewarded by a short quantisation-aware
+  fine-tune + evaluation (reference uq bit_optimizer.py:137-195), then the regular fine-tune with the best list."""
+  import logging
+  FLAGS, fake, tmp = cpu_learners
+  from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
+  from pocketflow_amd.learners.uniform_quantization.learner import UniformQuantLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  FLAGS.batch_size, FLAGS.batch_size_eval, FLAGS.nb_classes, FLAGS.resnet_size = 8, 8, 10, 8
+  FLAGS.uql_weight_bits, FLAGS.uql_activation_bits, FLAGS.uql_use_buckets = 4, 32, False
+  FLAGS.uql_enbl_rl_agent, FLAGS.uql_nb_rlouts, FLAGS.uql_tune_global_steps, FLAGS.uql_equivalent_bits = True, 8, 2, 5
+  FLAGS.uql_tune_save_path = str(tmp / 'rl_tune' / 'model.ckpt')
+  FLAGS.uql_save_quant_model_path = str(tmp / 'uql' / 'm.ckpt')
+  FLAGS.ddpg_seed, FLAGS.nb_iters_override = 7, 2
+  try:
+    mh = ModelHelper()
+    create_synthetic_checkpoint(mh)
+    pretrained = None
+    with caplog.at_level(logging.INFO, logger='pocketflow_amd'):
+      lrn = UniformQuantLearner(None, mh)
+    n = lrn.statistics['nb_matmuls']
+    w_bits, a_bits = lrn.optimal_w_bit_list, lrn.optimal_a_bit_list
+    assert len(w_bits) == n and a_bits == [32] * lrn.statistics['nb_activations']
+    assert all(isinstance(b, int) and FLAGS.uql_w_bit_min <= b <= FLAGS.uql_w_bit_max for b in w_bits)
+    used = sum(b * k for b, k in zip(w_bits, lrn.statistics['num_weights']))
+    assert used <= sum(lrn.statistics['num_weights']) * 5                       # the bit budget holds
+    assert lrn.ft_step == 0                                                     # ops['reset_ft_step'] after every tune
+    rolls = [r for r in caplog.records if r.getMessage().startswith('#_rlout')]
+    assert len(rolls) == 8
+    assert sum('a-loss' in r.getMessage() for r in caplog.records) == 8
+    # the agent's buffer (n * nb_rlouts // 4 rows) filled up after two roll-outs, so it did train
+    assert any('c-loss = 0.00e+00' not in r.getMessage() for r in caplog.records if 'a-loss' in r.getMessage())
+    assert len(set(r.getMessage() for r in rolls)) > 1                          # exploration: bit lists differ
+    rslt = lrn.train()
+    assert np.isfinite(rslt['loss'])
+  finally:
+    FLAGS.uql_enbl_rl_agent, FLAGS.ddpg_seed, FLAGS.nb_iters_override = False, -1, 0
+
+
+@pytest.mark.parametrize('opt_mode,use_buckets', [('both', True), ('weights', False)])
+def test_nuq_rl_bit_search_on_cpu(cpu_learners, caplog, opt_mode, use_buckets):
+  """`--nuql_enbl_rl_agent`: codebooks are re-sized and re-initialised per roll-out (reference nuq bit_optimizer.py
+  :227-238), fine-tuned with SGD when they are optimised, and the best list is used for the final fine-tune."""
+  import logging
+  FLAGS, fake, tmp = cpu_learners
+  from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
+  from pocketflow_amd.learners.nonuniform_quantization.learner import NonUniformQuantLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  FLAGS.batch_size, FLAGS.batch_size_eval, FLAGS.nb_classes, FLAGS.resnet_size = 8, 8, 10, 8
+  FLAGS.nuql_weight_bits, FLAGS.nuql_activation_bits = 3, 32
+  FLAGS.nuql_use_buckets, FLAGS.nuql_bucket_type, FLAGS.nuql_bucket_size, FLAGS.nuql_opt_mode = use_buckets, 'split', 128, opt_mode
+  FLAGS.nuql_enbl_rl_agent, FLAGS.nuql_nb_rlouts, FLAGS.nuql_tune_global_steps, FLAGS.nuql_equivalent_bits = True, 6, 2, 3
+  FLAGS.nuql_w_bit_max = 5
+  FLAGS.nuql_tune_save_path = str(tmp / 'rl_tune' / 'model.ckpt')
+  FLAGS.nuql_save_quant_model_path = str(tmp / 'nuql' / 'm.ckpt')
+  FLAGS.ddpg_seed, FLAGS.nb_iters_override = 11, 2
+  try:
+    mh = ModelHelper()
+    create_synthetic_checkpoint(mh)
+    with caplog.at_level(logging.INFO, logger='pocketflow_amd'):
+      lrn = NonUniformQuantLearner(None, mh)
+    n = lrn.statistics['nb_matmuls']
+    w_bits = lrn.optimal_w_bit_list
+    assert len(w_bits) == n and all(2 <= b <= 5 for b in w_bits)
+    assert sum(b * k for b, k in zip(w_bits, lrn.statistics['num_weights'])) <= 3 * sum(lrn.statistics['num_weights'])
+    assert (lrn.optimizer_fintune is not None) == (opt_mode == 'both')
+    nq = lrn.nonuni_quant
+    # codebooks: allocated for 2**5 rows, the live 2**bits rows ascending per bucket, zeros behind
+    vals = lrn.graph.store.export_numpy()
+    lrn.nonuni_quant.feed_bits(w_bits, lrn.optimal_a_bit_list)
+    lrn.init_clusters()
+    vals = lrn.graph.store.export_numpy()
+    for op, b in zip(nq.matmul_ops, w_bits):
+      c = vals[nq.cluster_vars[id(op.var)].name]
+      assert c.shape[0] == 32
+      assert np.all(c[2 ** b:] == 0) and np.all(np.diff(c[:2 ** b], axis=0) >= 0) and np.any(c[:2 ** b] != 0)
+    rslt = lrn.train()
+    assert np.isfinite(rslt['loss'])
+    vals = lrn.graph.store.export_numpy()
+    for op, b in zip(nq.matmul_ops, w_bits):
+      assert np.all(vals[nq.cluster_vars[id(op.var)].name][2 ** b:] == 0)        # dead rows never move
+    assert len([r for r in caplog.records if r.getMessage().startswith('#_rlout')]) == 6
+  finally:
+    FLAGS.nuql_enbl_rl_agent, FLAGS.ddpg_seed, FLAGS.nb_iters_override, FLAGS.nuql_w_bit_max = False, -1, 0, 8
