@@ -320,6 +320,8 @@ class Graph:
     # channel pruning (host side): when `taps` is a dict, Conv2D / DepthwiseConv2D layers record
     # {layer: (input, output, producer-of-input)}; BN / activation / pooling layers pass the producer tag on
     self.taps: Optional[Dict[object, tuple]] = None
+    self.tap_dense = False                     # also record Dense layers (input, MatMul output before the bias)
+    self.tap_stop = None                       # layer after whose tap the forward pass is abandoned (TapStop)
     self._names: Dict[str, int] = {}
 
   # -- naming like tf.layers (conv2d, conv2d_1, ...) ---------------------------------------------
@@ -437,6 +439,39 @@ class _BnActQuant(torch.autograd.Function):
     act, graph, rows, C = ctx.meta
     dx, dgamma, dbeta = _bn_backward(dq, x, scale_shift, mean_invstd, act, graph, rows, C, params=ctx.params)
     return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+class _BnEvalAct(torch.autograd.Function):
+  """Inference-mode BN -> act WITH gradients: the networks the pruning-ratio search re-trains are built with
+  forward_eval (reference pr_optimizer.py:176-196 "DO NOT USE forward_train() HERE"), i.e. BN normalises with
+  its moving statistics while gamma / beta (and everything upstream) are still trained.
+  y = act(scale * x + shift), scale = gamma * rsqrt(var + eps), shift = beta - mean * scale;
+  dgamma = sum dy * (x - mean) * rsqrt(var + eps), dbeta = sum dy, dx = scale * dy  (same kernels as the
+  training-mode backward: the statistics pass with the moving mean / invstd, the apply pass with zero sums)."""
+
+  @staticmethod
+  def forward(ctx, x, gamma, beta, layer, graph):
+    x = _nhwc(x)
+    C = gamma.numel()
+    rows = x.numel() // C
+    ss = torch.empty((2, C), dtype=torch.float32, device=x.device)
+    hip.bn_eval_scale_shift(gamma.detach(), beta.detach(), layer.moving_mean.tensor, layer.moving_var.tensor,
+                            layer.eps, ss)
+    mi = torch.stack([layer.moving_mean.tensor.float(),
+                      torch.rsqrt(layer.moving_var.tensor.float() + layer.eps)]).contiguous()
+    q = torch.empty_like(x)
+    hip.bn_act_quant_apply(x, q, rows, C, ss, layer.act, None, 8, False)
+    ctx.save_for_backward(x, ss, mi)
+    ctx.meta = (layer.act, graph, rows, C)
+    ctx.params = (gamma, beta)
+    return q
+
+  @staticmethod
+  def backward(ctx, dq):
+    x, ss, mi = ctx.saved_tensors
+    act, graph, rows, C = ctx.meta
+    dx, dgamma, dbeta = _bn_backward(dq, x, ss, mi, act, graph, rows, C, params=ctx.params, frozen=True)
+    return dx, dgamma, dbeta, None, None
 
 
 class _ActQuant(torch.autograd.Function):
@@ -582,10 +617,13 @@ def _grad_view(t: Optional[torch.Tensor], n: int):
   return None
 
 
-def _bn_backward(dq, x, scale_shift, mean_invstd, act, graph, rows, C, addend=None, params=None, pre=None):
+def _bn_backward(dq, x, scale_shift, mean_invstd, act, graph, rows, C, addend=None, params=None, pre=None,
+                 frozen=False):
   """Returns (dx, dgamma, dbeta); when `params` = (gamma leaf, beta leaf) carry flat-buffer gradient views,
   dgamma / dbeta are written there by pf_bn_bwd_finalize and None is returned for them (no accumulation
-  kernels; every BN layer is applied once per step and the buffers are zeroed by the optimiser)."""
+  kernels; every BN layer is applied once per step and the buffers are zeroed by the optimiser).
+  `frozen`: inference-mode BN (moving statistics are constants): the batch-statistics terms of dx vanish,
+  dx = scale * dy -- the same apply kernel fed with zero sums."""
   dq = _nhwc(dq)
   if dq.dtype != x.dtype:
     dq = dq.to(x.dtype)
@@ -609,7 +647,9 @@ def _bn_backward(dq, x, scale_shift, mean_invstd, act, graph, rows, C, addend=No
   hip.bn_bwd_finalize(partial, nblk, C, dgamma, dbeta)
   dx = torch.empty_like(x)
   with region('bn_bwd_apply', (4 if addend is not None else 3) * nbytes):   # reads dq, x [, addend], writes dx
-    hip.bn_bwd_apply(dq, x, dx, rows, C, scale_shift, mean_invstd, dgamma, dbeta, act, addend)
+    zero = graph.zero_row(C)[:C] if frozen else None
+    hip.bn_bwd_apply(dq, x, dx, rows, C, scale_shift, mean_invstd, zero if frozen else dgamma,
+                     zero if frozen else dbeta, act, addend)
   return (dx, None, None) if direct else (dx, dgamma, dbeta)
 
 
@@ -807,10 +847,16 @@ class Conv2D:
       self.graph.taps, self.graph.fuse_conv1x1 = taps, fuse
 
 
+class TapStop(Exception):
+  """Raised by the tap of `graph.tap_stop`: the caller only needed the network up to that layer."""
+
+
 def _tapped(layer, x, residual=None):
   g = layer.graph
   y = layer.plain(x)
   g.taps[layer] = (x, y, getattr(x, '_pf_src', None))
+  if g.tap_stop is layer:
+    raise TapStop()
   y._pf_src = layer
   return y if residual is None else y + residual     # a residual sum has no single producer: tag dropped
 
@@ -858,6 +904,7 @@ class Dense:
   """tf.layers.dense: kernel [in, out] (stored [out, in]) + bias."""
 
   def __init__(self, graph: Graph, name: str, cin: int, cout: int, init=None, l2: bool = True):
+    self.graph = graph
     ref_shape = (cin, cout)
     init = init or glorot_uniform_init(ref_shape, cin, cout)
     self.kernel = graph.store.add(name + '/kernel', ref_shape, 'dense', True, l2, init)
@@ -865,7 +912,19 @@ class Dense:
     self.op = graph.add_matmul_op('MatMul', name + '/MatMul', self.kernel)
 
   def __call__(self, x) -> torch.Tensor:
+    g = self.graph
+    if g.taps is not None and g.tap_dense:
+      x = materialize(x)
+      y = self.plain(x)
+      g.taps[self] = (x, y, None)
+      if g.tap_stop is self:
+        raise TapStop()
+      return y + self.bias.tensor.to(x.dtype)
     return F.linear(materialize(x), self.kernel.tensor, self.bias.tensor.to(x.dtype))
+
+  def plain(self, x: torch.Tensor) -> torch.Tensor:
+    """The MatMul op alone (no BiasAdd)."""
+    return F.linear(x, self.kernel.tensor)
 
 
 class Activation:
@@ -919,6 +978,10 @@ class BatchNormAct:
         box.append(lazy_out)
         return (lazy_out, skip) if getattr(self, '_want_skip', False) else lazy_out
       return _BnActQuant.apply(x, self.gamma.tensor, self.beta.tensor, self, g, True, slot, bits, stats)
+    if torch.is_grad_enabled() and not g.frozen and (x.requires_grad or self.gamma.tensor.requires_grad):
+      if bits is not None:
+        raise NotImplementedError('inference-mode BN with gradients and activation quantisation (no learner needs it)')
+      return _BnEvalAct.apply(materialize(x), self.gamma.tensor, self.beta.tensor, self, g)
     x = _nhwc(x)
     C = self.C
     rows = x.numel() // C

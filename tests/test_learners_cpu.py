@@ -319,3 +319,154 @@ def test_nuq_rl_bit_search_on_cpu(cpu_learners, caplog, opt_mode, use_buckets):
     assert len([r for r in caplog.records if r.getMessage().startswith('#_rlout')]) == 6
   finally:
     FLAGS.nuql_enbl_rl_agent, FLAGS.ddpg_seed, FLAGS.nb_iters_override, FLAGS.nuql_w_bit_max = False, -1, 0, 8
+
+
+def test_inference_mode_bn_with_gradients(cpu_learners):
+  """graph._BnEvalAct (frozen statistics, trainable gamma / beta) against plain torch autograd."""
+  FLAGS, fake, tmp = cpu_learners
+  import pocketflow_amd.graph as G
+  g = G.Graph('model', 'cpu', torch.float32)
+  bn = G.BatchNormAct(g, 'bn', 24, 'Relu', 0.997, 1e-5)
+  g.finalize(requires_grad=True)
+  rng = np.random.RandomState(0)
+  with torch.no_grad():
+    bn.gamma.tensor.copy_(torch.from_numpy((1 + 0.2 * rng.randn(24)).astype(np.float32)))
+    bn.beta.tensor.copy_(torch.from_numpy((0.2 * rng.randn(24)).astype(np.float32)))
+    bn.moving_mean.tensor.copy_(torch.from_numpy((0.3 * rng.randn(24)).astype(np.float32)))
+    bn.moving_var.tensor.copy_(torch.from_numpy((0.5 + rng.rand(24)).astype(np.float32)))
+  x = torch.from_numpy(rng.randn(4, 24, 5, 5).astype(np.float32)).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+  up = torch.from_numpy(rng.randn(4, 24, 5, 5).astype(np.float32))
+  g.training = False
+  with g.as_default():
+    y = bn(x)
+  (y * up).sum().backward()
+  mm, mv = bn.moving_mean.tensor.clone(), bn.moving_var.tensor.clone()
+  xr = x.detach().clone().requires_grad_(True)
+  gam, bet = bn.gamma.tensor.detach().clone().requires_grad_(True), bn.beta.tensor.detach().clone().requires_grad_(True)
+  yr = torch.relu((xr - mm.view(1, -1, 1, 1)) * torch.rsqrt(mv + 1e-5).view(1, -1, 1, 1) * gam.view(1, -1, 1, 1) + bet.view(1, -1, 1, 1))
+  (yr * up).sum().backward()
+  np.testing.assert_allclose(y.detach().numpy(), yr.detach().numpy(), rtol=1e-5, atol=1e-5)
+  np.testing.assert_allclose(x.grad.numpy(), xr.grad.numpy(), rtol=1e-5, atol=1e-5)
+  np.testing.assert_allclose(bn.gamma.tensor.grad.numpy(), gam.grad.numpy(), rtol=1e-4, atol=1e-4)
+  np.testing.assert_allclose(bn.beta.tensor.grad.numpy(), bet.grad.numpy(), rtol=1e-4, atol=1e-4)
+  assert torch.equal(bn.moving_mean.tensor, mm) and torch.equal(bn.moving_var.tensor, mv)      # statistics stay frozen
+
+
+def test_ws_optimal_pruning_ratio_search_on_cpu(cpu_learners, monkeypatch, caplog):
+  """`ws_prune_ratio_prtl=optimal` (the reference's default): DDPG roll-outs, each = masks from the full network +
+  layer-wise regression + masked fine-tune on inference-mode networks (reference pr_optimizer.py:411-564)."""
+  import logging
+  FLAGS, fake, tmp = cpu_learners
+  import pocketflow_amd.learners.weight_sparsification.pr_optimizer as PR
+  from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  from pocketflow_amd.learners.weight_sparsification.learner import WeightSparseLearner
+  monkeypatch.setattr(PR, 'hip', fake)
+  FLAGS.batch_size, FLAGS.batch_size_eval, FLAGS.nb_classes, FLAGS.resnet_size = 8, 8, 10, 8
+  FLAGS.ws_prune_ratio, FLAGS.ws_prune_ratio_prtl, FLAGS.ws_reward_type = 0.6, 'optimal', 'single-obj'
+  FLAGS.ws_nb_rlouts, FLAGS.ws_nb_rlouts_min, FLAGS.ws_nb_iters_rg, FLAGS.ws_nb_iters_ft, FLAGS.ws_nb_iters_feval = 4, 1, 2, 3, 2
+  FLAGS.ws_save_path = str(tmp / 'ws' / 'm.ckpt')
+  FLAGS.ddpg_seed, FLAGS.exec_mode = 5, 'train'
+  try:
+    mh = ModelHelper()
+    create_synthetic_checkpoint(mh)
+    with caplog.at_level(logging.INFO, logger='pocketflow_amd'):
+      opt = PR.PROptimizer(mh, None)
+      pairs = opt.run()
+    names = [v.name for v in opt.vars_full['maskable']]
+    assert [n for n, _ in pairs] == names and len(pairs) == 11           # ResNet-8: stem + 3 x (projection + 2 convs) + dense
+    ratios = np.array([r for _, r in pairs])
+    n = np.array([v.numel for v in opt.vars_full['maskable']], dtype=np.float64)
+    assert ratios[0] == 0.0 and ratios[-1] == 0.0                      # CIFAR-10: head & tail stay dense
+    assert np.all(ratios >= 0) and np.all(ratios <= 1 - 0.4 / 3 + 1e-6)
+    assert np.sum(n * ratios) / np.sum(n) >= 0.6 - 1e-4                # single-objective: overall target is met
+    assert len(opt.reward_history) == 4 and max(opt.reward_history) == opt.reward_history[int(np.argmax(opt.reward_history))]
+    # the pruned network honours the masks after regression + fine-tune, and only maskable kernels are sparse
+    st = opt.graph_prnd.store
+    for v in opt.vars_prnd['maskable']:
+      sl = slice(v.offset, v.offset + v.numel)
+      assert float((st.w_master[sl] * (1 - opt.masks[sl])).abs().max()) == 0.0
+    msgs = [r.getMessage() for r in caplog.records]
+    assert sum(m.startswith('loss: ') for m in msgs) == 4 and sum('time consumption' in m for m in msgs) == 4
+    # the learner consumes the searched ratios
+    FLAGS.ws_nb_rlouts = 1
+    lrn = WeightSparseLearner(None, mh)
+    assert [n for n, _ in lrn.var_names_n_prune_ratios] == names
+  finally:
+    FLAGS.ws_prune_ratio_prtl, FLAGS.ddpg_seed = 'uniform', -1
+
+
+def test_ws_optimal_rollout_pieces_on_cpu(cpu_learners, monkeypatch):
+  """Masks = |w_full| > percentile(|w_full|, r * 100) (reference pr_optimizer.py:254-281); one layer-wise regression
+  step = Adam on l2_loss(conv_i(pruned) - conv_i(full)) w.r.t. kernel i only, masked (:283-316)."""
+  FLAGS, fake, tmp = cpu_learners
+  from oracle import pf_oracle as O
+  import pocketflow_amd.learners.weight_sparsification.pr_optimizer as PR
+  from pocketflow_amd.nets.lenet_at_cifar10 import ModelHelper
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  monkeypatch.setattr(PR, 'hip', fake)
+  FLAGS.batch_size, FLAGS.batch_size_eval, FLAGS.nb_classes = 8, 8, 10
+  FLAGS.ws_prune_ratio, FLAGS.ws_prune_ratio_prtl, FLAGS.ws_nb_rlouts, FLAGS.ws_nb_rlouts_min = 0.5, 'optimal', 1, 1
+  FLAGS.synthetic_pool = 1                                # every regression step sees the same batch
+  lr_rg_saved, FLAGS.ws_lrn_rate_rg = FLAGS.ws_lrn_rate_rg, 1e-3
+  try:
+    mh = ModelHelper()
+    create_synthetic_checkpoint(mh)
+    opt = PR.PROptimizer(mh, None)
+    opt.graph_full.store.load_numpy(__import__('pocketflow_amd.utils.checkpoint', fromlist=['x']).load(
+        __import__('pocketflow_amd.utils.checkpoint', fromlist=['x']).latest_checkpoint(str(tmp / 'models'))), strict=False)
+    full = opt.graph_full.store.export_numpy()
+    ratios = [0.0, 0.5, 0.3, 0.7][:len(opt.vars_prnd['maskable'])]
+    assert len(opt.vars_prnd['maskable']) == 4                       # LeNet: conv1, conv2, fc3, fc4 kernels
+    opt._PROptimizer__init_pruned_network(ratios)
+    prnd = opt.graph_prnd.store.export_numpy()
+    for v_f, v_p, r in zip(opt.vars_full['maskable'], opt.vars_prnd['maskable'], ratios):
+      w = full[v_f.name]
+      thr = O.percentile_nearest(np.abs(w), np.float32(np.float32(r) * np.float32(100.0)))
+      want_mask = (np.abs(w) > thr).astype(np.float32)
+      got_mask = v_p.to_ref(opt.masks[v_p.offset:v_p.offset + v_p.numel].numpy())
+      assert np.array_equal(got_mask, want_mask), v_p.name
+      assert np.array_equal(prnd[v_p.name], w * want_mask)
+    for name, val in prnd.items():                                   # everything else is a copy of the full network
+      if name not in [v.name for v in opt.vars_prnd['maskable']]:
+        assert np.array_equal(val, full[name.replace('pruned_model', 'model', 1)]), name
+
+    # one regression step on conv2 (idx 1) against a direct computation
+    idx, lr = 1, FLAGS.ws_lrn_rate_rg
+    var = opt.vars_prnd['maskable'][idx]
+    lf, lp = opt.core_full[idx], opt.core_prnd[idx]
+    images, _ = opt.iter_trn.get_next()
+    opt.iter_trn.reset()
+    y_full = opt._PROptimizer__forward_tapped(opt.graph_full, images, lf)[lf][1]
+    x_prnd = opt._PROptimizer__forward_tapped(opt.graph_prnd, images, lp)[lp][0]
+    w0 = lp.kernel.tensor.detach().clone().requires_grad_(True)
+    y = torch.nn.functional.conv2d(x_prnd, w0, lp.bias.tensor.detach(), stride=lp.stride, padding=2 if lp.padding == 'SAME' else 0)
+    loss0 = ((y - y_full) ** 2).sum() / 2
+    (g,) = torch.autograd.grad(loss0, w0)
+    mask = opt.masks[var.offset:var.offset + var.numel].view(var.storage_shape)
+    g_st = g.permute(0, 2, 3, 1).contiguous() * mask                       # logical OIHW -> storage KRSC
+    p0 = var.master.detach().clone()
+    want, _, _ = O.adam_step(p0.numpy().reshape(-1), g_st.numpy().reshape(-1), np.zeros(var.numel, np.float32),
+                             np.zeros(var.numel, np.float32), 1, lr)
+    before = opt.graph_prnd.store.export_numpy()
+    st = opt.graph_prnd.store
+    base = opt.opt_rg
+    opt.rg_mask.zero_()
+    opt.rg_mask[var.offset:var.offset + var.numel] = opt.masks[var.offset:var.offset + var.numel]
+    base.w_mask, base.o_mask = opt.rg_mask, torch.zeros_like(st.o_master)
+    losses = [float(opt._PROptimizer__regression_step(idx).detach()) for _ in range(4)]
+    assert abs(losses[0] - float(loss0.detach())) <= 1e-4 * max(1.0, float(loss0.detach()))
+    assert losses[-1] < losses[0]                                          # same batch every step: the loss falls
+    after = opt.graph_prnd.store.export_numpy()
+    for name in after:
+      if name != var.name:
+        assert np.array_equal(after[name], before[name]), name              # only the regressed kernel moves
+    assert np.all(after[var.name][var.to_ref(mask.numpy()) == 0] == 0)       # pruned weights stay at zero
+    # first Adam step: compare through a fresh optimiser state
+    opt._PROptimizer__init_pruned_network(ratios)
+    opt.iter_trn.reset()
+    opt._PROptimizer__regression_step(idx)
+    got = var.master.detach().numpy().reshape(-1)
+    assert np.max(np.abs(got - want)) <= 2e-3 * lr + 1e-7
+  finally:
+    FLAGS.ws_prune_ratio_prtl, FLAGS.synthetic_pool, FLAGS.ws_lrn_rate_rg = 'uniform', 2, lr_rg_saved
