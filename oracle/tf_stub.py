@@ -629,7 +629,8 @@ def install() -> types.ModuleType:
   tf.layers = _ns('tensorflow.layers', conv2d=_conv2d, batch_normalization=_batch_normalization, dense=_dense,
                   max_pooling2d=_max_pooling2d, flatten=_flatten)
   tf.test = _ns('tensorflow.test', is_built_with_cuda=lambda: False)
-  tf.logging = _ns('tensorflow.logging', info=lambda *a, **k: None, warning=lambda *a, **k: None)
+  tf.logging = _ns('tensorflow.logging', info=lambda *a, **k: None, warning=lambda *a, **k: None, debug=lambda *a, **k: None,
+                   error=lambda *a, **k: None)
   dist = _ns('tensorflow.contrib.distributions', percentile=_percentile)
   ge = _ns('tensorflow.contrib.graph_editor')
   slim = _ns('tensorflow.contrib.slim', arg_scope=_arg_scope, conv2d=_slim_conv2d, separable_conv2d=_slim_separable_conv2d,

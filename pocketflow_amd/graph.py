@@ -854,11 +854,12 @@ class TapStop(Exception):
 def _tapped(layer, x, residual=None):
   g = layer.graph
   y = layer.plain(x)
-  g.taps[layer] = (x, y, getattr(x, '_pf_src', None))
+  y_add = None if residual is None else y + residual   # a residual sum has no single producer: tag dropped
+  g.taps[layer] = (x, y, getattr(x, '_pf_src', None), y_add)
   if g.tap_stop is layer:
     raise TapStop()
   y._pf_src = layer
-  return y if residual is None else y + residual     # a residual sum has no single producer: tag dropped
+  return y if residual is None else y_add
 
 
 def _pass_tag(x, y):

@@ -10,10 +10,19 @@ What runs on the MI355X: the `cp_nb_batches` x (1 + #layers) forward passes that
 feature maps and convolution inputs (the executor's tap mode, graph.Graph.taps); the LASSO / least
 squares stay in scikit-learn on the host like in the reference.
 
-Supported topologies: chains of Conv2D / DepthwiseConv2dNative with BN / ReLU(6) between them
-(MobileNet-v1 = BASELINE config 3, LeNet-like nets).  Networks with residual additions need the
-reference's `residual_branch_diff` correction (:579-586), which is not implemented: such convolutions
-are reported as not prunable.  The RL mode (`cp_prune_option auto`) is out of scope.
+Topologies: chains of Conv2D / DepthwiseConv2dNative with BN / ReLU(6) / pooling between them (MobileNet-v1 =
+BASELINE config 3, LeNet-like nets) and residual networks: a convolution fed by a residual sum is not
+"W1-prunable" (its producer is not a single convolution, :343-370) and a convolution whose output enters a
+residual sum is re-fitted against `Y + residual_branch_diff` (:579-586, 611-614).
+
+RL mode (`cp_prune_option auto`, :118-213): one 8-number state per convolution
+[layer, n, c, H, W, stride, maxreduce, layercomp] / column maximum, the action (preserve ratio) constrained so
+that the FLOP target `cp_preserve_ratio` stays reachable when every later layer is pruned to the lower bound.
+
+Deviations (documented, host-side): feature maps are sampled with inference-mode BN (the reference builds the
+pruner's graph with forward_train, i.e. batch statistics, learner.py:255); the residual-sum samples are taken at
+the SAME points as the convolution's (the reference draws independent points for the two tensors, :327-331,
+which mis-aligns the correction); the sampling generator is seeded (`cp_seed`).
 """
 from __future__ import annotations
 
@@ -30,7 +39,7 @@ from pocketflow_amd.graph import Conv2D, DepthwiseConv2D, Graph, to_device_image
 
 flags.DEFINE_boolean('cp_lasso', True, 'If True use lasso and reconstruction otherwise prune according to weight magnitude')
 flags.DEFINE_boolean('cp_quadruple', False, 'Restric the channels after pruning is a mutiple of 4')
-flags.DEFINE_string('cp_reward_policy', 'accuracy', 'reward policy of the RL mode (unused: RL mode is out of scope)')
+flags.DEFINE_string('cp_reward_policy', 'accuracy', "'accuracy': best accuracy under the FLOP target | 'flops': fewest FLOPs at guaranteed accuracy")
 flags.DEFINE_integer('cp_nb_points_per_layer', 10, 'Sample how many point for each layer')
 flags.DEFINE_integer('cp_nb_batches', 30, 'Input how many bathes data into a model')
 flags.DEFINE_integer('cp_seed', 2018, 'seed of the host-side sampling (the reference never seeds np.random)')
@@ -115,33 +124,34 @@ def compute_pruned_kernel(X, W2, Y, c_new, rng, alpha=1e-4, tolerance=0.02, quad
 class ChannelPruner(object):  # pylint: disable=too-many-instance-attributes
   """Prunes the convolutions of one Graph in creation order; `compress(ratio)` handles one layer."""
 
-  def __init__(self, graph: Graph, forward_eval, batches, sm_writer=None):
+  FEATURE_NAMES = ['layer', 'n', 'c', 'H', 'W', 'stride', 'maxreduce', 'layercomp']
+
+  def __init__(self, graph: Graph, forward_eval, batches, sm_writer=None, lbound=0, calc_loss=None,
+               trainable_vars=None):
     self.graph = graph
     self.forward_eval = forward_eval
     self.batches = batches                       # list of (images NHWC float32 device tensor, labels)
     self.sm_writer = sm_writer
+    self.lbound = lbound
+    self.calc_loss, self.trainable_vars = calc_loss, trainable_vars
     self.rng = np.random.RandomState(FLAGS.cp_seed)
     self.state = 0
     self.points: Dict = {}
     self.feats_dict: Dict[object, np.ndarray] = {}
+    self.feats_add: Dict[object, np.ndarray] = {}
+    self.max_reduced_flops = 0
+    self.preserve_ratio = None
     self.__trace()
-    self.fake_pruning_dict = {}
-    self.max_strategy_dict = {}
-    for conv in self.thisconvs:
-      cin, cout = conv.kernel.ref_shape[2], conv.kernel.ref_shape[3]
-      self.fake_pruning_dict[conv.op.name] = [[True] * cin, [True] * cout]
-      self.max_strategy_dict[conv.op.name] = [1.0, 1.0]
-    self.model_flops = self.compute_model_flops(fake=False)
-    log.info('The original model flops is {}'.format(self.model_flops))
+    self.initialize_state()
 
   # -- topology ------------------------------------------------------------------------------------
   def __run(self, images):
-    """One eval-mode forward in tap mode; returns {layer: (input, output, producer)}."""
+    """One eval-mode forward in tap mode; returns {layer: (input, output, producer, residual sum)}."""
     g = self.graph
     g.taps = OrderedDict()
     try:
       with torch.no_grad(), g.as_default():
-        self.forward_eval(to_device_images(images, g))
+        self.logits = self.forward_eval(to_device_images(images, g))
       return g.taps
     finally:
       g.taps = None
@@ -152,6 +162,7 @@ class ChannelPruner(object):  # pylint: disable=too-many-instance-attributes
     self.thisconvs: List[Conv2D] = [l for l in self.layers if isinstance(l, Conv2D)]
     self.fathers: Dict[object, Optional[object]] = {l: taps[l][2] for l in self.layers}
     self.out_hw = {l: (taps[l][1].shape[2], taps[l][1].shape[3]) for l in self.layers}
+    self.last_in_resblock = {l for l in self.thisconvs if taps[l][3] is not None}
     self.names = [c.op.name for c in self.thisconvs]
 
   def is_W1_prunable(self, conv) -> bool:
@@ -161,6 +172,70 @@ class ChannelPruner(object):  # pylint: disable=too-many-instance-attributes
   def finallayer(self, offset=1):
     return len(self.thisconvs) - offset == self.state
 
+  # -- RL state (:118-164) ----------------------------------------------------------------------------
+  def getState(self, conv):
+    kh, kw, c, n = conv.kernel.ref_shape
+    H, W = self.out_hw[conv]
+    return [self.state, n, c, H, W, conv.stride, 1., self.compute_layer_flops(conv)]
+
+  def initialize_state(self):
+    """States of all layers, FLOP targets, and the optimistic strategy table `max_strategy_dict[op] =
+    [input preserve ratio, output preserve ratio]` (lbound where a later decision may still shrink it)."""
+    self.best = -np.inf
+    self.bestinfo = []
+    allstate = []
+    for self.state, conv in enumerate(self.thisconvs):
+      allstate.append(self.getState(conv))
+    self.state = 0
+    states = np.array(allstate, dtype=np.float64)
+    self.states = states / states.max(axis=0)
+    self.layer_flops = self.states[:, 7].copy()
+    self.model_flops = self.compute_model_flops()
+    log.info('The original model flops is {}'.format(self.model_flops))
+    self.currentStates = self.states.copy()
+    self.desired_reduce = (1 - FLAGS.cp_preserve_ratio) * self.model_flops
+    self.desired_preserve = FLAGS.cp_preserve_ratio * self.model_flops
+    self.max_strategy_dict = {}
+    self.fake_pruning_dict = {}
+    for i, conv in enumerate(self.thisconvs):
+      if self.is_W1_prunable(conv):
+        father = self.fathers[conv]
+        if isinstance(father, DepthwiseConv2D):
+          if self.is_W1_prunable(father) and self.fathers[father].op.name in self.max_strategy_dict:
+            self.max_strategy_dict[self.fathers[father].op.name][1] = self.lbound
+        else:
+          self.max_strategy_dict[father.op.name][1] = self.lbound
+      inner = not (i == 0 or i == len(self.thisconvs) - 1)
+      self.max_strategy_dict[conv.op.name] = [self.lbound, 1.] if inner else [1., 1.]
+      cin, cout = conv.kernel.ref_shape[2], conv.kernel.ref_shape[3]
+      self.fake_pruning_dict[conv.op.name] = [[True] * cin, [True] * cout]
+
+  def __action_constraint(self, action):
+    """Clip the preserve ratio so that the FLOP target stays reachable (:166-213)."""
+    action = min(max(float(np.asarray(action).reshape(-1)[0]), 0.), 1.)
+    if self.finallayer():
+      return 1
+    conv_op = self.thisconvs[self.state]
+    prunable = self.is_W1_prunable(conv_op)
+    father = self.fathers[conv_op] if prunable else None
+    this_flops, other_flops = 0, 0
+    for conv in self.thisconvs:
+      curr_flops = self.compute_layer_flops(conv)
+      strategy = self.max_strategy_dict[conv.op.name]
+      if prunable and conv is father:
+        this_flops += curr_flops * strategy[0]
+      elif conv is conv_op:
+        this_flops += curr_flops * strategy[1]
+      else:
+        other_flops += curr_flops * strategy[0] * strategy[1]
+    self.max_reduced_flops = other_flops + this_flops * action
+    if FLAGS.cp_reward_policy != 'accuracy' or self.state == 0:
+      return action
+    recommand_action = (self.desired_preserve - other_flops) / this_flops
+    log.info('max_reduced_flops {} | desired_preserve {} | this flops {} | recommand action {}'.format(
+        self.max_reduced_flops, self.desired_preserve, this_flops, recommand_action))
+    return np.minimum(action, recommand_action)
+
   # -- flops -----------------------------------------------------------------------------------------
   def compute_layer_flops(self, conv) -> float:
     kh, kw, cin, cout = conv.kernel.ref_shape
@@ -168,27 +243,30 @@ class ChannelPruner(object):  # pylint: disable=too-many-instance-attributes
     return 2.0 * ho * wo * kh * kw * cin * cout
 
   def compute_model_flops(self, fake=False) -> float:
+    """FLOPs of the Conv2D layers (depthwise layers are not counted, as in the reference: :240-254 iterates
+    `get_operations_by_type()` = Conv2D); `fake`: scaled by the current strategy table."""
     flops = 0.0
     for conv in self.thisconvs:
       f = self.compute_layer_flops(conv)
       if fake:
-        keep_in, keep_out = self.fake_pruning_dict[conv.op.name]
-        f *= (sum(keep_in) / float(len(keep_in))) * (sum(keep_out) / float(len(keep_out)))
+        f *= self.max_strategy_dict[conv.op.name][0] * self.max_strategy_dict[conv.op.name][1]
       flops += f
-    for l in self.layers:
-      if isinstance(l, DepthwiseConv2D):
-        kh, kw, c, _ = l.kernel.ref_shape
-        ho, wo = self.out_hw[l]
-        flops += 2.0 * ho * wo * kh * kw * c
     return flops
 
   # -- sampling ----------------------------------------------------------------------------------------
+  @staticmethod
+  def __sample(y, xs, ys):
+    sel = y[:, :, torch.as_tensor(xs, device=y.device), torch.as_tensor(ys, device=y.device)]
+    return sel.permute(0, 2, 1).reshape(-1, y.shape[1]).float().cpu().numpy().astype(np.float64)
+
   def extract_features(self):
-    """Outputs of every convolution of the ORIGINAL model at cp_nb_points_per_layer random points per
-    batch (the same points for every image of a batch), over cp_nb_batches batches (:263-341)."""
+    """Outputs of every convolution (and of the residual sum it feeds, if any) of the ORIGINAL model at
+    cp_nb_points_per_layer random points per batch (the same points for every image of a batch), over
+    cp_nb_batches batches (:263-341)."""
     npts = FLAGS.cp_nb_points_per_layer
     nb_batches = min(FLAGS.cp_nb_batches, len(self.batches))
     feats = {c: [] for c in self.thisconvs}
+    adds = {c: [] for c in self.last_in_resblock}
     self.points = {}
     for b in range(nb_batches):
       taps = self.__run(self.batches[b][0])
@@ -197,11 +275,36 @@ class ChannelPruner(object):  # pylint: disable=too-many-instance-attributes
         xs = self.rng.randint(0, h, npts)
         ys = self.rng.randint(0, w, npts)
         self.points[(b, conv)] = (xs.copy(), ys.copy())
-        y = taps[conv][1]                                   # logical NCHW
-        sel = y[:, :, torch.as_tensor(xs, device=y.device), torch.as_tensor(ys, device=y.device)]
-        feats[conv].append(sel.permute(0, 2, 1).reshape(-1, y.shape[1]).float().cpu().numpy().astype(np.float64))
+        feats[conv].append(self.__sample(taps[conv][1], xs, ys))       # logical NCHW
+        if conv in adds:
+          adds[conv].append(self.__sample(taps[conv][3], xs, ys))
     self.feats_dict = {c: np.vstack(v) for c, v in feats.items()}
+    self.feats_add = {c: np.vstack(v) for c, v in adds.items()}
     self.nb_batches = nb_batches
+
+  def residual_branch_diff(self, conv):
+    """Change of the residual sum behind `conv` caused by the pruning done so far (:579-586)."""
+    log.info("approximating residual branch diff")
+    cur = []
+    for b in range(self.nb_batches):
+      xs, ys = self.points[(b, conv)]
+      cur.append(self.__sample(self.__run(self.batches[b][0])[conv][3], xs, ys))
+    return self.feats_add[conv] - np.vstack(cur)
+
+  def accuracy(self):
+    """Mean `accuracy` metric of the current (partially pruned) model over the cached batches (:414-434)."""
+    acc_list, rows, names = [], [], []
+    for b in range(self.nb_batches if self.points else min(FLAGS.cp_nb_batches, len(self.batches))):
+      images, labels = self.batches[b]
+      self.__run(images)
+      with torch.no_grad(), self.graph.as_default():
+        __, metrics = self.calc_loss(labels.to(self.logits.device), self.logits, self.trainable_vars)
+      acc_list.append(float(metrics['accuracy']))
+      names = list(metrics.keys())
+      rows.append([float(v) for v in metrics.values()])
+    for k, v in zip(names, np.mean(np.array(rows), axis=0)):
+      log.info('{}: {}'.format(k, v))
+    return float(np.mean(acc_list))
 
   def __extract_input(self, conv) -> np.ndarray:
     """Input patches [n, kh, kw, cin] of `conv` at its sampled output points, from the CURRENT
@@ -239,6 +342,8 @@ class ChannelPruner(object):  # pylint: disable=too-many-instance-attributes
     nb_channel_new = max(int(np.around(c * ratio)), 1)
     newX = self.__extract_input(conv)
     Y = self.feats_dict[conv]
+    if conv in self.feats_add:                             # the output feeds a residual sum (:611-614)
+      Y = Y + self.residual_branch_diff(conv)
     W2 = conv.kernel.to_ref(conv.kernel.master.detach().float().cpu().numpy()).astype(np.float64)
     if FLAGS.cp_lasso:
       idxs, newW2 = compute_pruned_kernel(newX, W2, Y, nb_channel_new, self.rng, quadruple=FLAGS.cp_quadruple)
@@ -250,7 +355,7 @@ class ChannelPruner(object):  # pylint: disable=too-many-instance-attributes
       reg = LinearRegression(fit_intercept=False)
       reg.fit(newX[:, :, :, idxs].reshape(newX.shape[0], -1), Y)
       newW2 = reg.coef_
-    rel = lambda A, B: np.mean((A - B) ** 2) ** .5 / np.mean(A ** 2) ** .5
+    rel = lambda A, B: np.mean((A - B) ** 2) ** .5 / max(np.mean(A ** 2) ** .5, 1e-30)
     log.info('Prune {} c_in from {} to {} | feature map rmse {:.4f}'.format(
         conv.op.name, newX.shape[-1], int(sum(idxs)),
         rel(newX[:, :, :, idxs].reshape(newX.shape[0], -1).dot(newW2.T), Y)))
@@ -296,13 +401,26 @@ class ChannelPruner(object):  # pylint: disable=too-many-instance-attributes
     self.__assign(conv.kernel, w)
 
   def compress(self, c_ratio):
-    """Prune the layer at `self.state` with preserve ratio `c_ratio`; returns done (:727-799)."""
+    """Prune the layer at `self.state` with preserve ratio `c_ratio` (:727-799).
+    Returns (state of the next layer, [accuracy, pruned flops] (final layer) or [0, 1], done, applied ratio)."""
+    auto = FLAGS.cp_prune_option == 'auto'
     if self.state == 0:
       c_ratio = 1.0                                        # first layer is not prunable
+      if self.calc_loss is not None:
+        self.accuracy()
     if self.finallayer():
       c_ratio = 1                                          # final layer is not prunable
+    if auto:
+      log.info('preserve ratio before constraint {}'.format(c_ratio))
+      c_ratio = self.__action_constraint(c_ratio)
+      log.info('preserve ratio after constraint {}'.format(c_ratio))
     conv = self.thisconvs[self.state]
-    if c_ratio != 1:
+    if c_ratio == 1:
+      if auto:
+        self.max_strategy_dict[conv.op.name][0] = c_ratio
+        if self.is_W1_prunable(conv) and self.fathers[conv].op.name in self.max_strategy_dict:
+          self.max_strategy_dict[self.fathers[conv].op.name][1] = c_ratio
+    else:
       idxs, W2, c_ratio = self.prune_kernel(conv, c_ratio)
       if self.is_W1_prunable(conv):
         father = self.fathers[conv]
@@ -316,11 +434,17 @@ class ChannelPruner(object):  # pylint: disable=too-many-instance-attributes
       self.prune_W2(conv, idxs, W2)
       self.graph.store.sync_compute()
     log.info('Channel pruning the {} layer, the pruning rate is {}'.format(conv.op.name, c_ratio))
+
     if self.finallayer():
+      acc = self.accuracy() if self.calc_loss is not None else 0.0
       pruned_flops = self.compute_model_flops(fake=True)
-      log.info('The pruned flops is {} | the speedup ratio is {}'.format(pruned_flops, pruned_flops / self.model_flops))
-      log.info('The max strategy dict is {}'.format(self.max_strategy_dict))
       self.preserve_ratio = pruned_flops / self.model_flops
-      return True
+      log.info('The accuracy is {} and the flops after pruning is {}'.format(acc, pruned_flops))
+      log.info('The speedup ratio is {} | the original model flops is {}'.format(self.preserve_ratio, self.model_flops))
+      log.info('The max strategy dict is {}'.format(self.max_strategy_dict))
+      return self.currentStates[self.state].copy(), [acc, pruned_flops], True, c_ratio
+
     self.state += 1
-    return False
+    if auto:
+      self.currentStates[self.state, 6] = self.max_reduced_flops / self.model_flops        # 'maxreduce'
+    return self.currentStates[self.state].copy(), [0, 1], False, c_ratio

@@ -7,13 +7,17 @@ network with per-channel gradient masks (`__calc_grads_pruned`, :381-421: mask =
 pruned cin rows and cout columns zeroed) -- here the masks live in one flat buffer parallel to the
 kernel buffer and are applied inside the fused optimiser kernel (pf_adam_flat / pf_momentum_flat).
 
-`cp_prune_option`: 'uniform' (every layer at cp_uniform_preserve_ratio) and 'list' (ratios from
-cp_prune_list_file, optionally fine-tuning between groups of cp_list_group layers).  'auto' (DDPG
-search, :623-695) is outside the hot path and raises.
+`cp_prune_option`: 'uniform' (every layer at cp_uniform_preserve_ratio), 'list' (ratios from
+cp_prune_list_file, optionally fine-tuning between groups of cp_list_group layers) and 'auto' (the
+reference's default, :601-695): a DDPG agent proposes one preserve ratio per convolution from the 8-number
+layer state, the pruner constrains it to keep the FLOP target reachable and prunes the layer, the roll-out's
+reward is the pruned model's accuracy on the cached batches (or -max(tol, 1 - acc) * log(flops)); the best
+strategy of cp_nb_rlouts roll-outs is then replayed through the 'list' path.
 """
 from __future__ import annotations
 
 import logging
+import math
 import os
 from collections import deque
 from timeit import default_timer as timer
@@ -28,24 +32,25 @@ from pocketflow_amd.learners.abstract_learner import AbstractLearner
 from pocketflow_amd.learners.channel_pruning.channel_pruner import ChannelPruner
 from pocketflow_amd.learners.distillation_helper import DistillationHelper
 from pocketflow_amd.optim import FlatOptimizer
+from pocketflow_amd.rl_agents.ddpg.agent import Agent as DdpgAgent
 from pocketflow_amd.utils import checkpoint
 from pocketflow_amd.utils.multi_gpu_wrapper import MultiGpuWrapper as mgw
 
-flags.DEFINE_string('cp_prune_option', 'auto', "'uniform': one ratio for every layer | 'list': ratios from a file | 'auto': RL (out of scope)")
+flags.DEFINE_string('cp_prune_option', 'auto', "'uniform': one ratio for every layer | 'list': ratios from a file | 'auto': DDPG search")
 flags.DEFINE_string('cp_prune_list_file', 'ratio.list', 'the prune list file which contains the compression ratio of each convolution layers')
 flags.DEFINE_string('cp_channel_pruned_path', './models/pruned_model.ckpt', 'channel pruned model\'s save path')
 flags.DEFINE_string('cp_best_path', './models/best_model.ckpt', 'channel pruned model\'s temporary save path')
 flags.DEFINE_string('cp_original_path', './models/original_model.ckpt', 'channel pruned model\'s temporary save path')
 flags.DEFINE_float('cp_preserve_ratio', 0.5, 'How much computation cost desired to be preserved after pruning')
 flags.DEFINE_float('cp_uniform_preserve_ratio', 0.6, 'How much computation cost desired to be preserved each layer')
-flags.DEFINE_float('cp_noise_tolerance', 0.15, 'noise tolerance of the RL reward (unused)')
+flags.DEFINE_float('cp_noise_tolerance', 0.15, 'the noise tolerance which restricts the maximum reward of the flops policy')
 flags.DEFINE_float('cp_lrn_rate_ft', 1e-4, 'CP: learning rate for global fine-tuning')
 flags.DEFINE_float('cp_nb_iters_ft_ratio', 0.2, 'CP: the ratio of total iterations for global fine-tuning')
 flags.DEFINE_boolean('cp_finetune', False, 'CP: whether finetuning between each list group')
 flags.DEFINE_boolean('cp_retrain', False, 'CP: whether retraining between each list group')
 flags.DEFINE_integer('cp_list_group', 1000, 'CP: # of layers pruned between two fine-tuning phases')
-flags.DEFINE_integer('cp_nb_rlouts', 200, 'CP: # of roll-outs for the RL agent (unused)')
-flags.DEFINE_integer('cp_nb_rlouts_min', 50, 'CP: # of roll-outs for the RL agent (unused)')
+flags.DEFINE_integer('cp_nb_rlouts', 200, 'CP: # of roll-outs for the RL agent')
+flags.DEFINE_integer('cp_nb_rlouts_min', 50, 'CP: # of roll-outs whose transitions fill the replay buffer')
 
 log = logging.getLogger('pocketflow_amd')
 
@@ -66,6 +71,10 @@ class ChannelPrunedLearner(AbstractLearner):  # pylint: disable=too-many-instanc
     self.w_mask = torch.ones_like(self.graph.store.w_master)
     self.last_speed = None
     self.last_eval = None
+    self.agent = None
+    self.bestinfo = None
+    self.lbound = math.log(FLAGS.cp_preserve_ratio + 1, 10) * 1.5
+    self.rbound = 1.0
 
   # -- reference surface ------------------------------------------------------------------------------
   def train(self):
@@ -81,7 +90,7 @@ class ChannelPrunedLearner(AbstractLearner):  # pylint: disable=too-many-instanc
     elif FLAGS.cp_prune_option == 'list':
       self.__prune_and_finetune_list()
     elif FLAGS.cp_prune_option == 'auto':
-      raise ValueError("cp_prune_option 'auto' (DDPG search) is outside the MI355X hot path (SURVEY section 8f)")
+      self.__prune_and_finetune_auto()
     else:
       raise ValueError('unrecognized cp_prune_option: ' + str(FLAGS.cp_prune_option))
     return self.last_eval
@@ -90,7 +99,8 @@ class ChannelPrunedLearner(AbstractLearner):  # pylint: disable=too-many-instanc
     nb = FLAGS.cp_nb_batches
     batches = [self.iter_train.get_next() for _ in range(nb)]
     self.iter_train.reset()
-    self.pruner = ChannelPruner(self.graph, self.forward_eval, batches, self.sm_writer)
+    self.pruner = ChannelPruner(self.graph, self.forward_eval, batches, self.sm_writer, lbound=self.lbound,
+                                calc_loss=self.calc_loss, trainable_vars=self.trainable_vars)
 
   def evaluate(self):
     """Restore the latest checkpoint and evaluate it (:181-206)."""
@@ -130,7 +140,7 @@ class ChannelPrunedLearner(AbstractLearner):  # pylint: disable=too-many-instanc
       start = timer()
       done = False
       while not done:
-        done = self.pruner.compress(FLAGS.cp_uniform_preserve_ratio)
+        _, _, done, _ = self.pruner.compress(FLAGS.cp_uniform_preserve_ratio)
       log.info('uniform channl pruning time cost: {}s'.format(timer() - start))
       self.save_vars(FLAGS.cp_channel_pruned_path)
     self.auto_barrier()
@@ -155,7 +165,7 @@ class ChannelPrunedLearner(AbstractLearner):  # pylint: disable=too-many-instanc
       i = 0
       while not done and i < n:
         ratio = queue.pop() if queue else 1
-        done = self.pruner.compress(ratio)
+        _, _, done, _ = self.pruner.compress(ratio)
         i += 1
       self.save_vars(FLAGS.cp_channel_pruned_path)
     if FLAGS.enbl_multi_gpu:
@@ -163,6 +173,80 @@ class ChannelPrunedLearner(AbstractLearner):  # pylint: disable=too-many-instanc
       done = self.mpi_comm.bcast(done, root=0)
     self.__finetune_pruned_model(path=FLAGS.cp_channel_pruned_path, finetune=False if done else FLAGS.cp_finetune)
     return done
+
+  def __prune_and_finetune_auto(self):
+    if self.is_primary_worker('global'):
+      self.__prune_rl()
+      self.restore_vars(FLAGS.cp_original_path)           # the replay below starts from the original weights
+      self.create_pruner()
+    if FLAGS.enbl_multi_gpu:
+      self.auto_barrier()
+      self.bestinfo = self.mpi_comm.bcast(self.bestinfo, root=0)
+    ratio_list = list(self.bestinfo[0])
+    log.info('best split ratio is: {}'.format(ratio_list))
+    ratio_list.reverse()
+    queue = deque(ratio_list)
+    done = False
+    while not done:
+      done = self.__prune_n_layers(FLAGS.cp_list_group, queue)
+
+  @classmethod
+  def __calc_reward(cls, accuracy, flops):
+    if FLAGS.cp_reward_policy == 'accuracy':
+      reward = accuracy * np.ones((1, 1))
+    elif FLAGS.cp_reward_policy == 'flops':
+      reward = -np.maximum(FLAGS.cp_noise_tolerance, (1 - accuracy)) * np.log(flops) * np.ones((1, 1))
+    else:
+      raise ValueError('unrecognized reward type: ' + FLAGS.cp_reward_policy)
+    return reward
+
+  def __prune_rl(self):  # pylint: disable=too-many-locals
+    """Search the per-layer preserve ratios with the DDPG agent (rank 0 only, :623-695)."""
+    log.info('preserve lower bound: {}, preserve ratio: {}, preserve upper bound: {}'.format(
+        self.lbound, FLAGS.cp_preserve_ratio, self.rbound))
+    nb_layers = len(self.pruner.states)
+    self.agent = DdpgAgent(None, self.pruner.states.shape[1], 1, FLAGS.cp_nb_rlouts,
+                           nb_layers * FLAGS.cp_nb_rlouts_min, self.lbound, self.rbound)
+    self.agent.init()
+    self.bestinfo = None
+    reward_best = -np.inf
+    self.reward_history = []
+    for idx_rlout in range(FLAGS.cp_nb_rlouts):
+      self.agent.init_rlout()
+      states_n_actions = []
+      self.restore_vars(FLAGS.cp_original_path)           # create_pruner() of the reference re-imports the original model
+      self.create_pruner()
+      self.pruner.extract_features()
+      state = self.pruner.currentStates[0][None, :]
+      start = timer()
+      while True:
+        action = self.agent.actions_noisy(state)
+        log.info('RL choosed preserv ratio: {}'.format(action))
+        state_next, acc_flops, done, real_action = self.pruner.compress(action)
+        log.info('Actural preserv ratio: {}'.format(real_action))
+        states_n_actions += [(state, real_action * np.ones((1, 1)))]
+        state = state_next[None, :]
+        actor_loss, critic_loss, noise_std = self.agent.train()
+        if done:
+          break
+      log.info('roll-out #%d: a-loss = %.2e | c-loss = %.2e | noise std. = %.2e'
+               % (idx_rlout, actor_loss, critic_loss, noise_std))
+      reward = self.__calc_reward(acc_flops[0], acc_flops[1])
+      self.reward_history.append(float(reward[0, 0]))
+      self.agent.finalize_rlout(reward * np.ones(nb_layers))
+      strategy = []
+      for idx, (state, action) in enumerate(states_n_actions):
+        strategy.append(float(action[0, 0]))
+        last = idx == len(states_n_actions) - 1
+        terminal = np.ones((1, 1)) if last else np.zeros((1, 1))
+        state_next = np.zeros_like(state) if last else states_n_actions[idx + 1][0]
+        self.agent.record(state, action, reward, terminal, state_next)
+      if reward_best < float(reward[0, 0]):
+        log.info('best reward updated: %.4f -> %.4f' % (reward_best, float(reward[0, 0])))
+        reward_best = float(reward[0, 0])
+        self.bestinfo = [strategy, acc_flops[0], acc_flops[1]]
+        log.info('The best pruned model occured with strategy: {}, accuracy: {} and pruned ratio: {}'.format(*self.bestinfo))
+      log.info('automatic channl pruning time cost: {}s'.format(timer() - start))
 
   # -- masked fine-tune ------------------------------------------------------------------------------------
   def __calc_grads_pruned(self):

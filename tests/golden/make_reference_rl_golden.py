@@ -14,6 +14,10 @@ Lifted (paths relative to /root/reference):
   learners/nonuniform_quantization/rl_helper.py  RLHelper
   learners/weight_sparsification/rl_helper.py    RLHelper
   learners/channel_pruning/learner.py            ChannelPrunedLearner.__calc_reward
+  learners/channel_pruning/channel_pruner.py     ChannelPruner.initialize_state, getState, __action_constraint, __conv_left,
+                                                 __compute_model_flops, finallayer  (RL state table, strategy table and the
+                                                 FLOP-target action constraint, run on a stand-in model wrapper that
+                                                 describes two small topologies; pandas is the real one)
 Not executable here (TF graph construction / sessions): Agent.__build / train, BitOptimizer, PROptimizer roll-out
 loops; they are restated in oracle/ddpg_oracle.py and pocketflow_amd and anchored on the pieces above.
 """
@@ -231,6 +235,96 @@ def gen_cp_reward(meta):
   meta['cp_reward'] = rows
 
 
+class _Op(object):
+  def __init__(self, name, type_, n=0, c=0, k=1, stride=1, hw=0):
+    self.name, self.type, self.n, self.c, self.k, self.stride, self.hw = name, type_, n, c, k, stride, hw
+    self.flops = 2.0 * hw * hw * k * k * c * n
+
+
+class _Wrapper(object):
+  """Stand-in for learners/channel_pruning/model_wrapper.py:Model with a hand-written topology."""
+
+  def __init__(self, ops, fathers):
+    self.ops, self.fathers, self.g = ops, fathers, self
+  def get_operation_by_name(self, name): return [o for o in self.ops if o.name == name][0]
+  def get_operations_by_type(self, otype='Conv2D'): return [o for o in self.ops if o.type == otype]
+  def is_W1_prunable(self, conv): return self.fathers[conv.name] is not None
+  def get_conv_def(self, op): return {'n': op.n, 'c': op.c, 'h': op.k, 'w': op.k, 'strides': [1, op.stride, op.stride, 1]}
+  def get_outname_by_opname(self, name): return name
+  def output_width(self, name): return self.get_operation_by_name(name).hw
+  def output_height(self, name): return self.get_operation_by_name(name).hw
+  def compute_layer_flops(self, op): return op.flops
+
+
+CP_TOPOLOGIES = {
+    # MobileNet-like chain: conv, (depthwise, pointwise) x 2, 1x1 classifier behind a global pool
+    'chain': ([('conv0', 'Conv2D', 8, 3, 3, 2, 16), ('dw1', 'DepthwiseConv2dNative', 8, 8, 3, 1, 16), ('pw1', 'Conv2D', 16, 8, 1, 1, 16),
+               ('dw2', 'DepthwiseConv2dNative', 16, 16, 3, 2, 8), ('pw2', 'Conv2D', 32, 16, 1, 1, 8), ('fc', 'Conv2D', 10, 32, 1, 1, 1)],
+              {'conv0': None, 'dw1': 'conv0', 'pw1': 'dw1', 'dw2': 'pw1', 'pw2': 'dw2', 'fc': None}),
+    # pre-activation residual net: stem, block 1 (identity shortcut), block 2 (1x1 stride-2 projection shortcut);
+    # the convolutions fed by a residual sum (b2p, b2c1) have no single producer
+    'resnet': ([('stem', 'Conv2D', 8, 3, 3, 1, 16), ('b1c1', 'Conv2D', 8, 8, 3, 1, 16), ('b1c2', 'Conv2D', 8, 8, 3, 1, 16),
+                ('b2p', 'Conv2D', 16, 8, 1, 2, 8), ('b2c1', 'Conv2D', 16, 8, 3, 2, 8), ('b2c2', 'Conv2D', 16, 16, 3, 1, 8)],
+               {'stem': None, 'b1c1': 'stem', 'b1c2': 'b1c1', 'b2p': None, 'b2c1': None, 'b2c2': 'b2c1'}),
+}
+
+
+def gen_cp_states(out, meta):
+  import math
+  import pandas as pd
+  ns = G.lift('learners/channel_pruning/channel_pruner.py',
+              ['ChannelPruner.initialize_state', 'ChannelPruner.getState', 'ChannelPruner.__action_constraint',
+               'ChannelPruner.__conv_left', 'ChannelPruner.__compute_model_flops', 'ChannelPruner.finallayer'],
+              {'pd': pd, 'math': math})
+  CP = ns['ChannelPruner']
+  rows = []
+  for topo, (ops, fathers) in CP_TOPOLOGIES.items():
+    for preserve, policy in ((0.5, 'accuracy'), (0.3, 'accuracy'), (0.5, 'flops')):
+      set_flags(cp_preserve_ratio=preserve, cp_reward_policy=policy, cp_prune_option='auto')
+      model = _Wrapper([_Op(*o) for o in ops], fathers)
+      pr = CP()
+      pr._model, pr.lbound, pr.state, pr.drop_conv = model, math.log(preserve + 1, 10) * 1.5, 0, set([])
+      pr.thisconvs = model.get_operations_by_type()
+      pr.initialize_state()
+      tag = 'cp_states/%s_p%g_%s' % (topo, preserve, policy)
+      out[tag + '/states'] = pr.states.values.astype(np.float64)
+      strategy0 = {k: list(v) for k, v in pr.max_strategy_dict.items()}
+      for case, actions in enumerate(([0.9, 0.8, 0.7, 0.6, 0.5, 0.4], [0.25, 0.3, 0.35, 1.0, 0.2, 0.9], [1.5, -0.2, 0.45, 0.45, 0.45, 0.45])):
+        pr.initialize_state()
+        got, maxred = [], []
+        for i, conv in enumerate(pr.thisconvs):
+          a = actions[i]
+          if pr.state == 0:
+            a = 1.0
+          if pr.finallayer():
+            a = 1
+          c = pr._ChannelPruner__action_constraint(a)
+          got.append(float(c))
+          maxred.append(float(pr.max_reduced_flops))
+          # the bookkeeping compress() / prune_W1 / prune_W2 do with the ratio that was applied (:665-770)
+          father = model.fathers[conv.name]
+          if c == 1:
+            pr.max_strategy_dict[conv.name][0] = c
+            if father is not None and father in pr.max_strategy_dict:
+              pr.max_strategy_dict[father][1] = c
+          else:
+            pr.max_strategy_dict[conv.name][0] = c
+            while father is not None and model.get_operation_by_name(father).type == 'DepthwiseConv2dNative' and model.fathers[father] is not None:
+              father = model.fathers[father]
+            if father is not None and father in pr.max_strategy_dict:
+              pr.max_strategy_dict[father][1] = c
+          if not pr.finallayer():
+            pr.state += 1
+            pr.currentStates['maxreduce'][pr.state] = pr.max_reduced_flops / pr.model_flops
+        out['%s/case%d/current_states' % (tag, case)] = pr.currentStates.values.astype(np.float64)
+        rows.append(dict(topo=topo, preserve=preserve, policy=policy, case=case, actions=list(actions), constrained=got,
+                         max_reduced_flops=maxred, model_flops=float(pr.model_flops), lbound=float(pr.lbound),
+                         desired_preserve=float(pr.desired_preserve), strategy0=strategy0,
+                         pruned_flops=float(pr._ChannelPruner__compute_model_flops(fake=True))))
+  meta['cp_states'] = rows
+  meta['cp_topologies'] = {k: {'ops': [list(o) for o in v[0]], 'fathers': v[1]} for k, v in CP_TOPOLOGIES.items()}
+
+
 def main():
   arrays, meta = {}, {}
   gen_actor_critic(arrays, meta)
@@ -240,6 +334,7 @@ def main():
   gen_bit_helpers(arrays, meta)
   gen_ws_helper(arrays, meta)
   gen_cp_reward(meta)
+  gen_cp_states(arrays, meta)
   np.savez_compressed(os.path.join(HERE, 'reference_rl.npz'), **arrays)
   with open(os.path.join(HERE, 'reference_rl.json'), 'w') as f:
     json.dump(meta, f, indent=1, sort_keys=True)

@@ -64,3 +64,113 @@ def test_lasso_selector_matches_the_reference_code(name):
   assert np.array_equal(idx_o, ref_idxs)
   kept = int(ref_idxs.sum())
   np.testing.assert_allclose(new_o, np.transpose(ref_new.reshape(-1, kh, kh, kept), (1, 2, 3, 0)), rtol=1e-5, atol=1e-6)
+
+
+# -- RL state table / strategy table / action constraint against the reference's own code ---------------------------------
+import json
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_RL_A = np.load(os.path.join(_HERE, 'golden', 'reference_rl.npz'))
+_RL_M = json.load(open(os.path.join(_HERE, 'golden', 'reference_rl.json')))
+
+
+def _build_topology(G, g, name):
+  """The two stand-in topologies of tests/golden/make_reference_rl_golden.py as real layer graphs."""
+  bn = lambda n, c: G.BatchNormAct(g, n, c, 'Relu', 0.997, 1e-5)
+  if name == 'chain':
+    L = dict(conv0=G.Conv2D(g, 'conv0', 3, 8, 3, 2), bn0=bn('bn0', 8), dw1=G.DepthwiseConv2D(g, 'dw1', 8, 3, 1), bn1=bn('bn1', 8),
+             pw1=G.Conv2D(g, 'pw1', 8, 16, 1), bn2=bn('bn2', 16), dw2=G.DepthwiseConv2D(g, 'dw2', 16, 3, 2), bn3=bn('bn3', 16),
+             pw2=G.Conv2D(g, 'pw2', 16, 32, 1), bn4=bn('bn4', 32), fc=G.Conv2D(g, 'fc', 32, 10, 1))
+
+    def forward(x):
+      y = L['bn0'](L['conv0'](x))
+      y = L['bn2'](L['pw1'](L['bn1'](L['dw1'](y))))
+      y = L['bn4'](L['pw2'](L['bn3'](L['dw2'](y))))
+      return L['fc'](y.mean(dim=(2, 3), keepdim=True)).flatten(1)
+    return forward, 32
+  L = dict(stem=G.Conv2D(g, 'stem', 3, 8, 3, 1), p1=bn('p1', 8), b1c1=G.Conv2D(g, 'b1c1', 8, 8, 3, 1), m1=bn('m1', 8),
+           b1c2=G.Conv2D(g, 'b1c2', 8, 8, 3, 1), p2=bn('p2', 8), b2p=G.Conv2D(g, 'b2p', 8, 16, 1, 2),
+           b2c1=G.Conv2D(g, 'b2c1', 8, 16, 3, 2), m2=bn('m2', 16), b2c2=G.Conv2D(g, 'b2c2', 16, 16, 3, 1))
+
+  def forward(x):
+    y = L['stem'](x)
+    y = L['b1c2'](L['m1'](L['b1c1'](L['p1'](y))), residual=y)
+    pre = L['p2'](y)
+    shortcut = L['b2p'](pre)
+    y = L['b2c2'](L['m2'](L['b2c1'](pre)), residual=shortcut)
+    return y.mean(dim=(2, 3))
+  return forward, 16
+
+
+@pytest.fixture
+def cp_env(monkeypatch):
+  import torch
+  import pocketflow_amd.graph as G
+  import pocketflow_amd.learners.channel_pruning.learner  # noqa: F401 (flags)
+  from pocketflow_amd.flags import FLAGS
+  from fake_hip import FakeHipFull
+  monkeypatch.setattr(G, 'hip', FakeHipFull())
+  saved = {k: getattr(FLAGS, k) for k in ('cp_preserve_ratio', 'cp_reward_policy', 'cp_prune_option', 'cp_nb_batches')}
+  yield G, FLAGS, torch
+  for k, v in saved.items():
+    setattr(FLAGS, k, v)
+
+
+@pytest.mark.parametrize('topo', ['chain', 'resnet'])
+def test_rl_states_and_action_constraint_match_the_reference_code(cp_env, topo):
+  import math
+  G, FLAGS, torch = cp_env
+  from pocketflow_amd.learners.channel_pruning.channel_pruner import ChannelPruner
+  g = G.Graph('model', 'cpu', torch.float32)
+  forward, size = _build_topology(G, g, topo)
+  g.finalize(requires_grad=False)
+  g.training = False
+  batches = [(torch.from_numpy(np.random.RandomState(0).randn(2, size, size, 3).astype(np.float32)), None)]
+  ops = _RL_M['cp_topologies'][topo]
+  for row in [r for r in _RL_M['cp_states'] if r['topo'] == topo]:
+    FLAGS.cp_preserve_ratio, FLAGS.cp_reward_policy, FLAGS.cp_prune_option = row['preserve'], row['policy'], 'auto'
+    pr = ChannelPruner(g, forward, batches, lbound=math.log(row['preserve'] + 1, 10) * 1.5)
+    convs = [o[0] for o in ops['ops'] if o[1] == 'Conv2D']
+    assert [c.op.name.split('/')[1] for c in pr.thisconvs] == convs
+    # topology discovered by the taps == the hand-written wrapper
+    for c in pr.thisconvs:
+      f = pr.fathers[c]
+      assert (f.op.name.split('/')[1] if f is not None else None) == ops['fathers'][c.op.name.split('/')[1]]
+    tag = 'cp_states/%s_p%g_%s' % (topo, row['preserve'], row['policy'])
+    np.testing.assert_allclose(pr.states, _RL_A[tag + '/states'], rtol=0, atol=1e-12)
+    assert pr.model_flops == row['model_flops'] and pr.lbound == row['lbound'] and pr.desired_preserve == row['desired_preserve']
+    assert {k.split('/')[1]: v for k, v in pr.max_strategy_dict.items()} == row['strategy0']
+    got, maxred = [], []
+    for i, conv in enumerate(pr.thisconvs):
+      a = row['actions'][i]
+      if pr.state == 0:
+        a = 1.0
+      if pr.finallayer():
+        a = 1
+      c = pr._ChannelPruner__action_constraint(a)
+      got.append(float(c))
+      maxred.append(float(pr.max_reduced_flops))
+      # bookkeeping of compress() with the applied ratio (what prune_W1 / prune_W2 record)
+      father = pr.fathers[conv]
+      pr.max_strategy_dict[conv.op.name][0] = c
+      while isinstance(father, G.DepthwiseConv2D) and pr.fathers[father] is not None:
+        father = pr.fathers[father]
+      if father is not None and father.op.name in pr.max_strategy_dict:
+        pr.max_strategy_dict[father.op.name][1] = c
+      if not pr.finallayer():
+        pr.state += 1
+        pr.currentStates[pr.state, 6] = pr.max_reduced_flops / pr.model_flops
+    np.testing.assert_allclose(got, row['constrained'], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(maxred, row['max_reduced_flops'], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(pr.currentStates, _RL_A['%s/case%d/current_states' % (tag, row['case'])], rtol=1e-12, atol=1e-15)
+    assert abs(pr.compute_model_flops(fake=True) - row['pruned_flops']) <= 1e-9 * row['pruned_flops']
+
+
+def test_channel_pruning_reward_matches_the_reference_code(cp_env):
+  G, FLAGS, torch = cp_env
+  from pocketflow_amd.learners.channel_pruning.learner import ChannelPrunedLearner
+  fn = getattr(ChannelPrunedLearner, '_ChannelPrunedLearner__calc_reward')
+  for row in _RL_M['cp_reward']:
+    FLAGS.cp_reward_policy, FLAGS.cp_noise_tolerance = row['policy'], 0.15
+    assert np.asarray(fn(row['acc'], row['flops'])).tolist() == row['reward']

@@ -470,3 +470,83 @@ def test_ws_optimal_rollout_pieces_on_cpu(cpu_learners, monkeypatch):
     assert np.max(np.abs(got - want)) <= 2e-3 * lr + 1e-7
   finally:
     FLAGS.ws_prune_ratio_prtl, FLAGS.synthetic_pool, FLAGS.ws_lrn_rate_rg = 'uniform', 2, lr_rg_saved
+
+
+def test_channel_pruned_auto_mode_on_cpu(cpu_learners, monkeypatch, caplog):
+  """`cp_prune_option=auto` (the reference's default, cp learner.py:601-695): DDPG roll-outs over per-layer preserve
+  ratios, the best strategy replayed through the list path, then the masked fine-tune."""
+  import logging
+  FLAGS, fake, tmp = cpu_learners
+  import pocketflow_amd.learners.channel_pruning.learner as CP
+  from pocketflow_amd.nets.mobilenet_at_ilsvrc12 import ModelHelper
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  monkeypatch.setattr(CP, 'hip', fake)
+  monkeypatch.setattr(torch.cuda, 'synchronize', lambda *a, **k: None)
+  FLAGS.batch_size, FLAGS.batch_size_eval, FLAGS.image_size, FLAGS.nb_classes = 8, 8, 32, 17
+  FLAGS.mobilenet_depth_mult = 0.25
+  FLAGS.cp_prune_option, FLAGS.cp_preserve_ratio, FLAGS.cp_nb_batches, FLAGS.cp_nb_points_per_layer = 'auto', 0.5, 4, 10
+  FLAGS.cp_nb_rlouts, FLAGS.cp_nb_rlouts_min, FLAGS.cp_reward_policy = 3, 1, 'accuracy'
+  FLAGS.cp_channel_pruned_path = str(tmp / 'models' / 'pruned_model.ckpt')
+  FLAGS.cp_best_path = str(tmp / 'models' / 'best_model.ckpt')
+  FLAGS.cp_original_path = str(tmp / 'models' / 'original_model.ckpt')
+  FLAGS.nb_iters_override, FLAGS.summ_step, FLAGS.synthetic_pool, FLAGS.ddpg_seed = 2, 2, 4, 3
+  try:
+    mh = ModelHelper()
+    create_synthetic_checkpoint(mh)
+    lrn = CP.ChannelPrunedLearner(None, mh)
+    with caplog.at_level(logging.INFO, logger='pocketflow_amd'):
+      rslt = lrn.train()
+    assert np.isfinite(rslt['loss'])
+    assert len(lrn.reward_history) == 3 and lrn.bestinfo is not None
+    strategy, acc, flops = lrn.bestinfo
+    n_convs = len(lrn.pruner.thisconvs)
+    assert len(strategy) == n_convs and strategy[0] == 1.0 and strategy[-1] == 1
+    assert all(0 < r <= 1 for r in strategy)
+    assert acc == max(lrn.reward_history)                                  # reward policy 'accuracy'
+    # 'accuracy' policy: the constraint keeps the FLOP target reachable -> the replayed model meets it
+    assert lrn.pruner.preserve_ratio <= 0.5 + 0.08, lrn.pruner.preserve_ratio
+    assert abs(lrn.pruner.compute_model_flops(fake=True) - flops) <= 0.15 * flops     # replay (fresh samples) ~ best roll-out
+    for op in lrn.graph.matmul_ops:
+      if op.name in lrn.fake_pruning_dict and op.var.kind == 'conv':
+        keep_in, keep_out = [np.asarray(k, bool) for k in lrn.fake_pruning_dict[op.name]]
+        w = op.var.to_ref(op.var.master.detach().numpy())
+        assert np.all(w[:, :, ~keep_in, :] == 0) and np.all(w[:, :, :, ~keep_out] == 0), op.name
+  finally:
+    FLAGS.cp_prune_option, FLAGS.ddpg_seed, FLAGS.nb_iters_override = 'uniform', -1, 0
+
+
+def test_channel_pruned_resnet_uniform_on_cpu(cpu_learners, monkeypatch):
+  """Residual network: convolutions fed by a residual sum keep their producer untouched (not W1-prunable) and the last
+  convolution of a block is re-fitted against Y + residual_branch_diff (reference channel_pruner.py:579-586, 611-614)."""
+  FLAGS, fake, tmp = cpu_learners
+  import pocketflow_amd.learners.channel_pruning.learner as CP
+  from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  monkeypatch.setattr(CP, 'hip', fake)
+  monkeypatch.setattr(torch.cuda, 'synchronize', lambda *a, **k: None)
+  FLAGS.batch_size, FLAGS.batch_size_eval, FLAGS.nb_classes, FLAGS.resnet_size = 8, 8, 10, 8
+  FLAGS.cp_prune_option, FLAGS.cp_uniform_preserve_ratio, FLAGS.cp_nb_batches, FLAGS.cp_nb_points_per_layer = 'uniform', 0.5, 4, 10
+  FLAGS.cp_channel_pruned_path = str(tmp / 'models' / 'pruned_model.ckpt')
+  FLAGS.cp_best_path = str(tmp / 'models' / 'best_model.ckpt')
+  FLAGS.cp_original_path = str(tmp / 'models' / 'original_model.ckpt')
+  FLAGS.nb_iters_override, FLAGS.summ_step, FLAGS.synthetic_pool = 2, 2, 4
+  try:
+    mh = ModelHelper()
+    create_synthetic_checkpoint(mh)
+    lrn = CP.ChannelPrunedLearner(None, mh)
+    rslt = lrn.train()
+    assert np.isfinite(rslt['loss'])
+    pr = lrn.pruner
+    names = [c.op.name for c in pr.thisconvs]
+    assert len(names) == 10                                      # stem + 3 x (projection, conv1, conv2)
+    assert len(pr.last_in_resblock) == 3 and len(pr.feats_add) == 3
+    prunable = [pr.is_W1_prunable(c) for c in pr.thisconvs]
+    # stem; block 1: projection + conv1 read BN(stem) (producer = stem), conv2 reads conv1; blocks 2, 3: fed by a sum
+    assert prunable == [False, True, True, True, False, False, True, False, False, True]
+    d = lrn.fake_pruning_dict
+    for c, p in zip(pr.thisconvs[1:-1], prunable[1:-1]):
+      assert 0 < sum(d[c.op.name][0]) < len(d[c.op.name][0])      # every inner layer lost input channels
+    assert all(d[names[0]][0]) and all(d[names[-1]][0])           # first & final layer are never pruned
+    assert 0.2 < pr.preserve_ratio < 0.8
+  finally:
+    FLAGS.nb_iters_override = 0
