@@ -15,6 +15,11 @@ def _setup(tmp_path, **kw):
   import pocketflow_amd.learners.learner_utils  # noqa: F401  (defines flags)
   import pocketflow_amd.learners.abstract_learner  # noqa: F401
   import pocketflow_amd.rl_agents.ddpg.agent  # noqa: F401
+  import pocketflow_amd.learners.weight_sparsification.learner  # noqa: F401
+  import pocketflow_amd.learners.channel_pruning.learner  # noqa: F401
+  import pocketflow_amd.learners.uniform_quantization.learner  # noqa: F401
+  import pocketflow_amd.nets.resnet_at_cifar10  # noqa: F401
+  import pocketflow_amd.nets.mobilenet_at_ilsvrc12  # noqa: F401
   FLAGS.save_path = str(tmp_path / 'models' / 'model.ckpt')
   FLAGS.save_path_eval = str(tmp_path / 'models_eval' / 'model.ckpt')
   FLAGS.synthetic_pool = 2
@@ -54,8 +59,8 @@ def test_inference_mode_bn_gradients_on_gpu():
     v = lambda t: t.view(1, -1, 1, 1)
     yr = torch.relu((xr - v(mm)) * torch.rsqrt(v(mv) + 1e-5) * v(gam) + v(bet))
     (yr * up).sum().backward()
-    scale = lambda t: float(t.abs().max())
-    assert float((y.float() - yr).abs().max()) <= tol * max(1.0, scale(yr))
+    scale = lambda t: float(t.detach().abs().max())
+    assert float((y.detach().float() - yr.detach()).abs().max()) <= tol * max(1.0, scale(yr))
     assert float((x.grad.float() - xr.grad).abs().max()) <= tol * max(1.0, scale(xr.grad))
     assert float((bn.gamma.tensor.grad - gam.grad).abs().max()) <= tol * max(1.0, scale(gam.grad))
     assert float((bn.beta.tensor.grad - bet.grad).abs().max()) <= tol * max(1.0, scale(bet.grad))
