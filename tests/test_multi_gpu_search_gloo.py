@@ -1,0 +1,101 @@
+"""The hyper-parameter searches with world_size 2 on CPU (backend gloo): rank 0 drives the DDPG agent, proposals
+and rewards travel through the mpi_comm shim (object broadcast), every rank runs the roll-out's fine-tune with the
+all-reduced gradients, and both ranks must end with the same decision and the same weights.  The HIP entry points
+are the float32 emulations of tests/fake_hip.py (no GPU here)."""
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def _patch_cpu():
+  sys.path.insert(0, ROOT)
+  sys.path.insert(0, os.path.join(ROOT, 'tests'))
+  from fake_hip import FakeHipFull
+  import pocketflow_amd.graph as G
+  import pocketflow_amd.plan as P
+  import pocketflow_amd.losses as L
+  import pocketflow_amd.optim as Opt
+  import pocketflow_amd.learners.abstract_learner as AL
+  import pocketflow_amd.learners.weight_sparsification.learner as WS
+  import pocketflow_amd.learners.weight_sparsification.pr_optimizer as PR
+  import pocketflow_amd.learners.nonuniform_quantization.utils as NU
+  fake = FakeHipFull()
+  for mod in (G, P, L, Opt, WS, PR, NU):
+    mod.hip = fake
+  AL.require_gpu = lambda: torch.device('cpu')
+  torch.cuda.synchronize = lambda *a, **k: None
+
+
+def _worker(rank, world, port, out_dir, what):
+  os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world),
+                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  torch.set_num_threads(2)
+  _patch_cpu()
+  import pocketflow_amd.learners.learner_utils  # noqa: F401
+  import pocketflow_amd.nets.resnet_at_cifar10 as net
+  from pocketflow_amd.flags import FLAGS
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  from pocketflow_amd.utils.multi_gpu_wrapper import MultiGpuWrapper as mgw
+  import torch.distributed as dist
+  FLAGS.enbl_multi_gpu = True
+  FLAGS.save_path = os.path.join(out_dir, 'models', 'model.ckpt')
+  FLAGS.synthetic_pool, FLAGS.compute_dtype, FLAGS.nb_eval_batches_override = 2, 'float32', 2
+  FLAGS.batch_size, FLAGS.batch_size_eval, FLAGS.nb_classes, FLAGS.resnet_size = 8, 8, 10, 8
+  FLAGS.ddpg_seed = 7
+  mgw.init()
+  mh = net.ModelHelper()
+  if rank == 0:
+    create_synthetic_checkpoint(mh)
+  dist.barrier()
+  if what == 'uq':
+    from pocketflow_amd.learners.uniform_quantization.learner import UniformQuantLearner
+    FLAGS.uql_weight_bits, FLAGS.uql_activation_bits = 4, 32
+    FLAGS.uql_enbl_rl_agent, FLAGS.uql_nb_rlouts, FLAGS.uql_tune_global_steps, FLAGS.uql_equivalent_bits = True, 5, 4, 5
+    FLAGS.uql_tune_save_path = os.path.join(out_dir, 'rl_tune', 'model.ckpt')
+    lrn = UniformQuantLearner(None, mh)
+    decision = [int(b) for b in lrn.optimal_w_bit_list]
+    weights = lrn.graph.store.w_master
+  else:
+    from pocketflow_amd.learners.weight_sparsification.pr_optimizer import PROptimizer
+    import pocketflow_amd.learners.weight_sparsification.learner  # noqa: F401
+    FLAGS.ws_prune_ratio, FLAGS.ws_prune_ratio_prtl = 0.6, 'optimal'
+    FLAGS.ws_nb_rlouts, FLAGS.ws_nb_rlouts_min, FLAGS.ws_nb_iters_rg, FLAGS.ws_nb_iters_ft, FLAGS.ws_nb_iters_feval = 3, 1, 2, 4, 2
+    FLAGS.ws_lrn_rate_rg = 1e-3
+    opt = PROptimizer(mh, lrn_comm())
+    decision = [float(r) for _, r in opt.run()]
+    weights = opt.graph_prnd.store.w_master
+  with open(os.path.join(out_dir, 'rank%d.json' % rank), 'w') as f:
+    json.dump({'decision': decision, 'checksum': float(weights.double().abs().sum()), 'first': weights[:16].tolist()}, f)
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def lrn_comm():
+  from pocketflow_amd.utils.misc_utils import MpiCommShim
+  return MpiCommShim()
+
+
+@pytest.mark.parametrize('what', ['uq', 'ws'])
+def test_search_with_two_ranks(tmp_path, what):
+  world = 2
+  mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), what), nprocs=world, join=True)
+  r0, r1 = [json.load(open(tmp_path / ('rank%d.json' % r))) for r in range(world)]
+  assert r0['decision'] == r1['decision'] and len(r0['decision']) > 0
+  # every rank fine-tuned from the same start with averaged gradients: identical weights
+  assert r0['first'] == r1['first'] and r0['checksum'] == r1['checksum']
