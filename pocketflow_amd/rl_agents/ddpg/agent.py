@@ -180,7 +180,8 @@ class Agent(object):  # pylint: disable=too-many-instance-attributes
       self.noise_spec.adapt(action_dist)
 
     mbatch = self.memory.sample(FLAGS.ddpg_batch_size)
-    if FLAGS.ddpg_enbl_bsln_func:
+    if FLAGS.ddpg_enbl_bsln_func and self.reward_ema is not None:
+      # (the reference would fail with `float - None` if the buffer filled up inside the very first roll-out)
       mbatch['rewards'] -= np.float32(self.reward_ema)
     target_q, actor_loss, critic_loss = self.train_on_batch(mbatch)
     if self.return_rms is not None:
