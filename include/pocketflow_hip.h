@@ -247,6 +247,24 @@ int pf_conv1x1_wrw(const void* dY, const void* X, void* dW, int dw_dtype, float*
                    const float* scale_shift, int act, const uint32_t* slot, int bits, int M, int N,
                    int K, int Ho, int Wo, int H, int Wd, int stride, void* stream);
 
+/* ---- K13: input pipeline tail -----------------------------------------------------------
+ * replaces, per image, the preprocessing chain of utils/external/imagenet_preprocessing.py:226-260 behind the JPEG
+ * decoder: training  random_flip_left_right -> tf.image.resize_images(BILINEAR, align_corners=False) -> - means;
+ *          eval      _aspect_preserving_resize(256) -> _central_crop(224, 224) -> - means
+ * (ilsvrc12_dataset.py:75-93 parse_fn).  `src` holds the decoded uint8 HWC (3-channel) images of one mini-batch back
+ * to back; desc[i] describes image i.  Output: [B][OH][OW][3] in out_dtype (PF_F32 / PF_BF16).
+ * Resize semantics: TF-1.x legacy bilinear (in = out * scale, no half-pixel offset); the flip mirrors the SOURCE.  */
+typedef struct PfImageDesc {
+  int64_t offset;          /* first byte of the image inside src                                                  */
+  int32_t h, w;            /* source height / width                                                               */
+  float scale_y, scale_x;  /* float32(in_size / out_size) of the (virtual) resized image                          */
+  int32_t off_y, off_x;    /* top-left corner of the output window inside the resized image (central crop)        */
+  int32_t flip;            /* 1: mirror the source horizontally before resizing                                   */
+  int32_t reserved;
+} PfImageDesc;
+int pf_image_resize_bilinear(const void* src, const PfImageDesc* desc, void* out, int out_dtype, int B, int OH,
+                             int OW, float mean_r, float mean_g, float mean_b, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

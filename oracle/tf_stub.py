@@ -39,6 +39,7 @@ import types
 import numpy as np
 
 float32, float64, int32, int64 = np.float32, np.float64, np.int32, np.int64
+builtins_range, builtins_slice = range, slice
 
 
 class _Dim(object):
@@ -53,6 +54,8 @@ class _Dim(object):
 
 
 class TensorShape(object):
+  ndims = property(lambda self: len(self.dims))
+
   def __init__(self, dims):
     self.dims = [_Dim(d) for d in dims]
 
@@ -83,6 +86,9 @@ class T(object):
     self.name = name
 
   # -- static shape API ---------------------------------------------------------------------------
+  def set_shape(self, shape):
+    assert tuple(int(d) for d in shape) == tuple(self.a.shape), (shape, self.a.shape)
+
   def get_shape(self):
     return TensorShape(self.a.shape)
 
@@ -129,6 +135,7 @@ class T(object):
       return T(np.asarray(b).astype(np.float64) / self.a.astype(np.float64))
     return T(b / self.a)
 
+  def __floordiv__(self, o): return T(self.a // T._b(o, self.a))
   def __pow__(self, o): return T(self.a ** T._b(o, self.a))
   def __rpow__(self, o): return T(T._b(o, self.a) ** self.a)
 
@@ -166,7 +173,15 @@ def reshape(x, shape, **kw): return T(np.reshape(_raw(x), [int(_raw(s)) for s in
 def ones(shape, dtype=np.float32, **kw): return T(np.ones(int(shape) if np.isscalar(shape) else [int(_raw(s)) for s in shape], dtype=dtype))
 def zeros(shape, dtype=np.float32, **kw): return T(np.zeros(shape, dtype=dtype))
 def concat(values, axis=0, **kw): return T(np.concatenate([np.atleast_1d(np.asarray(_raw(v))) for v in values], axis=axis))
-def expand_dims(x, axis, **kw): return T(np.expand_dims(_raw(x), int(axis)))
+def _py_default(x):
+  """Python numbers / lists become float32 / int32 tensors (tf.convert_to_tensor defaults)."""
+  if isinstance(x, (T, np.ndarray, np.generic)):
+    return _raw(x)
+  a = np.asarray(_raw(x))
+  return a.astype(np.float32) if a.dtype == np.float64 else (a.astype(np.int32) if a.dtype == np.int64 else a)
+
+
+def expand_dims(x, axis, **kw): return T(np.expand_dims(_py_default(x), int(axis)))
 def tile(x, multiples, **kw): return T(np.tile(_raw(x), [int(m) for m in np.asarray(_raw(multiples)).reshape(-1)]))
 def transpose(x, perm=None, **kw): return T(np.transpose(_raw(x), perm))
 def gather(params, indices, axis=0, **kw): return T(np.take(_raw(params), np.asarray(_raw(indices)), axis=axis))
@@ -444,6 +459,67 @@ def sigmoid(x, **kw):
 def shape(x, **kw): return T(np.array(np.shape(_raw(x)), dtype=np.int32))          # noqa: A001
 
 
+# -- tf.image (utils/external/imagenet_preprocessing.py) ---------------------------------------------------------
+image_hooks = {}     # 'window': (y, x, h, w) returned by sample_distorted_bounding_box; 'flip': bool
+
+
+def _decode_jpeg(contents, channels=3, **kw):
+  """libjpeg via Pillow (islow DCT, fancy upsampling: TF's defaults)."""
+  import io
+  from PIL import Image
+  img = Image.open(io.BytesIO(bytes(_raw(contents).tobytes() if isinstance(_raw(contents), np.ndarray) else _raw(contents))))
+  return T(np.asarray(img.convert('RGB' if channels == 3 else 'L'), dtype=np.uint8))
+
+
+def _extract_jpeg_shape(contents, **kw):
+  return T(np.array(_decode_jpeg(contents).a.shape, dtype=np.int32))
+
+
+def _sample_distorted_bounding_box(image_size, bounding_boxes, **kw):
+  y, x, h, w = image_hooks['window']
+  return T(np.array([y, x, 0], np.int32)), T(np.array([h, w, -1], np.int32)), None
+
+
+def _decode_and_crop_jpeg(contents, crop_window, channels=3, **kw):
+  y, x, h, w = [int(v) for v in np.asarray(_raw(crop_window)).reshape(-1)]
+  return T(_decode_jpeg(contents, channels).a[y:y + h, x:x + w])
+
+
+def _random_flip_left_right(image, **kw):
+  return T(_raw(image)[:, ::-1]) if image_hooks['flip'] else T(_raw(image))
+
+
+def _resize_images(images, size, method=0, align_corners=False, **kw):
+  """tf.image.resize_images(BILINEAR, align_corners=False) of TF 1.x [3P] (resize_bilinear_op.cc, legacy scaler):
+  in = out * (in_size / (float) out_size); lo = floor(in); hi = min(ceil(in), in_size - 1); lerp = in - lo;
+  out = top + (bottom - top) * ylerp with top = tl + (tr - tl) * xlerp; float32 throughout.  Written as plain loops
+  on purpose (the oracle's vectorised version is checked against this one through the fixtures)."""
+  assert method == 0 and not align_corners
+  img = np.asarray(_raw(images)).astype(np.float32)
+  ih, iw, ch = img.shape
+  oh, ow = [int(_raw(v)) for v in size]
+  sy, sx = np.float32(ih) / np.float32(oh), np.float32(iw) / np.float32(ow)
+  out = np.zeros((oh, ow, ch), np.float32)
+  for y in builtins_range(oh):
+    iy = np.float32(y) * sy
+    y0 = int(np.floor(iy)); y1 = min(int(np.ceil(iy)), ih - 1); ly = np.float32(iy - np.floor(iy))
+    for x in builtins_range(ow):
+      ix = np.float32(x) * sx
+      x0 = int(np.floor(ix)); x1 = min(int(np.ceil(ix)), iw - 1); lx = np.float32(ix - np.floor(ix))
+      top = img[y0, x0] + (img[y0, x1] - img[y0, x0]) * lx
+      bot = img[y1, x0] + (img[y1, x1] - img[y1, x0]) * lx
+      out[y, x] = top + (bot - top) * ly
+  return T(out)
+
+
+def unstack(x, **kw): return [T(v) for v in np.asarray(_raw(x))]
+def stack(values, axis=0, **kw): return T(np.stack([np.asarray(_raw(v)) for v in values], axis=axis))
+def slice(x, begin, size, **kw):                                                   # noqa: A001
+  a = np.asarray(_raw(x))
+  idx = tuple(builtins_slice(int(_raw(b)), None if int(_raw(s)) < 0 else int(_raw(b)) + int(_raw(s))) for b, s in zip(begin, size))
+  return T(a[idx])
+
+
 def _max_pooling2d(inputs, pool_size, strides, padding='valid', data_format='channels_last', **kw):
   import torch
   import torch.nn.functional as F
@@ -609,7 +685,7 @@ def install() -> types.ModuleType:
   this = sys.modules[__name__]
   tf = _ns('tensorflow')
   for k in dir(this):
-    if not k.startswith('_') and k not in ('install', 'sys', 'types', 'np', 'contextlib', 'annotations'):
+    if not k.startswith('_') and k not in ('install', 'sys', 'types', 'np', 'contextlib', 'annotations', 'builtins_range', 'builtins_slice', 'image_hooks'):
       setattr(tf, k, getattr(this, k))
   flags = _Flags()
   tf.app = _ns('tensorflow.app', flags=flags, run=lambda *a, **k: None)
@@ -628,6 +704,10 @@ def install() -> types.ModuleType:
   tf.summary = _ns('tensorflow.summary', scalar=lambda *a, **k: None)
   tf.layers = _ns('tensorflow.layers', conv2d=_conv2d, batch_normalization=_batch_normalization, dense=_dense,
                   max_pooling2d=_max_pooling2d, flatten=_flatten)
+  tf.image = _ns('tensorflow.image', decode_jpeg=_decode_jpeg, extract_jpeg_shape=_extract_jpeg_shape,
+                 sample_distorted_bounding_box=_sample_distorted_bounding_box, decode_and_crop_jpeg=_decode_and_crop_jpeg,
+                 random_flip_left_right=_random_flip_left_right, resize_images=_resize_images,
+                 ResizeMethod=_ns('ResizeMethod', BILINEAR=0))
   tf.test = _ns('tensorflow.test', is_built_with_cuda=lambda: False)
   tf.logging = _ns('tensorflow.logging', info=lambda *a, **k: None, warning=lambda *a, **k: None, debug=lambda *a, **k: None,
                    error=lambda *a, **k: None)

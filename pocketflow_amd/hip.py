@@ -42,7 +42,7 @@ SYMBOLS = [
     'pf_bn_act_quant_apply', 'pf_bn_bwd_stats', 'pf_bn_bwd_finalize', 'pf_bn_bwd_apply', 'pf_bn_bwd_apply_add',
     'pf_bn_eval_scale_shift', 'pf_gemm_bf16_nt', 'pf_gemm_bf16_nn', 'pf_gemm_bf16_tn',
     'pf_conv1x1_stats_groups', 'pf_conv1x1_fwd', 'pf_conv1x1_bwd_data_bnstats', 'pf_conv1x1_wrw_splits',
-    'pf_conv1x1_wrw',
+    'pf_conv1x1_wrw', 'pf_image_resize_bilinear',
 ]
 
 
@@ -337,3 +337,21 @@ def conv1x1_bwd_data_bnstats(dY, Wt, dQ, bn_x, bn_scale_shift, bn_mean_invstd, b
   _check(_lib.pf_conv1x1_bwd_data_bnstats(_ptr(dY), _ptr(Wt), _ptr(dQ), _ptr(bn_x), _ptr(bn_scale_shift),
                                           _ptr(bn_mean_invstd), c_int(ACT_CODES[bn_act]), _ptr(partial), c_int(M),
                                           c_int(N), c_int(K), _stream()), 'pf_conv1x1_bwd_data_bnstats')
+
+
+# ------------------------------------------------------------------------------------------------
+# input pipeline tail
+# ------------------------------------------------------------------------------------------------
+
+IMAGE_DESC_DTYPE = np.dtype([('offset', '<i8'), ('h', '<i4'), ('w', '<i4'), ('scale_y', '<f4'), ('scale_x', '<f4'),
+                             ('off_y', '<i4'), ('off_x', '<i4'), ('flip', '<i4'), ('reserved', '<i4')])   # = PfImageDesc
+
+
+def image_resize_bilinear(src_u8, desc_u8, out, mean) -> None:
+  """out [B, OH, OW, 3] (float32 / bfloat16) <- TF-1.x bilinear resize (+ flip, window, - mean) of the packed uint8
+  HWC images in `src_u8`, described by `desc_u8` (the bytes of an IMAGE_DESC_DTYPE array, on the device)."""
+  B, OH, OW, C = out.shape
+  assert C == 3 and out.is_contiguous() and desc_u8.numel() == B * IMAGE_DESC_DTYPE.itemsize
+  _check(_lib.pf_image_resize_bilinear(_ptr(src_u8), _ptr(desc_u8), _ptr(out), c_int(dtype_code(out)), c_int(B),
+                                       c_int(OH), c_int(OW), c_float(mean[0]), c_float(mean[1]), c_float(mean[2]),
+                                       _stream()), 'pf_image_resize_bilinear')

@@ -195,7 +195,7 @@ def _real_constants():
   from pocketflow_amd import hip as real
   return {k: getattr(real, k) for k in ('PF_F32', 'PF_BF16', 'PF_ACT_NONE', 'PF_ACT_RELU', 'PF_ACT_RELU6',
                                         'PF_BUCKET_TENSOR', 'PF_BUCKET_CHANNEL', 'PF_BUCKET_SPLIT', 'PF_CHUNK',
-                                        'SEG_DTYPE', 'BLOCK_DTYPE', 'ACT_CODES')}
+                                        'SEG_DTYPE', 'BLOCK_DTYPE', 'ACT_CODES', 'IMAGE_DESC_DTYPE')}
 
 
 class FakeHipFull(FakeHip):
@@ -373,3 +373,26 @@ class FakeHipFull(FakeHip):
     m.fill_(1.0)
     m[:, :, ~keep_in.bool()] = 0
     m[~keep_out.bool()] = 0
+
+  # -- input pipeline tail ----------------------------------------------------------------------------------------------
+  def image_resize_bilinear(self, src_u8, desc_u8, out, mean):
+    """pf_image_resize_bilinear, element by element from the PfImageDesc semantics (include/pocketflow_hip.h)."""
+    table = np.frombuffer(desc_u8.cpu().numpy().tobytes(), dtype=self.IMAGE_DESC_DTYPE)
+    src = src_u8.cpu().numpy()
+    B, OH, OW, _ = out.shape
+    res = np.zeros((B, OH, OW, 3), np.float32)
+    for b, d in enumerate(table):
+      h, w = int(d['h']), int(d['w'])
+      img = src[int(d['offset']):int(d['offset']) + h * w * 3].reshape(h, w, 3).astype(np.float32)
+      if d['flip']:
+        img = img[:, ::-1]
+      for y in range(OH):
+        iy = np.float32(y + int(d['off_y'])) * np.float32(d['scale_y'])
+        y0 = int(np.floor(iy)); y1 = min(int(np.ceil(iy)), h - 1); ly = np.float32(iy - np.floor(iy))
+        ix = (np.arange(OW) + int(d['off_x'])).astype(np.float32) * np.float32(d['scale_x'])
+        x0 = np.floor(ix).astype(np.int64); x1 = np.minimum(np.ceil(ix).astype(np.int64), w - 1)
+        lx = (ix - np.floor(ix)).astype(np.float32)[:, None]
+        top = img[y0, x0] + (img[y0, x1] - img[y0, x0]) * lx
+        bot = img[y1, x0] + (img[y1, x1] - img[y1, x0]) * lx
+        res[b, y] = (top + (bot - top) * ly) - np.asarray(mean, np.float32)
+    out.copy_(torch.from_numpy(res).to(out.dtype))
