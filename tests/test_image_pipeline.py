@@ -122,3 +122,75 @@ def test_resize_kernel_matches_oracle_on_gpu(dtype):
     assert np.array_equal(got, want)                         # same float32 operation order: bit-exact
   else:
     assert np.array_equal(got, torch.from_numpy(want).to(torch.bfloat16).float().numpy())
+
+
+# -- TFRecord dataset end to end (CPU, kernel emulated) ---------------------------------------------------------------------
+def _write_shards(tmp_path, prefix, nb_files, per_file, hw=(48, 64), first_label=1):
+  from PIL import Image
+  from pocketflow_amd.datasets.tfrecord import make_example, write_records
+  rng = np.random.RandomState(3)
+  label, images = first_label, {}
+  for k in range(nb_files):
+    recs = []
+    for _ in range(per_file):
+      h, w = hw[0] + rng.randint(0, 9), hw[1] + rng.randint(0, 9)
+      base = np.clip(rng.randint(0, 256, (1, 1, 3)) + 20 * np.sin(np.arange(h)[:, None, None] / 5.0) + np.zeros((h, w, 3)), 0, 255)
+      buf = io.BytesIO()
+      Image.fromarray(base.astype(np.uint8)).save(buf, format='JPEG', quality=95)
+      recs.append(make_example({'image/encoded': buf.getvalue(), 'image/class/label': np.array([label], np.int64),
+                                'image/class/text': b'n%08d' % label,
+                                'image/object/bbox/xmin': np.array([0.1], np.float32), 'image/object/bbox/ymin': np.array([0.2], np.float32),
+                                'image/object/bbox/xmax': np.array([0.9], np.float32), 'image/object/bbox/ymax': np.array([0.8], np.float32)}))
+      images[label] = buf.getvalue()
+      label += 1
+    write_records(str(tmp_path / ('%s-%05d-of-%05d' % (prefix, k, nb_files))), recs)
+  return images
+
+
+def test_ilsvrc12_tfrecord_dataset_on_cpu(fake_image_kernel, tmp_path, monkeypatch):
+  from oracle import image_oracle as O
+  import pocketflow_amd.datasets.ilsvrc12_dataset as D
+  from pocketflow_amd.flags import FLAGS
+  train_imgs = _write_shards(tmp_path, 'train', 3, 7)
+  val_imgs = _write_shards(tmp_path, 'validation', 2, 5, first_label=500)
+  FLAGS.data_dir_local, FLAGS.batch_size, FLAGS.batch_size_eval, FLAGS.image_size = str(tmp_path), 4, 5, 32
+  FLAGS.nb_classes, FLAGS.nb_smpls_val, FLAGS.buffer_size, FLAGS.nb_threads, FLAGS.prefetch_size = 1001, 6, 8, 2, 2
+  # evaluation: file order, no shuffling, exact preprocessing of every image
+  it = D.Ilsvrc12Dataset(is_train=False).build()
+  seen = []
+  for _ in range(2):
+    images, labels = it.get_next()
+    assert images.shape == (5, 32, 32, 3) and images.dtype == torch.float32 and labels.shape == (5, 1001)
+    for k in range(5):
+      lab = int(labels[k].argmax())
+      assert float(labels[k].sum()) == 1.0
+      seen.append(lab)
+      want = O.preprocess_eval(np.asarray(__import__('PIL.Image', fromlist=['x']).open(io.BytesIO(val_imgs[lab])).convert('RGB')), 32, 32)
+      assert np.array_equal(images[k].numpy(), want)
+  assert seen == [500, 505, 501, 506, 502, 507, 503, 508, 504, 509]           # round-robin interleave of the two shards
+  images, labels = it.get_next()                                             # repeat(): starts over
+  assert int(labels[0].argmax()) == 500
+  it.close()
+  # training: every record of the split shows up, shuffled, augmented; the validation split is disjoint
+  it_trn, it_val = D.Ilsvrc12Dataset(is_train=True).build(enbl_trn_val_split=True)
+  val_labels = set()
+  for _ in range(3):
+    images, labels = it_val.get_next()
+    val_labels.update(int(l.argmax()) for l in labels)
+  assert len(val_labels) == 6
+  trn_labels = []
+  for _ in range(12):
+    images, labels = it_trn.get_next()
+    assert images.shape == (4, 32, 32, 3) and torch.isfinite(images).all()
+    assert float(images.max()) <= 255 - 103.94 + 1e-3 and float(images.min()) >= -123.68 - 1e-3
+    trn_labels += [int(l.argmax()) for l in labels]
+  assert set(trn_labels) == set(train_imgs) - val_labels and len(set(trn_labels)) == 15
+  assert trn_labels[:15] != sorted(trn_labels[:15])                          # shuffled
+  # seeded: a second iterator reproduces the stream
+  it2, _v = D.Ilsvrc12Dataset(is_train=True).build(enbl_trn_val_split=True)
+  again = []
+  for _ in range(3):
+    again += [int(l.argmax()) for l in it2.get_next()[1]]
+  assert again == trn_labels[:12]
+  for i in (it_trn, it_val, it2, _v):
+    i.close()
