@@ -32,7 +32,10 @@ def create_learner(sm_writer, model_helper):
   elif FLAGS.learner == 'non-uniform':
     from pocketflow_amd.learners.nonuniform_quantization.learner import NonUniformQuantLearner
     learner = NonUniformQuantLearner(sm_writer, model_helper)
-  elif FLAGS.learner in ('chn-pruned-gpu', 'chn-pruned-rmt', 'dis-chn-pruned', 'uniform-tf'):
+  elif FLAGS.learner == 'chn-pruned-gpu':
+    from pocketflow_amd.learners.channel_pruning_gpu.learner import ChannelPrunedGpuLearner
+    learner = ChannelPrunedGpuLearner(sm_writer, model_helper)
+  elif FLAGS.learner in ('chn-pruned-rmt', 'dis-chn-pruned', 'uniform-tf'):
     raise ValueError('learner %r is outside the MI355X hot path (SURVEY section 2, rows 9-12)' % FLAGS.learner)
   else:
     raise ValueError('unrecognized learner\'s name: ' + FLAGS.learner)

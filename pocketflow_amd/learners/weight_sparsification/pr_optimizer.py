@@ -25,7 +25,6 @@ from __future__ import annotations
 import logging
 import math
 import os
-from collections import OrderedDict
 from timeit import default_timer as timer
 
 import numpy as np
@@ -33,6 +32,7 @@ import torch
 
 from pocketflow_amd import hip
 from pocketflow_amd.flags import FLAGS
+from pocketflow_amd.learners.layerwise import forward_tapped, layers_of_vars
 from pocketflow_amd.learners.weight_sparsification.rl_helper import RLHelper
 from pocketflow_amd.learners.weight_sparsification.utils import get_maskable_vars
 from pocketflow_amd.rl_agents.ddpg.agent import Agent as DdpgAgent
@@ -165,23 +165,11 @@ class PROptimizer(object):  # pylint: disable=too-many-instance-attributes
     self.core_prnd = self.__layers_by_var(self.graph_prnd, self.vars_prnd['maskable'], images)
 
   def __layers_by_var(self, graph, maskable, images):
-    taps = self.__forward_tapped(graph, images, None)
-    by_var = {id(layer.kernel): layer for layer in taps}
-    return [by_var[id(v)] for v in maskable]
+    return layers_of_vars(graph, self.model_helper.forward_eval, images, maskable)
 
   def __forward_tapped(self, graph, images, stop_layer):
-    """Inference forward pass in tap mode (no gradients) up to `stop_layer`; returns {layer: (input, output, _)}."""
-    from pocketflow_amd.graph import TapStop, to_device_images
-    graph.taps, graph.tap_dense, graph.tap_stop = OrderedDict(), True, stop_layer
-    try:
-      with torch.no_grad(), graph.as_default():
-        try:
-          self.model_helper.forward_eval(to_device_images(images, graph))
-        except TapStop:
-          pass
-      return graph.taps
-    finally:
-      graph.taps, graph.tap_dense, graph.tap_stop = None, False, None
+    """Inference forward pass in tap mode (no gradients) up to `stop_layer` (learners/layerwise.py)."""
+    return forward_tapped(graph, self.model_helper.forward_eval, images, stop_layer)
 
   def __build_rl_helper_n_agent(self):
     skip_head_n_tail = (self.dataset_name == 'cifar_10')  # skip head & tail layers on CIFAR-10

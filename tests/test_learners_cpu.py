@@ -550,3 +550,69 @@ def test_channel_pruned_resnet_uniform_on_cpu(cpu_learners, monkeypatch):
     assert 0.2 < pr.preserve_ratio < 0.8
   finally:
     FLAGS.nb_iters_override = 0
+
+
+def test_proximal_shrink_against_numpy():
+  """W <- W' * max(1 - tau / ||W'_c||, 0), tau = nearest-rank percentile of the channel norms
+  (reference channel_pruning_gpu/learner.py:369-376)."""
+  from oracle import pf_oracle as O
+  from pocketflow_amd.learners.channel_pruning_gpu.learner import proximal_shrink
+  rng = np.random.RandomState(0)
+  w_hwio = (rng.randn(3, 3, 12, 7) * rng.rand(1, 1, 12, 1)).astype(np.float32)
+  w_hwio[:, :, 5, :] = 0                                                # an already dead channel
+  for perctl in (0.0, 10.0, 37.5, 50.0, 100.0):
+    norm = np.sqrt(np.sum(np.square(w_hwio), axis=(0, 1, 3), keepdims=True))
+    thr = O.percentile_nearest(norm, np.float32(perctl))
+    with np.errstate(divide='ignore', invalid='ignore'):
+      shrk = np.maximum(1.0 - thr / norm, 0.0)
+    shrk = np.where(np.isnan(shrk), 0.0, shrk)
+    want = w_hwio * shrk
+    w_krsc = torch.from_numpy(np.ascontiguousarray(w_hwio.transpose(3, 0, 1, 2)).reshape(7, 9, 12))
+    got, n = proximal_shrink(w_krsc, perctl)
+    got_hwio = got.numpy().reshape(7, 3, 3, 12).transpose(1, 2, 3, 0)
+    np.testing.assert_allclose(got_hwio, want, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(n.numpy(), norm.reshape(-1), rtol=1e-6)
+    dead = int(np.sum(np.all(got_hwio == 0, axis=(0, 1, 3))))
+    assert dead >= int(np.floor(12 * perctl / 100.0)) or perctl == 0.0
+
+
+def test_channel_pruned_gpu_learner_on_cpu(cpu_learners, monkeypatch, caplog):
+  """'chn-pruned-gpu' (reference learners/channel_pruning_gpu/learner.py): proximal-gradient channel selection layer by
+  layer against the full network, masked per-layer re-fit, masked whole-network fine-tune."""
+  import logging
+  FLAGS, fake, tmp = cpu_learners
+  import pocketflow_amd.learners.channel_pruning_gpu.learner as CPG
+  import pocketflow_amd.learners.weight_sparsification.learner as WS
+  from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
+  from pocketflow_amd.learners.learner_utils import create_learner, create_synthetic_checkpoint
+  monkeypatch.setattr(CPG, 'hip', fake)
+  monkeypatch.setattr(WS, 'hip', fake)
+  FLAGS.batch_size, FLAGS.batch_size_eval, FLAGS.nb_classes, FLAGS.resnet_size = 8, 8, 10, 8
+  FLAGS.learner, FLAGS.cpg_prune_ratio, FLAGS.cpg_nb_iters_layer, FLAGS.cpg_lrn_rate_pgd_init = 'chn-pruned-gpu', 0.5, 6, 1e-6
+  FLAGS.cpg_save_path = str(tmp / 'cpg' / 'model.ckpt')
+  FLAGS.cpg_save_path_eval = str(tmp / 'cpg_eval' / 'model.ckpt')
+  FLAGS.nb_iters_override, FLAGS.summ_step = 3, 2
+  mh = ModelHelper()
+  create_synthetic_checkpoint(mh)
+  lrn = create_learner(None, mh)
+  assert isinstance(lrn, CPG.ChannelPrunedGpuLearner) and lrn.nb_layers == 10
+  full_before = lrn.graph_full.store.export_numpy()
+  with caplog.at_level(logging.INFO, logger='pocketflow_amd'):
+    rslt = lrn.train()
+  assert np.isfinite(rslt['loss']) and 0.0 < rslt['pr_msk'] < 0.6
+  vals = lrn.graph.store.export_numpy()
+  for idx, var in enumerate(lrn.vars_prnd['maskable']):
+    w = vals[var.name]
+    dead = np.all(w == 0, axis=(0, 1, 3))
+    m = var.to_ref(lrn.masks[var.offset:var.offset + var.numel].numpy())
+    if idx in (0, lrn.nb_layers - 1):
+      assert not dead.any() and np.all(m == 1)                          # head & tail are skipped
+      continue
+    cin = w.shape[2]
+    assert dead.sum() >= cin // 2 and dead.sum() < cin, (var.name, dead.sum())      # >= 50 % of the input channels are gone
+    assert np.array_equal(np.all(m == 0, axis=(0, 1, 3)), dead) and set(np.unique(m)) <= {0.0, 1.0}
+    assert abs(lrn.actual_prune_ratios[idx] - dead.mean()) < 1e-9
+  # the full network is untouched (weights and BN statistics)
+  for k, v in lrn.graph_full.store.export_numpy().items():
+    assert np.array_equal(v, full_before[k]), k
+  assert sum('(actual)' in r.getMessage() for r in caplog.records) == 8

@@ -20,6 +20,7 @@ def _setup(tmp_path, **kw):
   import pocketflow_amd.learners.uniform_quantization.learner  # noqa: F401
   import pocketflow_amd.nets.resnet_at_cifar10  # noqa: F401
   import pocketflow_amd.nets.mobilenet_at_ilsvrc12  # noqa: F401
+  import pocketflow_amd.learners.channel_pruning_gpu.learner  # noqa: F401
   FLAGS.save_path = str(tmp_path / 'models' / 'model.ckpt')
   FLAGS.save_path_eval = str(tmp_path / 'models_eval' / 'model.ckpt')
   FLAGS.synthetic_pool = 2
@@ -135,3 +136,27 @@ def test_channel_pruning_search(tmp_path):
   assert len(lrn.reward_history) == 2 and len(strategy) == len(lrn.pruner.thisconvs)
   assert strategy[0] == 1.0 and strategy[-1] == 1 and all(0 < r <= 1 for r in strategy)
   assert lrn.pruner.preserve_ratio <= 0.5 + 0.08
+
+
+def test_channel_pruned_gpu_learner(tmp_path):
+  """'chn-pruned-gpu': proximal-gradient channel selection against the full network, all on the device."""
+  from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
+  from pocketflow_amd.learners.learner_utils import create_learner, create_synthetic_checkpoint
+  import pocketflow_amd.learners.channel_pruning_gpu.learner as CPG
+  FLAGS = _setup(tmp_path, batch_size=16, batch_size_eval=16, resnet_size=8, nb_classes=10, learner='chn-pruned-gpu',
+                 cpg_prune_ratio=0.5, cpg_nb_iters_layer=6, cpg_lrn_rate_pgd_init=1e-6,
+                 cpg_save_path=str(tmp_path / 'cpg' / 'model.ckpt'), cpg_save_path_eval=str(tmp_path / 'cpg_eval' / 'model.ckpt'),
+                 nb_iters_override=3, summ_step=2)
+  mh = ModelHelper()
+  create_synthetic_checkpoint(mh)
+  lrn = create_learner(None, mh)
+  assert isinstance(lrn, CPG.ChannelPrunedGpuLearner)
+  rslt = lrn.train()
+  assert np.isfinite(rslt['loss']) and 0.0 < rslt['pr_msk'] < 0.6
+  vals = lrn.graph.store.export_numpy()
+  for idx, var in enumerate(lrn.vars_prnd['maskable']):
+    dead = np.all(vals[var.name] == 0, axis=(0, 1, 3))
+    if idx in (0, lrn.nb_layers - 1):
+      assert not dead.any()
+    else:
+      assert vals[var.name].shape[2] // 2 <= dead.sum() < vals[var.name].shape[2]
