@@ -11,7 +11,7 @@ Discontinuities.  An 8-bit activation fake-quant (and a pruning-mask refresh) is
 its input: float32 summation-order noise (1e-7) moves an activation maximum by one ulp, a handful of
 elements per layer land on the other side of a rounding boundary and change by one quantisation step
 (alpha / 255), and a deep BN network turns that into ~1e-3 relative loss noise -- between ANY two
-correct float32 implementations (measured: tools/gpu/debug_parity2.py).  Tight bars are therefore
+correct float32 implementations (measured: tools/gpu/quantiser_discontinuity_probe.py).  Tight bars are therefore
 asserted where the path is continuous (activation bits 32 = the reference's default,
 uq learner.py:38), every discontinuous op is pinned bit-exactly under identical inputs in
 tests/test_kernels_gpu.py, and the 8-bit-activation runs get a statistical bar (loss within 1e-2,
