@@ -1,0 +1,78 @@
+"""Static guards for the rules this repository is built under: the product never touches the oracle, nothing that
+runs on the GPU box reads /root/reference, every kernel source is part of the build, the header and the ctypes
+binding agree.  No GPU."""
+import ast
+import glob
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _py(pattern):
+  return sorted(glob.glob(os.path.join(ROOT, pattern), recursive=True))
+
+
+def _imports(path):
+  tree = ast.parse(open(path).read())
+  for node in ast.walk(tree):
+    if isinstance(node, ast.Import):
+      for a in node.names:
+        yield a.name
+    elif isinstance(node, ast.ImportFrom) and node.module:
+      yield node.module
+
+
+def test_product_never_imports_the_oracle_or_the_tests():
+  for path in _py('pocketflow_amd/**/*.py'):
+    for mod in _imports(path):
+      top = mod.split('.')[0]
+      assert top not in ('oracle', 'tests', 'fake_hip'), '%s imports %s' % (os.path.relpath(path, ROOT), mod)
+    assert not re.search(r'''(import_module|__import__)\(\s*['"](oracle|tests|fake_hip)''', open(path).read()), os.path.relpath(path, ROOT)
+
+
+def test_only_allowed_callers_use_the_oracle():
+  allowed = {'bench.py', '__graft_entry__.py'}
+  for path in _py('*.py') + _py('tools/**/*.py') + _py('scripts/**/*.py'):
+    rel = os.path.relpath(path, ROOT)
+    uses = any(m.split('.')[0] == 'oracle' for m in _imports(path))
+    if uses:
+      assert rel in allowed or rel.startswith('tools/gpu/'), rel      # tools/gpu: diagnostics, not shipped paths
+  # bench.py may only use it in its cpu_baseline leg
+  src = open(os.path.join(ROOT, 'bench.py')).read()
+  for m in re.finditer(r'oracle', src):
+    ctx = src[max(0, m.start() - 1500):m.start()]
+    assert 'cpu_baseline' in ctx or 'cpu baseline' in ctx.lower() or 'time_cpu_baseline' in src[m.start():m.start() + 200], m.start()
+
+
+def test_nothing_on_the_gpu_box_reads_the_reference_tree():
+  for path in _py('tests/*.py') + _py('pocketflow_amd/**/*.py') + [os.path.join(ROOT, 'bench.py'), os.path.join(ROOT, '__graft_entry__.py')]:
+    src = open(path).read()
+    code = '\n'.join(l for l in src.split('\n'))
+    for m in re.finditer(r'/root/reference', code):
+      line = code[code.rfind('\n', 0, m.start()) + 1:code.find('\n', m.start())]
+      # only prose (docstrings / comments citing reference files) may mention the tree
+      assert 'open(' not in line and 'sys.path' not in line and 'os.path.join' not in line, (os.path.relpath(path, ROOT), line)
+  # the fixture generators (build container only) are the one place that opens it
+  gens = [os.path.basename(p) for p in _py('tests/golden/*.py')]
+  assert sorted(gens) == ['make_reference_golden.py', 'make_reference_image_golden.py', 'make_reference_rl_golden.py']
+
+
+def test_every_kernel_source_is_built_and_every_symbol_is_bound():
+  build = open(os.path.join(ROOT, 'pocketflow_amd/csrc/build.sh')).read()
+  for path in _py('pocketflow_amd/csrc/*.hip'):
+    assert os.path.basename(path)[:-4] in build, path
+  header = open(os.path.join(ROOT, 'include/pocketflow_hip.h')).read()
+  declared = set(re.findall(r'\b(pf_[a-z0-9_]+)\s*\(', header))
+  from pocketflow_amd import hip
+  assert declared == set(hip.SYMBOLS), declared ^ set(hip.SYMBOLS)
+  # struct layouts mirrored in NumPy dtypes
+  import ctypes
+
+  class _Desc(ctypes.Structure):
+    _fields_ = [('offset', ctypes.c_int64), ('h', ctypes.c_int32), ('w', ctypes.c_int32), ('scale_y', ctypes.c_float),
+                ('scale_x', ctypes.c_float), ('off_y', ctypes.c_int32), ('off_x', ctypes.c_int32), ('flip', ctypes.c_int32),
+                ('reserved', ctypes.c_int32)]
+  assert ctypes.sizeof(_Desc) == hip.IMAGE_DESC_DTYPE.itemsize == 40
+  for f, _t in _Desc._fields_:
+    assert getattr(_Desc, f).offset == hip.IMAGE_DESC_DTYPE.fields[f][1], f
