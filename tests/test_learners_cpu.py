@@ -616,3 +616,27 @@ def test_channel_pruned_gpu_learner_on_cpu(cpu_learners, monkeypatch, caplog):
   for k, v in lrn.graph_full.store.export_numpy().items():
     assert np.array_equal(v, full_before[k]), k
   assert sum('(actual)' in r.getMessage() for r in caplog.records) == 8
+
+
+@pytest.mark.parametrize('net', ['resnet', 'lenet'])
+def test_full_prec_learner_on_cpu(cpu_learners, monkeypatch, net):
+  """FullPrecLearner (the teacher's trainer and the container of the frozen teacher): Momentum steps with the nets'
+  own learning-rate schedule against the oracle learner."""
+  FLAGS, fake, tmp = cpu_learners
+  from oracle.learner_oracle import OracleLearner
+  from pocketflow_amd.learners.full_precision.learner import FullPrecLearner
+  monkeypatch.setattr(torch.cuda, 'synchronize', lambda *a, **k: None)
+  FLAGS.batch_size, FLAGS.batch_size_eval, FLAGS.nb_classes = 8, 8, 10
+  if net == 'resnet':
+    from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
+    FLAGS.resnet_size = 20
+  else:
+    from pocketflow_amd.nets.lenet_at_cifar10 import ModelHelper
+  lrn = FullPrecLearner(None, ModelHelper())
+  ora = OracleLearner(lrn.graph.store.export_numpy(), _cfg(FLAGS, net, 'cifar_10', (32, 32, 3), learner='full-prec'), lrn.lrn_rate)
+  pool = _pool(lrn.iter_train)
+  for step in range(3):
+    lr, loss, _ = lrn.train_step()
+    ref = ora.train_step(*pool[step % 2])
+    assert abs(float(loss.detach()) - ref['loss']) <= 1e-4 * max(1.0, abs(ref['loss'])), (step, float(loss), ref['loss'])
+  assert _max_rel(lrn.graph.store.export_numpy(), {k: v for k, v in ora.export().items() if 'moving_' not in k}) <= 1e-4
