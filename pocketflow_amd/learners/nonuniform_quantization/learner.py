@@ -142,6 +142,16 @@ class NonUniformQuantLearner(AbstractLearner):
   def __op_reset_ft_step(self):
     self.ft_step = 0
 
+  def __op_layerwise_tune(self, n, w_bits, a_bits):
+    """layerwise_tune_ops[n] + layerwise_diff[n] under a bit-width feed (nuq learner.py:383-385)."""
+    from pocketflow_amd.learners.layerwise import LayerwiseTuner, layers_of_vars
+    self.nonuni_quant.feed_bits(w_bits, a_bits)
+    images, __ = self.iter_train.get_next()
+    if getattr(self, '_layer_tuner', None) is None:
+      layers = layers_of_vars(self.graph, self.forward_eval, images, [op.var for op in self.nonuni_quant.matmul_ops])
+      self._layer_tuner = LayerwiseTuner(self.graph, self.forward_train, layers)
+    return self._layer_tuner.step(n, images, self.nonuni_quant.quantize_weights)
+
   def init_clusters(self):
     """ops['cluster_init'] (+ bcast) -- after the weights are in place."""
     self.nonuni_quant.cluster_init()
@@ -269,6 +279,7 @@ class NonUniformQuantLearner(AbstractLearner):
     self.ops['bcast'] = mgw.broadcast_global_variables(0, [st], [optimizer]) if FLAGS.enbl_multi_gpu else None
     self.ops.update({'non_cluster_init': self.__op_non_cluster_init, 'cluster_init': self.__op_cluster_init,
                      'train': self.__op_train, 'eval': self.__op_eval, 'reset_ft_step': self.__op_reset_ft_step,
+                     'layerwise_tune': self.__op_layerwise_tune,
                      'rl_fintune': (lambda w, a: self.__op_train(w, a, self.optimizer_fintune)),
                      'restore': (lambda path: self.restore_vars(path, strict=False)),
                      'save': lambda path: self.save_vars(path)})

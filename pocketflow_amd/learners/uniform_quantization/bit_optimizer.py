@@ -13,9 +13,10 @@ bit widths under the budget `sum_i n_i * uql_equivalent_bits` (:137-195).  One r
 
 Differences from the reference, all on the control plane: the bit list travels through `mpi_comm.bcast` (RCCL /
 gloo object broadcast) instead of `./arranged_layer_bits.txt`; the learner hands over callables instead of TF ops
-and sessions (`ops['train'](w_bits, a_bits)`, `ops['eval'](w_bits, a_bits)`, `ops['restore'](path)`, ...); the
-layer-wise fine-tune (`uql_enbl_rl_layerwise_tune`, "working not very well" in the reference, off by default) is
-not implemented.
+and sessions (`ops['train'](w_bits, a_bits)`, `ops['eval'](w_bits, a_bits)`, `ops['restore'](path)`,
+`ops['layerwise_tune'](n, w_bits, a_bits)`, ...); after the rank-0-only layer-wise fine-tune
+(`uql_enbl_rl_layerwise_tune`, off by default, "working not very well" in the reference) the variables are broadcast
+so that the ranks stay consistent (the reference leaves them diverged, its TODO at :206).
 """
 from __future__ import annotations
 
@@ -76,14 +77,13 @@ class BitOptimizer(object):
     return getattr(FLAGS, '%s_%s' % (cls.PREFIX, name))
 
   def __build_agent(self):
-    if self._flag('enbl_rl_layerwise_tune'):
-      raise NotImplementedError('%s_enbl_rl_layerwise_tune is not implemented (reference: "working not very well", '
-                                'off by default); use the global fine-tune' % self.PREFIX)
     self.w_rl_helper = self.HELPER(None, self.total_bits, self.statistics['num_weights'], self.weights,
                                    random_layers=self._flag('enbl_random_layers'))
     self.s_dims = self.w_rl_helper.s_dims
     self.a_dims = 1
     buff_size = len(self.weights) * int(self._flag('nb_rlouts') // 4)
+    if buff_size < 1:
+      raise ValueError('%s_nb_rlouts must be at least 4 (the replay buffer holds nb_matmuls * nb_rlouts // 4 rows)' % self.PREFIX)
     self.agent = DdpgAgent(None, self.s_dims, self.a_dims,
                            self._flag('nb_rlouts'), buff_size, a_min=0., a_max=self._flag('w_bit_max') - self._flag('w_bit_min'))
 
@@ -152,6 +152,12 @@ class BitOptimizer(object):
   def _calc_rollout_reward(self, layer_bits, fp_a_bit_list):
     if self._flag('enbl_rl_global_tune') or self._flag('enbl_rl_layerwise_tune'):
       self._restore_for_finetune(layer_bits)
+    if self._flag('enbl_rl_layerwise_tune'):
+      if self.__is_primary_worker():
+        self.__layerwise_finetune(layer_bits, fp_a_bit_list)
+      self.auto_barrier()
+      if FLAGS.enbl_multi_gpu and self.ops.get('bcast'):
+        self.ops['bcast']()
     self.auto_barrier()
     if self._flag('enbl_rl_global_tune'):
       self._global_finetune(layer_bits, fp_a_bit_list)
@@ -170,6 +176,15 @@ class BitOptimizer(object):
 
   def _train_op(self):
     return self.ops['train']
+
+  def __layerwise_finetune(self, layer_bits, fp_a_bit_list):
+    """Rank 0 only: *_tune_layerwise_steps steps of every layer's tune op (:233-243)."""
+    for n in range(self.statistics['nb_matmuls']):
+      for t_step in range(self._flag('tune_layerwise_steps')):
+        diff = self.ops['layerwise_tune'](n, layer_bits, fp_a_bit_list)
+        if (t_step + 1) % 20 == 0:
+          log.info("Layerwise Tuning: {}, Step: {}, Bit: {}, Layer diff norm: {}".format(n, t_step + 1, layer_bits[n], diff))
+    log.info("Layerwise finetuning done")
 
   def _global_finetune(self, layer_bits, fp_a_bit_list):
     time_prev = timer()

@@ -147,6 +147,16 @@ class UniformQuantLearner(AbstractLearner):
   def __op_reset_ft_step(self):
     self.ft_step = 0
 
+  def __op_layerwise_tune(self, n, w_bits, a_bits):
+    """layerwise_tune_ops[n] + layerwise_diff[n] under a bit-width feed (uq utils.py:136-161)."""
+    from pocketflow_amd.learners.layerwise import LayerwiseTuner, layers_of_vars
+    self.__feed(w_bits, a_bits)
+    images, __ = self.iter_train.get_next()
+    if getattr(self, '_layer_tuner', None) is None:
+      layers = layers_of_vars(self.graph, self.forward_eval, images, [op.var for op in self.uni_quant.matmul_ops])
+      self._layer_tuner = LayerwiseTuner(self.graph, self.forward_train, layers)
+    return self._layer_tuner.step(n, images, self.uni_quant.quantize_weights)
+
   def train(self):
     total_iters = FLAGS.nb_iters_override or self.finetune_steps
     if FLAGS.enbl_warm_start:
@@ -236,6 +246,7 @@ class UniformQuantLearner(AbstractLearner):
         if FLAGS.enbl_multi_gpu else None
     self.ops.update({'init': self.__op_init, 'train': self.__op_train, 'eval': self.__op_eval,
                      'reset_ft_step': self.__op_reset_ft_step, 'restore': self.restore_vars,
+                     'layerwise_tune': self.__op_layerwise_tune,
                      'save': lambda path: self.save_vars(path)})
 
   def __build_eval(self):

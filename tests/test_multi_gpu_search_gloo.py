@@ -35,8 +35,9 @@ def _patch_cpu():
   import pocketflow_amd.learners.weight_sparsification.learner as WS
   import pocketflow_amd.learners.weight_sparsification.pr_optimizer as PR
   import pocketflow_amd.learners.nonuniform_quantization.utils as NU
+  import pocketflow_amd.learners.layerwise as LW
   fake = FakeHipFull()
-  for mod in (G, P, L, Opt, WS, PR, NU):
+  for mod in (G, P, L, Opt, WS, PR, NU, LW):
     mod.hip = fake
   AL.require_gpu = lambda: torch.device('cpu')
   torch.cuda.synchronize = lambda *a, **k: None
