@@ -35,10 +35,8 @@ def run_main(model_helper_cls, argv=None) -> int:
   import pocketflow_amd.learners.uniform_quantization.learner  # noqa: F401
   import pocketflow_amd.learners.nonuniform_quantization.learner  # noqa: F401
   import pocketflow_amd.learners.weight_sparsification.learner  # noqa: F401
-  try:
-    import pocketflow_amd.learners.channel_pruning.learner  # noqa: F401
-  except ImportError:
-    pass
+  import pocketflow_amd.learners.channel_pruning.learner  # noqa: F401
+  import pocketflow_amd.learners.channel_pruning_gpu.learner  # noqa: F401
   FLAGS.parse(argv)
   try:
     logging.basicConfig(level=logging.DEBUG if FLAGS.debug else logging.INFO,
