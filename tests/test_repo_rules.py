@@ -55,7 +55,7 @@ def test_nothing_on_the_gpu_box_reads_the_reference_tree():
       assert 'open(' not in line and 'sys.path' not in line and 'os.path.join' not in line, (os.path.relpath(path, ROOT), line)
   # the fixture generators (build container only) are the one place that opens it
   gens = [os.path.basename(p) for p in _py('tests/golden/*.py')]
-  assert sorted(gens) == ['make_reference_golden.py', 'make_reference_image_golden.py', 'make_reference_rl_golden.py']
+  assert sorted(gens) == ['make_reference_flags.py', 'make_reference_golden.py', 'make_reference_image_golden.py', 'make_reference_rl_golden.py']
 
 
 def test_every_kernel_source_is_built_and_every_symbol_is_bound():
@@ -76,3 +76,32 @@ def test_every_kernel_source_is_built_and_every_symbol_is_bound():
   assert ctypes.sizeof(_Desc) == hip.IMAGE_DESC_DTYPE.itemsize == 40
   for f, _t in _Desc._fields_:
     assert getattr(_Desc, f).offset == hip.IMAGE_DESC_DTYPE.fields[f][1], f
+
+
+def test_every_reference_flag_on_the_path_exists_with_the_same_default():
+  """The command lines of the reference stay valid: every tf.app.flags definition of the reference's learners / nets /
+  datasets / utils / rl_agents on the path (tests/golden/reference_flags.json) is defined here under the same name, and
+  flags the reference defines once have the same default."""
+  import json
+  import pocketflow_amd.nets.run_utils  # noqa: F401
+  import pocketflow_amd.learners.learner_utils  # noqa: F401
+  for mod in ('abstract_learner', 'distillation_helper', 'full_precision.learner', 'uniform_quantization.learner',
+              'nonuniform_quantization.learner', 'weight_sparsification.learner', 'channel_pruning.learner', 'channel_pruning_gpu.learner'):
+    __import__('pocketflow_amd.learners.' + mod)
+  for mod in ('resnet_at_ilsvrc12', 'mobilenet_at_ilsvrc12', 'lenet_at_cifar10', 'resnet_at_cifar10'):
+    __import__('pocketflow_amd.nets.' + mod)
+  from pocketflow_amd.flags import FLAGS
+  FLAGS.reset()
+  ours = FLAGS.flag_values_dict()
+  ref = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'reference_flags.json')))
+  missing = sorted(k for k in ref if k not in ours)
+  assert not missing, missing
+  for name, defs in ref.items():
+    defaults = {json.dumps(d['default']) for d in defs}
+    if len(defaults) == 1 and not isinstance(defs[0]['default'], str) or (len(defaults) == 1 and defs[0]['kind'] == 'string'):
+      want = defs[0]['default']
+      got = ours[name]
+      if isinstance(want, float) or isinstance(got, float):
+        assert got is not None and abs(float(got) - float(want)) <= 1e-12 * max(1.0, abs(float(want))), (name, got, want)
+      else:
+        assert got == want, (name, got, want)
