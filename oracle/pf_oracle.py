@@ -27,7 +27,6 @@ chain is a separate kernel producing a float32 tensor.
 """
 from __future__ import annotations
 
-import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np

@@ -11,7 +11,7 @@ never exist; only the decoded bytes cross PCIe (training: only the crop window).
 from __future__ import annotations
 
 import io
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 import torch

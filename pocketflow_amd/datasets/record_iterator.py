@@ -8,7 +8,7 @@ seeds: SURVEY section 4), decoding / augmentation / standardisation run batch-wi
 """
 from __future__ import annotations
 
-from typing import Callable, Optional
+from typing import Callable
 
 import torch
 

@@ -28,7 +28,6 @@ from __future__ import annotations
 
 import logging
 from collections import OrderedDict
-from timeit import default_timer as timer
 from typing import Dict, List, Optional
 
 import numpy as np

@@ -27,7 +27,6 @@ import torch
 
 from pocketflow_amd import hip
 from pocketflow_amd.flags import FLAGS, flags
-from pocketflow_amd.graph import Conv2D
 from pocketflow_amd.learners.abstract_learner import AbstractLearner
 from pocketflow_amd.learners.channel_pruning.channel_pruner import ChannelPruner
 from pocketflow_amd.learners.distillation_helper import DistillationHelper

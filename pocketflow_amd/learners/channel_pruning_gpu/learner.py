@@ -38,7 +38,6 @@ from pocketflow_amd.learners.abstract_learner import AbstractLearner
 from pocketflow_amd.learners.distillation_helper import DistillationHelper
 from pocketflow_amd.learners.layerwise import forward_tapped, layers_of_vars
 from pocketflow_amd.learners.weight_sparsification.learner import calc_prune_ratio
-from pocketflow_amd.learners.weight_sparsification.pr_optimizer import percentile_index
 from pocketflow_amd.optim import FlatOptimizer
 from pocketflow_amd.utils import checkpoint
 from pocketflow_amd.utils.multi_gpu_wrapper import MultiGpuWrapper as mgw

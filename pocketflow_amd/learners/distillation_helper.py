@@ -11,7 +11,6 @@ import logging
 import os
 import shutil
 
-import numpy as np
 import torch
 
 from pocketflow_amd import losses
