@@ -80,6 +80,25 @@ def describe_train(crop_h: int, crop_w: int, output_height: int, output_width: i
               scale_x=np.float32(crop_w) / np.float32(output_width), off_y=0, off_x=0, flip=int(bool(flip)))
 
 
+_STAGING = {}        # (device, slot) -> pinned uint8 buffer, grown geometrically (pinned allocations are expensive)
+_UPLOADED = {}       # (device, slot) -> event recorded behind the last asynchronous upload from that buffer
+
+
+def _staging_buffer(nbytes: int, device, pinned: bool, slot: int) -> torch.Tensor:
+  if not pinned:
+    return torch.empty(nbytes, dtype=torch.uint8)
+  key = (str(device), slot)
+  if key in _UPLOADED:
+    _UPLOADED[key].synchronize()                     # the previous upload from this buffer has left the host memory
+  buf = _STAGING.get(key)
+  if buf is None or buf.numel() < nbytes:
+    buf = _STAGING[key] = torch.empty(max(nbytes, 2 * (buf.numel() if buf is not None else 0)), dtype=torch.uint8, pin_memory=True)
+  return buf[:nbytes]
+
+
+_slot_counter = [0]
+
+
 def preprocess_batch(images_u8: Sequence[np.ndarray], descs: Sequence[dict], output_height: int, output_width: int,
                      device, dtype=torch.float32, pinned: bool = True) -> torch.Tensor:
   """Pack the decoded (training: cropped) uint8 HWC images, upload, run the resize kernel.
@@ -89,13 +108,18 @@ def preprocess_batch(images_u8: Sequence[np.ndarray], descs: Sequence[dict], out
   sizes = [int(im.shape[0]) * int(im.shape[1]) * 3 for im in images_u8]
   offsets = np.concatenate([[0], np.cumsum([(s + 15) // 16 * 16 for s in sizes])])        # 16-byte aligned starts
   use_pin = pinned and torch.device(device).type == 'cuda'
-  staging = torch.empty(int(offsets[-1]), dtype=torch.uint8, pin_memory=use_pin)
+  # two alternating pinned buffers: the asynchronous upload of batch i may still be in flight while batch i + 1 is packed
+  _slot_counter[0] ^= 1
+  staging = _staging_buffer(int(offsets[-1]), device, use_pin, _slot_counter[0])
   flat = staging.numpy()
   for i, (im, d) in enumerate(zip(images_u8, descs)):
     assert im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3 and im.shape[0] == d['h'] and im.shape[1] == d['w']
     flat[offsets[i]:offsets[i] + sizes[i]] = np.ascontiguousarray(im).reshape(-1)
     table[i] = (offsets[i], d['h'], d['w'], d['scale_y'], d['scale_x'], d['off_y'], d['off_x'], d['flip'], 0)
   src = staging.to(device, non_blocking=True)
+  if use_pin:
+    _UPLOADED[(str(device), _slot_counter[0])] = ev = torch.cuda.Event()
+    ev.record()
   desc = torch.from_numpy(np.frombuffer(table.tobytes(), dtype=np.uint8).copy()).to(device, non_blocking=True)
   out = torch.empty((B, output_height, output_width, 3), dtype=dtype, device=device)
   hip.image_resize_bilinear(src, desc, out, _CHANNEL_MEANS)
