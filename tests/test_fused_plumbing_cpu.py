@@ -199,3 +199,57 @@ def test_product_mobilenet_matches_the_reference_network_code(monkeypatch, dm, s
       got = logits.detach().numpy()
       assert np.max(np.abs(got - ref[mode])) <= 1e-3 * max(1.0, float(np.max(np.abs(ref[mode])))), (fuse, mode)
       g.store.load_numpy(vals, strict=True)
+
+
+def test_roofline_numerator_of_the_conv1x1_region(monkeypatch, tmp_path):
+  """bench.py's `roofline.achieved` = algorithmic bytes / measured time of the `conv1x1_fwd` region.  The bytes the
+  product accounts per launch, (M*K + M*N [+ M*N residual]) * 2 B, are checked here against an
+  independent walk over the ResNet-v2-50 bottleneck shapes: one quantised training step on CPU."""
+  import contextlib
+  import pocketflow_amd.graph as G
+  import pocketflow_amd.plan as P
+  import pocketflow_amd.losses as L
+  import pocketflow_amd.optim as Opt
+  import pocketflow_amd.learners.abstract_learner as AL
+  import pocketflow_amd.learners.learner_utils  # noqa: F401
+  from fake_hip import FakeHipFull
+  from pocketflow_amd.flags import FLAGS
+  from pocketflow_amd.nets.resnet_at_ilsvrc12 import ModelHelper
+  from pocketflow_amd.learners.uniform_quantization.learner import UniformQuantLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  fake = FakeHipFull()
+  for mod in (G, P, L, Opt):
+    monkeypatch.setattr(mod, 'hip', fake)
+  monkeypatch.setattr(AL, 'require_gpu', lambda: torch.device('cpu'))
+  monkeypatch.setattr(G, 'fusable_tensor', lambda t: True)        # the fused path is for bf16 / fp32 CUDA tensors
+  seen = []
+
+  @contextlib.contextmanager
+  def region(name, work=0.0):
+    seen.append((name, work))
+    yield
+  monkeypatch.setattr(G, 'region', region)
+  B, S = 2, 64
+  FLAGS.save_path = str(tmp_path / 'models' / 'model.ckpt')
+  FLAGS.uql_save_quant_model_path = str(tmp_path / 'uql' / 'm.ckpt')
+  FLAGS.resnet_size, FLAGS.nb_classes, FLAGS.image_size, FLAGS.batch_size, FLAGS.batch_size_eval = 50, 1001, S, B, B
+  FLAGS.compute_dtype, FLAGS.synthetic_pool, FLAGS.uql_weight_bits, FLAGS.uql_activation_bits = 'float32', 1, 8, 8
+  mh = ModelHelper()
+  create_synthetic_checkpoint(mh)
+  lrn = UniformQuantLearner(None, mh)
+  lrn.train_step()
+  got = sorted(w for n, w in seen if n == 'conv1x1_fwd')
+  # independent enumeration: stem 7x7/2 + max-pool/2 -> S/4; stages of (3, 4, 6, 3) bottlenecks, 64..512 filters
+  want, h, cin = [], S // 4, 64
+  for nblk, f, s in ((3, 64, 1), (4, 128, 2), (6, 256, 2), (3, 512, 2)):
+    for b in range(nblk):
+      stride = s if b == 0 else 1
+      ho = h // stride
+      if b == 0:
+        want.append((B * ho * ho * cin + B * ho * ho * 4 * f) * 2)            # projection shortcut (strided read)
+      want.append((B * h * h * cin + B * h * h * f) * 2)                      # conv1
+      want.append((B * ho * ho * f + 2 * B * ho * ho * 4 * f) * 2)            # conv3 + residual read
+      h, cin = ho, 4 * f
+  assert len(got) == len(want) == 4 + 2 * 16 and got == sorted(float(w) for w in want)
+  # the backward regions account the same tensors once per gradient GEMM
+  assert len([1 for n, _ in seen if n == 'conv1x1_wrw']) == 36 and len([1 for n, _ in seen if n == 'conv1x1_bwd_data']) == 36
