@@ -54,11 +54,15 @@ class Ilsvrc12Dataset(AbstractDataset):
     seed = FLAGS.synthetic_seed + rank + (0 if self.is_train else 100003)
     device = device if device is not None else self.device
     hw = (FLAGS.image_size, FLAGS.image_size)
+    # the resize kernel writes the compute dtype directly (bf16 = round-to-nearest-even of the float32 result, i.e.
+    # what the learners' cast would produce): the float32 batch of the reference's contract never exists in HBM
+    import torch
+    dtype = torch.bfloat16 if ('compute_dtype' in FLAGS and FLAGS.compute_dtype == 'bfloat16') else torch.float32
 
     def make(skip=0, take=None, seed_off=0):
       return TFRecordImageIterator(files, self.batch_size, self.is_train, FLAGS.nb_classes, seed + seed_off, device, hw,
                                    skip=skip, take=take, cycle_length=FLAGS.cycle_length, nb_threads=FLAGS.nb_threads,
-                                   buffer_size=FLAGS.buffer_size, prefetch_size=FLAGS.prefetch_size)
+                                   buffer_size=FLAGS.buffer_size, prefetch_size=FLAGS.prefetch_size, dtype=dtype)
     if self.is_train and enbl_trn_val_split:
       return make(skip=FLAGS.nb_smpls_val), make(take=FLAGS.nb_smpls_val, seed_off=50021)   # dataset.skip / dataset.take
     return make()
