@@ -499,7 +499,9 @@ class OracleLearner(object):
     return loss, model_loss, dst
 
   # -- one iteration --------------------------------------------------------------------------------
-  def train_step(self, images: np.ndarray, labels: np.ndarray, extra=None) -> Dict:
+  def compute_grads(self, images: np.ndarray, labels: np.ndarray, extra=None):
+    """Forward + backward of one rank's mini-batch: (losses dict, {variable: gradient}) -- BN moving statistics and
+    activation ranges are this replica's own, as in the reference's data-parallel runs (no sync-BN)."""
     x = torch.from_numpy(np.asarray(images, dtype=np.float32))
     y = torch.from_numpy(np.asarray(labels, dtype=np.float32))
     logits_dst = None
@@ -511,12 +513,22 @@ class OracleLearner(object):
     logits = self._forward(self.student, x, True, extra)
     loss, model_loss, dst = self._loss(y, logits, logits_dst)
     loss.backward()
+    grads = {}
+    for n in self.opt_vars:
+      t = self._tensor_of(n)
+      grads[n] = t.grad.numpy().copy() if t.grad is not None else np.zeros(tuple(t.shape), np.float32)
+    out = {'loss': float(loss.detach()), 'model_loss': float(model_loss.detach()),
+           'dst_loss': None if dst is None else float(dst.detach()), 'logits': logits.detach().numpy()}
+    return out, grads
+
+  def apply_grads(self, grads) -> float:
+    """apply_gradients of the (averaged) gradients: masks AFTER the reduction (ws learner.py:205-207), then the update."""
     lr = float(self.lrn_rate(self.step))
     if self.opt_kind == 'adam':
       self.adam_t += 1
     for n in self.opt_vars:
       t = self._tensor_of(n)
-      g = t.grad.numpy() if t.grad is not None else np.zeros(tuple(t.shape), np.float32)
+      g = grads[n]
       if n in self.masks:                               # __calc_grads_pruned (ws learner.py:314-332)
         g = O.masked_grad(g, self.masks[n])
       p = t.detach().numpy()
@@ -531,9 +543,12 @@ class OracleLearner(object):
       with torch.no_grad():
         t.copy_(torch.from_numpy(np.ascontiguousarray(p2)))
     self.step += 1
-    return {'loss': float(loss.detach()), 'model_loss': float(model_loss.detach()),
-            'dst_loss': None if dst is None else float(dst.detach()),
-            'lr': lr, 'logits': logits.detach().numpy()}
+    return lr
+
+  def train_step(self, images: np.ndarray, labels: np.ndarray, extra=None) -> Dict:
+    out, grads = self.compute_grads(images, labels, extra)
+    out['lr'] = self.apply_grads(grads)
+    return out
 
   def prune_step(self, nb_iters_train: int):
     """[prune_op, init_opt_op] (ws learner.py:124-131, 283-288): refresh masks, reset Momentum."""

@@ -100,3 +100,79 @@ def test_search_with_two_ranks(tmp_path, what):
   assert r0['decision'] == r1['decision'] and len(r0['decision']) > 0
   # every rank fine-tuned from the same start with averaged gradients: identical weights
   assert r0['first'] == r1['first'] and r0['checksum'] == r1['checksum']
+
+
+# -- data-parallel learner steps against an N-rank oracle (DP(N) != one process with batch N * B) ---------------
+def _dp_worker(rank, world, port, out_dir):
+  os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world),
+                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  torch.set_num_threads(2)
+  _patch_cpu()
+  import pocketflow_amd.learners.learner_utils  # noqa: F401
+  import pocketflow_amd.nets.resnet_at_cifar10 as net
+  from pocketflow_amd.flags import FLAGS
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  from pocketflow_amd.learners.uniform_quantization.learner import UniformQuantLearner
+  from pocketflow_amd.utils.multi_gpu_wrapper import MultiGpuWrapper as mgw
+  import torch.distributed as dist
+  FLAGS.enbl_multi_gpu = True
+  FLAGS.save_path = os.path.join(out_dir, 'models', 'model.ckpt')
+  FLAGS.uql_save_quant_model_path = os.path.join(out_dir, 'uql', 'm.ckpt')
+  FLAGS.synthetic_pool, FLAGS.compute_dtype = 2, 'float32'
+  FLAGS.batch_size, FLAGS.batch_size_eval, FLAGS.nb_classes, FLAGS.resnet_size = 8, 8, 10, 20
+  FLAGS.uql_weight_bits, FLAGS.uql_activation_bits, FLAGS.uql_use_buckets, FLAGS.uql_bucket_type = 8, 32, True, 'channel'
+  mgw.init()
+  mh = net.ModelHelper()
+  if rank == 0:
+    create_synthetic_checkpoint(mh)
+  dist.barrier()
+  lrn = UniformQuantLearner(None, mh)
+  if rank == 0:
+    np.savez(os.path.join(out_dir, 'init.npz'), **{k.replace('/', '|'): v for k, v in lrn.graph.store.export_numpy().items()})
+    with open(os.path.join(out_dir, 'lr.json'), 'w') as f:
+      json.dump([lrn.lrn_rate(s) for s in range(4)], f)
+  np.savez(os.path.join(out_dir, 'pool%d.npz' % rank), **{'x%d' % i: b[0].numpy() for i, b in enumerate(lrn.iter_train.batches)},
+           **{'y%d' % i: b[1].numpy() for i, b in enumerate(lrn.iter_train.batches)})
+  lrn.ops['bcast']()
+  losses = [float(lrn.train_step()['loss'].detach()) for _ in range(3)]
+  np.savez(os.path.join(out_dir, 'final%d.npz' % rank), **{k.replace('/', '|'): v for k, v in lrn.graph.store.export_numpy().items()})
+  with open(os.path.join(out_dir, 'loss%d.json' % rank), 'w') as f:
+    json.dump(losses, f)
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_data_parallel_steps_match_an_n_rank_oracle(tmp_path):
+  """Two ranks, per-rank data streams, gradients averaged by the flat all-reduce (1/N folded into the optimiser kernel),
+  BN statistics per rank -- against two oracle replicas whose gradients are averaged before every update."""
+  from oracle.learner_oracle import OracleLearner
+  world = 2
+  mp.spawn(_dp_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+  load = lambda name: {k.replace('|', '/'): v for k, v in np.load(str(tmp_path / name)).items()}
+  init, lrs = load('init.npz'), json.load(open(tmp_path / 'lr.json'))
+  cfg = dict(model='resnet', dataset='cifar_10', resnet_size=20, nb_classes=10, loss_w_dcy=2e-4, enbl_dst=False, momentum=0.9,
+             image_shape=(32, 32, 3), learner='uniform', uql_weight_bits=8, uql_activation_bits=32, uql_use_buckets=True,
+             uql_bucket_type='channel')
+  replicas = [OracleLearner(init, cfg, lambda s: lrs[s]) for _ in range(world)]
+  pools = [np.load(str(tmp_path / ('pool%d.npz' % r))) for r in range(world)]
+  assert not np.array_equal(pools[0]['x0'], pools[1]['x0'])                       # per-rank data (seed + rank)
+  ref_losses = [[], []]
+  for step in range(3):
+    outs = [rep.compute_grads(pools[r]['x%d' % (step % 2)], pools[r]['y%d' % (step % 2)]) for r, rep in enumerate(replicas)]
+    avg = {n: (outs[0][1][n] + outs[1][1][n]) / np.float32(world) for n in outs[0][1]}
+    for r, rep in enumerate(replicas):
+      rep.apply_grads(avg)
+      ref_losses[r].append(outs[r][0]['loss'])
+  finals = [load('final%d.npz' % r) for r in range(world)]
+  tol = 2 * 3 * lrs[0] + 1e-6                                                     # Adam bound, see tests/test_parity_gpu.py
+  for r in range(world):
+    got_losses = json.load(open(tmp_path / ('loss%d.json' % r)))
+    for a, b in zip(got_losses, ref_losses[r]):
+      assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (r, got_losses, ref_losses[r])    # Adam amplifies float32 noise (tests/test_parity_gpu.py)
+    ref = replicas[r].export()
+    for k, v in ref.items():
+      bar = tol if 'moving_' not in k else 1e-3
+      assert np.max(np.abs(finals[r][k] - v) / np.maximum(1.0, np.abs(v))) <= bar, (r, k)
+  trainable = [k for k in finals[0] if 'moving_' not in k]
+  assert all(np.array_equal(finals[0][k], finals[1][k]) for k in trainable)        # replicas stay in lock-step ...
+  assert any(not np.array_equal(finals[0][k], finals[1][k]) for k in finals[0] if 'moving_' in k)   # ... BN statistics do not
