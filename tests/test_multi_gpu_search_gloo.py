@@ -36,8 +36,9 @@ def _patch_cpu():
   import pocketflow_amd.learners.weight_sparsification.pr_optimizer as PR
   import pocketflow_amd.learners.nonuniform_quantization.utils as NU
   import pocketflow_amd.learners.layerwise as LW
+  import pocketflow_amd.learners.channel_pruning.learner as CP
   fake = FakeHipFull()
-  for mod in (G, P, L, Opt, WS, PR, NU, LW):
+  for mod in (G, P, L, Opt, WS, PR, NU, LW, CP):
     mod.hip = fake
   AL.require_gpu = lambda: torch.device('cpu')
   torch.cuda.synchronize = lambda *a, **k: None
@@ -72,6 +73,19 @@ def _worker(rank, world, port, out_dir, what):
     lrn = UniformQuantLearner(None, mh)
     decision = [int(b) for b in lrn.optimal_w_bit_list]
     weights = lrn.graph.store.w_master
+  elif what == 'cp':
+    # rank 0 prunes on the host and broadcasts the keep-masks; every rank fine-tunes with masked, averaged gradients
+    from pocketflow_amd.learners.channel_pruning.learner import ChannelPrunedLearner
+    FLAGS.cp_prune_option, FLAGS.cp_uniform_preserve_ratio, FLAGS.cp_nb_batches, FLAGS.cp_nb_points_per_layer = 'uniform', 0.5, 4, 10
+    FLAGS.cp_channel_pruned_path = os.path.join(out_dir, 'models', 'pruned_model.ckpt')
+    FLAGS.cp_best_path = os.path.join(out_dir, 'models', 'best_model.ckpt')
+    FLAGS.cp_original_path = os.path.join(out_dir, 'models', 'original_model.ckpt')
+    FLAGS.nb_iters_override, FLAGS.summ_step = 3, 2
+    lrn = ChannelPrunedLearner(None, mh)
+    lrn.train()
+    decision = [[int(sum(k_in)), int(sum(k_out))] for k_in, k_out in lrn.fake_pruning_dict.values()]
+    weights = lrn.graph.store.w_master
+    assert (lrn.pruner is not None) == (rank == 0)
   else:
     from pocketflow_amd.learners.weight_sparsification.pr_optimizer import PROptimizer
     import pocketflow_amd.learners.weight_sparsification.learner  # noqa: F401
@@ -92,7 +106,7 @@ def lrn_comm():
   return MpiCommShim()
 
 
-@pytest.mark.parametrize('what', ['uq', 'ws'])
+@pytest.mark.parametrize('what', ['uq', 'ws', 'cp'])
 def test_search_with_two_ranks(tmp_path, what):
   world = 2
   mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), what), nprocs=world, join=True)
