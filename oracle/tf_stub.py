@@ -168,6 +168,7 @@ def convert(x, dtype=None):
 # -- array ops ---------------------------------------------------------------------------------------
 
 def constant(value, dtype=None, **kw): return convert(value, dtype)
+uint8 = np.uint8
 def cast(x, dtype, **kw): return T(np.asarray(_raw(x)).astype(dtype))
 def reshape(x, shape, **kw): return T(np.reshape(_raw(x), [int(_raw(s)) for s in (shape.as_list() if isinstance(shape, TensorShape) else shape)]))
 def ones(shape, dtype=np.float32, **kw): return T(np.ones(int(shape) if np.isscalar(shape) else [int(_raw(s)) for s in shape], dtype=dtype))
@@ -512,6 +513,41 @@ def _resize_images(images, size, method=0, align_corners=False, **kw):
   return T(out)
 
 
+def decode_raw(bytes_, out_type, **kw):                                            # noqa: A002
+  return T(np.frombuffer(bytes(_raw(bytes_)) if not isinstance(_raw(bytes_), np.ndarray) else _raw(bytes_).tobytes(), dtype=out_type))
+
+
+def one_hot(indices, depth, **kw):
+  idx = np.asarray(_raw(indices)).astype(np.int64)
+  out = np.zeros(idx.shape + (int(depth),), np.float32)
+  np.put_along_axis(out, idx[..., None], 1.0, axis=-1) if idx.ndim else out.__setitem__(int(idx), 1.0)
+  return T(out)
+
+
+def random_crop(value, size, **kw):
+  """tf.random_crop with the offsets injected through image_hooks['crop'] = (oy, ox)."""
+  oy, ox = image_hooks['crop']
+  a = np.asarray(_raw(value))
+  return T(a[oy:oy + int(size[0]), ox:ox + int(size[1]), :int(size[2])])
+
+
+def _resize_image_with_crop_or_pad(image, target_height, target_width, **kw):
+  """tf.image.resize_image_with_crop_or_pad [3P]: centred zero padding (extra pixel at the end) / centred crop."""
+  a = np.asarray(_raw(image))
+  h, w = a.shape[:2]
+  out = a
+  for axis, (cur, tgt) in enumerate(((h, int(target_height)), (w, int(target_width)))):
+    if tgt > cur:
+      lo = (tgt - cur) // 2
+      pads = [(0, 0)] * out.ndim
+      pads[axis] = (lo, tgt - cur - lo)
+      out = np.pad(out, pads)
+    elif tgt < cur:
+      lo = (cur - tgt) // 2
+      out = np.take(out, np.arange(lo, lo + tgt), axis=axis)
+  return T(out)
+
+
 def unstack(x, **kw): return [T(v) for v in np.asarray(_raw(x))]
 def stack(values, axis=0, **kw): return T(np.stack([np.asarray(_raw(v)) for v in values], axis=axis))
 def slice(x, begin, size, **kw):                                                   # noqa: A001
@@ -707,6 +743,7 @@ def install() -> types.ModuleType:
   tf.image = _ns('tensorflow.image', decode_jpeg=_decode_jpeg, extract_jpeg_shape=_extract_jpeg_shape,
                  sample_distorted_bounding_box=_sample_distorted_bounding_box, decode_and_crop_jpeg=_decode_and_crop_jpeg,
                  random_flip_left_right=_random_flip_left_right, resize_images=_resize_images,
+                 resize_image_with_crop_or_pad=_resize_image_with_crop_or_pad,
                  ResizeMethod=_ns('ResizeMethod', BILINEAR=0))
   tf.test = _ns('tensorflow.test', is_built_with_cuda=lambda: False)
   tf.logging = _ns('tensorflow.logging', info=lambda *a, **k: None, warning=lambda *a, **k: None, debug=lambda *a, **k: None,

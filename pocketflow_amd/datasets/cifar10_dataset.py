@@ -45,24 +45,36 @@ def read_records(paths):
   return np.ascontiguousarray(images), labels
 
 
+def standardize(u8: torch.Tensor) -> torch.Tensor:
+  """decode_raw -> HWC float32 -> (x - IMAGE_AVE) / IMAGE_STD (reference :58-62)."""
+  dev = u8.device
+  return (u8.to(torch.float32) - torch.from_numpy(_MEAN).to(dev)) / torch.from_numpy(_STD).to(dev)
+
+
+def augment(x: torch.Tensor, oy: torch.Tensor, ox: torch.Tensor, flip: torch.Tensor) -> torch.Tensor:
+  """resize_image_with_crop_or_pad(+8) -> crop at (oy, ox) in [0, 8] -> optional left/right flip, batched (:65-68).
+  The padding is zeros in the STANDARDISED domain (the reference pads after the standardisation)."""
+  dev, B = x.device, x.shape[0]
+  xp = torch.nn.functional.pad(x, (0, 0, 4, 4, 4, 4))                       # [B, 40, 40, 3]
+  ar = torch.arange(IMAGE_HEI, device=dev)
+  rows = (oy.to(dev)[:, None] + ar[None, :])                                # [B, 32]
+  cols = (ox.to(dev)[:, None] + ar[None, :])
+  cols = torch.where(flip.to(dev)[:, None], cols.flip(1), cols)             # flip = reversed column order
+  bidx = torch.arange(B, device=dev)[:, None, None]
+  return xp[bidx, rows[:, :, None], cols[:, None, :], :]
+
+
 def make_transform(is_train: bool):
   """parse_fn after decode_raw: standardise; training: pad 4 (zeros) -> random crop 32x32 -> random flip."""
   def transform(u8: torch.Tensor, gen: torch.Generator) -> torch.Tensor:
-    dev = u8.device
-    x = (u8.to(torch.float32) - torch.from_numpy(_MEAN).to(dev)) / torch.from_numpy(_STD).to(dev)
+    x = standardize(u8)
     if not is_train:
       return x
     B = x.shape[0]
-    xp = torch.nn.functional.pad(x, (0, 0, 4, 4, 4, 4))                     # [B, 40, 40, 3]
-    oy = torch.randint(0, 9, (B,), generator=gen).to(dev)
-    ox = torch.randint(0, 9, (B,), generator=gen).to(dev)
-    flip = (torch.rand(B, generator=gen) < 0.5).to(dev)
-    ar = torch.arange(IMAGE_HEI, device=dev)
-    rows = (oy[:, None] + ar[None, :])                                      # [B, 32]
-    cols = (ox[:, None] + ar[None, :])
-    cols = torch.where(flip[:, None], cols.flip(1), cols)                   # flip = reversed column order
-    bidx = torch.arange(B, device=dev)[:, None, None]
-    return xp[bidx, rows[:, :, None], cols[:, None, :], :]
+    oy = torch.randint(0, 9, (B,), generator=gen)
+    ox = torch.randint(0, 9, (B,), generator=gen)
+    flip = torch.rand(B, generator=gen) < 0.5
+    return augment(x, oy, ox, flip)
   return transform
 
 

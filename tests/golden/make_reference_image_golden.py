@@ -60,6 +60,24 @@ def main():
   for (h, w) in ((480, 640), (333, 500), (1200, 900), (256, 256), (255, 257), (3000, 17)):
     nh, nw = ns['_smallest_size_at_least'](T(np.int32(h)), T(np.int32(w)), 256)
     cases.append(dict(size=[h, w], resized=[int(nh.a), int(nw.a)]))
+  # CIFAR-10: datasets/cifar10_dataset.py parse_fn on hand-made records (crop offsets and flip injected)
+  cns = G.lift('datasets/cifar10_dataset.py', ['parse_fn'],
+               {'LABEL_BYTES': 1, 'IMAGE_HEI': 32, 'IMAGE_WID': 32, 'IMAGE_CHN': 3, 'IMAGE_BYTES': 3072,
+                'IMAGE_AVE': tf.constant([[[125.3, 123.0, 113.9]]], dtype=tf.float32),
+                'IMAGE_STD': tf.constant([[[63.0, 62.1, 66.7]]], dtype=tf.float32)})
+  G.FLAGS.nb_classes = 10
+  crng = np.random.RandomState(5)
+  records = crng.randint(0, 256, size=(4, 3073)).astype(np.uint8)
+  records[:, 0] = [3, 0, 9, 7]
+  arrays['cifar/records'] = records
+  for i, rec in enumerate(records):
+    img, lab = cns['parse_fn'](rec.tobytes(), False)
+    arrays['cifar/eval%d' % i], arrays['cifar/label%d' % i] = img.numpy(), lab.numpy()
+    for k, (oy, ox, flip) in enumerate(((0, 0, False), (8, 8, True), (3, 6, True), (4, 4, False))):
+      stub.image_hooks.update(crop=(oy, ox), flip=flip)
+      img, _ = cns['parse_fn'](rec.tobytes(), True)
+      arrays['cifar/train%d_%d' % (i, k)] = img.numpy()
+  cases.append(dict(cifar_augment=[[0, 0, False], [8, 8, True], [3, 6, True], [4, 4, False]]))
   np.savez_compressed(os.path.join(HERE, 'reference_image.npz'), **arrays)
   with open(os.path.join(HERE, 'reference_image.json'), 'w') as f:
     json.dump({'cases': cases, 'means': [ns['_R_MEAN'], ns['_G_MEAN'], ns['_B_MEAN']], 'resize_min': ns['_RESIZE_MIN']}, f, indent=1)

@@ -77,3 +77,40 @@ def test_synthetic_fallback_has_the_same_contract(tmp_path):
   FLAGS.data_disk = 'hdfs'
   with pytest.raises(ValueError, match='HDFS'):
     C.Cifar10Dataset(is_train=True)
+
+
+def test_cifar10_parse_fn_matches_the_reference_code():
+  """standardize / augment (and the label one-hot) against the reference's own parse_fn executed on hand-made records
+  (tests/golden/make_reference_image_golden.py; crop offsets and flip injected): pins the CHW -> HWC transpose, the
+  standardisation constants, zero padding AFTER the standardisation, the crop origin and the flip."""
+  import json
+  import os
+  import numpy as np
+  import torch
+  from pocketflow_amd.datasets import cifar10_dataset as D
+  here = os.path.dirname(os.path.abspath(__file__))
+  A = np.load(os.path.join(here, 'golden', 'reference_image.npz'))
+  M = json.load(open(os.path.join(here, 'golden', 'reference_image.json')))
+  aug = [c for c in M['cases'] if 'cifar_augment' in c][0]['cifar_augment']
+  records = A['cifar/records']
+  path = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'pf_cifar_records_test.bin')
+  records.tofile(path)
+  try:
+    images, labels = D.read_records([path])
+  finally:
+    os.remove(path)
+  assert labels.tolist() == [3, 0, 9, 7]
+  x = D.standardize(torch.from_numpy(images))
+  for i in range(4):
+    assert np.array_equal(x[i].numpy(), A['cifar/eval%d' % i])
+    onehot = np.zeros(10, np.float32)
+    onehot[labels[i]] = 1
+    assert np.array_equal(A['cifar/label%d' % i], onehot)
+    for k, (oy, ox, flip) in enumerate(aug):
+      got = D.augment(x[i:i + 1], torch.tensor([oy]), torch.tensor([ox]), torch.tensor([bool(flip)]))
+      assert np.array_equal(got[0].numpy(), A['cifar/train%d_%d' % (i, k)]), (i, k)
+  # a whole batch with per-image parameters at once
+  oy = torch.tensor([a[0] for a in aug]); ox = torch.tensor([a[1] for a in aug]); fl = torch.tensor([bool(a[2]) for a in aug])
+  got = D.augment(x, oy, ox, fl)
+  for i in range(4):
+    assert np.array_equal(got[i].numpy(), A['cifar/train%d_%d' % (i, i)])
