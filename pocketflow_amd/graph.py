@@ -119,6 +119,7 @@ class VarStore:
     self.device = None
     self.compute_dtype = torch.float32
     self.weight_decay = 0.0                    # set by ModelHelper.calc_loss (loss_w_dcy)
+    self.grad_hook = None                      # optim.GradReducer: called once per variable whose gradient is final
 
   # -- declaration ------------------------------------------------------------------------------
   def add(self, name: str, ref_shape, kind: str, trainable: bool = True, l2: bool = True,
@@ -143,6 +144,12 @@ class VarStore:
   @property
   def matmul_vars(self) -> List[Variable]:
     return [v for v in self.vars if v.group == 'W']
+
+  def notify_grad(self, var: 'Variable') -> None:
+    """The gradient of `var` is complete in the flat gradient buffer (enqueued on the current stream): lets the
+    data-parallel reducer launch that bucket's all-reduce while the rest of the backward pass still runs."""
+    if self.grad_hook is not None:
+      self.grad_hook(var)
 
   # -- allocation -------------------------------------------------------------------------------
   def finalize(self, device, compute_dtype=torch.float32, separate_compute: bool = False,
@@ -206,6 +213,7 @@ class VarStore:
           elif v.kind == 'depthwise':
             g = g.unsqueeze(1)
           t.grad = g
+          t.register_post_accumulate_grad_hook(lambda _t, _v=v: self.notify_grad(_v))
         v.tensor = t
       elif v.group == 'O':
         v.master = self.o_master[v.offset:v.offset + n].view(v.storage_shape)
@@ -685,13 +693,14 @@ class _FusedConv1x1(torch.autograd.Function):
   """y = conv1x1(Q(x), W) [+ residual], Q = the producer BN's normalise/act/fake-quant (prologue)."""
 
   @staticmethod
-  def forward(ctx, x, w, residual, lazy, want_stats, stride, graph, box):
+  def forward(ctx, x, w, residual, lazy, want_stats, stride, graph, box, w_var=None):
     w2d = w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], w.shape[1])      # [N][K] (KRSC, R=S=1)
     res = _nhwc(residual) if residual is not None else None
     y = _run_conv1x1(x, w2d, lazy, res, want_stats, stride)
     ctx.save_for_backward(x, w2d)
     ctx.meta = (lazy, stride, graph, residual is not None, w.shape)
     ctx.w_leaf = w
+    ctx.w_var = w_var
     box.append(getattr(y, '_pf_stats', None))
     return y
 
@@ -719,6 +728,8 @@ class _FusedConv1x1(torch.autograd.Function):
         hip.conv1x1_wrw(dy, x, dw2d, ws, M, N, K, scale_shift=ss, act=act, slot=lazy.slot if quant else None,
                         bits=lazy.bits if quant else 8, geom=geom)
       dw = None if direct else dw2d.view(N, 1, 1, K).permute(0, 3, 1, 2)       # logical OIHW over KRSC memory
+      if direct:
+        graph.store.notify_grad(ctx.w_var)       # autograd sees no gradient for this leaf: report it ourselves
     if ctx.needs_input_grad[0]:
       wt = w2d.t().contiguous()                                                # [K][N]
       if geom is None:
@@ -735,7 +746,7 @@ class _FusedConv1x1(torch.autograd.Function):
           lazy.bwd_stats = (partial, G, dx.data_ptr())
         else:
           hip.conv1x1_fwd(dy, wt, dx, M, K, N, geom=geom, ymap=geom is not None)
-    return dx, dw, (dy if has_res else None), None, None, None, None, None
+    return dx, dw, (dy if has_res else None), None, None, None, None, None, None
 
 
 def fusable_tensor(t: torch.Tensor) -> bool:
@@ -815,7 +826,7 @@ class Conv2D:
       xin = lazy.x if lazy is not None else _nhwc(x)
       if torch.is_grad_enabled() and (xin.requires_grad or w.requires_grad):
         box = []
-        y = _FusedConv1x1.apply(xin, w, residual, lazy, want_stats, self.stride, self.graph, box)
+        y = _FusedConv1x1.apply(xin, w, residual, lazy, want_stats, self.stride, self.graph, box, self.kernel)
         if box and box[0] is not None:
           y._pf_stats = box[0]
         return y

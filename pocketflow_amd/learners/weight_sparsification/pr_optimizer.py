@@ -327,7 +327,9 @@ class PROptimizer(object):  # pylint: disable=too-many-instance-attributes
       self.rg_mask[sl] = self.masks[sl]
       base_rg.w_mask = self.rg_mask
       base_rg.o_mask = self.__zero_o_mask()
-      base_rg.beta1_power, base_rg.beta2_power = np.float32(base_rg.beta1), np.float32(base_rg.beta2)
+      # the reference builds a SEPARATE AdamOptimizer per layer (pr_optimizer.py:283-316): fresh m / v / beta powers,
+      # so that layers regressed earlier do not keep coasting on stale momentum while later layers are regressed
+      base_rg.reset_slots()
       for __ in range(nb_iters_rg):
         self.__regression_step(idx)
       st.sync_compute()

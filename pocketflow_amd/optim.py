@@ -36,6 +36,8 @@ class FlatOptimizer(object):
     self.w_mask: Optional[torch.Tensor] = None      # flat fp32 {0,1} over the W buffer (WS / CP)
     self.o_mask: Optional[torch.Tensor] = None      # flat fp32 {0,1} over the O buffer (var_list subsets)
     self.g_scale = 1.0
+    self.w_grad_src: Optional[torch.Tensor] = None  # set by the distributed wrapper: reduced gradients (staging)
+    self.o_grad_src: Optional[torch.Tensor] = None
 
   def state_tensors(self) -> List[torch.Tensor]:
     return self.slots_w + self.slots_o
@@ -50,54 +52,200 @@ class FlatOptimizer(object):
   def compute_gradients(self) -> None:
     """Gradients already sit in store.w_grad / store.o_grad after backward (single process)."""
     self.g_scale = 1.0
+    self.w_grad_src = self.o_grad_src = None
 
   def apply_gradients(self, lrn_rate: float) -> None:
     st = self.store
     wd = float(self.weight_decay)
+    w_grad = self.w_grad_src if self.w_grad_src is not None else st.w_grad
+    o_grad = self.o_grad_src if self.o_grad_src is not None else st.o_grad
     if self.kind == 'adam':
       b1p, b2p = float(self.beta1_power), float(self.beta2_power)
       if st.w_size:
-        hip.adam_flat(st.w_master, st.w_grad, self.slots_w[0], self.slots_w[1], self.w_mask, st.w_decay, wd,
+        hip.adam_flat(st.w_master, w_grad, self.slots_w[0], self.slots_w[1], self.w_mask, st.w_decay, wd,
                       self.g_scale, lrn_rate, self.beta1, self.beta2, self.epsilon, b1p, b2p)
       if st.o_size:
-        hip.adam_flat(st.o_master, st.o_grad, self.slots_o[0], self.slots_o[1], self.o_mask, st.o_decay, wd,
+        hip.adam_flat(st.o_master, o_grad, self.slots_o[0], self.slots_o[1], self.o_mask, st.o_decay, wd,
                       self.g_scale, lrn_rate, self.beta1, self.beta2, self.epsilon, b1p, b2p)
       self.beta1_power = np.float32(self.beta1_power * np.float32(self.beta1))
       self.beta2_power = np.float32(self.beta2_power * np.float32(self.beta2))
     else:
       if st.w_size:
-        hip.momentum_flat(st.w_master, st.w_grad, self.slots_w[0], self.w_mask, st.w_decay, wd, self.g_scale,
+        hip.momentum_flat(st.w_master, w_grad, self.slots_w[0], self.w_mask, st.w_decay, wd, self.g_scale,
                           lrn_rate, self.momentum)
       if st.o_size:
-        hip.momentum_flat(st.o_master, st.o_grad, self.slots_o[0], self.o_mask, st.o_decay, wd, self.g_scale,
+        hip.momentum_flat(st.o_master, o_grad, self.slots_o[0], self.o_mask, st.o_decay, wd, self.g_scale,
                           lrn_rate, self.momentum)
     st.zero_grad()
 
 
+class GradReducer(object):
+  """Gradient exchange of one VarStore: all-reduce(sum) of its flat gradient buffers over RCCL, launched from inside
+  the backward pass so that it overlaps with the remaining backward kernels (Horovod's fused, in-backward all-reduce,
+  reference utils/multi_gpu_wrapper.py:83-90).
+
+  * The matmul-kernel gradients (`w_grad`, 23.4 M elements for ResNet-50) are cut into contiguous buckets of
+    ~`bucket_elems` elements in buffer order.  The backward pass produces gradients from the END of the buffer towards
+    its beginning (layers are laid out in creation order); each gradient producer calls `VarStore.notify_grad(var)`
+    (fused convolutions write the flat buffer directly; every other leaf reports through a post-accumulate hook), and
+    when the last variable of a bucket has reported, that bucket's slice is all-reduced asynchronously.  xGMI is a
+    point-to-point mesh (7 links x ~153 GB/s per GPU): few, large messages keep every link busy, so buckets are tens of
+    MB, not per-tensor messages.
+  * Reduction dtype.  In bf16 compute mode the gradient buffer is bf16; summing 8 bf16 buffers in bf16 loses up to
+    ~3 bits (tests/test_multi_gpu_gloo.py bounds it), so by default every bucket is first widened into a float32
+    staging buffer and reduced there (`--allreduce_dtype float32`); the optimiser kernel then reads the staging
+    buffer.  `--allreduce_dtype compute` reduces in the buffer's own dtype (half the bytes on the links).
+  * `finish()` (called by DistributedFlatOptimizer.compute_gradients) launches whatever has not been launched
+    (variables that received no gradient this step), reduces the small `o_grad` buffer, waits for all handles and
+    returns the tensors the optimiser must read.  A variable reporting twice in one cycle (a second backward pass
+    before the update) invalidates the overlapped launches: everything is re-staged from the intact source buffers
+    and reduced again, blocking -- always correct, only slower.
+  """
+
+  def __init__(self, store: VarStore, bucket_elems: int = 8 << 20, reduce_dtype: Optional[torch.dtype] = torch.float32,
+               overlap: bool = True):
+    self.store = store
+    self.overlap = overlap
+    self.reduce_dtype = reduce_dtype
+    self.buckets = []          # [lo, hi, n_vars]
+    self.var_bucket = {}
+    self._build_buckets(bucket_elems)
+    self._stage_w: Optional[torch.Tensor] = None
+    self._stage_o: Optional[torch.Tensor] = None
+    self._reset_cycle()
+    store.grad_hook = self._on_grad
+    self.n_overlapped = 0      # buckets launched from inside backward in the last cycle (diagnostics / tests)
+
+  def _build_buckets(self, bucket_elems: int) -> None:
+    ws = sorted([v for v in self.store.vars if v.group == 'W' and v.trainable], key=lambda v: v.offset)
+    lo, cnt = 0, 0
+    for i, v in enumerate(ws):
+      self.var_bucket[v.name] = len(self.buckets)
+      cnt += 1
+      end = v.offset + v.numel
+      last = i == len(ws) - 1
+      if last:
+        end = self.store.w_size
+      if end - lo >= bucket_elems or last:
+        self.buckets.append([lo, end, cnt])
+        lo, cnt = end, 0
+
+  def _reset_cycle(self) -> None:
+    self.pending = [b[2] for b in self.buckets]
+    self.seen = set()
+    self.launched = [False] * len(self.buckets)
+    self.handles = []
+    self.dirty = False
+
+  def _active(self) -> bool:
+    return dist.is_initialized() and dist.get_world_size() > 1
+
+  def _stage(self, which: str) -> torch.Tensor:
+    st = self.store
+    src = st.w_grad if which == 'w' else st.o_grad
+    dt = self.reduce_dtype or src.dtype
+    buf = self._stage_w if which == 'w' else self._stage_o
+    if buf is None or buf.dtype != dt:
+      buf = torch.empty(src.numel(), dtype=dt, device=src.device)
+      if which == 'w':
+        self._stage_w = buf
+      else:
+        self._stage_o = buf
+    return buf
+
+  def _launch(self, b: int) -> None:
+    lo, hi, _ = self.buckets[b]
+    stage = self._stage('w')
+    stage[lo:hi].copy_(self.store.w_grad[lo:hi])
+    self.handles.append(dist.all_reduce(stage[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+    self.launched[b] = True
+
+  def _on_grad(self, var) -> None:
+    if not (self.overlap and self._active()) or var.group != 'W':
+      return
+    b = self.var_bucket.get(var.name)
+    if b is None:
+      return
+    if var.name in self.seen:
+      self.dirty = True
+      return
+    self.seen.add(var.name)
+    self.pending[b] -= 1
+    if self.pending[b] == 0 and not self.launched[b]:
+      self._launch(b)
+      self.n_overlapped += 1
+
+  def finish(self):
+    """-> (w_grad tensor, o_grad tensor, g_scale) the optimiser kernel must use for this update."""
+    st = self.store
+    if not self._active():
+      self._reset_cycle()
+      return st.w_grad, st.o_grad, 1.0
+    n_over = sum(self.launched)
+    if self.dirty:
+      for h in self.handles:
+        h.wait()
+      self.handles = []
+      self.launched = [False] * len(self.buckets)
+      n_over = 0
+    if st.w_size:
+      for b in range(len(self.buckets)):
+        if not self.launched[b]:
+          self._launch(b)
+    w_src = self._stage('w') if st.w_size else st.w_grad
+    o_src = st.o_grad
+    if st.o_size:
+      o_src = self._stage('o')
+      o_src.copy_(st.o_grad)
+      self.handles.append(dist.all_reduce(o_src, op=dist.ReduceOp.SUM, async_op=True))
+    for h in self.handles:
+      h.wait()
+    self._reset_cycle()
+    self.n_overlapped = n_over
+    return w_src, o_src, 1.0 / dist.get_world_size()
+
+
+def grad_reducer_of(store: VarStore) -> GradReducer:
+  """The store's (single) reducer: several optimisers may wrap one store (regression + fine-tune optimisers)."""
+  r = getattr(store, 'reducer', None)
+  if r is None:
+    import os
+    from pocketflow_amd.flags import FLAGS
+    rd = {'float32': torch.float32, 'compute': None}[FLAGS.allreduce_dtype if 'allreduce_dtype' in FLAGS else 'float32']
+    r = GradReducer(store, bucket_elems=int(os.environ.get('PF_ALLREDUCE_BUCKET', 8 << 20)), reduce_dtype=rd,
+                    overlap=os.environ.get('PF_OVERLAP_ALLREDUCE', '1') != '0')
+    store.reducer = r
+  return r
+
+
 class DistributedFlatOptimizer(object):
-  """mgw.DistributedOptimizer(optimizer): all-reduce(sum) of the flat gradient buffers, then the
-  wrapped optimiser with g_scale = 1 / world_size (Horovod's average).  Masks are applied AFTER the
-  reduction, as in the reference (ws learner.py:205-207)."""
+  """mgw.DistributedOptimizer(optimizer): all-reduce(sum) of the flat gradient buffers (GradReducer: bucketed,
+  launched from inside backward), then the wrapped optimiser with g_scale = 1 / world_size (Horovod's average).
+  Masks are applied AFTER the reduction, as in the reference (ws learner.py:205-207).
+
+  Attribute reads AND writes are forwarded to the wrapped optimiser: learners set `optimizer.weight_decay`,
+  `.w_mask`, `.o_mask` on whatever `mgw.DistributedOptimizer` returned, and apply_gradients() of the wrapped
+  object must see them (Horovod's wrapper subclasses the optimiser, so attributes are shared there too)."""
+
+  _OWN = ('opt', 'reducer')
 
   def __init__(self, optimizer: FlatOptimizer):
-    self.opt = optimizer
+    object.__setattr__(self, 'opt', optimizer)
+    object.__setattr__(self, 'reducer', grad_reducer_of(optimizer.store))
 
   def __getattr__(self, name):
     return getattr(self.opt, name)
 
-  def compute_gradients(self) -> None:
-    st = self.opt.store
-    if dist.is_initialized() and dist.get_world_size() > 1:
-      handles = []
-      if st.w_size:
-        handles.append(dist.all_reduce(st.w_grad, op=dist.ReduceOp.SUM, async_op=True))
-      if st.o_size:
-        handles.append(dist.all_reduce(st.o_grad, op=dist.ReduceOp.SUM, async_op=True))
-      for h in handles:
-        h.wait()
-      self.opt.g_scale = 1.0 / dist.get_world_size()
+  def __setattr__(self, name, value):
+    if name in DistributedFlatOptimizer._OWN:
+      object.__setattr__(self, name, value)
     else:
-      self.opt.g_scale = 1.0
+      setattr(self.opt, name, value)
+
+  def compute_gradients(self) -> None:
+    w_src, o_src, scale = self.reducer.finish()
+    self.opt.w_grad_src, self.opt.o_grad_src = w_src, o_src
+    self.opt.g_scale = scale
 
   def apply_gradients(self, lrn_rate: float) -> None:
     self.opt.apply_gradients(lrn_rate)

@@ -43,6 +43,9 @@ def latest_checkpoint(ckpt_dir: str) -> Optional[str]:
 
 
 def load(prefix: str) -> Dict[str, np.ndarray]:
+  if prefix is None:
+    raise FileNotFoundError('no checkpoint to restore: latest_checkpoint() found none (missing or stale `checkpoint` '
+                            'state file) -- was download_model() / a save run for this directory?')
   if not os.path.exists(prefix + '.npz') and os.path.exists(prefix + '.index'):
     from pocketflow_amd.utils import tf_checkpoint
     return tf_checkpoint.read_bundle(prefix)

@@ -7,6 +7,11 @@ from pocketflow_amd.flags import FLAGS, flags
 from pocketflow_amd.utils.multi_gpu_wrapper import MultiGpuWrapper as mgw
 
 flags.DEFINE_boolean('enbl_multi_gpu', False, 'enable multi-GPU training')
+flags.DEFINE_string('allreduce_dtype', 'float32', "dtype the gradient all-reduce sums in: 'float32' (bf16 gradient "
+                    "buffers are widened first) | 'compute' (the buffer's own dtype: half the bytes on xGMI)")
+flags.DEFINE_float('dist_timeout_hours', 24.0, 'collective timeout of the process group: rank-0-only phases (channel '
+                   'selection, searches, model download) keep the other ranks at a barrier for far longer than the '
+                   'RCCL default of 10 minutes')
 
 
 def auto_barrier(mpi_comm=None):

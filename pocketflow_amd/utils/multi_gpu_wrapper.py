@@ -9,6 +9,7 @@ large messages (tens of MB) is what keeps every link busy.
 """
 from __future__ import annotations
 
+import datetime
 import os
 
 import torch
@@ -32,7 +33,16 @@ class MultiGpuWrapper(object):
     if torch.cuda.is_available():
       torch.cuda.set_device(cls.device_index())
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group(backend=backend)
+    # rank 0 works alone for long stretches (LASSO channel selection, DDPG roll-outs, archive download) while the
+    # other ranks sit in a barrier / object broadcast: the default 10-minute RCCL watchdog would abort the job
+    hours = 24.0
+    try:
+      from pocketflow_amd.flags import FLAGS
+      if 'dist_timeout_hours' in FLAGS:
+        hours = float(FLAGS.dist_timeout_hours)
+    except Exception:  # pylint: disable=broad-except
+      pass
+    dist.init_process_group(backend=backend, timeout=datetime.timedelta(hours=hours))
     cls._initialized = True
 
   @classmethod

@@ -57,12 +57,84 @@ def _make_table():
 _CRC_TABLE = _make_table()
 
 
-def crc32c(data: bytes, crc: int = 0) -> int:
+def _crc32c_bytes(data, crc: int = 0) -> int:
+  """Byte-at-a-time table CRC (short inputs: record headers, index blocks)."""
   c = crc ^ 0xFFFFFFFF
   tbl = _CRC_TABLE
   for b in data:
     c = tbl[(c ^ b) & 0xFF] ^ (c >> 8)
   return c ^ 0xFFFFFFFF
+
+
+# -- long inputs (tensor payloads: ~100 MB per ResNet-50 checkpoint).  A CRC is sequential in its input, but linear
+# over GF(2): the buffer is cut into `_LANES` equal chunks whose CRCs advance in lockstep as one NumPy vector (one
+# table gather per byte POSITION, not per byte), and the chunk CRCs are chained with the "append n zero bytes"
+# operator (a 32x32 bit matrix, built by repeated squaring like zlib's crc32_combine).
+
+_LANES = 8192
+_CRC_TABLE_NP = np.array(_CRC_TABLE, dtype=np.uint32)
+
+
+def _gf2_times(mat, vec: int) -> int:
+  out, i = 0, 0
+  while vec:
+    if vec & 1:
+      out ^= mat[i]
+    vec >>= 1
+    i += 1
+  return out
+
+
+def _gf2_square(mat):
+  return [_gf2_times(mat, mat[i]) for i in range(32)]
+
+
+def _zeros_operator(nbytes: int):
+  """Matrix that maps crc(A) to the raw CRC state after `nbytes` further zero bytes."""
+  odd = [0x82F63B78] + [1 << i for i in range(31)]         # one zero BIT
+  even = _gf2_square(odd)                                   # two bits
+  odd = _gf2_square(even)                                   # four bits
+  result = None
+  n = nbytes
+  while n:
+    even = _gf2_square(odd)                                 # first pass: one zero byte
+    if n & 1:
+      result = even if result is None else [_gf2_times(even, result[i]) for i in range(32)]
+    n >>= 1
+    if not n:
+      break
+    odd = _gf2_square(even)
+    if n & 1:
+      result = odd if result is None else [_gf2_times(odd, result[i]) for i in range(32)]
+    n >>= 1
+  return result
+
+
+def _crc32c_combine(crc1: int, crc2: int, op) -> int:
+  """crc(A || B) from crc(A), crc(B) and the zeros operator of len(B) (zlib crc32_combine)."""
+  return _gf2_times(op, crc1) ^ crc2
+
+
+def crc32c(data, crc: int = 0) -> int:
+  buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data.reshape(-1).view(np.uint8)
+  n = buf.size
+  if n < (1 << 16):
+    return _crc32c_bytes(buf.tolist(), crc)
+  chunk = n // _LANES
+  body = buf[:chunk * _LANES].reshape(_LANES, chunk)
+  c = np.full(_LANES, 0xFFFFFFFF, dtype=np.uint32)
+  tbl = _CRC_TABLE_NP
+  for j in range(chunk):
+    c = tbl[(c ^ body[:, j]) & 0xFF] ^ (c >> 8)
+  c ^= 0xFFFFFFFF                                          # per-chunk CRCs (each from a zero start value)
+  op = _zeros_operator(chunk)
+  total = crc
+  for v in c.tolist():
+    total = _crc32c_combine(total, int(v), op)
+  tail = buf[chunk * _LANES:]
+  if tail.size:
+    total = _crc32c_bytes(tail.tolist(), total)
+  return total
 
 
 def mask_crc(crc: int) -> int:

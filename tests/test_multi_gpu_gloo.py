@@ -47,13 +47,14 @@ def _worker(rank, world, port, out_dir):
   st = g.store
 
   class _Opt(object):                                      # the wrapped optimiser: record what apply gets
-    store, g_scale, applied = st, None, None
+    store, g_scale, applied, weight_decay = st, None, None, 0.0
+    w_grad_src = o_grad_src = None
 
     def state_tensors(self):
       return [self.slot]
 
     def apply_gradients(self, lr):
-      self.applied = (lr, self.g_scale, st.w_grad.clone(), st.o_grad.clone())
+      self.applied = (lr, self.g_scale, self.w_grad_src.clone(), self.o_grad_src.clone(), self.weight_decay)
   opt = _Opt()
   opt.slot = torch.full((4,), float(rank))
   dopt = mgw.DistributedOptimizer(opt)
@@ -69,13 +70,51 @@ def _worker(rank, world, port, out_dir):
   # 2) gradient exchange: sum over ranks in the flat buffers, average via g_scale = 1 / N
   st.w_grad.copy_(torch.arange(st.w_grad.numel(), dtype=torch.float32) * (rank + 1))
   st.o_grad.fill_(float(rank + 1))
+  dopt.weight_decay = 5e-4                                 # learners set attributes on the WRAPPER
+  assert opt.weight_decay == 5e-4 and dopt.weight_decay == 5e-4
   dopt.compute_gradients()
   dopt.apply_gradients(0.5)
-  lr, g_scale, wg, og = opt.applied
+  lr, g_scale, wg, og, wd = opt.applied
   tot = sum(r + 1 for r in range(world))
-  assert lr == 0.5 and g_scale == 1.0 / world
+  assert lr == 0.5 and g_scale == 1.0 / world and wd == 5e-4
   assert torch.equal(wg, torch.arange(st.w_grad.numel(), dtype=torch.float32) * tot)
   assert torch.equal(og, torch.full_like(og, float(tot)))
+  # 2b) the same exchange launched from INSIDE backward: producers report variables in reverse creation order,
+  # buckets are reduced as they complete; a variable reporting twice falls back to a blocking re-reduction
+  from pocketflow_amd.optim import GradReducer
+  red = GradReducer(st, bucket_elems=1 << 12, reduce_dtype=torch.float32, overlap=True)
+  dopt.reducer = red
+  assert len(red.buckets) >= 2 and red.buckets[0][0] == 0 and red.buckets[-1][1] == st.w_size
+  wvars = sorted([v for v in st.vars if v.group == 'W'], key=lambda v: -v.offset)
+  for dirty in (False, True):
+    st.w_grad.copy_(torch.arange(st.w_grad.numel(), dtype=torch.float32) * (rank + 2))
+    st.o_grad.fill_(float(rank + 2))
+    for v in wvars:
+      st.notify_grad(v)
+    if dirty:
+      st.w_grad.mul_(2.0)                                  # a second backward pass accumulated into the buffer
+      st.notify_grad(wvars[0])
+    else:
+      assert all(red.launched), 'every bucket should be in flight before compute_gradients()'
+    dopt.compute_gradients()
+    dopt.apply_gradients(0.25)
+    _, g_scale, wg, og, _ = opt.applied
+    tot2 = sum(r + 2 for r in range(world)) * (2 if dirty else 1)
+    assert g_scale == 1.0 / world
+    assert torch.equal(wg, torch.arange(st.w_grad.numel(), dtype=torch.float32) * tot2)
+    assert red.n_overlapped == (0 if dirty else len(red.buckets))
+  # 2c) bf16 gradient buffer, float32 reduction: the sum is exact in float32 (no bf16 rounding of partial sums)
+  wg16 = (torch.arange(st.w_grad.numel(), dtype=torch.float32) % 251 + 0.5 * rank).to(torch.bfloat16)
+  st_w_grad_fp32 = st.w_grad
+  st.w_grad = wg16.clone()
+  red16 = GradReducer(st, bucket_elems=1 << 12, reduce_dtype=torch.float32, overlap=False)
+  dopt.reducer = red16
+  dopt.compute_gradients()
+  both = [torch.zeros_like(wg16) for _ in range(world)]
+  dist.all_gather(both, wg16)
+  assert opt.w_grad_src.dtype == torch.float32
+  assert torch.equal(opt.w_grad_src, sum(t.float() for t in both))
+  st.w_grad = st_w_grad_fp32
   # 3) mpi_comm shim: pickled-object broadcast (channel-pruning masks / decisions) + barrier
   comm = MpiCommShim()
   obj = comm.bcast({'conv1': [np.array([True, False]), np.array([True])]} if rank == 0 else None, root=0)
@@ -107,3 +146,21 @@ def test_wrapper_without_launcher_raises_like_the_reference():
   with pytest.raises(NameError, match='module <mgw> not imported'):
     mgw.init()
   assert mgw.size() == 1 and mgw.rank() == 0
+
+
+def test_bf16_sum_of_8_ranks_is_why_the_reduction_is_float32():
+  """a bf16 gradient buffer summed over 8 ranks in bf16 (what `--allreduce_dtype compute` does)
+  carries 8 mantissa bits through 7 additions; the float32 staging path (default) is exact up to float32 rounding.
+  Arithmetic emulation of a ring reduction (partial sums rounded to the wire dtype at every hop)."""
+  rng = np.random.RandomState(0)
+  g = torch.from_numpy((rng.randn(8, 1 << 16) * 1e-3).astype(np.float32)).to(torch.bfloat16)
+  exact = g.double().sum(0)
+  ring16 = g[0].clone()
+  for r in range(1, 8):
+    ring16 = (ring16 + g[r])                                # bf16 + bf16 -> bf16 (one rounding per hop)
+  ring32 = g.float().sum(0)
+  scale = float(exact.abs().mean())
+  e16 = float((ring16.double() - exact).abs().max()) / scale
+  e32 = float((ring32.double() - exact).abs().max()) / scale
+  assert e32 < 1e-5, e32
+  assert 1e-3 < e16 < 5e-2, e16                             # ~2^-8 per hop: above the 1e-3 parity bar of north_star
