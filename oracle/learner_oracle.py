@@ -349,8 +349,11 @@ class OracleLearner(object):
 
   cfg keys (all mirror reference flags): model ('lenet'|'resnet'|'mobilenet_v1'), dataset
   ('cifar_10'|'ilsvrc_12'), resnet_size, nb_classes, learner ('full-prec'|'uniform'|'non-uniform'|
-  'weight-sparse'), loss_w_dcy, enbl_dst, loss_w_dst, tempr_dst, momentum, and the learner's own
-  flags (uql_*, nuql_*, ws_*).  `lrn_rate(step)` is supplied by the caller (the schedules are
+  'weight-sparse'|'channel'), loss_w_dcy, enbl_dst, loss_w_dst, tempr_dst, momentum, and the learner's own
+  flags (uql_*, nuql_*, ws_*, cp_*).  'channel' = the masked fine-tune of the channel-pruned learner
+  (cp learner.py:313-471): cfg['cp_fake_pruning'] = {kernel variable name: (keep_in[bool C_in], keep_out[bool C_out])}
+  is the pruner's `fake_pruning_dict` re-keyed by variable, cfg['cp_optimizer'] = 'adam' (cp_finetune and not
+  cp_retrain: AdamOptimizer(cp_lrn_rate_ft), :357-359) | 'momentum' (:360-362).  `lrn_rate(step)` is supplied by the caller (the schedules are
   checked separately against pf_oracle.*setup_bnds_decay_rates / lrn_rate_piecewise).
   """
 
@@ -380,6 +383,8 @@ class OracleLearner(object):
       self._setup_nonuniform()
     elif self.kind == 'weight-sparse':
       self._setup_ws()
+    elif self.kind == 'channel':
+      self._setup_cp()
     self.opt_vars = self._select_opt_vars()
 
   # -- model dispatch ------------------------------------------------------------------------------
@@ -452,6 +457,16 @@ class OracleLearner(object):
     for n in names:                                     # __build_masks (ws learner.py:277-280)
       self.masks[n] = np.ones(tuple(self.student.v[n].shape), dtype=np.float32)
       self.bkups[n] = self.student.v[n].detach().numpy().copy()
+
+  def _setup_cp(self):
+    """__calc_grads_pruned (cp learner.py:381-421): one constant {0,1} mask per pruned Conv2D kernel,
+    ones(HWIO) with the pruned input rows and output columns zeroed; every other gradient passes unmasked
+    (depthwise kernels are never in fake_pruning_dict).  The optimiser follows __build_pruned_train_model
+    (:357-362); its slots are re-initialised by train_init_op (:376-377), i.e. start from zero as here."""
+    c = self.cfg
+    self.opt_kind = c.get('cp_optimizer', 'adam')
+    for name, (keep_in, keep_out) in c.get('cp_fake_pruning', {}).items():
+      self.masks[name] = O.cp_grad_mask(tuple(self.student.v[name].shape), keep_in, keep_out)
 
   def _select_opt_vars(self) -> List[str]:
     names = self.student.trainable_names()

@@ -265,9 +265,16 @@ class ChannelPrunedLearner(AbstractLearner):  # pylint: disable=too-many-instanc
       ko = torch.tensor(np.asarray(keep_out, dtype=np.uint8), device=self.device)
       hip.cp_build_mask(self.w_mask[var.offset:var.offset + var.numel], ki, ko, cout, kh * kw, cin)
 
-  def __finetune_pruned_model(self, path=None, finetune=False):
-    start = timer()
+  def setup_finetune(self, path=None, finetune=False, fake_pruning_dict=None):
+    """__build_pruned_train_model (:313-379) + train_init_op: restore the pruned checkpoint, build the gradient
+    masks, choose the optimiser (Adam(cp_lrn_rate_ft) for a fine-tune, the Momentum schedule for a re-train) with
+    fresh slots and step 0.  `fake_pruning_dict`: use these keep-masks instead of the pruner's (parity tests)."""
     self.restore_vars(path)                               # every rank starts from the pruned checkpoint
+    if fake_pruning_dict is not None:
+      class _Dict(object):
+        pass
+      self.pruner = self.pruner or _Dict()
+      self.pruner.fake_pruning_dict = fake_pruning_dict
     self.__calc_grads_pruned()
     self.global_step = 0
     self.lrn_rate, self.nb_iters_train = self.setup_lrn_rate(self.global_step)
@@ -281,6 +288,10 @@ class ChannelPrunedLearner(AbstractLearner):  # pylint: disable=too-many-instanc
     self.optimizer = mgw.DistributedOptimizer(base) if FLAGS.enbl_multi_gpu else base
     if FLAGS.enbl_multi_gpu:
       mgw.broadcast_global_variables(0, [st], [self.optimizer])()
+
+  def __finetune_pruned_model(self, path=None, finetune=False):
+    start = timer()
+    self.setup_finetune(path, finetune)
     self.__train_pruned_model(finetune=finetune)
     log.info('fintuning time cost: {}s'.format(timer() - start))
 

@@ -1,0 +1,113 @@
+"""Parity-test bodies shared by the GPU suite (tests/test_parity_gpu.py: real HIP kernels) and the CPU suite
+(tests/test_learners_cpu.py: float32 emulations of the HIP entry points) -- TEST INFRASTRUCTURE."""
+import numpy as np
+import torch
+
+
+def adam_tol(steps, lr):
+  return 2.0 * steps * lr + 1e-6
+
+
+def _pool(it):
+  return [(i.cpu().numpy(), l.cpu().numpy()) for i, l in it.batches]
+
+
+def _max_rel(a, b, skip=()):
+  worst, where = 0.0, None
+  for k, ref in b.items():
+    if any(s in k for s in skip) or not ref.size:
+      continue
+    e = float(np.max(np.abs(a[k] - ref) / np.maximum(1.0, np.abs(ref))))
+    if e > worst:
+      worst, where = e, k
+  return worst, where
+
+
+def _force_state(learner, ora):
+  """HIP learner <- oracle: variables (incl. BN moving statistics) and the Momentum accumulators."""
+  st = learner.graph.store
+  st.load_numpy(ora.export())
+  opt = getattr(learner.optimizer, 'opt', learner.optimizer)
+  for v in st.vars:
+    if not v.trainable or v.name not in ora.slots:
+      continue
+    flat = opt.slots_w[0] if v.group == 'W' else opt.slots_o[0]
+    acc = v.to_storage(ora.slots[v.name][0]).reshape(-1)
+    flat[v.offset:v.offset + v.numel] = torch.from_numpy(np.ascontiguousarray(acc)).to(flat.device)
+
+
+def run_cp_masked_finetune(FLAGS, tmp_path, optimizer, steps=3):
+  """BASELINE configs[3] shrunk: the masked fine-tune of the ChannelPrunedLearner (cp learner.py:381-471) on
+  MobileNet-v1 x0.5 @64 with distillation.  The keep-masks are a seeded stand-in for the LASSO selector's output
+  (which is pinned separately against the reference's own compute_pruned_kernel, tests/test_channel_pruner_host.py):
+  every Conv2D except the first's inputs / the last's outputs loses ~half of its input and output channels, the
+  checkpoint is "fake pruned" accordingly, and learner and oracle fine-tune from it.  Bar: masks bit-identical,
+  pruned rows / columns exactly zero after the steps, variables within the optimiser bound."""
+  from oracle import pf_oracle as O
+  from oracle.learner_oracle import OracleLearner
+  from pocketflow_amd.nets.mobilenet_at_ilsvrc12 import ModelHelper
+  from pocketflow_amd.learners.channel_pruning.learner import ChannelPrunedLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  from pocketflow_amd.utils import checkpoint
+  for k, v in dict(batch_size=16, batch_size_eval=16, image_size=64, nb_classes=17, mobilenet_depth_mult=0.5,
+                   enbl_dst=True, dst_eval_teacher=False, save_path_dst=str(tmp_path / 'models_dst' / 'model.ckpt'),
+                   cp_retrain=(optimizer == 'momentum'), cp_lrn_rate_ft=1e-4,
+                   cp_channel_pruned_path=str(tmp_path / 'models' / 'pruned_model.ckpt'),
+                   cp_best_path=str(tmp_path / 'models' / 'best_model.ckpt'),
+                   cp_original_path=str(tmp_path / 'models' / 'original_model.ckpt'), nb_eval_batches_override=1).items():
+    setattr(FLAGS, k, v)
+  mh = ModelHelper()
+  create_synthetic_checkpoint(mh)
+  learner = ChannelPrunedLearner(None, mh)
+  learner.restore_vars(checkpoint.latest_checkpoint(str(tmp_path / 'models')))
+  rng = np.random.RandomState(5)
+  convs = [op for op in learner.graph.matmul_ops if op.var.kind == 'conv']
+  fake, by_var = {}, {}
+  vals = learner.graph.store.export_numpy()
+  for i, op in enumerate(convs):
+    kh, kw, cin, cout = op.var.ref_shape
+    keep_in = np.ones(cin, bool) if i == 0 else rng.rand(cin) < 0.5
+    keep_out = np.ones(cout, bool) if i == len(convs) - 1 else rng.rand(cout) < 0.5
+    keep_in[0] = keep_out[0] = True
+    fake[op.name] = [keep_in.tolist(), keep_out.tolist()]
+    by_var[op.var.name] = (keep_in, keep_out)
+    vals[op.var.name] = vals[op.var.name] * O.cp_grad_mask(op.var.ref_shape, keep_in, keep_out)   # prune_W1 / prune_W2
+  pruned = checkpoint.save(vals, FLAGS.cp_channel_pruned_path, None)
+  learner.setup_finetune(pruned, finetune=True, fake_pruning_dict=fake)
+  st = learner.graph.store
+  # masks bit-identical to the oracle's (HWIO) masks
+  for op in convs:
+    got = op.var.to_ref(learner.w_mask[op.var.offset:op.var.offset + op.var.numel].cpu().numpy())
+    assert np.array_equal(got, O.cp_grad_mask(op.var.ref_shape, *by_var[op.var.name])), op.name
+  dw = [op.var for op in learner.graph.matmul_ops if op.var.kind == 'depthwise']
+  assert dw and all(float(learner.w_mask[v.offset:v.offset + v.numel].min()) == 1.0 for v in dw)   # never masked
+  init = st.export_numpy()
+  cfg = dict(model='mobilenet_v1', dataset='ilsvrc_12', resnet_size=0, nb_classes=FLAGS.nb_classes, loss_w_dcy=FLAGS.loss_w_dcy,
+             enbl_dst=True, loss_w_dst=FLAGS.loss_w_dst, tempr_dst=FLAGS.tempr_dst, momentum=FLAGS.momentum,
+             image_shape=(64, 64, 3), learner='channel', cp_fake_pruning=by_var, cp_optimizer=optimizer)
+  ora = OracleLearner(init, cfg, learner.lrn_rate)
+  net = learner.graph.nets[next(iter(learner.graph.nets))]
+  pool = _pool(learner.iter_train)
+  for step in range(steps):
+    seed_step = net.dropout_step
+    mask_rng = np.random.RandomState((net.dropout_seed + 7919 * seed_step) % (2 ** 31))
+    dmask = (mask_rng.uniform(size=(16, net.features)) < net.keep).astype(np.float32) / np.float32(net.keep)
+    lr, loss, _ = learner.train_step()
+    ref = ora.train_step(*pool[step % len(pool)], extra={'dropout_mask': dmask})
+    assert abs(float(loss.detach()) - ref['loss']) <= 5e-4 * max(1.0, abs(ref['loss'])), (step, float(loss.detach()), ref['loss'])
+    if optimizer == 'momentum':
+      # Momentum-SGD at the ILSVRC learning rate on a freshly pruned BN network is chaotic: a 1e-6 weight difference
+      # after one update flips single ReLU6 gates and moves per-channel gradients by 10 % at the next step (measured;
+      # with IDENTICAL weights the two gradient computations agree to 3e-4 absolute).  As in the weight-sparsification
+      # test, every step is therefore checked from a common state: compare, then teacher-force weights and slots.
+      worst, where = _max_rel(st.export_numpy(), ora.export(), skip=('moving_',))
+      assert worst <= 1e-4, 'step %d: variable %s differs by %.3e after one Momentum step from a common state' % (step, where, worst)
+      _force_state(learner, ora)
+  got = st.export_numpy()
+  for name, (keep_in, keep_out) in by_var.items():
+    assert np.all(got[name][:, :, ~keep_in, :] == 0) and np.all(got[name][:, :, :, ~keep_out] == 0), name
+  tol = adam_tol(steps, learner.lrn_rate(0)) if optimizer == 'adam' else 1e-4
+  worst, where = _max_rel(got, ora.export(), skip=('moving_',))
+  assert worst <= min(tol, 1e-3), 'variable %s differs by %.3e (tolerance %.1e)' % (where, worst, tol)
+  worst, where = _max_rel({k: v for k, v in got.items() if 'moving_' in k}, {k: v for k, v in ora.export().items() if 'moving_' in k})
+  assert worst <= 1e-3, (where, worst)

@@ -693,3 +693,15 @@ def test_layerwise_tune_op_on_cpu(cpu_learners):
   FLAGS.nb_eval_batches_override = 1
   lrn3 = UniformQuantLearner(None, mh)
   assert len(lrn3.optimal_w_bit_list) == 2 and all(2 <= b <= 8 for b in lrn3.optimal_w_bit_list)
+
+
+@pytest.mark.parametrize('optimizer', ['adam', 'momentum'])
+def test_cp_masked_finetune_matches_oracle_on_cpu(cpu_learners, monkeypatch, optimizer):
+  """The channel-pruned learner's masked fine-tune against the oracle's 'channel' mode (oracle/learner_oracle.py
+  _setup_cp; reference cp learner.py:381-471), HIP entry points emulated: same body as the GPU test."""
+  import pocketflow_amd.learners.channel_pruning.learner as CP
+  import pocketflow_amd.nets.mobilenet_at_ilsvrc12  # noqa: F401
+  from parity_common import run_cp_masked_finetune
+  FLAGS, fake, tmp = cpu_learners
+  monkeypatch.setattr(CP, 'hip', fake)
+  run_cp_masked_finetune(FLAGS, tmp, optimizer)
