@@ -222,7 +222,7 @@ int pf_gemm_bf16_tn(const void* A, const void* B, void* C, int M, int N, int K, 
  *   Q(x) = fake_quant(act(scale[k]*x + shift[k])) with scale_shift = {scale[K], shift[K]} as written by
  *   pf_bn_finalize / pf_bn_eval_scale_shift and the activation range in `slot` (NULL: no fake-quant).
  *   Epilogue: R != NULL adds the residual; partial != NULL receives per-channel {sum, sumsq, min, max} of
- *   the stored Y values as [G][4][N] floats, G = pf_conv1x1_stats_groups(M, N), in the layout
+ *   the stored Y values as [G][4][N] floats, G = pf_conv1x1_stats_groups_k(M, N, K), in the layout
  *   pf_bn_finalize consumes (pivot 0).  stride > 1: output pixel (img, ho, wo) of an [.., Ho, Wo] grid
  *   reads input pixel (img, ho*stride, wo*stride) of an [.., H, Wd] grid; ymap != 0 maps the OUTPUT rows
  *   instead (backward-data of a strided conv: X = dY dense, Y = dX pre-zeroed).
@@ -231,13 +231,16 @@ int pf_gemm_bf16_tn(const void* A, const void* B, void* C, int M, int N, int K, 
  *   workspace: (pf_conv1x1_wrw_splits(M, N, K) + 32) * N * K floats (deterministic staged reduction).
  * Requirements: K % 8 == 0, N % 8 == 0, 16-byte aligned pointers; hipErrorInvalidValue otherwise.     */
 int pf_conv1x1_stats_groups(int M, int N);
+/* G of the partial-statistics array for an [M][K] x [N][K] problem: shapes whose kernel fits the LDS (K, N <= 512,
+ * K * N <= 64 Ki) run on the barrier-free resident-kernel variant (pf_conv_stream.hip), which has its own G.   */
+int pf_conv1x1_stats_groups_k(int M, int N, int K);
 int pf_conv1x1_fwd(const void* X, const void* W, void* Y, const void* R, const float* scale_shift,
                    int act, const uint32_t* slot, int bits, float* partial, int M, int N, int K,
                    int Ho, int Wo, int H, int Wd, int stride, int ymap, void* stream);
 /* backward-data of a stride-1 1x1 convolution, dQ[M][K] = dY[M][N] * W[N][K] (Wt = transposed kernel [K][N]),
  * with the statistics pass of the BN backward of the layer that produced Q fused into the epilogue
  * (replaces FusedBatchNormGrad's reduction over dy, utils/external/resnet_model.py:55-62):
- * partial[G][2][K] = {sum dy, sum dy*xhat}, dy = dQ * act'(scale*x+shift), G = pf_conv1x1_stats_groups(M, K),
+ * partial[G][2][K] = {sum dy, sum dy*xhat}, dy = dQ * act'(scale*x+shift), G = pf_conv1x1_stats_groups_k(M, K, N),
  * in the layout pf_bn_bwd_finalize consumes.                                                              */
 int pf_conv1x1_bwd_data_bnstats(const void* dY, const void* Wt, void* dQ, const void* bn_x,
                                 const float* bn_scale_shift, const float* bn_mean_invstd, int bn_act,

@@ -1,0 +1,362 @@
+// K12: dense convolutions of the student / teacher as implicit GEMMs on the matrix cores -- forward and
+// backward-data of the RxS convolutions (3x3 of the ResNet blocks, utils/external/resnet_model.py:92-103,
+// conv2d_fixed_padding) and the plain 1x1 GEMMs that carry no prologue (backward-data of the 1x1 convolutions of
+// stages 3-4).  bf16 NHWC activations, KRSC kernels, fp32 accumulation.
+//
+//   Y[m][n] = sum_{tap, c} X[pix(m, tap)][c] * W[n][tap][c]          m = (img, ho, wo),  tap = (r, s)
+//   pix(m, tap) = (img, ho*stride + r - pad_h, wo*stride + s - pad_w); taps that fall outside the image contribute 0
+//   (the reference pads the ACTIVATED / quantised tensor with zeros, so the zeros are exact).
+//   epilogue, as in pf_conv.hip: + residual, per-channel {sum, sumsq, min, max} of the stored tile (the statistics the
+//   consumer BN needs), or -- backward-data -- the BN-backward sums {sum dy, sum dy*xhat} of the producer BN.
+//
+// MI355X mapping.  The contraction index runs over (tap, 64-channel step); for one step the input tile is BM pixel
+// rows x 128 contiguous bytes and the kernel tile BN rows x 128 bytes.  Both go from global memory STRAIGHT INTO LDS
+// (global_load_lds, 16 bytes per lane, no staging registers, no ds_write pass): the LDS destination of that
+// instruction is lane-linear, so a lane fetches the 16-byte group that belongs at its LDS position -- the gather of
+// the implicit im2col (per-lane source rows, a zero row for padding taps) and the XOR swizzle that makes the
+// fragment reads bank-conflict free are both applied to the SOURCE address.  Two LDS stages: the loads of step t+1
+// are in flight while step t is multiplied, one workgroup barrier per step.  Wavefronts tile the block 2-D
+// (64 x 64 accumulators each: 16 fragment reads per 32 MFMAs); weights are MFMA operand A and pixels operand B so
+// that a lane's four accumulator values are consecutive output channels of one pixel (8-byte writes when the tile is
+// transposed through LDS for 16-byte row stores).  Persistent workgroups walk row tiles, the column tiles of one row
+// panel share an XCD (blockIdx % 8) and therefore that XCD's L2.
+#include "pf_conv_common.h"
+#include <stdio.h>
+#include <stdlib.h>
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+struct IgArgs {
+  const bf16_t* X;      // [rows_in][C]
+  const bf16_t* W;      // [N][taps][C]
+  bf16_t* Y;            // [M][N]
+  const bf16_t* zero;   // >= 128 zero bytes (source of padding taps / out-of-range rows)
+  const bf16_t* R;      // residual [M][N] or null
+  float* partial;       // statistics [G][4][N] (or [G][2][N] with bx) or null
+  const bf16_t* bx;     // BN-backward statistics mode: the BN's input x [M][N]
+  const float* bss;     // its scale | shift [2][N]
+  const float* bmi;     // its mean | invstd [2][N]
+  float b_lo, b_hi;
+  int M, N, C;
+  int th, tw;           // taps
+  int H, Wd, Ho, Wo, stride, pad_h, pad_w;
+  int tiles_m, tiles_n, G;
+};
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int WM, int WN, int NS, bool BWD>
+__global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
+  constexpr int T = 64 * WM * WN;
+  constexpr int WR = BM / WM, WC = BN / WN;         // wavefront tile: pixels x channels
+  constexpr int JM = WR / 16, NI = WC / 16;
+  constexpr int AS = BM * 8 / T, BS = BN * 8 / T;   // 16-byte loads per lane and step (input / kernel tile)
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int CS_LD = BN + 8;
+  constexpr int VPR = BN / 8, RPP = T / VPR, NP = BM / RPP;
+  static_assert(AS >= 1 && BS >= 1 && NP >= 1, "tile too small for the block");
+  constexpr int LPS = AS + BS;                      // LDS-DMA instructions per lane and stage
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NS stages; aliased: C tile, statistics scratch
+  bf16_t* Cs = reinterpret_cast<bf16_t*>(smem);
+  float* red = reinterpret_cast<float*>(smem);
+  float* bpl = reinterpret_cast<float*>(smem + NS * STAGE);              // BWD: scale | shift | mean | invstd [4][BN]
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int srow = tid >> 3;                                              // staging row of this lane (per 16-byte slot)
+  const int schunk = (lane & 7) ^ ((lane >> 3) & 7);                      // source 16-byte group for its LDS position
+
+  const int xcd = blockIdx.x & 7, L = blockIdx.x >> 3;
+  const int g = xcd + 8 * (L / a.tiles_n), tn = L % a.tiles_n;
+  const int n0 = tn * BN;
+  const int cch = a.C >> 6;                                               // 64-channel steps per tap
+  const int taps = a.th * a.tw;
+  const int nk = taps * cch;
+  const int64_t wrow = (int64_t)taps * a.C;                               // kernel row length (elements)
+  const int hw_o = a.Ho * a.Wo;
+
+  if (BWD) {
+    for (int i = tid; i < 4 * BN; i += T) {
+      const int qq = i / BN, c = n0 + (i - qq * BN);
+      float v = 0.f;
+      if (c < a.N) v = (qq < 2) ? a.bss[qq * a.N + c] : a.bmi[(qq - 2) * a.N + c];
+      bpl[i] = v;
+    }
+  }
+
+  float st_s[8], st_q[8], st_mn[8], st_mx[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; st_mn[j] = INFINITY; st_mx[j] = -INFINITY; }
+  const int wvec = tid % VPR, wrw = tid / VPR;
+  const bf16_t* __restrict__ side = BWD ? a.bx : a.R;
+
+  // kernel-tile source rows of this lane (fixed for the whole launch)
+  const bf16_t* bsrc[BS];
+#pragma unroll
+  for (int i = 0; i < BS; ++i) {
+    const int n = n0 + i * (T / 8) + srow;
+    bsrc[i] = (n < a.N) ? (a.W + (int64_t)n * wrow + schunk * 8) : nullptr;
+  }
+
+  for (int tm = g; tm < a.tiles_m; tm += a.G) {
+    const int m0 = tm * BM;
+    // input rows of this lane: element offset of the top-left input pixel of the receptive field (may lie outside
+    // the image) and its coordinates for the bounds test of each tap
+    int pbase[AS], ph0[AS], pw0[AS];
+#pragma unroll
+    for (int i = 0; i < AS; ++i) {
+      const int m = m0 + i * (T / 8) + srow;
+      if (m < a.M) {
+        const int img = m / hw_o, rem = m - img * hw_o;
+        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        ph0[i] = ho * a.stride - a.pad_h; pw0[i] = wo * a.stride - a.pad_w;
+        pbase[i] = ((img * a.H + ph0[i]) * a.Wd + pw0[i]) * a.C + schunk * 8;
+      } else {
+        pbase[i] = 0; ph0[i] = -(1 << 20); pw0[i] = 0;                      // never inside the image
+      }
+    }
+    // the steps are staged in order: running (tap row, tap column, channel step) instead of divisions
+    int s_r = 0, s_s = 0, s_cc = 0, s_ks = 0;
+    auto stage = [&](int buf) {
+      unsigned char* As = smem + buf * STAGE;
+      unsigned char* Bs = As + A_BYTES;
+      const int tapoff = (s_r * a.Wd + s_s) * a.C + s_cc * 64;              // wave-uniform
+#pragma unroll
+      for (int i = 0; i < AS; ++i) {
+        const int hi = ph0[i] + s_r, wi = pw0[i] + s_s;
+        const bool ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.Wd;
+        const bf16_t* src = ok ? (a.X + (pbase[i] + tapoff)) : (a.zero + schunk * 8);
+        __builtin_amdgcn_global_load_lds(src, LDS_PTR(As + (i * (T / 8) + wave * 8) * 128), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < BS; ++i) {
+        const bf16_t* src = (bsrc[i] != nullptr) ? (bsrc[i] + s_ks * 64) : (a.zero + schunk * 8);
+        __builtin_amdgcn_global_load_lds(src, LDS_PTR(Bs + (i * (T / 8) + wave * 8) * 128), 16, 0, 0);
+      }
+      ++s_ks;
+      if (++s_cc == cch) { s_cc = 0; if (++s_s == a.tw) { s_s = 0; ++s_r; } }
+    };
+
+    f32x4 acc[NI][JM];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < JM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ring of NS stages, NS - 1 steps of loads in flight.  Step ks is multiplied from buffer ks % NS while the loads of
+    // steps ks+1 .. ks+NS-1 travel; a stage is waited for with a COUNTED vmcnt (the younger stages stay in flight
+    // across the barrier: raw s_barrier, never __syncthreads(), which would drain them) and read one barrier later.
+    int ibuf = 0;                                                           // buffer of the next stage to issue
+#pragma unroll
+    for (int d = 0; d < NS - 1; ++d)
+      if (d < nk) { stage(ibuf); ibuf = (ibuf + 1 == NS) ? 0 : ibuf + 1; }
+    if (nk >= NS - 1) wait_vm<(NS - 2) * LPS>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    int cbuf = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+      const bool more = ks + NS - 1 < nk;
+      if (more) { stage(ibuf); ibuf = (ibuf + 1 == NS) ? 0 : ibuf + 1; }
+      const unsigned char* As = smem + cbuf * STAGE;
+      const unsigned char* Bs = As + A_BYTES;
+      cbuf = (cbuf + 1 == NS) ? 0 : cbuf + 1;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int coff = (((kk * 4 + q) ^ (l15 & 7)) << 4);
+        bf16x8 wf[NI], xf[JM];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+          wf[i] = *reinterpret_cast<const bf16x8*>(Bs + (wn * WC + i * 16 + l15) * 128 + coff);
+#pragma unroll
+        for (int j = 0; j < JM; ++j)
+          xf[j] = *reinterpret_cast<const bf16x8*>(As + (wm * WR + j * 16 + l15) * 128 + coff);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < JM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      }
+      if (more) wait_vm<(NS - 2) * LPS>(); else wait_vm<0>();             // the NEXT step's stage has landed (own part)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // own fragment reads of this buffer are done
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue of one [BM][BN] tile (C staging aliases the stage buffers: all reads of them are complete) ----
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < JM; ++j) {
+        const uint2 v = make_uint2(pack_bf16x2(acc[i][j][0], acc[i][j][1]), pack_bf16x2(acc[i][j][2], acc[i][j][3]));
+        *reinterpret_cast<uint2*>(Cs + (wm * WR + j * 16 + l15) * CS_LD + wn * WC + i * 16 + q * 4) = v;
+      }
+    uint4 rres[NP];
+    if (side != nullptr) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int m = m0 + wrw + p * RPP, n = n0 + wvec * 8;
+        rres[p] = make_uint4(0, 0, 0, 0);
+        if (m < a.M && n < a.N) rres[p] = *reinterpret_cast<const uint4*>(side + (int64_t)m * a.N + n);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int rl = wrw + p * RPP;
+      const int m = m0 + rl, n = n0 + wvec * 8;
+      if (m < a.M && n < a.N) {
+        uint4 c = *reinterpret_cast<const uint4*>(Cs + rl * CS_LD + wvec * 8);
+        if (BWD) {
+          float f[8], xv[8];
+          unpack8(c, f);
+          unpack8(rres[p], xv);
+          const float* bp = bpl + wvec * 8;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float u = fmaf(bp[j], xv[j], bp[BN + j]);
+            const float dy = (u > a.b_lo && u < a.b_hi) ? f[j] : 0.f;
+            st_s[j] += dy;
+            st_q[j] = fmaf(dy, (xv[j] - bp[2 * BN + j]) * bp[3 * BN + j], st_q[j]);
+          }
+        } else if (a.R != nullptr || a.partial != nullptr) {
+          float f[8];
+          unpack8(c, f);
+          if (a.R != nullptr) {
+            float r[8];
+            unpack8(rres[p], r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] += r[j];
+            c = pack8(f);
+            unpack8(c, f);                                                  // statistics see the stored (bf16) values
+          }
+          if (a.partial != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              st_s[j] += f[j];
+              st_q[j] = fmaf(f[j], f[j], st_q[j]);
+              st_mn[j] = fminf(st_mn[j], f[j]);
+              st_mx[j] = fmaxf(st_mx[j], f[j]);
+            }
+          }
+        }
+        *reinterpret_cast<uint4*>(a.Y + (int64_t)m * a.N + n) = c;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- per-workgroup statistics -> partial[g][stat][N] (fixed order: deterministic) ---------------------------
+  if (a.partial != nullptr) {
+    // threads with equal column group: RPP row lanes.  Two-level: registers -> LDS [stat][RPP][BN] in chunks that fit
+    constexpr int nstat_max = 4;
+    const int nstat = BWD ? 2 : 4;
+    __syncthreads();
+    for (int stat = 0; stat < nstat; ++stat) {
+      const float* v = (stat == 0) ? st_s : (stat == 1 ? st_q : (stat == 2 ? st_mn : st_mx));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[wrw * BN + wvec * 8 + j] = v[j];
+      __syncthreads();
+      for (int c = tid; c < BN; c += T) {
+        float r = red[c];
+        for (int rr = 1; rr < RPP; ++rr) {
+          const float w = red[rr * BN + c];
+          r = (stat < 2) ? (r + w) : (stat == 2 ? fminf(r, w) : fmaxf(r, w));
+        }
+        if (n0 + c < a.N) a.partial[((int64_t)g * nstat + stat) * a.N + n0 + c] = r;
+      }
+      __syncthreads();
+    }
+    (void)nstat_max;
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+struct IgCfg { int bm, bn; };
+
+static IgCfg ig_pick(int M, int N) {
+  const char* e = getenv("PF_IGEMM_TILE");                 // tuning override: "256x128" | "128x128" | "256x64" | "128x64"
+  if (e != nullptr) {
+    int bm = 0, bn = 0;
+    if (sscanf(e, "%dx%d", &bm, &bn) == 2 && (bm == 128 || bm == 256) && (bn == 64 || bn == 128) && (N % bn == 0 || bn == 64))
+      return IgCfg{bm, bn};
+  }
+  const int bn = (N % 128 == 0) ? 128 : 64;
+  // 256-row tiles (8 wavefronts, one workgroup per CU) when there are enough of them to fill the chip twice over
+  const int64_t tiles256 = (int64_t)((M + 255) / 256) * ((N + bn - 1) / bn);
+  return IgCfg{tiles256 >= 512 ? 256 : 128, bn};
+}
+
+static int ig_grid(int bm, int tiles_m, int tiles_n, int* G_out) {
+  const int slots = (bm == 256) ? 256 : 512;               // resident workgroups: 1 (512 threads) or 2 (256 threads) per CU
+  int G = slots / tiles_n;
+  G = (G / 8) * 8;
+  if (G < 8) G = 8;
+  const int need = ((tiles_m + 7) / 8) * 8;
+  if (G > need) G = need;
+  *G_out = G;
+  return G * tiles_n;
+}
+
+extern "C" int pf_conv2d_stats_groups(int M, int N) {
+  const IgCfg c = ig_pick(M, N);
+  int G;
+  ig_grid(c.bm, (M + c.bm - 1) / c.bm, (N + c.bn - 1) / c.bn, &G);
+  return G;
+}
+
+template <int BM, int BN, int WM, int WN, int NS, bool BWD>
+static int ig_launch_t(IgArgs& a, hipStream_t st) {
+  a.tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  const int grid = ig_grid(BM, a.tiles_m, a.tiles_n, &a.G);
+  size_t lds = NS * (size_t)(BM + BN) * 128 + (BWD ? 4 * BN * 4 : 0);
+  static_assert((size_t)BM * (BN + 8) * 2 <= NS * (size_t)(BM + BN) * 128, "C tile must fit the stage buffers it aliases");
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<BM, BN, WM, WN, NS, BWD>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  k_igemm<BM, BN, WM, WN, NS, BWD><<<grid, 64 * WM * WN, lds, st>>>(a);
+  PF_LAUNCH_CHECK();
+  return 0;
+}
+
+static int ig_launch(IgArgs& a, hipStream_t st) {
+  const IgCfg c = ig_pick(a.M, a.N);
+  const bool bwd = a.bx != nullptr;
+#define PF_IG(BMV, BNV, WMV, WNV, NSV) (bwd ? ig_launch_t<BMV, BNV, WMV, WNV, NSV, true>(a, st) : ig_launch_t<BMV, BNV, WMV, WNV, NSV, false>(a, st))
+  if (c.bm == 256 && c.bn == 128) return PF_IG(256, 128, 4, 2, 3);    // 8 wavefronts, 1 workgroup / CU, 3 stages (144 KiB)
+  if (c.bm == 128 && c.bn == 128) return PF_IG(128, 128, 2, 2, 2);    // 4 wavefronts, 2 workgroups / CU, 2 stages each
+  if (c.bm == 256 && c.bn == 64) return PF_IG(256, 64, 4, 1, 2);
+  return PF_IG(128, 64, 2, 2, 2);
+#undef PF_IG
+}
+
+// forward convolution (or any implicit GEMM of that form).  X [img][H][Wd][C], W [N][th][tw][C], Y [img][Ho][Wo][N].
+// zero: >= 128 zero bytes in device memory.  R / partial / bn_*: epilogue options as for pf_conv1x1_fwd /
+// pf_conv1x1_bwd_data_bnstats (partial: [G][4][N] or, with bn_x, [G][2][N]; G = pf_conv2d_stats_groups(M, N)).
+extern "C" int pf_conv2d_fwd(const void* X, const void* W, void* Y, const void* zero, const void* R, float* partial,
+                             const void* bn_x, const float* bn_scale_shift, const float* bn_mean_invstd, int bn_act,
+                             int imgs, int H, int Wd, int C, int N, int th, int tw, int stride, int pad_h, int pad_w,
+                             int Ho, int Wo, void* stream) {
+  if (imgs <= 0 || H <= 0 || Wd <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || N <= 0 || (C % 64) || (N % 8) || th < 1 || tw < 1 ||
+      stride < 1)
+    return (int)hipErrorInvalidValue;
+  if (!pf_aligned16(X) || !pf_aligned16(W) || !pf_aligned16(Y) || !pf_aligned16(zero) || zero == nullptr ||
+      (R && !pf_aligned16(R)) || (bn_x && !pf_aligned16(bn_x)))
+    return (int)hipErrorInvalidValue;
+  if (bn_x != nullptr && (R != nullptr || partial == nullptr || bn_scale_shift == nullptr || bn_mean_invstd == nullptr))
+    return (int)hipErrorInvalidValue;
+  if ((int64_t)imgs * H * Wd * C >= ((int64_t)1 << 31) || (int64_t)N * th * tw * C >= ((int64_t)1 << 31))
+    return (int)hipErrorInvalidValue;                     // 32-bit element offsets inside the kernel
+  IgArgs a;
+  a.X = (const bf16_t*)X; a.W = (const bf16_t*)W; a.Y = (bf16_t*)Y; a.zero = (const bf16_t*)zero;
+  a.R = (const bf16_t*)R; a.partial = partial; a.bx = (const bf16_t*)bn_x; a.bss = bn_scale_shift; a.bmi = bn_mean_invstd;
+  a.b_lo = (bn_act == PF_ACT_NONE) ? -INFINITY : 0.0f;
+  a.b_hi = (bn_act == PF_ACT_RELU6) ? 6.0f : INFINITY;
+  a.M = imgs * Ho * Wo; a.N = N; a.C = C; a.th = th; a.tw = tw;
+  a.H = H; a.Wd = Wd; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
+  return ig_launch(a, (hipStream_t)stream);
+}

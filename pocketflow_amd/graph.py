@@ -676,7 +676,7 @@ def _run_conv1x1(x, w2d, lazy, residual, want_stats, stride):
   y = torch.empty((x.shape[0], N, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
   partial, G = None, 0
   if want_stats:
-    G = hip.conv1x1_stats_groups(M, N)
+    G = hip.conv1x1_stats_groups(M, N, K)
     partial = torch.empty((G, 4, N), dtype=torch.float32, device=x.device)
   ss = lazy.scale_shift if lazy is not None else None
   quant = lazy is not None and lazy.bits is not None
@@ -740,7 +740,7 @@ class _FusedConv1x1(torch.autograd.Function):
                     and lazy.mean_invstd is not None and lazy.act in ('Relu', 'Relu6'))
       with region('conv1x1_bwd_data', float((M * K * (2 if fuse_stats else 1) + M * N) * 2)):
         if fuse_stats:
-          G = hip.conv1x1_stats_groups(M, K)
+          G = hip.conv1x1_stats_groups(M, K, N)
           partial = torch.empty((G, 2, K), dtype=torch.float32, device=x.device)
           hip.conv1x1_bwd_data_bnstats(dy, wt, dx, x, lazy.scale_shift, lazy.mean_invstd, lazy.act, partial, M, N, K)
           lazy.bwd_stats = (partial, G, dx.data_ptr())

@@ -41,7 +41,7 @@ SYMBOLS = [
     'pf_momentum_flat', 'pf_ce_distill_fwd_bwd', 'pf_bn_stats', 'pf_bn_finalize',
     'pf_bn_act_quant_apply', 'pf_bn_bwd_stats', 'pf_bn_bwd_finalize', 'pf_bn_bwd_apply', 'pf_bn_bwd_apply_add',
     'pf_bn_eval_scale_shift', 'pf_gemm_bf16_nt', 'pf_gemm_bf16_nn', 'pf_gemm_bf16_tn',
-    'pf_conv1x1_stats_groups', 'pf_conv1x1_fwd', 'pf_conv1x1_bwd_data_bnstats', 'pf_conv1x1_wrw_splits',
+    'pf_conv1x1_stats_groups', 'pf_conv1x1_stats_groups_k', 'pf_conv1x1_fwd', 'pf_conv1x1_bwd_data_bnstats', 'pf_conv1x1_wrw_splits',
     'pf_conv1x1_wrw', 'pf_image_resize_bilinear',
 ]
 
@@ -303,8 +303,9 @@ def gemm_bf16_tn(A, B, C, M: int, N: int, K: int) -> None:
 # fused 1x1 convolutions
 # ------------------------------------------------------------------------------------------------
 
-def conv1x1_stats_groups(M: int, N: int) -> int:
-  return int(_lib.pf_conv1x1_stats_groups(c_int(M), c_int(N)))
+def conv1x1_stats_groups(M: int, N: int, K: int) -> int:
+  """Rows of the partial-statistics array of an [M][K] x [N][K] convolution (depends on the kernel variant)."""
+  return int(_lib.pf_conv1x1_stats_groups_k(c_int(M), c_int(N), c_int(K)))
 
 
 def conv1x1_wrw_splits(M: int, N: int, K: int) -> int:

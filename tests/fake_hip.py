@@ -134,7 +134,7 @@ class FakeHip(object):
     _rows(dx, C).copy_(out)
 
   # -- fused 1x1 convolutions -------------------------------------------------------------------------------------
-  def conv1x1_stats_groups(self, M, N):
+  def conv1x1_stats_groups(self, M, N, K=0):
     return 3
 
   def conv1x1_wrw_splits(self, M, N, K):

@@ -92,6 +92,7 @@ def run_cp_masked_finetune(FLAGS, tmp_path, optimizer, steps=3):
     seed_step = net.dropout_step
     mask_rng = np.random.RandomState((net.dropout_seed + 7919 * seed_step) % (2 ** 31))
     dmask = (mask_rng.uniform(size=(16, net.features)) < net.keep).astype(np.float32) / np.float32(net.keep)
+    prev = ora.export()
     lr, loss, _ = learner.train_step()
     ref = ora.train_step(*pool[step % len(pool)], extra={'dropout_mask': dmask})
     assert abs(float(loss.detach()) - ref['loss']) <= 5e-4 * max(1.0, abs(ref['loss'])), (step, float(loss.detach()), ref['loss'])
@@ -100,14 +101,24 @@ def run_cp_masked_finetune(FLAGS, tmp_path, optimizer, steps=3):
       # after one update flips single ReLU6 gates and moves per-channel gradients by 10 % at the next step (measured;
       # with IDENTICAL weights the two gradient computations agree to 3e-4 absolute).  As in the weight-sparsification
       # test, every step is therefore checked from a common state: compare, then teacher-force weights and slots.
-      worst, where = _max_rel(st.export_numpy(), ora.export(), skip=('moving_',))
-      assert worst <= 1e-4, 'step %d: variable %s differs by %.3e after one Momentum step from a common state' % (step, where, worst)
+      # One Momentum step from a common state IS a gradient comparison, so the bar is relative to the update:
+      # ||w_hip - w_oracle|| <= 5e-3 * ||w_oracle - w_before|| per variable (float32 reductions over 10^4..10^6 terms with
+      # inputs of magnitude 10^2 on the GPU; a wrong mask, a missing L2 term or a wrong accumulator is O(1) on this scale).
+      got_now, ref_now = st.export_numpy(), ora.export()
+      for name, ref_v in ref_now.items():
+        if 'moving_' in name:
+          continue
+        upd = float(np.linalg.norm((ref_v - prev[name]).astype(np.float64)))
+        err = float(np.linalg.norm((got_now[name] - ref_v).astype(np.float64)))
+        assert err <= 5e-3 * upd + 1e-6 * float(np.linalg.norm(ref_v)) + 1e-9, \
+            'step %d: %s: |hip - oracle| = %.3e vs |update| = %.3e' % (step, name, err, upd)
       _force_state(learner, ora)
   got = st.export_numpy()
   for name, (keep_in, keep_out) in by_var.items():
     assert np.all(got[name][:, :, ~keep_in, :] == 0) and np.all(got[name][:, :, :, ~keep_out] == 0), name
-  tol = adam_tol(steps, learner.lrn_rate(0)) if optimizer == 'adam' else 1e-4
-  worst, where = _max_rel(got, ora.export(), skip=('moving_',))
-  assert worst <= min(tol, 1e-3), 'variable %s differs by %.3e (tolerance %.1e)' % (where, worst, tol)
+  if optimizer == 'adam':
+    tol = adam_tol(steps, learner.lrn_rate(0))
+    worst, where = _max_rel(got, ora.export(), skip=('moving_',))
+    assert worst <= min(tol, 1e-3), 'variable %s differs by %.3e (tolerance %.1e)' % (where, worst, tol)
   worst, where = _max_rel({k: v for k, v in got.items() if 'moving_' in k}, {k: v for k, v in ora.export().items() if 'moving_' in k})
   assert worst <= 1e-3, (where, worst)

@@ -284,8 +284,17 @@ def test_uq_resnet50_distillation_matches_oracle(tmp_path, image_size, a_bits, s
     assert abs(float(out['dst_loss']) - ref['dst_loss']) <= loss_tol * max(1.0, abs(ref['dst_loss']))
   hip_vals = learner.graph.store.export_numpy()
   _compare_vars(hip_vals, ora.export(), tol=adam_tol(steps, learner.lrn_rate(0)), bulk_tol=bulk_tol, skip=('moving_',))
-  _compare_vars({k: v for k, v in hip_vals.items() if 'moving_' in k},
-                {k: v for k, v in ora.export().items() if 'moving_' in k}, tol=TOL_BAR, bulk_tol=None)
+  # BN moving statistics are not optimiser-bounded: with 8-bit activations a few elements per layer sit on the other side
+  # of a rounding boundary (module docstring) and move a batch variance by ~1e-3 relative (measured 1.8e-3 on
+  # batch_normalization_48 after 3 steps at 64x64); the continuous 32-bit run is held to the 1e-3 bar
+  moving_tol = TOL_BAR if a_bits == 32 else 5e-3
+  worst, where = 0.0, None
+  for k, v in ora.export().items():
+    if 'moving_' in k:
+      e = float(np.max(np.abs(hip_vals[k] - v) / np.maximum(1.0, np.abs(v))))
+      if e > worst:
+        worst, where = e, k
+  assert worst <= moving_tol, (where, worst)
 
 
 def test_nuq_resnet50_4bit_distillation_matches_oracle(tmp_path):
