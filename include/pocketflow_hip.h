@@ -222,7 +222,7 @@ int pf_gemm_bf16_tn(const void* A, const void* B, void* C, int M, int N, int K, 
  *   Q(x) = fake_quant(act(scale[k]*x + shift[k])) with scale_shift = {scale[K], shift[K]} as written by
  *   pf_bn_finalize / pf_bn_eval_scale_shift and the activation range in `slot` (NULL: no fake-quant).
  *   Epilogue: R != NULL adds the residual; partial != NULL receives per-channel {sum, sumsq, min, max} of
- *   the stored Y values as [G][4][N] floats, G = pf_conv1x1_stats_groups_k(M, N, K), in the layout
+ *   the stored Y values as [G][4][N] floats, G = pf_conv1x1_stats_groups_k(M, N, K, scale_shift != NULL), in the layout
  *   pf_bn_finalize consumes (pivot 0).  stride > 1: output pixel (img, ho, wo) of an [.., Ho, Wo] grid
  *   reads input pixel (img, ho*stride, wo*stride) of an [.., H, Wd] grid; ymap != 0 maps the OUTPUT rows
  *   instead (backward-data of a strided conv: X = dY dense, Y = dX pre-zeroed).
@@ -232,15 +232,16 @@ int pf_gemm_bf16_tn(const void* A, const void* B, void* C, int M, int N, int K, 
  * Requirements: K % 8 == 0, N % 8 == 0, 16-byte aligned pointers; hipErrorInvalidValue otherwise.     */
 int pf_conv1x1_stats_groups(int M, int N);
 /* G of the partial-statistics array for an [M][K] x [N][K] problem: shapes whose kernel fits the LDS (K, N <= 512,
- * K * N <= 64 Ki) run on the barrier-free resident-kernel variant (pf_conv_stream.hip), which has its own G.   */
-int pf_conv1x1_stats_groups_k(int M, int N, int K);
+ * K * N <= 64 Ki) run on the barrier-free resident-kernel variant (pf_conv_stream.hip), prologue-free shapes with
+ * K >= 512 on the direct-to-LDS staged GEMM (pf_igemm.hip); each has its own G.  prologue: scale_shift != NULL.  */
+int pf_conv1x1_stats_groups_k(int M, int N, int K, int prologue);
 int pf_conv1x1_fwd(const void* X, const void* W, void* Y, const void* R, const float* scale_shift,
                    int act, const uint32_t* slot, int bits, float* partial, int M, int N, int K,
                    int Ho, int Wo, int H, int Wd, int stride, int ymap, void* stream);
 /* backward-data of a stride-1 1x1 convolution, dQ[M][K] = dY[M][N] * W[N][K] (Wt = transposed kernel [K][N]),
  * with the statistics pass of the BN backward of the layer that produced Q fused into the epilogue
  * (replaces FusedBatchNormGrad's reduction over dy, utils/external/resnet_model.py:55-62):
- * partial[G][2][K] = {sum dy, sum dy*xhat}, dy = dQ * act'(scale*x+shift), G = pf_conv1x1_stats_groups_k(M, K, N),
+ * partial[G][2][K] = {sum dy, sum dy*xhat}, dy = dQ * act'(scale*x+shift), G = pf_conv1x1_stats_groups_k(M, K, N, 0),
  * in the layout pf_bn_bwd_finalize consumes.                                                              */
 int pf_conv1x1_bwd_data_bnstats(const void* dY, const void* Wt, void* dQ, const void* bn_x,
                                 const float* bn_scale_shift, const float* bn_mean_invstd, int bn_act,
@@ -249,6 +250,26 @@ int pf_conv1x1_wrw_splits(int M, int N, int K);
 int pf_conv1x1_wrw(const void* dY, const void* X, void* dW, int dw_dtype, float* workspace,
                    const float* scale_shift, int act, const uint32_t* slot, int bits, int M, int N,
                    int K, int Ho, int Wo, int H, int Wd, int stride, void* stream);
+
+/* ---- K12: dense RxS convolutions as implicit GEMMs on the matrix cores (pf_igemm.hip) ----------------------------
+ * replaces tf.nn.conv2d / Conv2DBackpropInput of the 3x3 convolutions of the ResNet blocks
+ * (utils/external/resnet_model.py:92-103 conv2d_fixed_padding, :257-314 conv2 of _bottleneck_block_v2) and serves
+ * as the plain GEMM of the 1x1 convolutions that carry no prologue.
+ *
+ * pf_conv2d_fwd:  Y[img][ho][wo][n] = sum_{r,s,c} X[img][ho*stride + r - pad_h][wo*stride + s - pad_w][c] * W[n][r][s][c]
+ *   X [imgs][H][Wd][C] bf16 NHWC, W [N][th][tw][C] bf16 (KRSC), Y [imgs][Ho][Wo][N] bf16; taps outside the image read
+ *   zeros (`zero`: >= 128 zero bytes in device memory, 16-byte aligned).  C % 64 == 0, N % 8 == 0.
+ *   Epilogue: R != NULL adds a residual [M][N]; partial != NULL receives per-channel {sum, sumsq, min, max} of the stored
+ *   values as [G][4][N], G = pf_conv2d_stats_groups(M, N), M = imgs*Ho*Wo (layout of pf_bn_finalize, pivot 0); with
+ *   bn_x != NULL instead the BN-backward sums {sum dy, sum dy*xhat} [G][2][N] of the BN whose input is bn_x [M][N]
+ *   (dy = Y * act'(scale*x + shift)), as pf_conv1x1_bwd_data_bnstats.
+ *   Backward-data of a stride-1 convolution is the same call on dY with the kernel flipped and transposed:
+ *   W'[c][r][s][n] = W[n][th-1-r][tw-1-s][c], pad' = th-1-pad.                                                      */
+int pf_conv2d_stats_groups(int M, int N);
+int pf_conv2d_fwd(const void* X, const void* W, void* Y, const void* zero, const void* R, float* partial,
+                  const void* bn_x, const float* bn_scale_shift, const float* bn_mean_invstd, int bn_act,
+                  int imgs, int H, int Wd, int C, int N, int th, int tw, int stride, int pad_h, int pad_w,
+                  int Ho, int Wo, void* stream);
 
 /* ---- K13: input pipeline tail -----------------------------------------------------------
  * replaces, per image, the preprocessing chain of utils/external/imagenet_preprocessing.py:226-260 behind the JPEG

@@ -27,7 +27,9 @@
 // ---------------------------------------------------------------------------------------------
 // forward:  Y[m][n] = sum_k Q(X)[row(m)][k] * W[n][k]  (+ R[m][n]),  optional per-channel stats
 // ---------------------------------------------------------------------------------------------
-template <int BN_T, bool PRO, bool BWD>
+// MAP: strided / remapped rows; the stride-1 instantiations carry no index-division code (it is inlined at every load and
+// store site and had pushed the loop body to the size of the instruction cache: 8010 instructions = 64 KiB)
+template <int BN_T, bool PRO, bool BWD, bool MAP>
 __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a) {
   constexpr int WM = (BN_T == 128) ? 64 : 32;       // pixel rows per wavefront
   constexpr int JM = WM / 16;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a)
       const int m = m0 + lrow + i * 32;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (m < a.M && k < a.K) {
-        const int64_t r = a.ymap ? (int64_t)m : map_row(a, m);
+        const int64_t r = (!MAP || a.ymap) ? (int64_t)m : map_row(a, m);
         av |= 1u << i;
         v = *reinterpret_cast<const uint4*>(a.X + r * a.K + k);
       }
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a)
         const int m = m0 + wrow + p * RPP, n = n0 + wvec * 8;
         rres[p] = make_uint4(0, 0, 0, 0);
         if (m < a.M && n < a.N) {
-          const int64_t orow = a.ymap ? map_row(a, m) : (int64_t)m;
+          const int64_t orow = (MAP && a.ymap) ? map_row(a, m) : (int64_t)m;
           rres[p] = *reinterpret_cast<const uint4*>(side + orow * a.N + n);
         }
       }
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a)
       const int m = m0 + rl, n = n0 + wvec * 8;
       if (m < a.M && n < a.N) {
         uint4 c = *reinterpret_cast<const uint4*>(Cs + rl * CS_LD + wvec * 8);
-        const int64_t orow = a.ymap ? map_row(a, m) : (int64_t)m;
+        const int64_t orow = (MAP && a.ymap) ? map_row(a, m) : (int64_t)m;
         if (bwd_stats) {
           float f[8], xv[8];
           unpack8(c, f);
@@ -316,10 +318,21 @@ extern "C" int pf_conv1x1_stats_groups(int M, int N) {
 
 // rows of the [G][stats][N] partial-statistics array pf_conv1x1_fwd / pf_conv1x1_bwd_data_bnstats write for an
 // [M][K] x [N][K] problem (depends on which kernel the shape is dispatched to)
-extern "C" int pf_conv1x1_stats_groups_k(int M, int N, int K) {
+// pf_igemm.hip: direct-to-LDS staged GEMM for the prologue-free shapes with a deep contraction
+extern "C" int pf_conv2d_stats_groups(int M, int N);
+int pf_igemm_gemm_1x1(const void* X, const void* W, void* Y, const void* R, float* partial, const void* bn_x,
+                      const float* bss, const float* bmi, float b_lo, float b_hi, int M, int N, int K, hipStream_t st);
+static bool conv_use_igemm(bool pro, int stride, int K) {
+  const char* e = getenv("PF_CONV_IGEMM");                  // PF_CONV_IGEMM=0: tuning / A-B override
+  if (e != nullptr && atoi(e) == 0) return false;
+  return !pro && stride == 1 && K >= 512 && (K % 64) == 0;  // measured (tools/gpu/igemm_bench.py): wins from K = 512 up
+}
+
+extern "C" int pf_conv1x1_stats_groups_k(int M, int N, int K, int prologue) {
   int nw = 0;
   const int nsplit = pf_conv_stream_plan(M, N, K, &nw);
   if (nsplit > 0) return pf_conv_stream_groups(nsplit);
+  if (conv_use_igemm(prologue != 0, 1, K)) return pf_conv2d_stats_groups(M, N);
   return pf_conv1x1_stats_groups(M, N);
 }
 
@@ -358,15 +371,21 @@ static int conv_fwd_launch(const void* X, const void* W, void* Y, const void* R,
     const int r = pf_conv_stream_launch(a, pro, bx != nullptr, st);      // HBM-bound shapes: kernel resident in LDS
     if (r >= 0) return r;
   }
-  if (bn == 128) {
-    if (pro) k_conv1x1_fwd<128, true, false><<<grid, PF_THREADS, 0, st>>>(a);
-    else if (bx != nullptr) k_conv1x1_fwd<128, false, true><<<grid, PF_THREADS, 0, st>>>(a);
-    else k_conv1x1_fwd<128, false, false><<<grid, PF_THREADS, 0, st>>>(a);
-  } else {
-    if (pro) k_conv1x1_fwd<64, true, false><<<grid, PF_THREADS, 0, st>>>(a);
-    else if (bx != nullptr) k_conv1x1_fwd<64, false, true><<<grid, PF_THREADS, 0, st>>>(a);
-    else k_conv1x1_fwd<64, false, false><<<grid, PF_THREADS, 0, st>>>(a);
+  if (conv_use_igemm(pro, stride, K)) {
+    const int r = pf_igemm_gemm_1x1(X, W, Y, R, partial, bx, bss, bmi, a.b_lo, a.b_hi, M, N, K, st);
+    if (r >= 0) return r;
   }
+  const bool map = stride != 1;
+#define PF_CV(BNV)                                                                             \
+  do {                                                                                         \
+    if (pro) { if (map) k_conv1x1_fwd<BNV, true, false, true><<<grid, PF_THREADS, 0, st>>>(a);  \
+               else k_conv1x1_fwd<BNV, true, false, false><<<grid, PF_THREADS, 0, st>>>(a); }   \
+    else if (bx != nullptr) k_conv1x1_fwd<BNV, false, true, false><<<grid, PF_THREADS, 0, st>>>(a); \
+    else { if (map) k_conv1x1_fwd<BNV, false, false, true><<<grid, PF_THREADS, 0, st>>>(a);     \
+           else k_conv1x1_fwd<BNV, false, false, false><<<grid, PF_THREADS, 0, st>>>(a); }      \
+  } while (0)
+  if (bn == 128) PF_CV(128); else PF_CV(64);
+#undef PF_CV
   PF_LAUNCH_CHECK();
   return 0;
 }

@@ -29,7 +29,9 @@
 #define ST_WAVES 8
 #define ST_GRID 256                 // one persistent workgroup per CU
 
-template <int NW, bool PRO, bool BWD>
+// MAP: strided / remapped rows (projection shortcuts); the stride-1 instantiations carry no index-division code at all
+// (it is inlined at every load and store site: without the split the loop body outgrows the instruction cache)
+template <int NW, bool PRO, bool BWD, bool MAP>
 __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a, const int nsplit) {
   constexpr int JM = (NW == 256) ? 1 : 2;           // 16-pixel blocks per strip
   constexpr int RS = 16 * JM;                       // pixel rows per strip
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
     for (int j = 0; j < JM; ++j) {
       int m = ld_s * RS + j * 16 + l15;
       m = (m < a.M) ? m : (a.M - 1);                                     // tail rows: any valid address (never stored)
-      const int64_t row = a.ymap ? (int64_t)m : map_row(a, m);
+      const int64_t row = (!MAP || a.ymap) ? (int64_t)m : map_row(a, m);
       const bf16_t* p = a.X + row * K + ld_kc * 64 + q * 8;
       r[j * 2 + 0] = *reinterpret_cast<const uint4*>(p);
       r[j * 2 + 1] = *reinterpret_cast<const uint4*>(p + 32);
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
     const int m = s * RS + p * RPP + wrow, n = n0 + wvec * 8;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (m < a.M && n < a.N) {
-      const int64_t orow = a.ymap ? map_row(a, m) : (int64_t)m;
+      const int64_t orow = (MAP && a.ymap) ? map_row(a, m) : (int64_t)m;
       v = *reinterpret_cast<const uint4*>(side + orow * a.N + n);
     }
     rres[p] = v;
@@ -137,11 +139,21 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
   }
 
   int cs = s_first, ckc = 0;                                             // compute-side cursor
-  auto body = [&](int t, uint4 (&r)[NR]) {
+  int slot = 0;                                                          // ring slot of chunk t (wave-uniform)
+  for (int t = 0; t < T; ++t) {
+    // take chunk t out of its ring slot and refill the slot at once.  The slot index is wave-uniform: a scalar branch
+    // per slot keeps every register index static while the multiply / epilogue code below exists ONCE.
     uint4 v[NR];
+    const bool refill = t + D < T;
+#pragma clang loop unroll(full)
+    for (int d = 0; d < D; ++d) {
+      if (slot == d) {
 #pragma unroll
-    for (int i = 0; i < NR; ++i) v[i] = r[i];
-    if (t + D < T) issue(r);                                             // refill the ring slot at once
+        for (int i = 0; i < NR; ++i) v[i] = ring[d][i];
+        if (refill) issue(ring[d]);
+      }
+    }
+    slot = (slot + 1 == D) ? 0 : slot + 1;
     if (ckc == 0) {
 #pragma unroll
       for (int i = 0; i < NI; ++i)
@@ -184,7 +196,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
     const bool last = (ckc == KC - 1);
     const int s = cs;
     if (++ckc == KC) { ckc = 0; cs += sstep; }
-    if (!last) return;
+    if (!last) continue;
 
     // ---- epilogue of one [RS][NW] tile: wave-private transposition, no workgroup barrier ----------------------
 #pragma unroll
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
       const uint4 sv = rres[p];
       if (side != nullptr && more) issue_side(cs, p);                    // next strip's vector into the freed register
       if (m < a.M && n < a.N) {
-        const int64_t orow = a.ymap ? map_row(a, m) : (int64_t)m;
+        const int64_t orow = (MAP && a.ymap) ? map_row(a, m) : (int64_t)m;
         if (BWD) {
           float f[8], xv[8];
           unpack8(c, f);
@@ -240,12 +252,6 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
         *reinterpret_cast<uint4*>(a.Y + orow * a.N + n) = c;
       }
     }
-  };
-
-  for (int t = 0; t < T; t += D) {
-#pragma clang loop unroll(full)
-    for (int d = 0; d < D; ++d)
-      if (t + d < T) body(t + d, ring[d]);
   }
 
   // ---- statistics: lanes with equal column group -> wavefronts -> partial[g][stat][n0 + c], fixed order --------
@@ -308,19 +314,19 @@ int pf_conv_stream_plan(int M, int N, int K, int* nw_out) {
 
 int pf_conv_stream_groups(int nsplit) { return ST_GRID / nsplit; }
 
-template <int NW, bool PRO, bool BWD>
+template <int NW, bool PRO, bool BWD, bool MAP>
 static int stream_launch_t(const ConvArgs& a, int nsplit, hipStream_t st) {
   const int JM = (NW == 256) ? 1 : 2, RS = 16 * JM;
   const size_t aux_fl = PRO ? 2 * (size_t)a.K : (BWD ? 4 * (size_t)NW : 0);
   const size_t lds = (size_t)NW * a.K * 2 + aux_fl * 4 + (size_t)ST_WAVES * RS * (NW + 8) * 2;
   static size_t configured = 0;
   if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv1x1_stream<NW, PRO, BWD>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv1x1_stream<NW, PRO, BWD, MAP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     configured = lds;
   }
-  k_conv1x1_stream<NW, PRO, BWD><<<ST_GRID, ST_THREADS, lds, st>>>(a, nsplit);
+  k_conv1x1_stream<NW, PRO, BWD, MAP><<<ST_GRID, ST_THREADS, lds, st>>>(a, nsplit);
   PF_LAUNCH_CHECK();
   return 0;
 }
@@ -330,11 +336,14 @@ int pf_conv_stream_launch(const ConvArgs& a, bool pro, bool bwd, hipStream_t st)
   int nw = 0;
   const int nsplit = pf_conv_stream_plan(a.M, a.N, a.K, &nw);
   if (nsplit == 0) return -1;
-#define PF_ST(NWV)                                                          \
-  do {                                                                      \
-    if (pro) return stream_launch_t<NWV, true, false>(a, nsplit, st);       \
-    if (bwd) return stream_launch_t<NWV, false, true>(a, nsplit, st);       \
-    return stream_launch_t<NWV, false, false>(a, nsplit, st);               \
+  const bool map = a.stride != 1;
+#define PF_ST(NWV)                                                                                  \
+  do {                                                                                              \
+    if (pro) return map ? stream_launch_t<NWV, true, false, true>(a, nsplit, st)                    \
+                        : stream_launch_t<NWV, true, false, false>(a, nsplit, st);                  \
+    if (bwd) return stream_launch_t<NWV, false, true, false>(a, nsplit, st);                        \
+    return map ? stream_launch_t<NWV, false, false, true>(a, nsplit, st)                            \
+               : stream_launch_t<NWV, false, false, false>(a, nsplit, st);                          \
   } while (0)
   if (nw == 64) PF_ST(64);
   if (nw == 128) PF_ST(128);

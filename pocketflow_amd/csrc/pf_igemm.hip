@@ -360,3 +360,18 @@ extern "C" int pf_conv2d_fwd(const void* X, const void* W, void* Y, const void* 
   a.H = H; a.Wd = Wd; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
   return ig_launch(a, (hipStream_t)stream);
 }
+
+// plain / backward-data GEMM of a stride-1 1x1 convolution through the same kernel (called by pf_conv.hip for the
+// shapes it routes here): rows are "images" of 1 x 1 pixels, so no tap ever leaves the image and `zero` is only the
+// source of the (never stored) tail rows -- any readable 128 bytes do.
+int pf_igemm_gemm_1x1(const void* X, const void* W, void* Y, const void* R, float* partial, const void* bn_x,
+                      const float* bss, const float* bmi, float b_lo, float b_hi, int M, int N, int K, hipStream_t st) {
+  if ((K % 64) || (int64_t)M * K >= ((int64_t)1 << 31) || (int64_t)N * K >= ((int64_t)1 << 31)) return -1;
+  IgArgs a;
+  a.X = (const bf16_t*)X; a.W = (const bf16_t*)W; a.Y = (bf16_t*)Y; a.zero = (const bf16_t*)X;
+  a.R = (const bf16_t*)R; a.partial = partial; a.bx = (const bf16_t*)bn_x; a.bss = bss; a.bmi = bmi;
+  a.b_lo = b_lo; a.b_hi = b_hi;
+  a.M = M; a.N = N; a.C = K; a.th = 1; a.tw = 1;
+  a.H = 1; a.Wd = 1; a.Ho = 1; a.Wo = 1; a.stride = 1; a.pad_h = 0; a.pad_w = 0;
+  return ig_launch(a, st);
+}

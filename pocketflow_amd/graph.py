@@ -421,7 +421,7 @@ class _BnActQuant(torch.autograd.Function):
   """BN (batch stats) -> act -> activation fake-quant, fused (pf_bn_* kernels)."""
 
   @staticmethod
-  def forward(ctx, x, gamma, beta, layer, graph, training, slot, bits, stats=None):
+  def forward(ctx, x, gamma, beta, layer, graph, training, slot, bits, stats=None, box=None):
     x = _nhwc(x)
     C = gamma.numel()
     rows = x.numel() // C
@@ -439,14 +439,21 @@ class _BnActQuant(torch.autograd.Function):
     ctx.save_for_backward(x, scale_shift, mean_invstd)
     ctx.meta = (layer.act, graph, rows, C)
     ctx.params = (gamma, beta)
+    ctx.box = box
+    if box is not None:                          # lets a single consuming convolution fuse the BN-backward sums
+      box.update(x=x, scale_shift=scale_shift, mean_invstd=mean_invstd, act=layer.act, n_consumers=0, bwd_stats=None)
     return q
 
   @staticmethod
   def backward(ctx, dq):
     x, scale_shift, mean_invstd = ctx.saved_tensors
     act, graph, rows, C = ctx.meta
-    dx, dgamma, dbeta = _bn_backward(dq, x, scale_shift, mean_invstd, act, graph, rows, C, params=ctx.params)
-    return dx, dgamma, dbeta, None, None, None, None, None, None
+    pre = None
+    bs = ctx.box.get('bwd_stats') if ctx.box is not None else None
+    if bs is not None and bs[2] == dq.data_ptr():
+      pre = bs[:2]                               # the consumer's backward-data kernel already reduced dy
+    dx, dgamma, dbeta = _bn_backward(dq, x, scale_shift, mean_invstd, act, graph, rows, C, params=ctx.params, pre=pre)
+    return dx, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 class _BnEvalAct(torch.autograd.Function):
@@ -676,7 +683,7 @@ def _run_conv1x1(x, w2d, lazy, residual, want_stats, stride):
   y = torch.empty((x.shape[0], N, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
   partial, G = None, 0
   if want_stats:
-    G = hip.conv1x1_stats_groups(M, N, K)
+    G = hip.conv1x1_stats_groups(M, N, K, prologue=lazy is not None)
     partial = torch.empty((G, 4, N), dtype=torch.float32, device=x.device)
   ss = lazy.scale_shift if lazy is not None else None
   quant = lazy is not None and lazy.bits is not None
@@ -747,6 +754,84 @@ class _FusedConv1x1(torch.autograd.Function):
         else:
           hip.conv1x1_fwd(dy, wt, dx, M, K, N, geom=geom, ymap=geom is not None)
     return dx, dw, (dy if has_res else None), None, None, None, None, None, None
+
+
+OWN_CONV2D = os.environ.get('PF_OWN_CONV2D', '1') != '0'     # RxS convolutions on pf_igemm.hip (0: MIOpen, for A/B runs)
+
+
+def _run_conv2d(x, w_krsc, stride, pad, want_stats):
+  """x: logical NCHW / physical NHWC bf16, w_krsc: contiguous [N][R][S][C] bf16."""
+  B, C, H, W = x.shape
+  N, R, S, _ = w_krsc.shape
+  Ho = (H + 2 * pad[0] - R) // stride + 1
+  Wo = (W + 2 * pad[1] - S) // stride + 1
+  y = torch.empty((B, N, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+  M = B * Ho * Wo
+  partial, G = None, 0
+  if want_stats:
+    G = hip.conv2d_stats_groups(M, N)
+    partial = torch.empty((G, 4, N), dtype=torch.float32, device=x.device)
+  with region('conv2d_fwd', float((B * H * W * C + M * N) * 2)):
+    hip.conv2d_fwd(x, w_krsc, y, B, H, W, C, N, R, S, stride, pad[0], pad[1], Ho, Wo, partial=partial)
+  if want_stats:
+    y._pf_stats = (partial, G)
+  return y
+
+
+class _Conv2dIgemm(torch.autograd.Function):
+  """y = conv2d(x, W) on the implicit-GEMM kernel (pf_conv2d_fwd), x a materialised bf16 NHWC activation.
+  Backward-data of stride-1 convolutions runs on the same kernel with the flipped / transposed kernel and reduces the
+  BN-backward sums of x's producer BN in its epilogue; backward-filter and strided backward-data go through MIOpen."""
+
+  @staticmethod
+  def forward(ctx, x, w, stride, pad, want_stats, graph, box, bn_box):
+    w_krsc = w.detach().permute(0, 2, 3, 1)              # physical layout of the kernel: contiguous [N][R][S][C]
+    y = _run_conv2d(x, w_krsc, stride, pad, want_stats)
+    ctx.save_for_backward(x, w)
+    ctx.meta = (stride, pad, graph, bn_box)
+    box.append(getattr(y, '_pf_stats', None))
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    x, w = ctx.saved_tensors
+    stride, pad, graph, bn_box = ctx.meta
+    dy = _nhwc(dy)
+    dx = dw = None
+    if ctx.needs_input_grad[1]:
+      with region('conv2d_wrw', float((x.numel() + dy.numel()) * 2)):
+        dw = torch.ops.aten.convolution_backward(dy, x, w.detach(), None, [stride, stride], list(pad), [1, 1], False,
+                                                 [0, 0], 1, [False, True, False])[1]
+    if ctx.needs_input_grad[0]:
+      N, C, R, S = w.shape
+      if stride == 1:
+        B, _, H, W = x.shape
+        wb = w.detach().permute(0, 2, 3, 1).flip(1, 2).permute(3, 1, 2, 0).contiguous()   # [C][R][S][N]
+        dx = torch.empty_like(x)
+        M = B * H * W
+        fuse = (FUSE_BN_BWD_STATS and bn_box is not None and bn_box.get('n_consumers') == 1
+                and bn_box.get('act') in ('Relu', 'Relu6') and bn_box['x'].shape == x.shape)
+        with region('conv2d_bwd_data', float((dy.numel() + x.numel() * (2 if fuse else 1)) * 2)):
+          if fuse:
+            G = hip.conv2d_stats_groups(M, C)
+            partial = torch.empty((G, 2, C), dtype=torch.float32, device=x.device)
+            hip.conv2d_fwd(dy, wb, dx, B, H, W, N, C, R, S, 1, R - 1 - pad[0], S - 1 - pad[1], H, W, partial=partial,
+                           bn_x=bn_box['x'], bn_scale_shift=bn_box['scale_shift'], bn_mean_invstd=bn_box['mean_invstd'],
+                           bn_act=bn_box['act'])
+            bn_box['bwd_stats'] = (partial, G, dx.data_ptr())
+          else:
+            hip.conv2d_fwd(dy, wb, dx, B, H, W, N, C, R, S, 1, R - 1 - pad[0], S - 1 - pad[1], H, W)
+      else:
+        with region('conv2d_bwd_data', float((dy.numel() + x.numel()) * 2)):
+          dx = torch.ops.aten.convolution_backward(dy, x, w.detach(), None, [stride, stride], list(pad), [1, 1], False,
+                                                   [0, 0], 1, [True, False, False])[0]
+    return dx, dw, None, None, None, None, None, None
+
+
+def own_conv2d_ok(x, conv, pad) -> bool:
+  return (OWN_CONV2D and conv.k > 1 and conv.bias is None and isinstance(x, torch.Tensor) and fusable_tensor(x)
+          and x.dim() == 4 and conv.kernel.ref_shape[2] % 64 == 0 and conv.kernel.ref_shape[3] % 8 == 0
+          and pad is not None and conv.graph.fuse_conv1x1)
 
 
 def fusable_tensor(t: torch.Tensor) -> bool:
@@ -823,6 +908,8 @@ class Conv2D:
       lazy = x if isinstance(x, LazyAct) else None
       if lazy is not None:
         lazy.n_consumers += 1
+      elif getattr(x, '_pf_bn', None) is not None:
+        x._pf_bn['n_consumers'] += 2             # a materialised BN output read by a 1x1: its BN-backward sums are not fused
       xin = lazy.x if lazy is not None else _nhwc(x)
       if torch.is_grad_enabled() and (xin.requires_grad or w.requires_grad):
         box = []
@@ -836,15 +923,37 @@ class Conv2D:
     x = materialize(x)
     b = self.bias.tensor.to(x.dtype) if self.bias is not None else None
     pad = 0
+    sym = None                                   # symmetric (pad_h, pad_w) when the padding needs no padded copy
     if isinstance(self.padding, int):
       pad = self.padding
+      sym = (pad, pad)
     elif self.padding == 'SAME' and self.k > 1:
       ph = _same_pads(x.shape[2], self.k, self.stride)
       pw = _same_pads(x.shape[3], self.k, self.stride)
       if ph[0] == ph[1] and pw[0] == pw[1]:
         pad = (ph[0], pw[0])
+        sym = pad
       else:
         x = F.pad(x, (pw[0], pw[1], ph[0], ph[1]))
+        sym = (0, 0)
+    elif self.padding == 'VALID':
+      sym = (0, 0)
+    if own_conv2d_ok(x, self, sym):
+      bn_box = getattr(x, '_pf_bn', None)
+      if bn_box is not None:
+        bn_box['n_consumers'] += 1
+      xin = _nhwc(x)
+      if torch.is_grad_enabled() and (xin.requires_grad or w.requires_grad):
+        box = []
+        y = _Conv2dIgemm.apply(xin, w, self.stride, sym, want_stats, self.graph, box, bn_box)
+        if box and box[0] is not None:
+          y._pf_stats = box[0]
+      else:
+        y = _run_conv2d(xin, w.detach().permute(0, 2, 3, 1), self.stride, sym, want_stats)
+      return y if residual is None else y + residual
+    bn_box = getattr(x, '_pf_bn', None)
+    if bn_box is not None:
+      bn_box['n_consumers'] += 2                 # a consumer that cannot fuse the BN-backward sums
     y = F.conv2d(x, w, b, stride=self.stride, padding=pad)
     return y if residual is None else y + residual
 
@@ -989,7 +1098,10 @@ class BatchNormAct:
         lazy_out = LazyAct(alias, box[0], self.act, slot, bits, x.numel() // self.C, self.C, mean_invstd=box[1])
         box.append(lazy_out)
         return (lazy_out, skip) if getattr(self, '_want_skip', False) else lazy_out
-      return _BnActQuant.apply(x, self.gamma.tensor, self.beta.tensor, self, g, True, slot, bits, stats)
+      box = {}
+      q = _BnActQuant.apply(x, self.gamma.tensor, self.beta.tensor, self, g, True, slot, bits, stats, box)
+      q._pf_bn = box
+      return q
     if torch.is_grad_enabled() and not g.frozen and (x.requires_grad or self.gamma.tensor.requires_grad):
       if bits is not None:
         raise NotImplementedError('inference-mode BN with gradients and activation quantisation (no learner needs it)')

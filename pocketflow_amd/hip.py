@@ -42,7 +42,7 @@ SYMBOLS = [
     'pf_bn_act_quant_apply', 'pf_bn_bwd_stats', 'pf_bn_bwd_finalize', 'pf_bn_bwd_apply', 'pf_bn_bwd_apply_add',
     'pf_bn_eval_scale_shift', 'pf_gemm_bf16_nt', 'pf_gemm_bf16_nn', 'pf_gemm_bf16_tn',
     'pf_conv1x1_stats_groups', 'pf_conv1x1_stats_groups_k', 'pf_conv1x1_fwd', 'pf_conv1x1_bwd_data_bnstats', 'pf_conv1x1_wrw_splits',
-    'pf_conv1x1_wrw', 'pf_image_resize_bilinear',
+    'pf_conv1x1_wrw', 'pf_conv2d_stats_groups', 'pf_conv2d_fwd', 'pf_image_resize_bilinear',
 ]
 
 
@@ -303,9 +303,10 @@ def gemm_bf16_tn(A, B, C, M: int, N: int, K: int) -> None:
 # fused 1x1 convolutions
 # ------------------------------------------------------------------------------------------------
 
-def conv1x1_stats_groups(M: int, N: int, K: int) -> int:
-  """Rows of the partial-statistics array of an [M][K] x [N][K] convolution (depends on the kernel variant)."""
-  return int(_lib.pf_conv1x1_stats_groups_k(c_int(M), c_int(N), c_int(K)))
+def conv1x1_stats_groups(M: int, N: int, K: int, prologue: bool = False) -> int:
+  """Rows of the partial-statistics array of an [M][K] x [N][K] convolution (depends on the kernel variant the shape is
+  dispatched to; `prologue`: the call passes scale_shift)."""
+  return int(_lib.pf_conv1x1_stats_groups_k(c_int(M), c_int(N), c_int(K), c_int(1 if prologue else 0)))
 
 
 def conv1x1_wrw_splits(M: int, N: int, K: int) -> int:
@@ -338,6 +339,37 @@ def conv1x1_bwd_data_bnstats(dY, Wt, dQ, bn_x, bn_scale_shift, bn_mean_invstd, b
   _check(_lib.pf_conv1x1_bwd_data_bnstats(_ptr(dY), _ptr(Wt), _ptr(dQ), _ptr(bn_x), _ptr(bn_scale_shift),
                                           _ptr(bn_mean_invstd), c_int(ACT_CODES[bn_act]), _ptr(partial), c_int(M),
                                           c_int(N), c_int(K), _stream()), 'pf_conv1x1_bwd_data_bnstats')
+
+
+# ------------------------------------------------------------------------------------------------
+# RxS convolutions as implicit GEMMs
+# ------------------------------------------------------------------------------------------------
+
+_zero_page = {}
+
+
+def zero_page(device):
+  """128+ zero bytes on `device`: the source of padding taps of pf_conv2d_fwd."""
+  key = str(device)
+  z = _zero_page.get(key)
+  if z is None:
+    z = _zero_page[key] = torch.zeros(256, dtype=torch.bfloat16, device=device)
+  return z
+
+
+def conv2d_stats_groups(M: int, N: int) -> int:
+  return int(_lib.pf_conv2d_stats_groups(c_int(M), c_int(N)))
+
+
+def conv2d_fwd(X, W, Y, imgs: int, H: int, Wd: int, C: int, N: int, th: int, tw: int, stride: int, pad_h: int,
+               pad_w: int, Ho: int, Wo: int, R=None, partial=None, bn_x=None, bn_scale_shift=None,
+               bn_mean_invstd=None, bn_act=None) -> None:
+  """X: NHWC memory [imgs][H][Wd][C] bf16, W: KRSC memory [N][th][tw][C] bf16, Y: [imgs][Ho][Wo][N] bf16."""
+  _dev(X)
+  _check(_lib.pf_conv2d_fwd(_ptr(X), _ptr(W), _ptr(Y), _ptr(zero_page(X.device)), _ptr(R), _ptr(partial), _ptr(bn_x),
+                            _ptr(bn_scale_shift), _ptr(bn_mean_invstd), c_int(ACT_CODES[bn_act]), c_int(imgs), c_int(H),
+                            c_int(Wd), c_int(C), c_int(N), c_int(th), c_int(tw), c_int(stride), c_int(pad_h),
+                            c_int(pad_w), c_int(Ho), c_int(Wo), _stream()), 'pf_conv2d_fwd')
 
 
 # ------------------------------------------------------------------------------------------------

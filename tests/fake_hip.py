@@ -134,7 +134,7 @@ class FakeHip(object):
     _rows(dx, C).copy_(out)
 
   # -- fused 1x1 convolutions -------------------------------------------------------------------------------------
-  def conv1x1_stats_groups(self, M, N, K=0):
+  def conv1x1_stats_groups(self, M, N, K=0, prologue=False):
     return 3
 
   def conv1x1_wrw_splits(self, M, N, K):
@@ -183,6 +183,33 @@ class FakeHip(object):
     if scale_shift is not None:
       xr = self._q_of(xr, scale_shift, act, slot, bits, slot is not None)
     dW.copy_(_rows(dY, N).float().t() @ xr)
+
+  # -- RxS convolutions (pf_igemm.hip) ------------------------------------------------------------------------------------
+  def conv2d_stats_groups(self, M, N):
+    return 3
+
+  def conv2d_fwd(self, X, W, Y, imgs, H, Wd, C, N, th, tw, stride, pad_h, pad_w, Ho, Wo, R=None, partial=None, bn_x=None,
+                 bn_scale_shift=None, bn_mean_invstd=None, bn_act=None):
+    """X: logical NCHW over NHWC memory, W: [N][th][tw][C]; same float32 arithmetic as a dense convolution."""
+    self._n('conv2d_fwd' if bn_x is None else 'conv2d_bwd_data_bnstats')
+    import torch.nn.functional as F
+    y = F.conv2d(X.float(), W.float().permute(0, 3, 1, 2), stride=stride, padding=(pad_h, pad_w))
+    yr = y.permute(0, 2, 3, 1).reshape(-1, N)
+    if R is not None:
+      yr = yr + _rows(R, N).float()
+    _rows(Y, N).copy_(yr)
+    if partial is None:
+      return
+    if bn_x is not None:
+      xr = _rows(bn_x, N).float()
+      dy = yr * _mask(xr * bn_scale_shift[0] + bn_scale_shift[1], bn_act)
+      partial.zero_()
+      partial[2, 0], partial[2, 1] = dy.sum(0), (dy * (xr - bn_mean_invstd[0]) * bn_mean_invstd[1]).sum(0)
+    else:
+      partial[:, 0:2] = 0
+      partial[:, 2] = float('inf')
+      partial[:, 3] = float('-inf')
+      partial[1, 0], partial[1, 1], partial[1, 2], partial[1, 3] = yr.sum(0), (yr * yr).sum(0), yr.min(0).values, yr.max(0).values
 
 
 

@@ -17,27 +17,27 @@ import torch.nn.functional as F
 from fake_hip import FakeHip  # noqa: E402  (tests/fake_hip.py: float32 torch emulation of the HIP entry points)
 
 
-def _build(fuse, fake, act_bits):
+def _build(fuse, fake, act_bits, filters=8):
   from pocketflow_amd import graph as G
   from pocketflow_amd.utils.external import resnet_model as R
   g = G.Graph('model', 'cpu', torch.float32)
   g.fuse_conv1x1 = fuse
-  net = R.Model(50, True, 7, 8, 3, 1, None, None, [2, 2], [1, 2], data_format='channels_last', graph=g)
+  net = R.Model(50, True, 7, filters, 3, 1, None, None, [2, 2], [1, 2], data_format='channels_last', graph=g)
   g.finalize(seed=3, requires_grad=True)
   for op in g.activation_ops:
     op.bits = act_bits
   return g, net
 
 
-@pytest.mark.parametrize('act_bits', [None, 6])
-def test_fused_plumbing_is_exact_on_cpu(monkeypatch, act_bits):
+@pytest.mark.parametrize('act_bits,filters', [(None, 8), (6, 8), (None, 64)])
+def test_fused_plumbing_is_exact_on_cpu(monkeypatch, act_bits, filters):
   from pocketflow_amd import graph as G
   results = {}
   for fuse in (False, True):
     fake = FakeHip()
     monkeypatch.setattr(G, 'hip', fake)
     monkeypatch.setattr(G, 'fusable_tensor', lambda t: True)
-    g, net = _build(fuse, fake, act_bits)
+    g, net = _build(fuse, fake, act_bits, filters)
     torch.manual_seed(0)
     x = torch.randn(4, 3, 12, 12).contiguous(memory_format=torch.channels_last)
     wts = torch.randn(4, 7)
@@ -55,11 +55,21 @@ def test_fused_plumbing_is_exact_on_cpu(monkeypatch, act_bits):
   assert b['calls'].get('conv1x1_fwd', 0) == 2 * 4 + 2 and a['calls'].get('conv1x1_fwd', 0) == 0
   assert b['calls']['bn_apply'] < a['calls']['bn_apply'] and b['calls']['bn_stats'] < a['calls']['bn_stats']
   assert b['calls'].get('conv1x1_bwd_data_bnstats', 0) >= 4 and b['calls'].get('bn_bwd_apply_add', 0) == 2
+  if filters == 64 and G.OWN_CONV2D:
+    # C % 64 == 0: the four 3x3 convolutions run on the implicit-GEMM entry point (pf_conv2d_fwd) and leave bn3's
+    # statistics; the three stride-1 ones also run backward-data there, with bn2's BN-backward sums in the epilogue
+    assert b['calls'].get('conv2d_fwd', 0) == 4 and b['calls'].get('conv2d_bwd_data_bnstats', 0) == 3, b['calls']
+    assert a['calls'].get('conv2d_fwd', 0) == 0
   for k in ('logits', 'w_grad', 'o_grad', 'state'):
     ref, got = a[k], b[k]
     err = float((ref - got).abs().max() / (ref.abs().max() + 1e-12))
     # exact (float32 round-off) without quantisers; a 6-bit quantiser flips a few elements on that round-off
     tol = 2e-5 if act_bits is None else 0.25
+    if filters == 64:
+      # wide layers: the epilogue statistics are un-pivoted float32 sums (sum x, sum x^2), whose cancellation error the BN
+      # backward amplifies into the kernel gradients (3.3e-3 here, with or without the 3x3 path: PF_OWN_CONV2D=0 gives the
+      # same figure); immaterial next to bf16 rounding, which is the only mode the fused path runs in on the GPU
+      tol = 1e-2
     assert err <= tol, (k, err)
   if act_bits is not None:
     # ... and the gradients still point the same way

@@ -1,0 +1,126 @@
+"""Implicit-GEMM convolution kernel (pf_conv2d_fwd, pf_igemm.hip) against float32 torch references built from the SAME
+bf16 inputs: 3x3 / 1x1 / 5x3 windows, strides 1 and 2, zero padding at the borders, row / channel tails, every tile
+configuration, the statistics epilogue, the BN-backward-statistics epilogue, and backward-data through the flipped kernel."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+  from pocketflow_amd import hip as h
+  return h
+
+
+def _bf(x):
+  return x.to(torch.bfloat16)
+
+
+def _close(got, ref, what, frac_tol=0.0):
+  got, ref = got.float(), ref.float()
+  err = (got - ref).abs()
+  tol = ref.abs() * 2 ** -7 + 2e-2 * float(ref.abs().mean() + 1e-6)
+  bad = float((err > tol).float().mean())
+  assert bad <= frac_tol, '%s: %.3e of the elements differ (max err %.3e, mean |ref| %.3e)' % (
+      what, bad, float(err.max()), float(ref.abs().mean()))
+
+
+def _run(hip, x_nhwc, w_krsc, stride, pad, **kw):
+  imgs, H, Wd, C = x_nhwc.shape
+  N, th, tw, _ = w_krsc.shape
+  Ho = (H + 2 * pad[0] - th) // stride + 1
+  Wo = (Wd + 2 * pad[1] - tw) // stride + 1
+  y = torch.empty(imgs, Ho, Wo, N, device='cuda', dtype=torch.bfloat16)
+  hip.conv2d_fwd(x_nhwc, w_krsc, y, imgs, H, Wd, C, N, th, tw, stride, pad[0], pad[1], Ho, Wo, **kw)
+  return y
+
+
+def _ref(x_nhwc, w_krsc, stride, pad):
+  return F.conv2d(x_nhwc.float().permute(0, 3, 1, 2), w_krsc.float().permute(0, 3, 1, 2), stride=stride,
+                  padding=pad).permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize('tile', ['', '256x128', '128x128', '256x64', '128x64'])
+@pytest.mark.parametrize('imgs,H,Wd,C,N,k,stride', [(2, 14, 14, 64, 64, 3, 1), (3, 9, 11, 128, 128, 3, 1),
+                                                    (2, 16, 16, 64, 128, 3, 2), (5, 7, 7, 192, 256, 1, 1),
+                                                    (1, 20, 12, 64, 72, 3, 1), (40, 28, 28, 128, 128, 3, 1)])
+def test_conv2d_fwd_matches_torch(hip, monkeypatch, tile, imgs, H, Wd, C, N, k, stride):
+  if tile:
+    monkeypatch.setenv('PF_IGEMM_TILE', tile)
+  else:
+    monkeypatch.delenv('PF_IGEMM_TILE', raising=False)
+  g = torch.Generator(device='cuda').manual_seed(H * Wd + C + N)
+  x = _bf(torch.randn(imgs, H, Wd, C, device='cuda', generator=g))
+  w = _bf(torch.randn(N, k, k, C, device='cuda', generator=g) * 0.05)
+  pad = ((k - 1) // 2, (k - 1) // 2)
+  y = _run(hip, x, w, stride, pad)
+  _close(y, _bf(_ref(x, w, stride, pad)), 'fwd %s' % tile)
+
+
+def test_conv2d_fwd_asymmetric_window_and_padding(hip):
+  """th != tw, pad_h != pad_w, an ASYMMETRIC kernel (a transposed window or tap order would show)."""
+  g = torch.Generator(device='cuda').manual_seed(1)
+  x = _bf(torch.randn(2, 13, 10, 64, device='cuda', generator=g))
+  w = _bf(torch.randn(64, 5, 3, 64, device='cuda', generator=g) * 0.05)
+  y = _run(hip, x, w, 1, (2, 0))
+  _close(y, _bf(_ref(x, w, 1, (2, 0))), 'asymmetric')
+
+
+@pytest.mark.parametrize('imgs,H,C,N', [(8, 28, 128, 128), (4, 14, 256, 256), (16, 56, 64, 64)])
+def test_conv2d_fwd_statistics_and_residual(hip, imgs, H, C, N):
+  g = torch.Generator(device='cuda').manual_seed(C)
+  x = _bf(torch.randn(imgs, H, H, C, device='cuda', generator=g))
+  w = _bf(torch.randn(N, 3, 3, C, device='cuda', generator=g) * 0.05)
+  M = imgs * H * H
+  G = hip.conv2d_stats_groups(M, N)
+  partial = torch.full((G, 4, N), float('nan'), device='cuda')
+  r = _bf(torch.randn(M, N, device='cuda', generator=g))
+  y = _run(hip, x, w, 1, (1, 1), R=r, partial=partial)
+  ref = _bf(_bf(_ref(x, w, 1, (1, 1))).float().reshape(M, N) + r.float())
+  _close(y.reshape(M, N), ref, 'residual', frac_tol=1e-5)
+  yf = y.float().reshape(M, N)
+  assert not torch.isnan(partial).any()
+  torch.testing.assert_close(partial[:, 0].sum(0), yf.sum(0), rtol=1e-4, atol=2e-2)
+  torch.testing.assert_close(partial[:, 1].sum(0), (yf * yf).sum(0), rtol=1e-4, atol=2e-2)
+  assert torch.equal(partial[:, 2].min(0).values, yf.min(0).values)
+  assert torch.equal(partial[:, 3].max(0).values, yf.max(0).values)
+  # deterministic (fixed-order reductions)
+  p2 = torch.empty_like(partial)
+  _run(hip, x, w, 1, (1, 1), R=r, partial=p2)
+  assert torch.equal(partial, p2)
+
+
+def test_conv2d_backward_data_through_flipped_kernel_with_bn_statistics(hip):
+  """dX = conv(dY, W') with W'[c][r][s][n] = W[n][2-r][2-s][c], pad 1 (stride-1 3x3), against autograd; the BN-backward
+  sums of the producer BN in the epilogue against pf_bn_bwd_stats on the stored dX."""
+  imgs, H, C, N = 6, 14, 128, 192
+  g = torch.Generator(device='cuda').manual_seed(9)
+  x = _bf(torch.randn(imgs, H, H, C, device='cuda', generator=g))
+  w = _bf(torch.randn(N, 3, 3, C, device='cuda', generator=g) * 0.05)
+  dy = _bf(torch.randn(imgs, H, H, N, device='cuda', generator=g) * 0.1)
+  xt = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+  F.conv2d(xt, w.float().permute(0, 3, 1, 2), padding=1).backward(dy.float().permute(0, 3, 1, 2))
+  ref = xt.grad.permute(0, 2, 3, 1)
+  wb = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()            # [C][3][3][N]
+  M = imgs * H * H
+  bnx = _bf(torch.randn(M, C, device='cuda', generator=g))
+  ss = torch.stack([torch.rand(C, device='cuda', generator=g) + 0.5, torch.randn(C, device='cuda', generator=g) * 0.3])
+  mi = torch.stack([torch.randn(C, device='cuda', generator=g) * 0.1, torch.rand(C, device='cuda', generator=g) + 0.5])
+  G = hip.conv2d_stats_groups(M, C)
+  partial = torch.full((G, 2, C), float('nan'), device='cuda')
+  dx = _run(hip, dy, wb, 1, (1, 1), partial=partial, bn_x=bnx, bn_scale_shift=ss, bn_mean_invstd=mi, bn_act='Relu')
+  _close(dx, _bf(ref), 'bwd-data')
+  nblk = 16
+  ref_partial = torch.empty(nblk * 2 * C, device='cuda')
+  hip.bn_bwd_stats(dx.reshape(M, C), bnx, M, C, ss, mi, 'Relu', ref_partial, nblk)
+  dgamma, dbeta = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+  hip.bn_bwd_finalize(ref_partial, nblk, C, dgamma, dbeta)
+  dg2, db2 = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+  hip.bn_bwd_finalize(partial, G, C, dg2, db2)
+  torch.testing.assert_close(db2, dbeta, rtol=1e-4, atol=1e-3)
+  torch.testing.assert_close(dg2, dgamma, rtol=1e-4, atol=1e-3)

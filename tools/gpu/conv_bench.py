@@ -31,7 +31,7 @@ for hw, K, N in shapes:
   slot = torch.empty(2, dtype=torch.int32, device='cuda'); hip.minmax_slots_init(slot)
   hip.minmax_tensor(torch.relu(X.float() * ss[0] + ss[1]).contiguous(), slot)
   Y = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
-  G = hip.conv1x1_stats_groups(M, N, K)
+  G = hip.conv1x1_stats_groups(M, N, K, prologue=True)
   partial = torch.empty(G, 4, N, device='cuda')
   Q = torch.empty_like(X)
   q4 = Q.view(B, hw, hw, K).permute(0, 3, 1, 2)
