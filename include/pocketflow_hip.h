@@ -271,6 +271,23 @@ int pf_conv2d_fwd(const void* X, const void* W, void* Y, const void* zero, const
                   int imgs, int H, int Wd, int C, int N, int th, int tw, int stride, int pad_h, int pad_w,
                   int Ho, int Wo, void* stream);
 
+/* pf_conv2d_wrw: backward-filter of the same convolutions (Conv2DBackpropFilter), dW[n][r][s][c] = sum_m dY[m][n] *
+ * X[pix(m, r, s)][c], dW float32 or bf16 in KRSC layout; deterministic (fixed-order reductions, no atomics).
+ * C % 64 == 0, N % 64 == 0, M = imgs*Ho*Wo >= 2048; workspace: (pf_conv2d_wrw_splits(M, N, C, th*tw) + 32) * N*th*tw*C
+ * floats (pf_conv2d_wrw_splits returns 0 for unsupported shapes).                                                   */
+int pf_conv2d_wrw_splits(int M, int N, int C, int taps);
+int pf_conv2d_wrw(const void* dY, const void* X, void* dW, int dw_dtype, float* workspace, int imgs, int H, int Wd, int C,
+                  int N, int th, int tw, int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream);
+
+/* ---- K13: max-pooling of the ResNet stem (tf.layers.max_pooling2d, padding SAME: utils/external/resnet_model.py:522-526)
+ * and MaxPoolGrad, NHWC float32 / bf16, C % 8 == 0.  Padding is -inf (clipped windows).  idx[B][Ho][Wo][C] (uint8, may be
+ * NULL in the forward call) holds r*k+s of the FIRST maximum of each window, the element the gradient is routed to.
+ * pf_maxpool_bwd writes every dx element exactly once (gather over the windows that contain it): no atomics.           */
+int pf_maxpool_fwd(const void* x, void* y, void* idx, int dtype, int B, int H, int W, int C, int k, int stride,
+                   int pad_h, int pad_w, int Ho, int Wo, void* stream);
+int pf_maxpool_bwd(const void* dy, const void* idx, void* dx, int dtype, int B, int H, int W, int C, int k, int stride,
+                   int pad_h, int pad_w, int Ho, int Wo, void* stream);
+
 /* ---- K13: input pipeline tail -----------------------------------------------------------
  * replaces, per image, the preprocessing chain of utils/external/imagenet_preprocessing.py:226-260 behind the JPEG
  * decoder: training  random_flip_left_right -> tf.image.resize_images(BILINEAR, align_corners=False) -> - means;

@@ -81,17 +81,27 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a)
   uint4 ra0[4], ra1[4], rb[NBV];
   uint32_t av0 = 0, av1 = 0;                        // validity bits of the staged vectors
 
+  // MAP: the input rows of a tile are the same for all of its k-steps -- the index divisions of map_row() run once per
+  // tile, not once per load (the strided projection shortcuts spent more VALU time on them than on the prologue)
+  int64_t arow[4] = {0, 0, 0, 0};
   auto gloadA = [&](int it, uint4 (&ra)[4], uint32_t& av) {
     const int ti = it / nk, ks = it - ti * nk;
     const int m0 = (g + ti * a.G) * CV_BM;
     const int k = ks * CV_BK + kp * 8;
+    if (MAP && ks == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + lrow + i * 32;
+        arow[i] = (m < a.M) ? (a.ymap ? (int64_t)m : map_row(a, m)) : 0;
+      }
+    }
     av = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + lrow + i * 32;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (m < a.M && k < a.K) {
-        const int64_t r = (!MAP || a.ymap) ? (int64_t)m : map_row(a, m);
+        const int64_t r = MAP ? arow[i] : (int64_t)m;
         av |= 1u << i;
         v = *reinterpret_cast<const uint4*>(a.X + r * a.K + k);
       }
@@ -572,8 +582,38 @@ __global__ __launch_bounds__(PF_THREADS) void k_wrw_reduce(const float* __restri
   if (sg == 0 && e < n) store_one<TO>(out + (int64_t)blockIdx.y * out_stride + e, (l[0][e_l] + l[1][e_l]) + (l[2][e_l] + l[3][e_l]));
 }
 
+// pf_wrw.hip: backward-filter on transposed LDS reads (ds_read_b64_tr_b16), barrier-free main loop
+int pf_wrw_tr_splits(int M, int N, int C, int taps);
+int pf_wrw_tr_launch(const void* dY, const void* X, float* slabs, const float* scale_shift, int act,
+                     const uint32_t* slot, int bits, int M, int N, int C, int th, int tw, int H, int Wd, int Ho, int Wo,
+                     int stride, int pad_h, int pad_w, int S, hipStream_t st);
+
+// sum of the S split slabs [S][n] -> dW (float32 / bf16), fixed order; workspace holds (S + 32) * n floats
+int pf_wrw_reduce(float* workspace, int S, int64_t n, void* dW, int dw_dtype, hipStream_t st) {
+  const int gx = (int)((n + 63) / 64);
+  int ry = 1;                                           // split ranges of the first reduction stage
+  while (ry < 32 && gx * ry < 1024 && ry * 8 <= S) ry *= 2;
+  float* stage = workspace + (int64_t)S * n;            // [ry][n] floats behind the split slabs
+  if (ry > 1) {
+    k_wrw_reduce<float><<<dim3(gx, ry), PF_THREADS, 0, st>>>(workspace, S, n, stage, n);
+    if (dw_dtype == PF_F32) k_wrw_reduce<float><<<dim3(gx, 1), PF_THREADS, 0, st>>>(stage, ry, n, (float*)dW, 0);
+    else if (dw_dtype == PF_BF16) k_wrw_reduce<bf16_t><<<dim3(gx, 1), PF_THREADS, 0, st>>>(stage, ry, n, (bf16_t*)dW, 0);
+    else return (int)hipErrorInvalidValue;
+  } else {
+    if (dw_dtype == PF_F32) k_wrw_reduce<float><<<dim3(gx, 1), PF_THREADS, 0, st>>>(workspace, S, n, (float*)dW, 0);
+    else if (dw_dtype == PF_BF16) k_wrw_reduce<bf16_t><<<dim3(gx, 1), PF_THREADS, 0, st>>>(workspace, S, n, (bf16_t*)dW, 0);
+    else return (int)hipErrorInvalidValue;
+  }
+  PF_LAUNCH_CHECK();
+  return 0;
+}
+
 // number of pixel splits; the workspace must hold (splits + 32) * N * K floats
 extern "C" int pf_conv1x1_wrw_splits(int M, int N, int K) {
+  {
+    const int s2 = pf_wrw_tr_splits(M, N, K, 1);
+    if (s2 > 0) return s2;
+  }
   const int tiles = ((N + WR_TN - 1) / WR_TN) * ((K + WR_TK - 1) / WR_TK);
   int S = (768 + tiles - 1) / tiles;
   const int maxS = (M + 4 * WR_BM - 1) / (4 * WR_BM);       // at least 4 pixel steps per workgroup
@@ -604,29 +644,21 @@ extern "C" int pf_conv1x1_wrw(const void* dY, const void* X, void* dW, int dw_dt
   a.tiles_n = (N + WR_TN - 1) / WR_TN;
   const int tiles_k = (K + WR_TK - 1) / WR_TK;
   const int S = pf_conv1x1_wrw_splits(M, N, K);
-  int rows = (M + S - 1) / S;
-  rows = ((rows + WR_BM - 1) / WR_BM) * WR_BM;
-  a.rows_per_split = rows;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(a.tiles_n * tiles_k, S);
-  if (scale_shift != nullptr) k_conv1x1_wrw<true><<<grid, PF_THREADS, 0, st>>>(a);
-  else k_conv1x1_wrw<false><<<grid, PF_THREADS, 0, st>>>(a);
-  PF_LAUNCH_CHECK();
-  const int64_t n = (int64_t)N * K;
-  const int gx = (int)((n + 63) / 64);
-  int ry = 1;                                           // split ranges of the first reduction stage
-  while (ry < 32 && gx * ry < 1024 && ry * 8 <= S) ry *= 2;
-  float* stage = workspace + (int64_t)S * n;            // [ry][n] floats behind the split slabs
-  if (ry > 1) {
-    k_wrw_reduce<float><<<dim3(gx, ry), PF_THREADS, 0, st>>>(workspace, S, n, stage, n);
-    if (dw_dtype == PF_F32) k_wrw_reduce<float><<<dim3(gx, 1), PF_THREADS, 0, st>>>(stage, ry, n, (float*)dW, 0);
-    else if (dw_dtype == PF_BF16) k_wrw_reduce<bf16_t><<<dim3(gx, 1), PF_THREADS, 0, st>>>(stage, ry, n, (bf16_t*)dW, 0);
-    else return (int)hipErrorInvalidValue;
-  } else {
-    if (dw_dtype == PF_F32) k_wrw_reduce<float><<<dim3(gx, 1), PF_THREADS, 0, st>>>(workspace, S, n, (float*)dW, 0);
-    else if (dw_dtype == PF_BF16) k_wrw_reduce<bf16_t><<<dim3(gx, 1), PF_THREADS, 0, st>>>(workspace, S, n, (bf16_t*)dW, 0);
-    else return (int)hipErrorInvalidValue;
+  const int s_tr = pf_wrw_tr_splits(M, N, K, 1);
+  int done = -1;
+  if (s_tr > 0)
+    done = pf_wrw_tr_launch(dY, X, workspace, scale_shift, act, slot, bits, M, N, K, 1, 1, H, Wd, Ho, Wo, a.stride, 0, 0,
+                            s_tr, st);
+  if (done > 0) return done;
+  if (done < 0) {
+    int rows = (M + S - 1) / S;
+    rows = ((rows + WR_BM - 1) / WR_BM) * WR_BM;
+    a.rows_per_split = rows;
+    dim3 grid(a.tiles_n * tiles_k, S);
+    if (scale_shift != nullptr) k_conv1x1_wrw<true><<<grid, PF_THREADS, 0, st>>>(a);
+    else k_conv1x1_wrw<false><<<grid, PF_THREADS, 0, st>>>(a);
+    PF_LAUNCH_CHECK();
   }
-  PF_LAUNCH_CHECK();
-  return 0;
+  return pf_wrw_reduce(workspace, (done == 0) ? s_tr : S, (int64_t)N * K, dW, dw_dtype, st);
 }

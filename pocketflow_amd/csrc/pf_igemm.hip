@@ -281,9 +281,12 @@ static IgCfg ig_pick(int M, int N) {
       return IgCfg{bm, bn};
   }
   const int bn = (N % 128 == 0) ? 128 : 64;
-  // 256-row tiles (8 wavefronts, one workgroup per CU) when there are enough of them to fill the chip twice over
-  const int64_t tiles256 = (int64_t)((M + 255) / 256) * ((N + bn - 1) / bn);
-  return IgCfg{tiles256 >= 512 ? 256 : 128, bn};
+  // measured on the ResNet-50 shapes at batch 256 (tools/gpu/igemm_bench.py): 128-row tiles with two workgroups per CU
+  // (2 LDS stages each) beat 256-row tiles with one workgroup per CU and 3 stages on every shape (e.g. 3x3 C = 256 at
+  // 14x14: 85 vs 96 us; 3x3 C = 64 at 56x56: 127 vs 165 us): the second workgroup hides the barrier / DMA waits of the
+  // first better than a deeper pipeline does
+  (void)M;
+  return IgCfg{128, bn};
 }
 
 static int ig_grid(int bm, int tiles_m, int tiles_n, int* G_out) {

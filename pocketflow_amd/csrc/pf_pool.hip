@@ -1,0 +1,129 @@
+// K13: the stem's max-pooling (tf.layers.max_pooling2d, padding SAME -- utils/external/resnet_model.py:522-526) and its
+// gradient (MaxPoolGrad) on NHWC tensors.  HBM-bound: one lane = 8 consecutive channels (16 bytes) of one pixel.
+//   forward : y = max over the window (padding = -inf, i.e. clipped windows); writes the position of the FIRST maximum
+//             in window order (r * k + s) as one byte per element -- what the gradient routes to (TF's and torch's rule)
+//   backward: gather form -- every INPUT pixel collects dy from the <= ceil(k/stride)^2 windows that contain it and
+//             selected it; no atomics, every dx element is written exactly once (also the zeros), deterministic.
+// Algorithmic bytes per output element (k = 3, stride 2, bf16): forward 4*2 (input, read once through L2) + 2 + 1,
+// backward 4*2 (dx) + 2 + 1.
+#include "pf_common.h"
+
+template <typename T>
+__global__ __launch_bounds__(PF_THREADS) void k_maxpool_fwd(const T* __restrict__ x, T* __restrict__ y,
+                                                            uint8_t* __restrict__ idx, int B, int H, int W, int C,
+                                                            int k, int stride, int pad_h, int pad_w, int Ho, int Wo) {
+  const int CV = C >> 3;
+  const int64_t total = (int64_t)B * Ho * Wo * CV;
+  for (int64_t e = (int64_t)blockIdx.x * PF_THREADS + threadIdx.x; e < total; e += (int64_t)gridDim.x * PF_THREADS) {
+    const int cv = (int)(e % CV);
+    int64_t p = e / CV;
+    const int wo = (int)(p % Wo); p /= Wo;
+    const int ho = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    float best[8];
+    int arg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; arg[j] = 0; }
+    for (int r = 0; r < k; ++r) {
+      const int hi = ho * stride + r - pad_h;
+      if ((unsigned)hi >= (unsigned)H) continue;
+      for (int s = 0; s < k; ++s) {
+        const int wi = wo * stride + s - pad_w;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        float v[8];
+        load8<T>(x + (((int64_t)b * H + hi) * W + wi) * C + (cv << 3), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (v[j] > best[j] || v[j] != v[j]) { best[j] = v[j]; arg[j] = r * k + s; }
+      }
+    }
+    const int64_t o = (((int64_t)b * Ho + ho) * Wo + wo) * C + (cv << 3);
+    store8<T>(y + o, best);
+    if (idx != nullptr) {
+      uint2 pk;
+      pk.x = (uint32_t)arg[0] | ((uint32_t)arg[1] << 8) | ((uint32_t)arg[2] << 16) | ((uint32_t)arg[3] << 24);
+      pk.y = (uint32_t)arg[4] | ((uint32_t)arg[5] << 8) | ((uint32_t)arg[6] << 16) | ((uint32_t)arg[7] << 24);
+      *reinterpret_cast<uint2*>(idx + o) = pk;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(PF_THREADS) void k_maxpool_bwd(const T* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                            T* __restrict__ dx, int B, int H, int W, int C, int k,
+                                                            int stride, int pad_h, int pad_w, int Ho, int Wo) {
+  const int CV = C >> 3;
+  const int64_t total = (int64_t)B * H * W * CV;
+  for (int64_t e = (int64_t)blockIdx.x * PF_THREADS + threadIdx.x; e < total; e += (int64_t)gridDim.x * PF_THREADS) {
+    const int cv = (int)(e % CV);
+    int64_t p = e / CV;
+    const int wi = (int)(p % W); p /= W;
+    const int hi = (int)(p % H);
+    const int b = (int)(p / H);
+    float g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = 0.f;
+    // windows containing (hi, wi): ho*stride - pad_h <= hi <= ho*stride - pad_h + k - 1
+    const int ho_hi = (hi + pad_h) / stride;
+    const int wo_hi = (wi + pad_w) / stride;
+    for (int ho = ho_hi; ho >= 0 && ho * stride - pad_h + k - 1 >= hi; --ho) {
+      if (ho >= Ho) continue;
+      const int r = hi - (ho * stride - pad_h);
+      for (int wo = wo_hi; wo >= 0 && wo * stride - pad_w + k - 1 >= wi; --wo) {
+        if (wo >= Wo) continue;
+        const int s = wi - (wo * stride - pad_w);
+        const int64_t o = (((int64_t)b * Ho + ho) * Wo + wo) * C + (cv << 3);
+        const uint2 pk = *reinterpret_cast<const uint2*>(idx + o);
+        float d[8];
+        load8<T>(dy + o, d);
+        const uint32_t want = (uint32_t)(r * k + s);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t a = ((j < 4 ? pk.x : pk.y) >> ((j & 3) * 8)) & 0xFFu;
+          if (a == want) g[j] += d[j];
+        }
+      }
+    }
+    store8<T>(dx + (((int64_t)b * H + hi) * W + wi) * C + (cv << 3), g);
+  }
+}
+
+extern "C" int pf_maxpool_fwd(const void* x, void* y, void* idx, int dtype, int B, int H, int W, int C, int k, int stride,
+                              int pad_h, int pad_w, int Ho, int Wo, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || k < 1 || k > 15 || stride < 1 || Ho <= 0 || Wo <= 0)
+    return (int)hipErrorInvalidValue;
+  if (!pf_aligned16(x) || !pf_aligned16(y) || (idx && (((uintptr_t)idx) & 7))) return (int)hipErrorInvalidValue;
+  const int64_t total = (int64_t)B * Ho * Wo * (C / 8);
+  const int grid = pf_grid_for(total, PF_THREADS);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == PF_F32)
+    k_maxpool_fwd<float><<<grid, PF_THREADS, 0, st>>>((const float*)x, (float*)y, (uint8_t*)idx, B, H, W, C, k, stride,
+                                                       pad_h, pad_w, Ho, Wo);
+  else if (dtype == PF_BF16)
+    k_maxpool_fwd<bf16_t><<<grid, PF_THREADS, 0, st>>>((const bf16_t*)x, (bf16_t*)y, (uint8_t*)idx, B, H, W, C, k, stride,
+                                                        pad_h, pad_w, Ho, Wo);
+  else
+    return (int)hipErrorInvalidValue;
+  PF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pf_maxpool_bwd(const void* dy, const void* idx, void* dx, int dtype, int B, int H, int W, int C, int k,
+                              int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || k < 1 || k > 15 || stride < 1 || Ho <= 0 || Wo <= 0 || idx == nullptr)
+    return (int)hipErrorInvalidValue;
+  if (!pf_aligned16(dy) || !pf_aligned16(dx) || (((uintptr_t)idx) & 7)) return (int)hipErrorInvalidValue;
+  const int64_t total = (int64_t)B * H * W * (C / 8);
+  const int grid = pf_grid_for(total, PF_THREADS);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == PF_F32)
+    k_maxpool_bwd<float><<<grid, PF_THREADS, 0, st>>>((const float*)dy, (const uint8_t*)idx, (float*)dx, B, H, W, C, k,
+                                                       stride, pad_h, pad_w, Ho, Wo);
+  else if (dtype == PF_BF16)
+    k_maxpool_bwd<bf16_t><<<grid, PF_THREADS, 0, st>>>((const bf16_t*)dy, (const uint8_t*)idx, (bf16_t*)dx, B, H, W, C, k,
+                                                        stride, pad_h, pad_w, Ho, Wo);
+  else
+    return (int)hipErrorInvalidValue;
+  PF_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,317 @@
+// K12, backward-filter (Conv2DBackpropFilter of the student's convolutions, utils/external/resnet_model.py:92-103,
+// :257-314) with the producer's BN + ReLU + fake-quant re-applied to the input operand (K13 / K4 prologue):
+//
+//     dW[n][tap][c] = sum_m dY[m][n] * Q(X)[pix(m, tap)][c]          m = (img, ho, wo)
+//
+// The contraction runs over PIXELS, the slow index of both NHWC operands, so both MFMA operands are "transposed".
+// gfx950 reads a [4 pixels][16 channels] bf16 block out of LDS transposed in one instruction (ds_read_b64_tr_b16:
+// lane i of a 16-lane group supplies the i-th 8-byte piece of the block and receives column i); this kernel is
+// built around it:
+//   * tiles go from global memory straight into LDS (global_load_lds, no staging registers, no 2-byte scatter) in a
+//     block layout [8 pixels][16 channels] = 256 contiguous bytes per block, so that the 32 lanes the LDS services
+//     together read one full 256-byte line: bank-conflict free.  The order in which pixels map to MFMA k-slots is a free
+//     permutation (a contraction index), chosen for exactly that;
+//   * every WAVEFRONT owns its own pixel stream and accumulates the whole [BN x 64] output tile of the workgroup: each
+//     element of dY and X is read by exactly one wavefront (the prologue runs once per element, on one channel per
+//     lane -- scale / shift live in two registers), nothing is shared in the main loop, there is NO barrier in it,
+//     and each wavefront keeps three stages (24-36 KiB) of LDS-DMA in flight behind counted vmcnt waits;
+//   * the four wavefronts are combined through LDS in a fixed order, pixel splits through the staged reduction of
+//     pf_conv.hip (k_wrw_reduce): bit-reproducible, no float atomics.
+// The (n, k) tiles of one pixel split occupy consecutive workgroups of one XCD, so the rows they all read are fetched
+// from HBM once and shared through that XCD's L2.
+#include "pf_conv_common.h"
+#include <stdlib.h>
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+
+// source of out-of-range rows / padding taps: the products must vanish, so these are real zeros (not "any readable bytes")
+__device__ __attribute__((aligned(16))) const uint32_t pf_wrw_zero_page[64] = {0};
+
+struct WrwArgs {
+  const bf16_t* dY;     // [M][N]
+  const bf16_t* X;      // [rows_in][C]
+  float* slabs;         // [S][N][taps*C]
+  const float* ss;      // prologue scale | shift [2][C] or null
+  const uint32_t* slot;
+  float kq, act_lo, act_hi;
+  int M, N, C;
+  int th, tw, H, Wd, Ho, Wo, stride, pad_h, pad_w;
+  int tiles_n, tiles, rows_per_split;
+};
+
+template <int N> __device__ __forceinline__ void wrw_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// BN: output channels of the tile (64 | 128); PRO: prologue on X; MAP: taps / strides (input row != output row)
+template <int BN, bool PRO, bool MAP>
+__global__ __launch_bounds__(256) void k_wrw_tr(const WrwArgs a) {
+  constexpr int NB = BN / 16;                       // 16-channel blocks of the dY tile
+  constexpr int NS = 3;                             // LDS stages per wavefront
+  constexpr int DY_BYTES = 4 * NB * 256, X_BYTES = 4 * 4 * 256, STAGE = DY_BYTES + X_BYTES;   // 32 pixels per stage
+  constexpr int LPS = NB + 4;                       // LDS-DMA instructions per lane and stage
+  constexpr int NBLK = NB * 4;                      // 16x16 accumulator blocks
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l15 = lane & 15, q = lane >> 4;
+  unsigned char* ring = smem + wave * (NS * STAGE);
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(pf_wrw_zero_page);
+
+  // XCD-aware order (see k_conv1x1_wrw): the tiles of one pixel split are consecutive on one XCD
+  const int nwg = gridDim.x;
+  int wg = blockIdx.x;
+  {
+    const int xcd = wg & 7, idx = wg >> 3;
+    const int qq = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
+  }
+  const int tile = wg % a.tiles, split = wg / a.tiles;
+  const int tn = tile % a.tiles_n, tk = tile / a.tiles_n;
+  const int n0 = tn * BN;
+  const int cch = a.C >> 6;
+  const int tap = tk / cch, c0 = (tk - tap * cch) * 64;
+  const int tap_r = tap / a.tw, tap_s = tap - tap_r * a.tw;
+  const int ktot = a.th * a.tw * a.C;
+  const int mbeg = split * a.rows_per_split;
+  const int mend = (mbeg + a.rows_per_split < a.M) ? (mbeg + a.rows_per_split) : a.M;
+  const int nsteps = (mend > mbeg) ? (mend - mbeg + 31) / 32 : 0;
+  const int my_steps = (nsteps > wave) ? (nsteps - wave + 3) / 4 : 0;      // wavefront w takes steps w, w+4, ...
+
+  // prologue constants: this lane's channels are c0 + j*16 + l15 in every X fragment
+  float psc[4], psh[4];
+  float p_beta = 0.f, p_c1 = 1.f, p_c2 = 1.f;
+  bool p_quant = false;
+  if (PRO) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { psc[j] = a.ss[c0 + j * 16 + l15]; psh[j] = a.ss[a.C + c0 + j * 16 + l15]; }
+    if (a.slot != nullptr) {
+      float alpha, beta;
+      slot_alpha_beta(a.slot, alpha, beta);
+      p_quant = true; p_beta = beta; p_c1 = a.kq / alpha; p_c2 = alpha / a.kq;
+    }
+  }
+
+  // staging roles of this lane inside one LDS-DMA instruction: block b (of 4), pixel row (of 8), 16-byte half
+  const int sb = lane >> 4, srow = (lane & 15) >> 1, sch = lane & 1;
+  const int hw_o = a.Ho * a.Wo;
+  auto stage = [&](int step, int buf) {
+    unsigned char* dst = ring + buf * STAGE;
+    const int mb = mbeg + step * 32;
+#pragma unroll
+    for (int pg = 0; pg < 4; ++pg) {
+      const int m = mb + pg * 8 + srow;
+      const bool ok = m < mend;
+      // dY: NB/4 instructions of 4 channel blocks each
+#pragma unroll
+      for (int g4 = 0; g4 < NB / 4; ++g4) {
+        const int n = n0 + (g4 * 4 + sb) * 16 + sch * 8;
+        const bf16_t* src = (ok && n < a.N) ? (a.dY + (int64_t)m * a.N + n) : (zero + sch * 8);
+        __builtin_amdgcn_global_load_lds(src, LDS_PTR(dst + (pg * NB + g4 * 4) * 256), 16, 0, 0);
+      }
+      // X: one instruction (4 channel blocks = the 64-channel step)
+      bool okx = ok;
+      int64_t row = m;
+      if (MAP && ok) {
+        const int img = m / hw_o, rem = m - img * hw_o;
+        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        const int hi = ho * a.stride + tap_r - a.pad_h, wi = wo * a.stride + tap_s - a.pad_w;
+        okx = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.Wd;
+        row = ((int64_t)img * a.H + hi) * a.Wd + wi;
+      }
+      const bf16_t* srcx = okx ? (a.X + row * a.C + c0 + sb * 16 + sch * 8) : (zero + sch * 8);
+      __builtin_amdgcn_global_load_lds(srcx, LDS_PTR(dst + DY_BYTES + pg * 4 * 256), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[NB][4];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // transposed-read address of this lane inside a block pair: k-slot group q -> pixel block (q >> 1) + 2h, half q & 1
+  const int tr_off = (q & 1) * 128 + (l15 >> 2) * 32 + (l15 & 3) * 8;
+  const int pg_lo = q >> 1;                                               // h = 0: blocks 0 / 1, h = 1: blocks 2 / 3
+
+  if (my_steps > 0) stage(wave, 0);
+  if (my_steps > 1) stage(wave + 4, 1);
+  int ibuf = 2, cbuf = 0;
+  for (int t = 0; t < my_steps; ++t) {
+    if (t + 2 < my_steps) {
+      stage(wave + (t + 2) * 4, ibuf);
+      ibuf = (ibuf == NS - 1) ? 0 : ibuf + 1;
+      wrw_wait_vm<2 * LPS>();
+    } else if (t + 1 < my_steps) {
+      wrw_wait_vm<LPS>();
+    } else {
+      wrw_wait_vm<0>();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* sbase = ring + cbuf * STAGE;
+    cbuf = (cbuf == NS - 1) ? 0 : cbuf + 1;
+    // X fragments (operand B: columns = channels), prologue on the registers
+    bf16x8 xf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) v4s*)(sbase + DY_BYTES + (pg_lo * 4 + j) * 256 + tr_off));
+      const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) v4s*)(sbase + DY_BYTES + ((pg_lo + 2) * 4 + j) * 256 + tr_off));
+      uint4 u;
+      u.x = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+      u.y = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+      u.z = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+      u.w = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+      if (PRO) {
+        float f[8];
+        unpack8(u, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float y = fminf(fmaxf(fmaf(psc[j], f[e], psh[j]), a.act_lo), a.act_hi);
+          if (p_quant) y = fmaf(rintf((y - p_beta) * p_c1), p_c2, p_beta);   // folded constants, as pro_apply()
+          f[e] = y;
+        }
+        u = pack8(f);
+      }
+      xf[j] = *reinterpret_cast<const bf16x8*>(&u);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) v4s*)(sbase + (pg_lo * NB + i) * 256 + tr_off));
+      const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) v4s*)(sbase + ((pg_lo + 2) * NB + i) * 256 + tr_off));
+      v8s d8;
+      d8[0] = lo[0]; d8[1] = lo[1]; d8[2] = lo[2]; d8[3] = lo[3];
+      d8[4] = hi[0]; d8[5] = hi[1]; d8[6] = hi[2]; d8[7] = hi[3];
+      const bf16x8 df = *reinterpret_cast<const bf16x8*>(&d8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, xf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- the four wavefronts -> one tile (fixed order), then the split's slab --------------------------------
+  __syncthreads();                                   // every ring is idle (each wavefront ended on vmcnt(0))
+  float4* red = reinterpret_cast<float4*>(smem);     // [4 wavefronts][NBLK][64 lanes]
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      red[(wave * NBLK + i * 4 + j) * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+  __syncthreads();
+  float* out = a.slabs + (int64_t)split * a.N * ktot;
+  const int kcol = tap * a.C + c0;
+#pragma unroll
+  for (int b = 0; b < NBLK / 4; ++b) {
+    const int blk = wave * (NBLK / 4) + b;
+    const int i = blk >> 2, j = blk & 3;
+    float4 s = red[(0 * NBLK + blk) * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 v = red[(w * NBLK + blk) * 64 + lane];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const int k = kcol + j * 16 + l15;
+    const int n = n0 + i * 16 + q * 4;
+    const float e[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (n + r < a.N) out[(int64_t)(n + r) * ktot + k] = e[r];
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+static bool wrw_tr_enabled() {
+  const char* e = getenv("PF_WRW_TR");                    // PF_WRW_TR=0: tuning / A-B override
+  return e == nullptr || atoi(e) != 0;
+}
+
+static int wrw_tr_bn(int N) { return (N % 128 == 0) ? 128 : 64; }
+
+// pixel splits of the transposed-read kernel (0: the kernel does not apply)
+int pf_wrw_tr_splits(int M, int N, int C, int taps) {
+  if (!wrw_tr_enabled() || (C % 64) || (N % 64) || M < 2048) return 0;
+  const int bn = wrw_tr_bn(N);
+  const int tiles = (N / bn) * (taps * C / 64);
+  int S = (256 + tiles - 1) / tiles;                      // ~ one workgroup (4 wavefronts, <= 144 KiB LDS) per CU
+  const int maxS = (M + 511) / 512;                       // >= 4 steps of 32 pixels per wavefront
+  if (S > maxS) S = maxS;
+  if (S < 1) S = 1;
+  int rows = (M + S - 1) / S;
+  rows = ((rows + 127) / 128) * 128;
+  return (M + rows - 1) / rows;
+}
+
+template <int BN, bool PRO, bool MAP>
+static int wrw_tr_launch_t(const WrwArgs& a, int grid, hipStream_t st) {
+  constexpr int NB = BN / 16;
+  const size_t ring = 4 * (size_t)3 * ((4 * NB + 16) * 256);
+  const size_t red = (size_t)4 * NB * 4 * 64 * 16;
+  const size_t lds = ring > red ? ring : red;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wrw_tr<BN, PRO, MAP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  k_wrw_tr<BN, PRO, MAP><<<grid, 256, lds, st>>>(a);
+  PF_LAUNCH_CHECK();
+  return 0;
+}
+
+// slabs: [S][N][taps*C] floats; returns -1 when the kernel does not apply, else a hipError_t
+int pf_wrw_tr_launch(const void* dY, const void* X, float* slabs, const float* scale_shift, int act,
+                     const uint32_t* slot, int bits, int M, int N, int C, int th, int tw, int H, int Wd, int Ho, int Wo,
+                     int stride, int pad_h, int pad_w, int S, hipStream_t st) {
+  if (S <= 0) return -1;
+  WrwArgs a;
+  a.dY = (const bf16_t*)dY; a.X = (const bf16_t*)X; a.slabs = slabs;
+  a.ss = scale_shift; a.slot = slot;
+  a.kq = uq_k_of_bits(slot ? bits : 8);
+  a.act_lo = (act == PF_ACT_NONE) ? -INFINITY : 0.0f;
+  a.act_hi = (act == PF_ACT_RELU6) ? 6.0f : INFINITY;
+  a.M = M; a.N = N; a.C = C; a.th = th; a.tw = tw; a.H = H; a.Wd = Wd; a.Ho = Ho; a.Wo = Wo;
+  a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
+  const int bn = wrw_tr_bn(N);
+  a.tiles_n = N / bn;
+  a.tiles = a.tiles_n * (th * tw * C / 64);
+  int rows = (M + S - 1) / S;
+  rows = ((rows + 127) / 128) * 128;
+  a.rows_per_split = rows;
+  const int grid = a.tiles * S;
+  const bool pro = scale_shift != nullptr;
+  const bool map = stride != 1 || th * tw > 1;
+  if (pro && th * tw > 1) return -1;                      // padding taps need Q = 0, not Q(0): materialised inputs only
+#define PF_WT(BNV)                                                                            \
+  do {                                                                                        \
+    if (pro) return map ? wrw_tr_launch_t<BNV, true, true>(a, grid, st) : wrw_tr_launch_t<BNV, true, false>(a, grid, st);   \
+    return map ? wrw_tr_launch_t<BNV, false, true>(a, grid, st) : wrw_tr_launch_t<BNV, false, false>(a, grid, st);          \
+  } while (0)
+  if (bn == 128) PF_WT(128);
+  PF_WT(64);
+#undef PF_WT
+}
+
+// ---- RxS backward-filter behind the C ABI ------------------------------------------------------------------------
+int pf_wrw_reduce(float* workspace, int S, int64_t n, void* dW, int dw_dtype, hipStream_t st);   // pf_conv.hip
+
+// pixel splits of pf_conv2d_wrw (0: shape not supported); the workspace must hold (splits + 32) * N * th*tw*C floats
+extern "C" int pf_conv2d_wrw_splits(int M, int N, int C, int taps) { return pf_wrw_tr_splits(M, N, C, taps); }
+
+// dW[n][r][s][c] = sum_m dY[m][n] * X[pix(m, r, s)][c]  (KRSC, float32 or bf16), X a materialised NHWC activation
+extern "C" int pf_conv2d_wrw(const void* dY, const void* X, void* dW, int dw_dtype, float* workspace, int imgs, int H,
+                             int Wd, int C, int N, int th, int tw, int stride, int pad_h, int pad_w, int Ho, int Wo,
+                             void* stream) {
+  if (imgs <= 0 || H <= 0 || Wd <= 0 || Ho <= 0 || Wo <= 0 || th < 1 || tw < 1 || stride < 1) return (int)hipErrorInvalidValue;
+  if (!pf_aligned16(dY) || !pf_aligned16(X) || !pf_aligned16(dW) || !pf_aligned16(workspace)) return (int)hipErrorInvalidValue;
+  const int M = imgs * Ho * Wo;
+  const int S = pf_wrw_tr_splits(M, N, C, th * tw);
+  if (S <= 0) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  const int r = pf_wrw_tr_launch(dY, X, workspace, nullptr, PF_ACT_NONE, nullptr, 8, M, N, C, th, tw, H, Wd, Ho, Wo, stride,
+                                 pad_h, pad_w, S, st);
+  if (r != 0) return r < 0 ? (int)hipErrorInvalidValue : r;
+  return pf_wrw_reduce(workspace, S, (int64_t)N * th * tw * C, dW, dw_dtype, st);
+}

@@ -756,6 +756,8 @@ class _FusedConv1x1(torch.autograd.Function):
     return dx, dw, (dy if has_res else None), None, None, None, None, None, None
 
 
+OWN_POOL = os.environ.get('PF_OWN_POOL', '1') != '0'         # stem max-pooling on pf_pool.hip (0: aten, for A/B runs)
+OWN_CONV2D_WRW = os.environ.get('PF_OWN_CONV2D_WRW', '1') != '0'   # their backward-filter on pf_wrw.hip (0: MIOpen)
 OWN_CONV2D = os.environ.get('PF_OWN_CONV2D', '1') != '0'     # RxS convolutions on pf_igemm.hip (0: MIOpen, for A/B runs)
 
 
@@ -784,7 +786,8 @@ class _Conv2dIgemm(torch.autograd.Function):
   BN-backward sums of x's producer BN in its epilogue; backward-filter and strided backward-data go through MIOpen."""
 
   @staticmethod
-  def forward(ctx, x, w, stride, pad, want_stats, graph, box, bn_box):
+  def forward(ctx, x, w, stride, pad, want_stats, graph, box, bn_box, w_var=None):
+    ctx.w_var = w_var
     w_krsc = w.detach().permute(0, 2, 3, 1)              # physical layout of the kernel: contiguous [N][R][S][C]
     y = _run_conv2d(x, w_krsc, stride, pad, want_stats)
     ctx.save_for_backward(x, w)
@@ -799,9 +802,27 @@ class _Conv2dIgemm(torch.autograd.Function):
     dy = _nhwc(dy)
     dx = dw = None
     if ctx.needs_input_grad[1]:
+      N_, C_, R_, S_ = w.shape
+      B_, _, H_, W_ = x.shape
+      Ho_, Wo_ = dy.shape[2], dy.shape[3]
+      M_ = B_ * Ho_ * Wo_
+      splits = hip.conv2d_wrw_splits(M_, N_, C_, R_ * S_) if OWN_CONV2D_WRW else 0
       with region('conv2d_wrw', float((x.numel() + dy.numel()) * 2)):
-        dw = torch.ops.aten.convolution_backward(dy, x, w.detach(), None, [stride, stride], list(pad), [1, 1], False,
-                                                 [0, 0], 1, [False, True, False])[1]
+        if splits > 0:
+          # the kernel's gradient view inside the flat gradient buffer (KRSC memory): written directly, like the 1x1 path
+          gw = getattr(w, 'grad', None)
+          direct = (gw is not None and gw.shape == w.shape and gw.permute(0, 2, 3, 1).is_contiguous()
+                    and gw.dtype in (torch.float32, torch.bfloat16))
+          dwk = gw.permute(0, 2, 3, 1) if direct else torch.empty((N_, R_, S_, C_), dtype=w.dtype, device=x.device)
+          ws = graph.scratch((splits + 32) * N_ * R_ * S_ * C_)
+          hip.conv2d_wrw(dy, x, dwk, ws, B_, H_, W_, C_, N_, R_, S_, stride, pad[0], pad[1], Ho_, Wo_)
+          if direct:
+            graph.store.notify_grad(ctx.w_var)
+          else:
+            dw = dwk.permute(0, 3, 1, 2)
+        else:
+          dw = torch.ops.aten.convolution_backward(dy, x, w.detach(), None, [stride, stride], list(pad), [1, 1], False,
+                                                   [0, 0], 1, [False, True, False])[1]
     if ctx.needs_input_grad[0]:
       N, C, R, S = w.shape
       if stride == 1:
@@ -825,7 +846,7 @@ class _Conv2dIgemm(torch.autograd.Function):
         with region('conv2d_bwd_data', float((dy.numel() + x.numel()) * 2)):
           dx = torch.ops.aten.convolution_backward(dy, x, w.detach(), None, [stride, stride], list(pad), [1, 1], False,
                                                    [0, 0], 1, [True, False, False])[0]
-    return dx, dw, None, None, None, None, None, None
+    return dx, dw, None, None, None, None, None, None, None
 
 
 def own_conv2d_ok(x, conv, pad) -> bool:
@@ -945,7 +966,7 @@ class Conv2D:
       xin = _nhwc(x)
       if torch.is_grad_enabled() and (xin.requires_grad or w.requires_grad):
         box = []
-        y = _Conv2dIgemm.apply(xin, w, self.stride, sym, want_stats, self.graph, box, bn_box)
+        y = _Conv2dIgemm.apply(xin, w, self.stride, sym, want_stats, self.graph, box, bn_box, self.kernel)
         if box and box[0] is not None:
           y._pf_stats = box[0]
       else:
@@ -1161,10 +1182,43 @@ def _bn_call_tagged(self, x, with_skip: bool = False):
 BatchNormAct.__call__ = _bn_call_tagged
 
 
+class _MaxPool(torch.autograd.Function):
+  """Max-pooling on pf_maxpool_fwd / pf_maxpool_bwd (NHWC, clipped windows = -inf padding, first-maximum gradient)."""
+
+  @staticmethod
+  def forward(ctx, x, k, stride, ph, pw):
+    x = _nhwc(x)
+    B, C, H, W = x.shape
+    Ho = (H + ph[0] + ph[1] - k) // stride + 1
+    Wo = (W + pw[0] + pw[1] - k) // stride + 1
+    y = torch.empty((B, C, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    need_grad = x.requires_grad
+    idx = torch.empty((B, Ho, Wo, C), dtype=torch.uint8, device=x.device) if need_grad else None
+    with region('maxpool_fwd', float((x.numel() + y.numel()) * x.element_size())):
+      hip.maxpool_fwd(x, y, idx, B, H, W, C, k, stride, ph[0], pw[0], Ho, Wo)
+    ctx.meta = (k, stride, ph[0], pw[0], x.shape)
+    if need_grad:
+      ctx.save_for_backward(idx)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    (idx,) = ctx.saved_tensors
+    k, stride, ph0, pw0, xshape = ctx.meta
+    dy = _nhwc(dy)
+    B, C, H, W = xshape
+    dx = torch.empty(xshape, dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+    with region('maxpool_bwd', float((dx.numel() + dy.numel()) * dy.element_size())):
+      hip.maxpool_bwd(dy, idx, dx, B, H, W, C, k, stride, ph0, pw0, dy.shape[2], dy.shape[3])
+    return dx, None, None, None, None
+
+
 def max_pool_same(x: torch.Tensor, k: int, stride: int) -> torch.Tensor:
   """tf.layers.max_pooling2d(padding='SAME'): pad with -inf, extra pixel at the end."""
   ph = _same_pads(x.shape[2], k, stride)
   pw = _same_pads(x.shape[3], k, stride)
+  if x.is_cuda and x.dim() == 4 and x.shape[1] % 8 == 0 and x.dtype in (torch.float32, torch.bfloat16) and OWN_POOL:
+    return _MaxPool.apply(x, k, stride, ph, pw)
   if ph[0] == 0 and pw[0] == 0:
     # padding only at the end: identical to a ceil-mode pool (clipped last window), no padded copy
     return F.max_pool2d(x, k, stride, ceil_mode=True)

@@ -42,7 +42,8 @@ SYMBOLS = [
     'pf_bn_act_quant_apply', 'pf_bn_bwd_stats', 'pf_bn_bwd_finalize', 'pf_bn_bwd_apply', 'pf_bn_bwd_apply_add',
     'pf_bn_eval_scale_shift', 'pf_gemm_bf16_nt', 'pf_gemm_bf16_nn', 'pf_gemm_bf16_tn',
     'pf_conv1x1_stats_groups', 'pf_conv1x1_stats_groups_k', 'pf_conv1x1_fwd', 'pf_conv1x1_bwd_data_bnstats', 'pf_conv1x1_wrw_splits',
-    'pf_conv1x1_wrw', 'pf_conv2d_stats_groups', 'pf_conv2d_fwd', 'pf_image_resize_bilinear',
+    'pf_conv1x1_wrw', 'pf_conv2d_stats_groups', 'pf_conv2d_fwd', 'pf_conv2d_wrw_splits', 'pf_conv2d_wrw', 'pf_maxpool_fwd', 'pf_maxpool_bwd',
+    'pf_image_resize_bilinear',
 ]
 
 
@@ -370,6 +371,39 @@ def conv2d_fwd(X, W, Y, imgs: int, H: int, Wd: int, C: int, N: int, th: int, tw:
                             _ptr(bn_scale_shift), _ptr(bn_mean_invstd), c_int(ACT_CODES[bn_act]), c_int(imgs), c_int(H),
                             c_int(Wd), c_int(C), c_int(N), c_int(th), c_int(tw), c_int(stride), c_int(pad_h),
                             c_int(pad_w), c_int(Ho), c_int(Wo), _stream()), 'pf_conv2d_fwd')
+
+
+def conv2d_wrw_splits(M: int, N: int, C: int, taps: int) -> int:
+  return int(_lib.pf_conv2d_wrw_splits(c_int(M), c_int(N), c_int(C), c_int(taps)))
+
+
+def conv2d_wrw(dY, X, dW, workspace, imgs: int, H: int, Wd: int, C: int, N: int, th: int, tw: int, stride: int,
+               pad_h: int, pad_w: int, Ho: int, Wo: int) -> None:
+  """dW: KRSC memory [N][th][tw][C], float32 or bf16."""
+  _dev(X)
+  _check(_lib.pf_conv2d_wrw(_ptr(dY), _ptr(X), _ptr(dW), c_int(dtype_code(dW)), _ptr(workspace), c_int(imgs), c_int(H),
+                            c_int(Wd), c_int(C), c_int(N), c_int(th), c_int(tw), c_int(stride), c_int(pad_h),
+                            c_int(pad_w), c_int(Ho), c_int(Wo), _stream()), 'pf_conv2d_wrw')
+
+
+# ------------------------------------------------------------------------------------------------
+# max-pooling
+# ------------------------------------------------------------------------------------------------
+
+def maxpool_fwd(x, y, idx, B: int, H: int, W: int, C: int, k: int, stride: int, pad_h: int, pad_w: int, Ho: int,
+                Wo: int) -> None:
+  _dev(x)
+  _check(_lib.pf_maxpool_fwd(_ptr(x), _ptr(y), _ptr(idx), c_int(dtype_code(x)), c_int(B), c_int(H), c_int(W), c_int(C),
+                             c_int(k), c_int(stride), c_int(pad_h), c_int(pad_w), c_int(Ho), c_int(Wo), _stream()),
+         'pf_maxpool_fwd')
+
+
+def maxpool_bwd(dy, idx, dx, B: int, H: int, W: int, C: int, k: int, stride: int, pad_h: int, pad_w: int, Ho: int,
+                Wo: int) -> None:
+  _dev(dy)
+  _check(_lib.pf_maxpool_bwd(_ptr(dy), _ptr(idx), _ptr(dx), c_int(dtype_code(dy)), c_int(B), c_int(H), c_int(W), c_int(C),
+                             c_int(k), c_int(stride), c_int(pad_h), c_int(pad_w), c_int(Ho), c_int(Wo), _stream()),
+         'pf_maxpool_bwd')
 
 
 # ------------------------------------------------------------------------------------------------

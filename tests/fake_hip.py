@@ -184,6 +184,18 @@ class FakeHip(object):
       xr = self._q_of(xr, scale_shift, act, slot, bits, slot is not None)
     dW.copy_(_rows(dY, N).float().t() @ xr)
 
+  def conv2d_wrw_splits(self, M, N, C, taps):
+    return 2
+
+  def conv2d_wrw(self, dY, X, dW, workspace, imgs, H, Wd, C, N, th, tw, stride, pad_h, pad_w, Ho, Wo):
+    """dW: KRSC memory view [N][th][tw][C]."""
+    self._n('conv2d_wrw')
+    import torch
+    w0 = torch.zeros((N, C, th, tw), dtype=torch.float32)
+    g = torch.ops.aten.convolution_backward(dY.float(), X.float(), w0, None, [stride, stride], [pad_h, pad_w], [1, 1],
+                                            False, [0, 0], 1, [False, True, False])[1]
+    dW.copy_(g.permute(0, 2, 3, 1))
+
   # -- RxS convolutions (pf_igemm.hip) ------------------------------------------------------------------------------------
   def conv2d_stats_groups(self, M, N):
     return 3

@@ -124,3 +124,30 @@ def test_conv2d_backward_data_through_flipped_kernel_with_bn_statistics(hip):
   hip.bn_bwd_finalize(partial, G, C, dg2, db2)
   torch.testing.assert_close(db2, dbeta, rtol=1e-4, atol=1e-3)
   torch.testing.assert_close(dg2, dgamma, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize('imgs,H,C,N,k,stride,dw_dtype', [(8, 28, 128, 128, 3, 1, torch.float32), (6, 14, 256, 256, 3, 1, torch.bfloat16),
+                                                          (16, 56, 64, 64, 3, 1, torch.float32), (8, 28, 128, 128, 3, 2, torch.float32),
+                                                          (4, 30, 64, 192, 1, 2, torch.float32)])
+def test_conv2d_wrw_matches_autograd(hip, imgs, H, C, N, k, stride, dw_dtype):
+  """Backward-filter on the transposed-LDS-read kernel (pf_conv2d_wrw): 3x3 stride 1 / 2 with zero padding at the borders
+  (padding taps must contribute exactly 0), KRSC output, deterministic."""
+  g = torch.Generator(device='cuda').manual_seed(C + N + H)
+  pad = (k - 1) // 2
+  x = _bf(torch.randn(imgs, H, H, C, device='cuda', generator=g))
+  Ho = (H + 2 * pad - k) // stride + 1
+  dy = _bf(torch.randn(imgs, Ho, Ho, N, device='cuda', generator=g) * 0.1)
+  M = imgs * Ho * Ho
+  S = hip.conv2d_wrw_splits(M, N, C, k * k)
+  assert S > 0
+  ws = torch.empty((S + 32) * N * k * k * C, device='cuda')
+  dw = torch.empty(N, k, k, C, device='cuda', dtype=dw_dtype)
+  hip.conv2d_wrw(dy, x, dw, ws, imgs, H, H, C, N, k, k, stride, pad, pad, Ho, Ho)
+  w0 = torch.zeros(N, C, k, k, device='cuda')
+  ref = torch.ops.aten.convolution_backward(dy.float().permute(0, 3, 1, 2), x.float().permute(0, 3, 1, 2), w0, None,
+                                            [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+  ref = ref.permute(0, 2, 3, 1)
+  torch.testing.assert_close(dw.float(), ref, rtol=2e-2 if dw_dtype == torch.bfloat16 else 2e-3, atol=3e-2)
+  dw2 = torch.empty_like(dw)
+  hip.conv2d_wrw(dy, x, dw2, ws, imgs, H, H, C, N, k, k, stride, pad, pad, Ho, Ho)
+  assert torch.equal(dw, dw2)

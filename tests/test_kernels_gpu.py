@@ -496,3 +496,27 @@ def test_fullsize_activation_quant_properties(hip):
   hip.uq_apply(xf, y1, slot[0], 8)
   hip.uq_apply(y1, y2, slot[0], 8)
   assert torch.equal(y1, y2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# K13: stem max-pooling (tf.layers.max_pooling2d, padding SAME) and its gradient
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,C,H,W,k,stride', [(3, 64, 112, 112, 3, 2), (2, 16, 15, 9, 3, 2), (2, 8, 8, 8, 2, 2), (1, 24, 7, 7, 3, 1)])
+def test_maxpool_same_forward_and_gradient_match_torch(dtype, B, C, H, W, k, stride):
+  """Clipped windows == -inf padding (extra pixel at the END, TF 'SAME'); the gradient goes to the FIRST maximum of a
+  window.  Inputs are drawn from a small integer set so that ties inside a window are common."""
+  import torch.nn.functional as F
+  from pocketflow_amd import graph as G
+  g = torch.Generator(device='cuda').manual_seed(B * C + H)
+  x = torch.randint(-3, 4, (B, C, H, W), device='cuda', generator=g).to(dtype).contiguous(memory_format=torch.channels_last)
+  x.requires_grad_(True)
+  y = G.max_pool_same(x, k, stride)
+  ph, pw = G._same_pads(H, k, stride), G._same_pads(W, k, stride)
+  xr = x.detach().float().requires_grad_(True)
+  ref = F.max_pool2d(F.pad(xr, (pw[0], pw[1], ph[0], ph[1]), value=float('-inf')), k, stride)
+  assert y.shape == ref.shape and torch.equal(y.float(), ref)
+  dy = torch.randint(-2, 3, ref.shape, device='cuda', generator=g).float()
+  y.backward(dy.to(dtype).contiguous(memory_format=torch.channels_last))
+  ref.backward(dy)
+  assert torch.equal(x.grad.float(), xr.grad)
