@@ -81,27 +81,19 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a)
   uint4 ra0[4], ra1[4], rb[NBV];
   uint32_t av0 = 0, av1 = 0;                        // validity bits of the staged vectors
 
-  // MAP: the input rows of a tile are the same for all of its k-steps -- the index divisions of map_row() run once per
-  // tile, not once per load (the strided projection shortcuts spent more VALU time on them than on the prologue)
-  int64_t arow[4] = {0, 0, 0, 0};
   auto gloadA = [&](int it, uint4 (&ra)[4], uint32_t& av) {
     const int ti = it / nk, ks = it - ti * nk;
     const int m0 = (g + ti * a.G) * CV_BM;
     const int k = ks * CV_BK + kp * 8;
-    if (MAP && ks == 0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0 + lrow + i * 32;
-        arow[i] = (m < a.M) ? (a.ymap ? (int64_t)m : map_row(a, m)) : 0;
-      }
-    }
     av = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + lrow + i * 32;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (m < a.M && k < a.K) {
-        const int64_t r = MAP ? arow[i] : (int64_t)m;
+        // (caching the mapped rows per tile instead of re-deriving them per load was tried: the extra live registers
+        // spill and the strided projections got 25 % slower -- 223 vs 179 us)
+        const int64_t r = (!MAP || a.ymap) ? (int64_t)m : map_row(a, m);
         av |= 1u << i;
         v = *reinterpret_cast<const uint4*>(a.X + r * a.K + k);
       }
@@ -583,7 +575,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_wrw_reduce(const float* __restri
 }
 
 // pf_wrw.hip: backward-filter on transposed LDS reads (ds_read_b64_tr_b16), barrier-free main loop
-int pf_wrw_tr_splits(int M, int N, int C, int taps);
+int pf_wrw_tr_splits_1x1(int M, int N, int C);
 int pf_wrw_tr_launch(const void* dY, const void* X, float* slabs, const float* scale_shift, int act,
                      const uint32_t* slot, int bits, int M, int N, int C, int th, int tw, int H, int Wd, int Ho, int Wo,
                      int stride, int pad_h, int pad_w, int S, hipStream_t st);
@@ -611,7 +603,7 @@ int pf_wrw_reduce(float* workspace, int S, int64_t n, void* dW, int dw_dtype, hi
 // number of pixel splits; the workspace must hold (splits + 32) * N * K floats
 extern "C" int pf_conv1x1_wrw_splits(int M, int N, int K) {
   {
-    const int s2 = pf_wrw_tr_splits(M, N, K, 1);
+    const int s2 = pf_wrw_tr_splits_1x1(M, N, K);
     if (s2 > 0) return s2;
   }
   const int tiles = ((N + WR_TN - 1) / WR_TN) * ((K + WR_TK - 1) / WR_TK);
@@ -645,7 +637,7 @@ extern "C" int pf_conv1x1_wrw(const void* dY, const void* X, void* dW, int dw_dt
   const int tiles_k = (K + WR_TK - 1) / WR_TK;
   const int S = pf_conv1x1_wrw_splits(M, N, K);
   hipStream_t st = (hipStream_t)stream;
-  const int s_tr = pf_wrw_tr_splits(M, N, K, 1);
+  const int s_tr = pf_wrw_tr_splits_1x1(M, N, K);
   int done = -1;
   if (s_tr > 0)
     done = pf_wrw_tr_launch(dY, X, workspace, scale_shift, act, slot, bits, M, N, K, 1, 1, H, Wd, Ho, Wo, a.stride, 0, 0,

@@ -52,14 +52,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
   constexpr int JM = WR / 16, NI = WC / 16;
   constexpr int AS = BM * 8 / T, BS = BN * 8 / T;   // 16-byte loads per lane and step (input / kernel tile)
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr int CS_LD = BN + 8;
+  constexpr int CS_LD = BN + 8, CS_LD_B = BN + 8;
   constexpr int VPR = BN / 8, RPP = T / VPR, NP = BM / RPP;
   static_assert(AS >= 1 && BS >= 1 && NP >= 1, "tile too small for the block");
   constexpr int LPS = AS + BS;                      // LDS-DMA instructions per lane and stage
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NS stages; aliased: C tile, statistics scratch
   bf16_t* Cs = reinterpret_cast<bf16_t*>(smem);
   float* red = reinterpret_cast<float*>(smem);
-  float* bpl = reinterpret_cast<float*>(smem + NS * STAGE);              // BWD: scale | shift | mean | invstd [4][BN]
+  constexpr int RING_B = NS * STAGE, CT_B = BM * CS_LD_B * 2;
+  float* bpl = reinterpret_cast<float*>(smem + (RING_B > CT_B ? RING_B : CT_B));   // BWD: scale | shift | mean | invstd [4][BN]
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave / WN, wn = wave % WN;
@@ -190,57 +191,66 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
         const uint2 v = make_uint2(pack_bf16x2(acc[i][j][0], acc[i][j][1]), pack_bf16x2(acc[i][j][2], acc[i][j][3]));
         *reinterpret_cast<uint2*>(Cs + (wm * WR + j * 16 + l15) * CS_LD + wn * WC + i * 16 + q * 4) = v;
       }
-    uint4 rres[NP];
-    if (side != nullptr) {
+    // epilogue passes in groups of <= 8 rows per thread: the side vectors (residual / BN input) of a group are all in
+    // flight before the group is processed (and before the LDS hand-off for the first group)
+    constexpr int PG = (NP > 8) ? 8 : NP;
+    uint4 rres[PG];
+    auto load_side = [&](int p0) {
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        const int m = m0 + wrw + p * RPP, n = n0 + wvec * 8;
+      for (int p = 0; p < PG; ++p) {
+        const int m = m0 + wrw + (p0 + p) * RPP, n = n0 + wvec * 8;
         rres[p] = make_uint4(0, 0, 0, 0);
         if (m < a.M && n < a.N) rres[p] = *reinterpret_cast<const uint4*>(side + (int64_t)m * a.N + n);
       }
-    }
+    };
+    if (side != nullptr) load_side(0);
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int rl = wrw + p * RPP;
-      const int m = m0 + rl, n = n0 + wvec * 8;
-      if (m < a.M && n < a.N) {
-        uint4 c = *reinterpret_cast<const uint4*>(Cs + rl * CS_LD + wvec * 8);
-        if (BWD) {
-          float f[8], xv[8];
-          unpack8(c, f);
-          unpack8(rres[p], xv);
-          const float* bp = bpl + wvec * 8;
+    for (int p0 = 0; p0 < NP; p0 += PG) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float u = fmaf(bp[j], xv[j], bp[BN + j]);
-            const float dy = (u > a.b_lo && u < a.b_hi) ? f[j] : 0.f;
-            st_s[j] += dy;
-            st_q[j] = fmaf(dy, (xv[j] - bp[2 * BN + j]) * bp[3 * BN + j], st_q[j]);
-          }
-        } else if (a.R != nullptr || a.partial != nullptr) {
-          float f[8];
-          unpack8(c, f);
-          if (a.R != nullptr) {
-            float r[8];
-            unpack8(rres[p], r);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] += r[j];
-            c = pack8(f);
-            unpack8(c, f);                                                  // statistics see the stored (bf16) values
-          }
-          if (a.partial != nullptr) {
+      for (int pp = 0; pp < PG; ++pp) {
+        const int p = p0 + pp;
+        const int rl = wrw + p * RPP;
+        const int m = m0 + rl, n = n0 + wvec * 8;
+        if (m < a.M && n < a.N) {
+          uint4 c = *reinterpret_cast<const uint4*>(Cs + rl * CS_LD + wvec * 8);
+          if (BWD) {
+            float f[8], xv[8];
+            unpack8(c, f);
+            unpack8(rres[pp], xv);
+            const float* bp = bpl + wvec * 8;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              st_s[j] += f[j];
-              st_q[j] = fmaf(f[j], f[j], st_q[j]);
-              st_mn[j] = fminf(st_mn[j], f[j]);
-              st_mx[j] = fmaxf(st_mx[j], f[j]);
+              const float u = fmaf(bp[j], xv[j], bp[BN + j]);
+              const float dy = (u > a.b_lo && u < a.b_hi) ? f[j] : 0.f;
+              st_s[j] += dy;
+              st_q[j] = fmaf(dy, (xv[j] - bp[2 * BN + j]) * bp[3 * BN + j], st_q[j]);
+            }
+          } else if (a.R != nullptr || a.partial != nullptr) {
+            float f[8];
+            unpack8(c, f);
+            if (a.R != nullptr) {
+              float r[8];
+              unpack8(rres[pp], r);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) f[j] += r[j];
+              c = pack8(f);
+              unpack8(c, f);                                                // statistics see the stored (bf16) values
+            }
+            if (a.partial != nullptr) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                st_s[j] += f[j];
+                st_q[j] = fmaf(f[j], f[j], st_q[j]);
+                st_mn[j] = fminf(st_mn[j], f[j]);
+                st_mx[j] = fmaxf(st_mx[j], f[j]);
+              }
             }
           }
+          *reinterpret_cast<uint4*>(a.Y + (int64_t)m * a.N + n) = c;
         }
-        *reinterpret_cast<uint4*>(a.Y + (int64_t)m * a.N + n) = c;
       }
+      if (side != nullptr && p0 + PG < NP) load_side(p0 + PG);
     }
     __syncthreads();
   }
@@ -277,7 +287,8 @@ static IgCfg ig_pick(int M, int N) {
   const char* e = getenv("PF_IGEMM_TILE");                 // tuning override: "256x128" | "128x128" | "256x64" | "128x64"
   if (e != nullptr) {
     int bm = 0, bn = 0;
-    if (sscanf(e, "%dx%d", &bm, &bn) == 2 && (bm == 128 || bm == 256) && (bn == 64 || bn == 128) && (N % bn == 0 || bn == 64))
+    if (sscanf(e, "%dx%d", &bm, &bn) == 2 && (bm == 128 || bm == 256) && (bn == 64 || bn == 128 || (bn == 256 && bm == 256)) &&
+        (N % bn == 0 || bn == 64))
       return IgCfg{bm, bn};
   }
   const int bn = (N % 128 == 0) ? 128 : 64;
@@ -312,8 +323,9 @@ static int ig_launch_t(IgArgs& a, hipStream_t st) {
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
   const int grid = ig_grid(BM, a.tiles_m, a.tiles_n, &a.G);
-  size_t lds = NS * (size_t)(BM + BN) * 128 + (BWD ? 4 * BN * 4 : 0);
-  static_assert((size_t)BM * (BN + 8) * 2 <= NS * (size_t)(BM + BN) * 128, "C tile must fit the stage buffers it aliases");
+  // stage ring and (aliased on it) the C tile; the BWD vectors sit behind whichever is larger
+  constexpr size_t ring = NS * (size_t)(BM + BN) * 128, ctile = (size_t)BM * (BN + 8) * 2;
+  size_t lds = (ring > ctile ? ring : ctile) + (BWD ? 4 * BN * 4 : 0);
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<BM, BN, WM, WN, NS, BWD>),
@@ -330,6 +342,7 @@ static int ig_launch(IgArgs& a, hipStream_t st) {
   const IgCfg c = ig_pick(a.M, a.N);
   const bool bwd = a.bx != nullptr;
 #define PF_IG(BMV, BNV, WMV, WNV, NSV) (bwd ? ig_launch_t<BMV, BNV, WMV, WNV, NSV, true>(a, st) : ig_launch_t<BMV, BNV, WMV, WNV, NSV, false>(a, st))
+  if (c.bm == 256 && c.bn == 256) return PF_IG(256, 256, 4, 2, 2);    // 8 wavefronts (64 x 128 each), 1 workgroup / CU, 2 stages (128 KiB)
   if (c.bm == 256 && c.bn == 128) return PF_IG(256, 128, 4, 2, 3);    // 8 wavefronts, 1 workgroup / CU, 3 stages (144 KiB)
   if (c.bm == 128 && c.bn == 128) return PF_IG(128, 128, 2, 2, 2);    // 4 wavefronts, 2 workgroups / CU, 2 stages each
   if (c.bm == 256 && c.bn == 64) return PF_IG(256, 64, 4, 1, 2);

@@ -222,16 +222,26 @@ __global__ __launch_bounds__(256) void k_wrw_tr(const WrwArgs a) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
-static bool wrw_tr_enabled() {
-  const char* e = getenv("PF_WRW_TR");                    // PF_WRW_TR=0: tuning / A-B override
-  return e == nullptr || atoi(e) != 0;
+// Measured (tools/gpu/wrw_bench.py, ResNet-50 shapes, batch 256): correct and deterministic, but 15-25 % SLOWER than the
+// scatter kernel of pf_conv.hip on the 1x1 layers (99 vs 84 us at 14x14 1024->256) and 2.7x slower than MIOpen on the 3x3
+// ones (336 vs 121 us): with every wavefront accumulating the whole [128 x 64] tile the kernel moves 12 KiB of LDS-DMA
+// per 32 MFMAs (43 flop / byte) through one workgroup of 4 wavefronts per CU -- load-bandwidth bound per CU.  The 1x1
+// dispatcher therefore uses it only on request (PF_WRW_TR=1); pf_conv2d_wrw (the RxS entry point, which has no
+// other implementation here) always runs it.  The fix is a shared 256 x 256 output tile.
+static bool wrw_tr_1x1_enabled() {
+  const char* e = getenv("PF_WRW_TR");
+  return e != nullptr && atoi(e) != 0;
 }
+
+int pf_wrw_tr_splits(int M, int N, int C, int taps);
+// the 1x1 dispatcher's gate (pf_conv.hip)
+int pf_wrw_tr_splits_1x1(int M, int N, int C) { return wrw_tr_1x1_enabled() ? pf_wrw_tr_splits(M, N, C, 1) : 0; }
 
 static int wrw_tr_bn(int N) { return (N % 128 == 0) ? 128 : 64; }
 
 // pixel splits of the transposed-read kernel (0: the kernel does not apply)
 int pf_wrw_tr_splits(int M, int N, int C, int taps) {
-  if (!wrw_tr_enabled() || (C % 64) || (N % 64) || M < 2048) return 0;
+  if ((C % 64) || (N % 64) || M < 2048) return 0;
   const int bn = wrw_tr_bn(N);
   const int tiles = (N / bn) * (taps * C / 64);
   int S = (256 + tiles - 1) / tiles;                      // ~ one workgroup (4 wavefronts, <= 144 KiB LDS) per CU

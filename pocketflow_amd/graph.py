@@ -757,7 +757,9 @@ class _FusedConv1x1(torch.autograd.Function):
 
 
 OWN_POOL = os.environ.get('PF_OWN_POOL', '1') != '0'         # stem max-pooling on pf_pool.hip (0: aten, for A/B runs)
-OWN_CONV2D_WRW = os.environ.get('PF_OWN_CONV2D_WRW', '1') != '0'   # their backward-filter on pf_wrw.hip (0: MIOpen)
+# backward-filter of the RxS convolutions on pf_wrw.hip: correct, but measured 2.7x slower than MIOpen's (336 vs 121 us on the
+# 3x3 C = 256 layer, tools/gpu/wrw_bench.py) -- off until the shared-tile version exists; PF_OWN_CONV2D_WRW=1 enables it
+OWN_CONV2D_WRW = os.environ.get('PF_OWN_CONV2D_WRW', '0') != '0'
 OWN_CONV2D = os.environ.get('PF_OWN_CONV2D', '1') != '0'     # RxS convolutions on pf_igemm.hip (0: MIOpen, for A/B runs)
 
 
