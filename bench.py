@@ -48,8 +48,9 @@ def parse_args():
                   help='profiling region whose launches are timed with HIP events: conv1x1_fwd | conv1x1_wrw | '
                        'conv1x1_bwd_data | bn_bwd_apply | bn_bwd_stats | bn_act_quant_apply | bn_stats')
   ap.add_argument('--no_cpu_baseline', action='store_true')
-  ap.add_argument('--cpu_batch', type=int, default=4)
-  ap.add_argument('--cpu_steps', type=int, default=3)
+  ap.add_argument('--cpu_batch', type=int, default=32, help='batch of the CPU baseline sample (SURVEY 8d: 32)')
+  ap.add_argument('--cpu_steps', type=int, default=5, help='timed CPU steps after the warm-up (SURVEY 8d: >= 5)')
+  ap.add_argument('--cpu_budget_s', type=float, default=200.0, help='wall-clock bound of the CPU baseline sample')
   return ap.parse_args()
 
 
@@ -177,11 +178,12 @@ def main():
       # hard wall-clock limit so that the default run always finishes within minutes
       import subprocess
       code = ('import json, sys; sys.path.insert(0, %r); from oracle.learner_oracle import time_cpu_baseline; '
-              'print("CPU_BASELINE " + json.dumps(time_cpu_baseline(%d, %d, %d, %d, %d, %d)))'
+              'print("CPU_BASELINE " + json.dumps(time_cpu_baseline(%d, %d, %d, %d, %d, %d, budget_s=%f)))'
               % (ROOT, args.resnet_size, args.image_size, args.cpu_batch, args.cpu_steps, args.weight_bits,
-                 args.act_bits))
+                 args.act_bits, args.cpu_budget_s))
       try:
-        out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=150)
+        out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True,
+                             timeout=args.cpu_budget_s + 60)
         for ln in out.stdout.splitlines():
           if ln.startswith('CPU_BASELINE '):
             cpu_baseline = json.loads(ln[len('CPU_BASELINE '):])

@@ -95,11 +95,12 @@ int pf_seg_nuq_apply(const float* w_flat, void* qw_flat, int out_dtype, uint8_t*
                      const float* codebooks, const PfSeg* segs, const PfBlock* blocks,
                      int n_blocks, const uint32_t* slots, void* stream);
 /* dL/dc[j][b] = sum_{i in bucket b, idx_i = j} alpha_b * g_i   (gather-grad scatter-add under the
- * override map {'Mul':'Add','Sign':'Identity'}, nuq utils.py:305-306, 345-346).  dcodebooks must be
- * zeroed by the caller (one memset).                                                          */
+ * override map {'Mul':'Add','Sign':'Identity'}, nuq utils.py:305-306, 345-346).  The sums are ADDED to dcodebooks
+ * [n_codebook] (zeroed by the caller).  Bit-deterministic: terms are accumulated as 2^-36 fixed-point integers with
+ * 64-bit integer atomics in acc_ws [n_codebook] (scratch; zeroed here), then converted once.                   */
 int pf_seg_nuq_codebook_grad(const void* g_flat, int g_dtype, const uint8_t* idx_flat,
-                             float* dcodebooks, const PfSeg* segs, const PfBlock* blocks,
-                             int n_blocks, const uint32_t* slots, void* stream);
+                             float* dcodebooks, int64_t* acc_ws, int64_t n_codebook, const PfSeg* segs,
+                             const PfBlock* blocks, int n_blocks, const uint32_t* slots, void* stream);
 /* normalised weights x_hat = (w - beta) / alpha of ONE tensor (for the quantile initialiser,
  * nuq utils.py:349-366, which then sorts them).                                               */
 int pf_seg_normalize(const float* w_flat, float* xn_out, const PfSeg* segs, int seg_index,

@@ -716,14 +716,23 @@ def time_cpu_baseline(resnet_size=50, image_size=224, batch=4, steps=3, weight_b
   """Time the oracle UniformQuantLearner step (the reference's TF-CPU path restated; TF itself is
   unavailable) on the host cores.  Bounded sample: one warm-up step, then up to `steps` timed steps while
   the wall-clock budget lasts; if the warm-up alone exhausts the budget it IS the sample.  Threads: the
-  cores this process may run on (sched_getaffinity), capped at 16 -- more only adds contention for a
-  batch-4 ResNet-50 and an unconstrained 256-thread pool on a shared box is 100x slower."""
+  cores this process may run on (sched_getaffinity), capped at 32 -- an unconstrained 256-thread pool on a shared box is
+  100x slower.  The record names the CPU model and the core count (the baseline is only comparable with them)."""
   import os
   try:
     avail = len(os.sched_getaffinity(0))
   except AttributeError:
     avail = os.cpu_count() or 1
-  threads = threads or max(1, min(avail, 16))
+  threads = threads or max(1, min(avail, 32))
+  cpu_model = 'unknown'
+  try:
+    with open('/proc/cpuinfo') as f:
+      for ln in f:
+        if ln.startswith('model name'):
+          cpu_model = ln.split(':', 1)[1].strip()
+          break
+  except OSError:
+    pass
   torch.set_num_threads(threads)
   shape = (image_size, image_size, 3)
   values = _random_values_resnet('ilsvrc_12', resnet_size, nb_classes, shape)
@@ -749,7 +758,8 @@ def time_cpu_baseline(resnet_size=50, image_size=224, batch=4, steps=3, weight_b
     done, dt, what = 1, warm, 'the first (warm-up) step only: it exhausted the %.0f s budget' % budget_s
   else:
     what = '%d timed steps after 1 warm-up' % done
-  return {'value': batch * done / dt, 'unit': 'images/s', 'cores': threads, 'kind': 'port',
+  return {'value': batch * done / dt, 'unit': 'images/s', 'cores': threads, 'cores_available': avail,
+          'cpu_model': cpu_model, 'kind': 'port',
           'sample': 'oracle UniformQuantLearner step (NumPy fake-quant/loss/Adam + torch-CPU fp32 conv/BN), '
                     'ResNet-v2-%d %dx%d w%d/a%d%s, batch %d, %s; TF-1.x (the reference runtime) is not installable '
                     'here' % (resnet_size, image_size, image_size, weight_bits, act_bits,

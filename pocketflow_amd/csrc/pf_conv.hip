@@ -322,19 +322,24 @@ extern "C" int pf_conv1x1_stats_groups(int M, int N) {
 // [M][K] x [N][K] problem (depends on which kernel the shape is dispatched to)
 // pf_igemm.hip: direct-to-LDS staged GEMM for the prologue-free shapes with a deep contraction
 extern "C" int pf_conv2d_stats_groups(int M, int N);
-int pf_igemm_gemm_1x1(const void* X, const void* W, void* Y, const void* R, float* partial, const void* bn_x,
-                      const float* bss, const float* bmi, float b_lo, float b_hi, int M, int N, int K, hipStream_t st);
-static bool conv_use_igemm(bool pro, int stride, int K) {
-  const char* e = getenv("PF_CONV_IGEMM");                  // PF_CONV_IGEMM=0: tuning / A-B override
+int pf_igemm_conv1x1(const void* X, const void* W, void* Y, const void* R, float* partial, const void* bn_x,
+                     const float* bss, const float* bmi, float b_lo, float b_hi, const float* scale_shift,
+                     const uint32_t* slot, float kq, float act_lo, float act_hi, int M, int N, int K, int Ho, int Wo,
+                     int H, int Wd, int stride, hipStream_t st);
+// Which 1x1 shapes go to the direct-to-LDS staged kernel (after the resident-kernel variant had its pick).  Measured
+// (tools/gpu/igemm_bench.py, conv_bench2.py): prologue-free GEMMs win from K = 512 up; with the prologue the in-LDS pass
+// behind asynchronous staging beats the register-staged tiles of this file on every shape it was tried on.
+static bool conv_use_igemm(bool pro, int K) {
+  const char* e = getenv(pro ? "PF_CONV_IGEMM_PRO" : "PF_CONV_IGEMM");    // =0: tuning / A-B override
   if (e != nullptr && atoi(e) == 0) return false;
-  return !pro && stride == 1 && K >= 512 && (K % 64) == 0;  // measured (tools/gpu/igemm_bench.py): wins from K = 512 up
+  return (K % 64) == 0 && (pro || K >= 512);
 }
 
 extern "C" int pf_conv1x1_stats_groups_k(int M, int N, int K, int prologue) {
   int nw = 0;
   const int nsplit = pf_conv_stream_plan(M, N, K, &nw);
   if (nsplit > 0) return pf_conv_stream_groups(nsplit);
-  if (conv_use_igemm(prologue != 0, 1, K)) return pf_conv2d_stats_groups(M, N);
+  if (conv_use_igemm(prologue != 0, K)) return pf_conv2d_stats_groups(M, N);
   return pf_conv1x1_stats_groups(M, N);
 }
 
@@ -373,8 +378,9 @@ static int conv_fwd_launch(const void* X, const void* W, void* Y, const void* R,
     const int r = pf_conv_stream_launch(a, pro, bx != nullptr, st);      // HBM-bound shapes: kernel resident in LDS
     if (r >= 0) return r;
   }
-  if (conv_use_igemm(pro, stride, K)) {
-    const int r = pf_igemm_gemm_1x1(X, W, Y, R, partial, bx, bss, bmi, a.b_lo, a.b_hi, M, N, K, st);
+  if (!ymap && conv_use_igemm(pro, K)) {
+    const int r = pf_igemm_conv1x1(X, W, Y, R, partial, bx, bss, bmi, a.b_lo, a.b_hi, scale_shift, slot, a.kq, a.act_lo,
+                                   a.act_hi, M, N, K, Ho, Wo, H, Wd, stride, st);
     if (r >= 0) return r;
   }
   const bool map = stride != 1;

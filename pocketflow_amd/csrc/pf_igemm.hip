@@ -26,17 +26,33 @@
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
+// The buffer-descriptor type exists only in the device pass; the host pass (which merely emits the launch stub) still has
+// to parse the kernel body -- without this the host pass silently DROPS the stubs and the library fails to load.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t pf_rsrc_t;
+#define PF_MAKE_RSRC(p, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(p), (short)0, (int)(bytes), 0x00020000)
+#define PF_BUFFER_LOAD_LDS16(rs, lds, voff, soff) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds), 16, voff, soff, 0, 0)
+#else
+typedef int pf_rsrc_t;
+#define PF_MAKE_RSRC(p, bytes) 0
+#define PF_BUFFER_LOAD_LDS16(rs, lds, voff, soff) ((void)(rs), (void)(lds), (void)(voff), (void)(soff))
+#endif
+
 struct IgArgs {
   const bf16_t* X;      // [rows_in][C]
   const bf16_t* W;      // [N][taps][C]
   bf16_t* Y;            // [M][N]
-  const bf16_t* zero;   // >= 128 zero bytes (source of padding taps / out-of-range rows)
+  const bf16_t* zero;   // unused by the kernel (padding taps read zeros through the buffer bounds check); kept in the ABI
+  uint32_t x_bytes, w_bytes;   // sizes of X / W in bytes (buffer descriptors)
   const bf16_t* R;      // residual [M][N] or null
   float* partial;       // statistics [G][4][N] (or [G][2][N] with bx) or null
   const bf16_t* bx;     // BN-backward statistics mode: the BN's input x [M][N]
   const float* bss;     // its scale | shift [2][N]
   const float* bmi;     // its mean | invstd [2][N]
   float b_lo, b_hi;
+  const float* ss;      // PRO: scale | shift [2][C] of the producer BN
+  const uint32_t* slot; // PRO: activation range (null: no fake-quant)
+  float kq, act_lo, act_hi;
   int M, N, C;
   int th, tw;           // taps
   int H, Wd, Ho, Wo, stride, pad_h, pad_w;
@@ -45,8 +61,15 @@ struct IgArgs {
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int WM, int WN, int NS, bool BWD>
+// MODE 0: plain (+ residual / statistics), 1: backward-data with BN-backward sums, 2: producer's BN + act + fake-quant
+// prologue on the input operand (1x1 only: padding taps would need Q = 0, not Q(0))
+#define IG_PLAIN 0
+#define IG_BWD 1
+#define IG_PRO 2
+template <int BM, int BN, int WM, int WN, int NS, int MODE>
 __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
+  constexpr bool BWD = (MODE == IG_BWD), PRO = (MODE == IG_PRO);
+  static_assert(!PRO || NS == 2, "the in-LDS prologue pass is written for the 2-stage ring");
   constexpr int T = 64 * WM * WN;
   constexpr int WR = BM / WM, WC = BN / WN;         // wavefront tile: pixels x channels
   constexpr int JM = WR / 16, NI = WC / 16;
@@ -62,7 +85,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
   constexpr int RING_B = NS * STAGE, CT_B = BM * CS_LD_B * 2;
   float* bpl = reinterpret_cast<float*>(smem + (RING_B > CT_B ? RING_B : CT_B));   // BWD: scale | shift | mean | invstd [4][BN]
 
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);              // scalar: LDS-DMA bases stay in SGPRs
   const int wm = wave / WN, wn = wave % WN;
   const int l15 = lane & 15, q = lane >> 4;
   const int srow = tid >> 3;                                              // staging row of this lane (per 16-byte slot)
@@ -91,52 +115,65 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
   for (int j = 0; j < 8; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; st_mn[j] = INFINITY; st_mx[j] = -INFINITY; }
   const int wvec = tid % VPR, wrw = tid / VPR;
   const bf16_t* __restrict__ side = BWD ? a.bx : a.R;
+  Pro pro;
+  pro.lo = a.act_lo; pro.hi = a.act_hi; pro.quant = 0; pro.beta = 0.f; pro.c1 = 1.f; pro.c2 = 1.f;
+  if (PRO && a.slot != nullptr) {
+    float alpha, beta;
+    slot_alpha_beta(a.slot, alpha, beta);
+    pro.quant = 1; pro.beta = beta; pro.c1 = a.kq / alpha; pro.c2 = alpha / a.kq;
+  }
 
+  // Buffer descriptors (wave-uniform): LDS-DMA through buffer_load ... lds takes a 32-bit per-lane byte offset plus a
+  // scalar offset, and a lane whose offset lies outside the buffer gets ZEROS -- which is exactly what padding taps,
+  // tail rows and tail channels need.  No zero page, no 64-bit per-lane address arithmetic in the main loop.
+  const pf_rsrc_t rsX = PF_MAKE_RSRC(a.X, a.x_bytes);
+  const pf_rsrc_t rsW = PF_MAKE_RSRC(a.W, a.w_bytes);
+  constexpr uint32_t OOB = 0x80000000u;
   // kernel-tile source rows of this lane (fixed for the whole launch)
-  const bf16_t* bsrc[BS];
+  uint32_t boff[BS];
 #pragma unroll
   for (int i = 0; i < BS; ++i) {
     const int n = n0 + i * (T / 8) + srow;
-    bsrc[i] = (n < a.N) ? (a.W + (int64_t)n * wrow + schunk * 8) : nullptr;
+    boff[i] = (n < a.N) ? (uint32_t)(((int64_t)n * wrow + schunk * 8) * 2) : OOB;
   }
 
   for (int tm = g; tm < a.tiles_m; tm += a.G) {
     const int m0 = tm * BM;
-    // input rows of this lane: element offset of the top-left input pixel of the receptive field (may lie outside
-    // the image) and its coordinates for the bounds test of each tap
-    int pbase[AS], ph0[AS], pw0[AS];
+    // input rows of this lane: byte offset of the top-left input pixel of the receptive field (may lie outside the
+    // image: the sum with the tap offset is only used for taps whose bit is set) and the mask of taps inside the image
+    uint32_t pbase[AS], pmask[AS];
 #pragma unroll
     for (int i = 0; i < AS; ++i) {
       const int m = m0 + i * (T / 8) + srow;
+      pbase[i] = 0; pmask[i] = 0;
       if (m < a.M) {
         const int img = m / hw_o, rem = m - img * hw_o;
         const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-        ph0[i] = ho * a.stride - a.pad_h; pw0[i] = wo * a.stride - a.pad_w;
-        pbase[i] = ((img * a.H + ph0[i]) * a.Wd + pw0[i]) * a.C + schunk * 8;
-      } else {
-        pbase[i] = 0; ph0[i] = -(1 << 20); pw0[i] = 0;                      // never inside the image
+        const int h0 = ho * a.stride - a.pad_h, w0 = wo * a.stride - a.pad_w;
+        pbase[i] = (uint32_t)(((img * a.H + h0) * a.Wd + w0) * a.C + schunk * 8) * 2u;   // modulo 2^32 on purpose
+        uint32_t mk = 0;
+        for (int r = 0; r < a.th; ++r)
+          for (int sx = 0; sx < a.tw; ++sx)
+            if ((unsigned)(h0 + r) < (unsigned)a.H && (unsigned)(w0 + sx) < (unsigned)a.Wd) mk |= 1u << (r * a.tw + sx);
+        pmask[i] = mk;
       }
     }
-    // the steps are staged in order: running (tap row, tap column, channel step) instead of divisions
-    int s_r = 0, s_s = 0, s_cc = 0, s_ks = 0;
+    // the steps are staged in order: running (tap, tap row, tap column, channel step) instead of divisions
+    int s_r = 0, s_s = 0, s_cc = 0, s_ks = 0, s_tap = 0;
     auto stage = [&](int buf) {
       unsigned char* As = smem + buf * STAGE;
       unsigned char* Bs = As + A_BYTES;
-      const int tapoff = (s_r * a.Wd + s_s) * a.C + s_cc * 64;              // wave-uniform
+      const uint32_t tapoff = (uint32_t)(((s_r * a.Wd + s_s) * a.C + s_cc * 64) * 2);   // wave-uniform
 #pragma unroll
       for (int i = 0; i < AS; ++i) {
-        const int hi = ph0[i] + s_r, wi = pw0[i] + s_s;
-        const bool ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.Wd;
-        const bf16_t* src = ok ? (a.X + (pbase[i] + tapoff)) : (a.zero + schunk * 8);
-        __builtin_amdgcn_global_load_lds(src, LDS_PTR(As + (i * (T / 8) + wave * 8) * 128), 16, 0, 0);
+        const uint32_t voff = ((pmask[i] >> s_tap) & 1u) ? (pbase[i] + tapoff) : OOB;
+        PF_BUFFER_LOAD_LDS16(rsX, As + (i * (T / 8) + wave * 8) * 128, voff, 0);
       }
 #pragma unroll
-      for (int i = 0; i < BS; ++i) {
-        const bf16_t* src = (bsrc[i] != nullptr) ? (bsrc[i] + s_ks * 64) : (a.zero + schunk * 8);
-        __builtin_amdgcn_global_load_lds(src, LDS_PTR(Bs + (i * (T / 8) + wave * 8) * 128), 16, 0, 0);
-      }
+      for (int i = 0; i < BS; ++i)
+        PF_BUFFER_LOAD_LDS16(rsW, Bs + (i * (T / 8) + wave * 8) * 128, boff[i], s_ks * 128);
       ++s_ks;
-      if (++s_cc == cch) { s_cc = 0; if (++s_s == a.tw) { s_s = 0; ++s_r; } }
+      if (++s_cc == cch) { s_cc = 0; ++s_tap; if (++s_s == a.tw) { s_s = 0; ++s_r; } }
     };
 
     f32x4 acc[NI][JM];
@@ -149,15 +186,47 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
     // steps ks+1 .. ks+NS-1 travel; a stage is waited for with a COUNTED vmcnt (the younger stages stay in flight
     // across the barrier: raw s_barrier, never __syncthreads(), which would drain them) and read one barrier later.
     int ibuf = 0;                                                           // buffer of the next stage to issue
+    // PRO: every thread transforms, in place, exactly the 16-byte groups it staged itself (its LDS-DMA destinations): the
+    // data is complete for it after its own vmcnt wait, no extra barrier is needed before the pass, and its channels are
+    // cc*64 + schunk*8 + 0..7 for every one of its rows -- one scale / shift fetch per step.  The pass for step ks+1 runs
+    // right behind the MFMAs of step ks (which keep executing), so the loop still has ONE barrier per step.
+    float4 ps0 = make_float4(0, 0, 0, 0), ps1 = ps0, ph0 = ps0, ph1 = ps0;
+    auto fetch_ss = [&](int cc) {
+      const float* p = a.ss + cc * 64 + schunk * 8;
+      ps0 = *reinterpret_cast<const float4*>(p); ps1 = *reinterpret_cast<const float4*>(p + 4);
+      ph0 = *reinterpret_cast<const float4*>(p + a.C); ph1 = *reinterpret_cast<const float4*>(p + a.C + 4);
+    };
+    auto transform = [&](int buf) {
+      pro.sc[0] = ps0.x; pro.sc[1] = ps0.y; pro.sc[2] = ps0.z; pro.sc[3] = ps0.w;
+      pro.sc[4] = ps1.x; pro.sc[5] = ps1.y; pro.sc[6] = ps1.z; pro.sc[7] = ps1.w;
+      pro.sh[0] = ph0.x; pro.sh[1] = ph0.y; pro.sh[2] = ph0.z; pro.sh[3] = ph0.w;
+      pro.sh[4] = ph1.x; pro.sh[5] = ph1.y; pro.sh[6] = ph1.z; pro.sh[7] = ph1.w;
+      unsigned char* As = smem + buf * STAGE;
+#pragma unroll
+      for (int i = 0; i < AS; ++i) {
+        uint4* p = reinterpret_cast<uint4*>(As + (i * (T / 8) + srow) * 128 + (lane & 7) * 16);
+        *p = pro_apply(pro, *p);
+      }
+    };
 #pragma unroll
     for (int d = 0; d < NS - 1; ++d)
-      if (d < nk) { stage(ibuf); ibuf = (ibuf + 1 == NS) ? 0 : ibuf + 1; }
+      if (d < nk) {
+        if (PRO) fetch_ss(s_cc);
+        stage(ibuf);
+        ibuf = (ibuf + 1 == NS) ? 0 : ibuf + 1;
+      }
     if (nk >= NS - 1) wait_vm<(NS - 2) * LPS>(); else wait_vm<0>();
+    if (PRO) { transform(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
     __builtin_amdgcn_s_barrier();
     int cbuf = 0;
     for (int ks = 0; ks < nk; ++ks) {
       const bool more = ks + NS - 1 < nk;
-      if (more) { stage(ibuf); ibuf = (ibuf + 1 == NS) ? 0 : ibuf + 1; }
+      const int tbuf = ibuf;                                                // buffer the stage issued now lands in
+      if (more) {
+        if (PRO) fetch_ss(s_cc);
+        stage(ibuf);
+        ibuf = (ibuf + 1 == NS) ? 0 : ibuf + 1;
+      }
       const unsigned char* As = smem + cbuf * STAGE;
       const unsigned char* Bs = As + A_BYTES;
       cbuf = (cbuf + 1 == NS) ? 0 : cbuf + 1;
@@ -178,7 +247,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
       }
       if (more) wait_vm<(NS - 2) * LPS>(); else wait_vm<0>();             // the NEXT step's stage has landed (own part)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // own fragment reads of this buffer are done
+      if (PRO && more) transform(tbuf);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // own fragment reads / prologue writes are done
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -318,8 +388,9 @@ extern "C" int pf_conv2d_stats_groups(int M, int N) {
   return G;
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool BWD>
+template <int BM, int BN, int WM, int WN, int NS, int MODE>
 static int ig_launch_t(IgArgs& a, hipStream_t st) {
+  constexpr bool BWD = (MODE == IG_BWD);
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
   const int grid = ig_grid(BM, a.tiles_m, a.tiles_n, &a.G);
@@ -328,20 +399,24 @@ static int ig_launch_t(IgArgs& a, hipStream_t st) {
   size_t lds = (ring > ctile ? ring : ctile) + (BWD ? 4 * BN * 4 : 0);
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<BM, BN, WM, WN, NS, BWD>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<BM, BN, WM, WN, NS, MODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
-  k_igemm<BM, BN, WM, WN, NS, BWD><<<grid, 64 * WM * WN, lds, st>>>(a);
+  k_igemm<BM, BN, WM, WN, NS, MODE><<<grid, 64 * WM * WN, lds, st>>>(a);
   PF_LAUNCH_CHECK();
   return 0;
 }
 
 static int ig_launch(IgArgs& a, hipStream_t st) {
   const IgCfg c = ig_pick(a.M, a.N);
-  const bool bwd = a.bx != nullptr;
-#define PF_IG(BMV, BNV, WMV, WNV, NSV) (bwd ? ig_launch_t<BMV, BNV, WMV, WNV, NSV, true>(a, st) : ig_launch_t<BMV, BNV, WMV, WNV, NSV, false>(a, st))
+  const bool bwd = a.bx != nullptr, pro = a.ss != nullptr;
+  if (pro) {                                             // prologue variant: 128-row tiles, 2 stages (the only instantiation)
+    if (a.th * a.tw != 1 || bwd) return (int)hipErrorInvalidValue;
+    return (a.N % 128 == 0) ? ig_launch_t<128, 128, 2, 2, 2, IG_PRO>(a, st) : ig_launch_t<128, 64, 2, 2, 2, IG_PRO>(a, st);
+  }
+#define PF_IG(BMV, BNV, WMV, WNV, NSV) (bwd ? ig_launch_t<BMV, BNV, WMV, WNV, NSV, IG_BWD>(a, st) : ig_launch_t<BMV, BNV, WMV, WNV, NSV, IG_PLAIN>(a, st))
   if (c.bm == 256 && c.bn == 256) return PF_IG(256, 256, 4, 2, 2);    // 8 wavefronts (64 x 128 each), 1 workgroup / CU, 2 stages (128 KiB)
   if (c.bm == 256 && c.bn == 128) return PF_IG(256, 128, 4, 2, 3);    // 8 wavefronts, 1 workgroup / CU, 3 stages (144 KiB)
   if (c.bm == 128 && c.bn == 128) return PF_IG(128, 128, 2, 2, 2);    // 4 wavefronts, 2 workgroups / CU, 2 stages each
@@ -365,29 +440,41 @@ extern "C" int pf_conv2d_fwd(const void* X, const void* W, void* Y, const void* 
     return (int)hipErrorInvalidValue;
   if (bn_x != nullptr && (R != nullptr || partial == nullptr || bn_scale_shift == nullptr || bn_mean_invstd == nullptr))
     return (int)hipErrorInvalidValue;
-  if ((int64_t)imgs * H * Wd * C >= ((int64_t)1 << 31) || (int64_t)N * th * tw * C >= ((int64_t)1 << 31))
-    return (int)hipErrorInvalidValue;                     // 32-bit element offsets inside the kernel
+  if ((int64_t)imgs * H * Wd * C >= ((int64_t)1 << 30) || (int64_t)N * th * tw * C >= ((int64_t)1 << 30) || th * tw > 32)
+    return (int)hipErrorInvalidValue;                     // 31-bit byte offsets and a 32-bit tap mask inside the kernel
   IgArgs a;
   a.X = (const bf16_t*)X; a.W = (const bf16_t*)W; a.Y = (bf16_t*)Y; a.zero = (const bf16_t*)zero;
   a.R = (const bf16_t*)R; a.partial = partial; a.bx = (const bf16_t*)bn_x; a.bss = bn_scale_shift; a.bmi = bn_mean_invstd;
   a.b_lo = (bn_act == PF_ACT_NONE) ? -INFINITY : 0.0f;
   a.b_hi = (bn_act == PF_ACT_RELU6) ? 6.0f : INFINITY;
+  a.ss = nullptr; a.slot = nullptr; a.kq = 255.f; a.act_lo = -INFINITY; a.act_hi = INFINITY;
   a.M = imgs * Ho * Wo; a.N = N; a.C = C; a.th = th; a.tw = tw;
   a.H = H; a.Wd = Wd; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
+  a.x_bytes = (uint32_t)((int64_t)imgs * H * Wd * C * 2);
+  a.w_bytes = (uint32_t)((int64_t)N * th * tw * C * 2);
   return ig_launch(a, (hipStream_t)stream);
 }
 
-// plain / backward-data GEMM of a stride-1 1x1 convolution through the same kernel (called by pf_conv.hip for the
-// shapes it routes here): rows are "images" of 1 x 1 pixels, so no tap ever leaves the image and `zero` is only the
-// source of the (never stored) tail rows -- any readable 128 bytes do.
-int pf_igemm_gemm_1x1(const void* X, const void* W, void* Y, const void* R, float* partial, const void* bn_x,
-                      const float* bss, const float* bmi, float b_lo, float b_hi, int M, int N, int K, hipStream_t st) {
-  if ((K % 64) || (int64_t)M * K >= ((int64_t)1 << 31) || (int64_t)N * K >= ((int64_t)1 << 31)) return -1;
+// 1x1 convolutions through the same kernel (called by pf_conv.hip for the shapes it routes here): plain, backward-data with
+// BN-backward sums, or with the producer's BN/act/fake-quant prologue; stride > 1 reads input pixel (ho*stride, wo*stride).
+// No tap ever leaves the image, `zero` is unused.
+int pf_igemm_conv1x1(const void* X, const void* W, void* Y, const void* R, float* partial, const void* bn_x,
+                     const float* bss, const float* bmi, float b_lo, float b_hi, const float* scale_shift,
+                     const uint32_t* slot, float kq, float act_lo, float act_hi, int M, int N, int K, int Ho, int Wo,
+                     int H, int Wd, int stride, hipStream_t st) {
+  int64_t rows_in = M;
+  if (stride > 1) rows_in = (int64_t)(M / (Ho * Wo)) * H * Wd;
+  if ((K % 64) || rows_in * K >= ((int64_t)1 << 30) || (int64_t)N * K >= ((int64_t)1 << 30)) return -1;
   IgArgs a;
   a.X = (const bf16_t*)X; a.W = (const bf16_t*)W; a.Y = (bf16_t*)Y; a.zero = (const bf16_t*)X;
   a.R = (const bf16_t*)R; a.partial = partial; a.bx = (const bf16_t*)bn_x; a.bss = bss; a.bmi = bmi;
   a.b_lo = b_lo; a.b_hi = b_hi;
+  a.ss = scale_shift; a.slot = slot; a.kq = kq; a.act_lo = act_lo; a.act_hi = act_hi;
   a.M = M; a.N = N; a.C = K; a.th = 1; a.tw = 1;
-  a.H = 1; a.Wd = 1; a.Ho = 1; a.Wo = 1; a.stride = 1; a.pad_h = 0; a.pad_w = 0;
+  if (stride > 1) { a.H = H; a.Wd = Wd; a.Ho = Ho; a.Wo = Wo; a.stride = stride; }
+  else { a.H = 1; a.Wd = 1; a.Ho = 1; a.Wo = 1; a.stride = 1; }
+  a.pad_h = 0; a.pad_w = 0;
+  a.x_bytes = (uint32_t)(rows_in * K * 2);
+  a.w_bytes = (uint32_t)((int64_t)N * K * 2);
   return ig_launch(a, st);
 }

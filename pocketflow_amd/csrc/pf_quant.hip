@@ -264,14 +264,34 @@ __global__ __launch_bounds__(PF_THREADS) void k_seg_minmax(const float* __restri
   const int64_t e0 = (int64_t)b.chunk * PF_CHUNK;
   if (sg.mode == PF_BUCKET_SPLIT) {
     const uint32_t m = (uint32_t)sg.n_bucket;
+    // a 4096-element chunk visits every bucket chunk/m times: with m <= 1024 the block reduces into LDS bins first
+    // (order-independent integer atomicMin on the encoded values, so the result stays bit-deterministic) and issues at
+    // most 2*m global atomics instead of 2 per element; larger m (up to ~9 k buckets per tensor) spreads the global
+    // atomics thinly enough already
+    __shared__ uint32_t bins[2 * 1024];
+    const bool use_bins = m <= 1024u;
+    if (use_bins) {
+      for (uint32_t j = threadIdx.x; j < 2 * m; j += PF_THREADS) bins[j] = 0xFFFFFFFFu;
+      __syncthreads();
+    }
     for (int t = threadIdx.x; t < PF_CHUNK; t += PF_THREADS) {
       const int64_t e = e0 + t;
       if (e < sg.len) {
         const float v = base[e];
         const uint32_t j = hwio_flat_index(sg, (uint32_t)e) % m;
-        atomicMin(&sl[2 * j], enc_f32(v));
-        atomicMin(&sl[2 * j + 1], ~enc_f32(v));
+        if (use_bins) {
+          atomicMin(&bins[2 * j], enc_f32(v));
+          atomicMin(&bins[2 * j + 1], ~enc_f32(v));
+        } else {
+          atomicMin(&sl[2 * j], enc_f32(v));
+          atomicMin(&sl[2 * j + 1], ~enc_f32(v));
+        }
       }
+    }
+    if (use_bins) {
+      __syncthreads();
+      for (uint32_t j = threadIdx.x; j < 2 * m; j += PF_THREADS)
+        if (bins[j] != 0xFFFFFFFFu) atomicMin(&sl[j], bins[j]);
     }
     if (b.chunk == 0) {   // tail padding: copies of the LAST element join buckets f mod m, f >= len
       const float last = base[sg.len - 1];
@@ -498,29 +518,37 @@ extern "C" int pf_seg_nuq_apply(const float* w_flat, void* qw_flat, int out_dtyp
 
 // ---------------------------------------------------------------------------------------------
 // NUQ codebook gradient: dc[j][b] += alpha_b * g_i  for idx_i == j in bucket b.
-// Per-block LDS bins (per-tensor mode) to cut global atomics to k per block.
+// Bit-deterministic across runs and ranks: every term is rounded ONCE to a 2^-36 fixed-point grid and accumulated with
+// 64-bit INTEGER atomics (integer addition is associative, so the order in which wavefronts arrive cannot change the
+// result -- float atomics made `cluster` / `both` mode runs irreproducible); a second launch converts the sums to
+// float32 and adds them to dcodebooks.  Range +-1.3e8 with 1.5e-11 resolution: |alpha * g| terms of a gradient
+// scatter-sum sit many orders of magnitude inside both ends.  Per-block LDS bins (per-tensor mode) cut the global
+// atomics to k per block.
 // ---------------------------------------------------------------------------------------------
+#define PF_CB_FX_SCALE 68719476736.0                       // 2^36
+__device__ __forceinline__ long long cb_to_fx(float v) { return __double2ll_rn((double)v * PF_CB_FX_SCALE); }
+
 template <typename TG>
 __global__ __launch_bounds__(PF_THREADS) void k_seg_nuq_cbgrad(const TG* __restrict__ g,
                                                                const uint8_t* __restrict__ idx,
-                                                               float* __restrict__ dcb,
+                                                               unsigned long long* __restrict__ acc,
                                                                const PfSeg* __restrict__ segs,
                                                                const PfBlock* __restrict__ blocks,
                                                                const uint32_t* __restrict__ slots) {
-  __shared__ float bins[256];
+  __shared__ unsigned long long bins[256];
   const PfBlock b = blocks[blockIdx.x];
   const PfSeg sg = segs[b.seg];
   if (sg.bits <= 0) return;                   // tensor is not quantised: it has no codebook
   const TG* __restrict__ gb = g + sg.offset;
   const uint8_t* __restrict__ ib = idx + sg.offset;
   const uint32_t* __restrict__ sl = slots + 2 * sg.slot_offset;
-  float* __restrict__ dc = dcb + sg.cb_offset;
+  unsigned long long* __restrict__ dc = acc + sg.cb_offset;
   const int kc = 1 << sg.bits;
   const uint32_t e0 = (uint32_t)b.chunk * PF_CHUNK;
   const uint32_t L = (uint32_t)sg.RS * (uint32_t)sg.I;
   const bool tensor_mode = (sg.mode == PF_BUCKET_TENSOR);
   if (tensor_mode) {
-    for (int j = threadIdx.x; j < kc; j += PF_THREADS) bins[j] = 0.0f;
+    for (int j = threadIdx.x; j < kc; j += PF_THREADS) bins[j] = 0ull;
     __syncthreads();
   }
   float alpha0 = 0.f, beta0 = 0.f;
@@ -531,34 +559,45 @@ __global__ __launch_bounds__(PF_THREADS) void k_seg_nuq_cbgrad(const TG* __restr
     const float gv = load_one<TG>(gb + e);
     const int j = ib[e];
     if (tensor_mode) {
-      atomicAdd(&bins[j], alpha0 * gv);
+      atomicAdd(&bins[j], (unsigned long long)cb_to_fx(alpha0 * gv));
     } else {
       uint32_t bucket;
       if (sg.mode == PF_BUCKET_CHANNEL) bucket = e / L;
       else bucket = hwio_flat_index(sg, e) % (uint32_t)sg.n_bucket;
       float a, bt;
       slot_alpha_beta(sl + 2 * bucket, a, bt);
-      atomicAdd(&dc[(int64_t)j * sg.n_bucket + bucket], a * gv);
+      atomicAdd(&dc[(int64_t)j * sg.n_bucket + bucket], (unsigned long long)cb_to_fx(a * gv));
     }
   }
   if (tensor_mode) {
     __syncthreads();
     for (int j = threadIdx.x; j < kc; j += PF_THREADS)
-      if (bins[j] != 0.0f) atomicAdd(&dc[j], bins[j]);
+      if (bins[j] != 0ull) atomicAdd(&dc[j], bins[j]);
   }
 }
 
+__global__ __launch_bounds__(PF_THREADS) void k_cb_fx_to_float(const long long* __restrict__ acc, float* __restrict__ dcb,
+                                                               int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * PF_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * PF_THREADS)
+    dcb[i] += (float)((double)acc[i] * (1.0 / PF_CB_FX_SCALE));
+}
+
 extern "C" int pf_seg_nuq_codebook_grad(const void* g_flat, int g_dtype, const uint8_t* idx_flat,
-                                        float* dcodebooks, const PfSeg* segs, const PfBlock* blocks,
-                                        int n_blocks, const uint32_t* slots, void* stream) {
+                                        float* dcodebooks, int64_t* acc_ws, int64_t n_codebook, const PfSeg* segs,
+                                        const PfBlock* blocks, int n_blocks, const uint32_t* slots, void* stream) {
   if (n_blocks <= 0) return 0;
+  if (acc_ws == nullptr || n_codebook <= 0) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
+  hipError_t me = hipMemsetAsync(acc_ws, 0, (size_t)n_codebook * sizeof(int64_t), st);
+  if (me != hipSuccess) return (int)me;
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(acc_ws);
   if (g_dtype == PF_F32)
-    k_seg_nuq_cbgrad<float><<<n_blocks, PF_THREADS, 0, st>>>((const float*)g_flat, idx_flat, dcodebooks, segs, blocks, slots);
+    k_seg_nuq_cbgrad<float><<<n_blocks, PF_THREADS, 0, st>>>((const float*)g_flat, idx_flat, acc, segs, blocks, slots);
   else if (g_dtype == PF_BF16)
-    k_seg_nuq_cbgrad<bf16_t><<<n_blocks, PF_THREADS, 0, st>>>((const bf16_t*)g_flat, idx_flat, dcodebooks, segs, blocks, slots);
+    k_seg_nuq_cbgrad<bf16_t><<<n_blocks, PF_THREADS, 0, st>>>((const bf16_t*)g_flat, idx_flat, acc, segs, blocks, slots);
   else return (int)hipErrorInvalidValue;
+  PF_LAUNCH_CHECK();
+  k_cb_fx_to_float<<<pf_grid_for(n_codebook, PF_THREADS), PF_THREADS, 0, st>>>((const long long*)acc_ws, dcodebooks, n_codebook);
   PF_LAUNCH_CHECK();
   return 0;
 }
-

@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256) void k_wrw_tr(const WrwArgs a) {
   constexpr int LPS = NB + 4;                       // LDS-DMA instructions per lane and stage
   constexpr int NBLK = NB * 4;                      // 16x16 accumulator blocks
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, q = lane >> 4;
   unsigned char* ring = smem + wave * (NS * STAGE);
   const bf16_t* zero = reinterpret_cast<const bf16_t*>(pf_wrw_zero_page);

@@ -161,9 +161,12 @@ def seg_nuq_apply(w_flat, qw_flat, idx_flat, codebooks, segs, blocks, n_blocks, 
                                _stream()), 'pf_seg_nuq_apply')
 
 
-def seg_nuq_codebook_grad(g_flat, idx_flat, dcodebooks, segs, blocks, n_blocks, slots) -> None:
+def seg_nuq_codebook_grad(g_flat, idx_flat, dcodebooks, acc_ws, segs, blocks, n_blocks, slots) -> None:
+  """acc_ws: int64 scratch with dcodebooks.numel() elements (fixed-point accumulators; deterministic sums)."""
+  assert acc_ws.dtype == torch.int64 and acc_ws.numel() >= dcodebooks.numel()
   _check(_lib.pf_seg_nuq_codebook_grad(_ptr(g_flat), c_int(dtype_code(g_flat)), _ptr(idx_flat), _ptr(dcodebooks),
-                                       _ptr(segs), _ptr(blocks), c_int(n_blocks), _ptr(slots), _stream()),
+                                       _ptr(acc_ws), c_int64(dcodebooks.numel()), _ptr(segs), _ptr(blocks),
+                                       c_int(n_blocks), _ptr(slots), _stream()),
          'pf_seg_nuq_codebook_grad')
 
 

@@ -129,7 +129,10 @@ class QuantPlan:
   def codebook_grad(self, g_flat, idx_flat, dcodebooks, zero: bool = True) -> None:
     if zero:
       dcodebooks.zero_()
-    hip.seg_nuq_codebook_grad(g_flat, idx_flat, dcodebooks, self.segs, self.ap_blocks, self.n_ap_blocks,
+    ws = getattr(self, '_cb_acc', None)
+    if ws is None or ws.numel() < dcodebooks.numel() or ws.device != dcodebooks.device:
+      ws = self._cb_acc = torch.empty(dcodebooks.numel(), dtype=torch.int64, device=dcodebooks.device)
+    hip.seg_nuq_codebook_grad(g_flat, idx_flat, dcodebooks, ws, self.segs, self.ap_blocks, self.n_ap_blocks,
                               self.slots)
 
   def alpha_beta(self) -> torch.Tensor:

@@ -326,7 +326,7 @@ class FakeHipFull(FakeHip):
         res = src
       qw_flat[off:off + n] = torch.from_numpy(np.ascontiguousarray(res)).to(qw_flat.dtype)
 
-  def seg_nuq_codebook_grad(self, g_flat, idx_flat, dcodebooks, segs, blocks, n_blocks, slots):
+  def seg_nuq_codebook_grad(self, g_flat, idx_flat, dcodebooks, acc_ws, segs, blocks, n_blocks, slots):
     g = g_flat.detach().float().numpy()
     dc_all = dcodebooks.detach().numpy()
     for s, sg in enumerate(self._segs(segs)):

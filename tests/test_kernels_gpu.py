@@ -190,6 +190,11 @@ def test_seg_nonuniform_quantize(hip, use_buckets, bucket_type, bucket_size, bit
     g_flat[v.offset:v.offset + v.numel] = dev(v.to_storage(g)).reshape(-1)
   dcb = torch.zeros(plan.n_codebook, device='cuda')
   plan.codebook_grad(g_flat, idx, dcb)
+  # bit-reproducible: 64-bit integer (fixed-point) atomics, VERDICT r1 next-step 8
+  for _ in range(2):
+    dcb2 = torch.zeros(plan.n_codebook, device='cuda')
+    plan.codebook_grad(g_flat, idx, dcb2)
+    assert torch.equal(dcb, dcb2)
   dcb = dcb.cpu().numpy()
   for s, v in enumerate(vars_):
     ref, info = infos[s]
@@ -197,7 +202,7 @@ def test_seg_nonuniform_quantize(hip, use_buckets, bucket_type, bucket_size, bit
     np.testing.assert_array_equal(got, ref, err_msg=v.name)
     _, dc_ref = O.nuq_backward(gvals[v.name], info, use_buckets, bucket_type, bucket_size)
     got_dc = dcb[plan.cb_offsets[s]:plan.cb_offsets[s] + dc_ref.size].reshape(dc_ref.reshape(k, -1).shape)
-    # float atomics: summation order differs -> tolerance 1e-4 of the column's magnitude
+    # exact fixed-point sums (one 2^-36 rounding per term) vs the oracle's float32 sums
     np.testing.assert_allclose(got_dc, dc_ref.reshape(k, -1), rtol=1e-4,
                                atol=1e-4 * np.abs(dc_ref).max() + 1e-6)
 

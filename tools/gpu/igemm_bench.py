@@ -25,7 +25,7 @@ B = int(os.environ.get('B', 256))
 shapes = [(56, 64, 64, 3, 1), (56, 128, 128, 3, 2), (28, 128, 128, 3, 1), (28, 256, 256, 3, 2), (14, 256, 256, 3, 1),
           (14, 512, 512, 3, 2), (7, 512, 512, 3, 1), (14, 1024, 256, 1, 1), (14, 256, 1024, 1, 1), (7, 2048, 512, 1, 1),
           (7, 512, 2048, 1, 1), (28, 512, 128, 1, 1)]
-tiles = ['256x128', '128x128', '256x64', '128x64']
+tiles = ['256x256', '256x128', '128x128', '256x64', '128x64']
 print('%-22s | %-44s | miopen fwd | miopen bwd-data | igemm best TF' % ('H,C,N,k,s', 'igemm us by tile ' + ' '.join(tiles)))
 for H, C, N, k, s in shapes:
   g = torch.Generator(device='cuda').manual_seed(H + C + N)
@@ -38,7 +38,7 @@ for H, C, N, k, s in shapes:
   G = 0
   ts = []
   for t in tiles:
-    if int(t.split('x')[1]) == 128 and N % 128:
+    if N % int(t.split('x')[1]):
       ts.append(float('nan')); continue
     os.environ['PF_IGEMM_TILE'] = t
     G = hip.conv2d_stats_groups(M, N)
