@@ -582,6 +582,10 @@ __global__ __launch_bounds__(PF_THREADS) void k_wrw_reduce(const float* __restri
 
 // pf_wrw.hip: backward-filter on transposed LDS reads (ds_read_b64_tr_b16), barrier-free main loop
 int pf_wrw_tr_splits_1x1(int M, int N, int C);
+int pf_wrw2_splits(int M, int N, int C, int taps);
+int pf_wrw2_launch(const void* dY, const void* X, float* slabs, const float* scale_shift, int act, const uint32_t* slot,
+                   int bits, int M, int N, int C, int th, int tw, int H, int Wd, int Ho, int Wo, int stride, int pad_h,
+                   int pad_w, int S, int64_t x_rows, hipStream_t st);
 int pf_wrw_tr_launch(const void* dY, const void* X, float* slabs, const float* scale_shift, int act,
                      const uint32_t* slot, int bits, int M, int N, int C, int th, int tw, int H, int Wd, int Ho, int Wo,
                      int stride, int pad_h, int pad_w, int S, hipStream_t st);
@@ -645,9 +649,16 @@ extern "C" int pf_conv1x1_wrw(const void* dY, const void* X, void* dW, int dw_dt
   hipStream_t st = (hipStream_t)stream;
   const int s_tr = pf_wrw_tr_splits_1x1(M, N, K);
   int done = -1;
-  if (s_tr > 0)
-    done = pf_wrw_tr_launch(dY, X, workspace, scale_shift, act, slot, bits, M, N, K, 1, 1, H, Wd, Ho, Wo, a.stride, 0, 0,
-                            s_tr, st);
+  if (s_tr > 0) {
+    if (pf_wrw2_splits(M, N, K, 1) > 0) {
+      const int64_t x_rows = (a.stride > 1) ? (int64_t)(M / (Ho * Wo)) * H * Wd : (int64_t)M;
+      done = pf_wrw2_launch(dY, X, workspace, scale_shift, act, slot, bits, M, N, K, 1, 1, H, Wd, Ho, Wo, a.stride, 0, 0,
+                            s_tr, x_rows, st);
+    }
+    if (done < 0)
+      done = pf_wrw_tr_launch(dY, X, workspace, scale_shift, act, slot, bits, M, N, K, 1, 1, H, Wd, Ho, Wo, a.stride, 0, 0,
+                              s_tr, st);
+  }
   if (done > 0) return done;
   if (done < 0) {
     int rows = (M + S - 1) / S;

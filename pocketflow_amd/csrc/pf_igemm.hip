@@ -414,6 +414,8 @@ static int ig_launch(IgArgs& a, hipStream_t st) {
   const bool bwd = a.bx != nullptr, pro = a.ss != nullptr;
   if (pro) {                                             // prologue variant: 128-row tiles, 2 stages (the only instantiation)
     if (a.th * a.tw != 1 || bwd) return (int)hipErrorInvalidValue;
+    // (256 x 256 prologue tiles were tried for N >= 512 -- half as many column tiles repeat the prologue pass -- and lost:
+    // 116 vs 100 us on 14x14 256 -> 1024; the 57 spilled registers of that instantiation dominate)
     return (a.N % 128 == 0) ? ig_launch_t<128, 128, 2, 2, 2, IG_PRO>(a, st) : ig_launch_t<128, 64, 2, 2, 2, IG_PRO>(a, st);
   }
 #define PF_IG(BMV, BNV, WMV, WNV, NSV) (bwd ? ig_launch_t<BMV, BNV, WMV, WNV, NSV, IG_BWD>(a, st) : ig_launch_t<BMV, BNV, WMV, WNV, NSV, IG_PLAIN>(a, st))

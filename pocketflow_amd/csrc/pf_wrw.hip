@@ -235,8 +235,13 @@ static bool wrw_tr_1x1_enabled() {
 }
 
 int pf_wrw_tr_splits(int M, int N, int C, int taps);
-// the 1x1 dispatcher's gate (pf_conv.hip)
-int pf_wrw_tr_splits_1x1(int M, int N, int C) { return wrw_tr_1x1_enabled() ? pf_wrw_tr_splits(M, N, C, 1) : 0; }
+// the 1x1 dispatcher's gate (pf_conv.hip): > 0 -> this many pixel splits on a kernel of this file
+int pf_wrw2_splits(int M, int N, int C, int taps);
+int pf_wrw_tr_splits_1x1(int M, int N, int C) {
+  const int s2 = pf_wrw2_splits(M, N, C, 1);
+  if (s2 > 0) return s2;
+  return wrw_tr_1x1_enabled() ? pf_wrw_tr_splits(M, N, C, 1) : 0;
+}
 
 static int wrw_tr_bn(int N) { return (N % 128 == 0) ? 128 : 64; }
 
@@ -305,11 +310,320 @@ int pf_wrw_tr_launch(const void* dY, const void* X, float* slabs, const float* s
 #undef PF_WT
 }
 
+// =====================================================================================================================
+// Second generation: SHARED output tile.  The wave-private kernel above moves 12 KiB of LDS-DMA per 32 MFMAs (43 flop per
+// byte) through 4 wavefronts per CU and is load-bandwidth bound.  Here a workgroup of 4 / 8 wavefronts shares one staged
+// [32 pixels][TN + TK channels] tile per step and every wavefront owns a disjoint [WTN x WTK] block of the [TN x TK] output
+// tile (256 x 128: 85 flop per byte, no cross-wavefront reduction at all).  Same block layout and transposed reads as
+// above; staging through buffer_load ... lds (out-of-range rows / padding taps read zeros from the bounds check); two LDS
+// stages, ONE barrier per step; with the prologue, every thread transforms in place exactly the 16-byte groups of X it
+// staged itself (8 consecutive channels of one pixel: its scale / shift live in registers for the whole launch), right
+// behind the MFMAs of the previous step.
+// =====================================================================================================================
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t pf_wrsrc_t;
+#define PF_W_MAKE_RSRC(p, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(p), (short)0, (int)(bytes), 0x00020000)
+#define PF_W_BUFFER_LOAD_LDS16(rs, lds, voff) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds), 16, voff, 0, 0, 0)
+#else
+typedef int pf_wrsrc_t;                               // host pass: the kernel body only has to parse (see pf_igemm.hip)
+#define PF_W_MAKE_RSRC(p, bytes) 0
+#define PF_W_BUFFER_LOAD_LDS16(rs, lds, voff) ((void)(rs), (void)(lds), (void)(voff))
+#endif
+
+struct Wrw2Args {
+  const bf16_t* dY;
+  const bf16_t* X;
+  float* slabs;
+  const float* ss;
+  const uint32_t* slot;
+  float kq, act_lo, act_hi;
+  uint32_t dy_bytes, x_bytes;
+  int M, N, C;
+  int th, tw, H, Wd, Ho, Wo, stride, pad_h, pad_w;
+  int tiles_n, tiles, rows_per_split;
+};
+
+template <int TN, int TK, int WTN, int WTK, bool PRO, bool MAP>
+__global__ __launch_bounds__(64 * (TN / WTN) * (TK / WTK)) void k_wrw2(const Wrw2Args a) {
+  constexpr int WN = TN / WTN, WK = TK / WTK, NWAVE = WN * WK, T = 64 * NWAVE;
+  constexpr int NI = WTN / 16, NJ = WTK / 16;        // 16x16 accumulator blocks of one wavefront
+  constexpr int NBN = TN / 16, NBK = TK / 16;        // 16-channel blocks of the staged tiles
+  constexpr int DY_BYTES = 4 * NBN * 256, X_BYTES = 4 * NBK * 256, STAGE = DY_BYTES + X_BYTES;
+  constexpr int IDY = 4 * (TN / 64), IX = 4 * (TK / 64), INS = IDY + IX;      // LDS-DMA instructions per stage
+  static_assert(IDY % NWAVE == 0, "dY instructions must split evenly over the wavefronts (slot kinds are static)");
+  constexpr int KDY = IDY / NWAVE;                   // slots 0..KDY-1 of every wavefront stage dY, the rest stage X
+  constexpr int XS = (IX + NWAVE - 1) / NWAVE;       // X slots per wavefront (slot x is live iff wave + x*NWAVE < IX)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+  const int wn = wave / WK, wk = wave % WK;
+
+  const int nwg = gridDim.x;
+  int wg = blockIdx.x;
+  {
+    const int xcd = wg & 7, idx = wg >> 3;
+    const int qq = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
+  }
+  const int tile = wg % a.tiles, split = wg / a.tiles;
+  const int tn = tile % a.tiles_n, tk = tile / a.tiles_n;
+  const int n0 = tn * TN;
+  const int kt = a.C / TK;                            // channel tiles per tap
+  const int tap = tk / kt, c0 = (tk - tap * kt) * TK;
+  const int tap_r = tap / a.tw, tap_s = tap - tap_r * a.tw;
+  const int ktot = a.th * a.tw * a.C;
+  const int mbeg = split * a.rows_per_split;
+  const int mend = (mbeg + a.rows_per_split < a.M) ? (mbeg + a.rows_per_split) : a.M;
+  const int nsteps = (mend > mbeg) ? (mend - mbeg + 31) / 32 : 0;
+
+  const pf_wrsrc_t rsY = PF_W_MAKE_RSRC(a.dY, a.dy_bytes);
+  const pf_wrsrc_t rsX = PF_W_MAKE_RSRC(a.X, a.x_bytes);
+  constexpr uint32_t OOB = 0x80000000u;
+  const int sb = lane >> 4, srow = (lane & 15) >> 1, sch = lane & 1;       // role inside one LDS-DMA instruction
+  const int hw_o = a.Ho * a.Wo;
+
+  // this wavefront's instruction slots: id = wave + k * NWAVE; id < IDY: dY piece (pg, g4), else X piece (pg, g4)
+  float psc[XS][8], psh[XS][8];
+  Pro pro;
+  pro.lo = a.act_lo; pro.hi = a.act_hi; pro.quant = 0; pro.beta = 0.f; pro.c1 = 1.f; pro.c2 = 1.f;
+  if (PRO) {
+    if (a.slot != nullptr) {
+      float alpha, beta;
+      slot_alpha_beta(a.slot, alpha, beta);
+      pro.quant = 1; pro.beta = beta; pro.c1 = a.kq / alpha; pro.c2 = alpha / a.kq;
+    }
+#pragma unroll
+    for (int x = 0; x < XS; ++x) {
+      const int xi = wave + x * NWAVE;
+      if (xi < IX) {
+        const int g4 = xi % (TK / 64);
+        const int c = c0 + (g4 * 4 + sb) * 16 + sch * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { psc[x][j] = a.ss[c + j]; psh[x][j] = a.ss[a.C + c + j]; }
+      }
+    }
+  }
+
+  // MAP: output pixel -> (img, ho, wo) of this lane's X rows, advanced by 32 pixels per step WITHOUT divisions (the
+  // stages are issued in step order; two index divisions per lane and step cost more VALU time than the MFMAs of the step)
+  int px_img[XS], px_ho[XS], px_wo[XS];
+  const int adv_q = 32 / a.Wo, adv_r = 32 - adv_q * a.Wo;
+  if (MAP) {
+#pragma unroll
+    for (int x = 0; x < XS; ++x) {
+      const int xi = wave + x * NWAVE;
+      const int pg = (xi < IX) ? xi / (TK / 64) : 0;
+      const int m = mbeg + pg * 8 + srow;
+      const int img = m / hw_o, rem = m - img * hw_o;
+      px_img[x] = img; px_ho[x] = rem / a.Wo; px_wo[x] = rem - px_ho[x] * a.Wo;
+    }
+  }
+  auto stage = [&](int step, int buf) {
+    unsigned char* dst = smem + buf * STAGE;
+    const int mb = mbeg + step * 32;
+#pragma unroll
+    for (int k = 0; k < KDY; ++k) {
+      const int id = wave + k * NWAVE;                                      // wave-uniform
+      const int pg = id / (TN / 64), g4 = id % (TN / 64);
+      const int m = mb + pg * 8 + srow;
+      const int n = n0 + (g4 * 4 + sb) * 16 + sch * 8;
+      const uint32_t voff = (m < mend && n < a.N) ? (uint32_t)(m * a.N + n) * 2u : OOB;
+      PF_W_BUFFER_LOAD_LDS16(rsY, dst + (pg * NBN + g4 * 4) * 256, voff);
+    }
+#pragma unroll
+    for (int x = 0; x < XS; ++x) {
+      const int xi = wave + x * NWAVE;
+      if (xi < IX) {
+        const int pg = xi / (TK / 64), g4 = xi % (TK / 64);
+        const int m = mb + pg * 8 + srow;
+        bool ok = m < mend;
+        int row = m;
+        if (MAP) {
+          const int hi = px_ho[x] * a.stride + tap_r - a.pad_h, wi = px_wo[x] * a.stride + tap_s - a.pad_w;
+          ok = ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.Wd;
+          row = (px_img[x] * a.H + hi) * a.Wd + wi;
+          // advance to the pixel of the next step
+          px_wo[x] += adv_r; px_ho[x] += adv_q;
+          if (px_wo[x] >= a.Wo) { px_wo[x] -= a.Wo; ++px_ho[x]; }
+          while (px_ho[x] >= a.Ho) { px_ho[x] -= a.Ho; ++px_img[x]; }
+        }
+        const uint32_t voff = ok ? (uint32_t)(row * a.C + c0 + (g4 * 4 + sb) * 16 + sch * 8) * 2u : OOB;
+        PF_W_BUFFER_LOAD_LDS16(rsX, dst + DY_BYTES + (pg * NBK + g4 * 4) * 256, voff);
+      }
+    }
+  };
+  auto transform = [&](int buf) {                                            // own X pieces, in place
+    unsigned char* dst = smem + buf * STAGE;
+#pragma unroll
+    for (int x = 0; x < XS; ++x) {
+      const int xi = wave + x * NWAVE;
+      if (xi < IX) {
+        const int pg = xi / (TK / 64), g4 = xi % (TK / 64);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { pro.sc[j] = psc[x][j]; pro.sh[j] = psh[x][j]; }
+        uint4* p = reinterpret_cast<uint4*>(dst + DY_BYTES + (pg * NBK + g4 * 4) * 256 + lane * 16);
+        *p = pro_apply(pro, *p);
+      }
+    }
+  };
+
+  f32x4 acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int tr_off = (q & 1) * 128 + (l15 >> 2) * 32 + (l15 & 3) * 8;
+  const int pg_lo = q >> 1;
+
+  if (nsteps > 0) stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (PRO && nsteps > 0) { transform(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+  __builtin_amdgcn_s_barrier();
+  for (int t = 0; t < nsteps; ++t) {
+    const int buf = t & 1;
+    const bool more = t + 1 < nsteps;
+    if (more) stage(t + 1, buf ^ 1);
+    const unsigned char* sbase = smem + buf * STAGE;
+    bf16x8 xf[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int cb = wk * NJ + j;
+      const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) v4s*)(sbase + DY_BYTES + (pg_lo * NBK + cb) * 256 + tr_off));
+      const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) v4s*)(sbase + DY_BYTES + ((pg_lo + 2) * NBK + cb) * 256 + tr_off));
+      v8s x8;
+      x8[0] = lo[0]; x8[1] = lo[1]; x8[2] = lo[2]; x8[3] = lo[3];
+      x8[4] = hi[0]; x8[5] = hi[1]; x8[6] = hi[2]; x8[7] = hi[3];
+      xf[j] = *reinterpret_cast<const bf16x8*>(&x8);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int nb = wn * NI + i;
+      const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) v4s*)(sbase + (pg_lo * NBN + nb) * 256 + tr_off));
+      const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) v4s*)(sbase + ((pg_lo + 2) * NBN + nb) * 256 + tr_off));
+      v8s d8;
+      d8[0] = lo[0]; d8[1] = lo[1]; d8[2] = lo[2]; d8[3] = lo[3];
+      d8[4] = hi[0]; d8[5] = hi[1]; d8[6] = hi[2]; d8[7] = hi[3];
+      const bf16x8 df = *reinterpret_cast<const bf16x8*>(&d8);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, xf[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // own pieces of the next stage have landed
+    if (PRO && more) transform(buf ^ 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  float* out = a.slabs + (int64_t)split * a.N * ktot;
+  const int kcol = tap * a.C + c0 + wk * WTK;
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int k = kcol + j * 16 + l15;
+      const int n = n0 + wn * WTN + i * 16 + q * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < a.N) out[(int64_t)(n + r) * ktot + k] = acc[i][j][r];
+    }
+}
+
+struct Wrw2Cfg { int tn, tk; };
+static Wrw2Cfg wrw2_pick(int N, int C) {
+  const int tn = (N % 256 == 0) ? 256 : ((N % 128 == 0) ? 128 : 64);
+  int tk = (C % 128 == 0) ? 128 : 64;
+  if (tn == 128 && tk == 64) return Wrw2Cfg{64, 64};     // (128, 64) has no instantiation: two 64-wide tiles
+  return Wrw2Cfg{tn, tk};
+}
+
+static bool wrw2_enabled() {
+  const char* e = getenv("PF_WRW2");                       // PF_WRW2=0: tuning / A-B override
+  return e == nullptr || atoi(e) != 0;
+}
+
+// pixel splits of the shared-tile kernel (0: does not apply)
+int pf_wrw2_splits(int M, int N, int C, int taps) {
+  if (!wrw2_enabled() || (C % 64) || (N % 64) || M < 2048) return 0;
+  if ((int64_t)M * N >= ((int64_t)1 << 30)) return 0;
+  const Wrw2Cfg c = wrw2_pick(N, C);
+  const int tiles = (N / c.tn) * (taps * C / c.tk);
+  int S = (512 + tiles - 1) / tiles;                      // ~ two workgroups per CU
+  const int maxS = (M + 255) / 256;                       // >= 8 steps of 32 pixels per workgroup
+  if (S > maxS) S = maxS;
+  if (S < 1) S = 1;
+  int rows = (M + S - 1) / S;
+  rows = ((rows + 31) / 32) * 32;
+  return (M + rows - 1) / rows;
+}
+
+template <int TN, int TK, int WTN, int WTK, bool PRO, bool MAP>
+static int wrw2_launch_t(const Wrw2Args& a, int grid, hipStream_t st) {
+  const size_t lds = 2 * (size_t)(4 * (TN / 16) * 256 + 4 * (TK / 16) * 256);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wrw2<TN, TK, WTN, WTK, PRO, MAP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  k_wrw2<TN, TK, WTN, WTK, PRO, MAP><<<grid, 64 * (TN / WTN) * (TK / WTK), lds, st>>>(a);
+  PF_LAUNCH_CHECK();
+  return 0;
+}
+
+int pf_wrw2_launch(const void* dY, const void* X, float* slabs, const float* scale_shift, int act, const uint32_t* slot,
+                   int bits, int M, int N, int C, int th, int tw, int H, int Wd, int Ho, int Wo, int stride, int pad_h,
+                   int pad_w, int S, int64_t x_rows, hipStream_t st) {
+  if (S <= 0) return -1;
+  if (x_rows * C >= ((int64_t)1 << 30)) return -1;
+  Wrw2Args a;
+  a.dY = (const bf16_t*)dY; a.X = (const bf16_t*)X; a.slabs = slabs; a.ss = scale_shift; a.slot = slot;
+  a.kq = uq_k_of_bits(slot ? bits : 8);
+  a.act_lo = (act == PF_ACT_NONE) ? -INFINITY : 0.0f;
+  a.act_hi = (act == PF_ACT_RELU6) ? 6.0f : INFINITY;
+  a.dy_bytes = (uint32_t)((int64_t)M * N * 2);
+  a.x_bytes = (uint32_t)(x_rows * C * 2);
+  a.M = M; a.N = N; a.C = C; a.th = th; a.tw = tw; a.H = H; a.Wd = Wd; a.Ho = Ho; a.Wo = Wo;
+  a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
+  const Wrw2Cfg c = wrw2_pick(N, C);
+  a.tiles_n = N / c.tn;
+  a.tiles = a.tiles_n * (th * tw * C / c.tk);
+  int rows = (M + S - 1) / S;
+  rows = ((rows + 31) / 32) * 32;
+  a.rows_per_split = rows;
+  const int grid = a.tiles * S;
+  const bool pro = scale_shift != nullptr;
+  const bool map = stride != 1 || th * tw > 1;
+  if (pro && th * tw > 1) return -1;
+#define PF_W2(TNV, TKV, WTNV, WTKV)                                                                           \
+  do {                                                                                                        \
+    if (pro) return map ? wrw2_launch_t<TNV, TKV, WTNV, WTKV, true, true>(a, grid, st)                         \
+                        : wrw2_launch_t<TNV, TKV, WTNV, WTKV, true, false>(a, grid, st);                       \
+    return map ? wrw2_launch_t<TNV, TKV, WTNV, WTKV, false, true>(a, grid, st)                                 \
+               : wrw2_launch_t<TNV, TKV, WTNV, WTKV, false, false>(a, grid, st);                               \
+  } while (0)
+  if (c.tn == 256 && c.tk == 128) PF_W2(256, 128, 64, 64);
+  if (c.tn == 128 && c.tk == 128) PF_W2(128, 128, 64, 64);
+  if (c.tn == 256 && c.tk == 64) PF_W2(256, 64, 64, 32);
+  if (c.tn == 64 && c.tk == 128) PF_W2(64, 128, 32, 64);
+  PF_W2(64, 64, 32, 32);
+#undef PF_W2
+}
+
 // ---- RxS backward-filter behind the C ABI ------------------------------------------------------------------------
 int pf_wrw_reduce(float* workspace, int S, int64_t n, void* dW, int dw_dtype, hipStream_t st);   // pf_conv.hip
 
 // pixel splits of pf_conv2d_wrw (0: shape not supported); the workspace must hold (splits + 32) * N * th*tw*C floats
-extern "C" int pf_conv2d_wrw_splits(int M, int N, int C, int taps) { return pf_wrw_tr_splits(M, N, C, taps); }
+extern "C" int pf_conv2d_wrw_splits(int M, int N, int C, int taps) {
+  const int s2 = pf_wrw2_splits(M, N, C, taps);
+  return s2 > 0 ? s2 : pf_wrw_tr_splits(M, N, C, taps);
+}
 
 // dW[n][r][s][c] = sum_m dY[m][n] * X[pix(m, r, s)][c]  (KRSC, float32 or bf16), X a materialised NHWC activation
 extern "C" int pf_conv2d_wrw(const void* dY, const void* X, void* dW, int dw_dtype, float* workspace, int imgs, int H,
@@ -318,11 +632,17 @@ extern "C" int pf_conv2d_wrw(const void* dY, const void* X, void* dW, int dw_dty
   if (imgs <= 0 || H <= 0 || Wd <= 0 || Ho <= 0 || Wo <= 0 || th < 1 || tw < 1 || stride < 1) return (int)hipErrorInvalidValue;
   if (!pf_aligned16(dY) || !pf_aligned16(X) || !pf_aligned16(dW) || !pf_aligned16(workspace)) return (int)hipErrorInvalidValue;
   const int M = imgs * Ho * Wo;
-  const int S = pf_wrw_tr_splits(M, N, C, th * tw);
-  if (S <= 0) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
-  const int r = pf_wrw_tr_launch(dY, X, workspace, nullptr, PF_ACT_NONE, nullptr, 8, M, N, C, th, tw, H, Wd, Ho, Wo, stride,
-                                 pad_h, pad_w, S, st);
+  const int s2 = pf_wrw2_splits(M, N, C, th * tw);
+  const int S = s2 > 0 ? s2 : pf_wrw_tr_splits(M, N, C, th * tw);
+  if (S <= 0) return (int)hipErrorInvalidValue;
+  int r = -1;
+  if (s2 > 0)
+    r = pf_wrw2_launch(dY, X, workspace, nullptr, PF_ACT_NONE, nullptr, 8, M, N, C, th, tw, H, Wd, Ho, Wo, stride, pad_h,
+                       pad_w, S, (int64_t)imgs * H * Wd, st);
+  if (r < 0)
+    r = pf_wrw_tr_launch(dY, X, workspace, nullptr, PF_ACT_NONE, nullptr, 8, M, N, C, th, tw, H, Wd, Ho, Wo, stride,
+                         pad_h, pad_w, S, st);
   if (r != 0) return r < 0 ? (int)hipErrorInvalidValue : r;
   return pf_wrw_reduce(workspace, S, (int64_t)N * th * tw * C, dW, dw_dtype, st);
 }

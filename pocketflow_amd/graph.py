@@ -757,9 +757,8 @@ class _FusedConv1x1(torch.autograd.Function):
 
 
 OWN_POOL = os.environ.get('PF_OWN_POOL', '1') != '0'         # stem max-pooling on pf_pool.hip (0: aten, for A/B runs)
-# backward-filter of the RxS convolutions on pf_wrw.hip: correct, but measured 2.7x slower than MIOpen's (336 vs 121 us on the
-# 3x3 C = 256 layer, tools/gpu/wrw_bench.py) -- off until the shared-tile version exists; PF_OWN_CONV2D_WRW=1 enables it
-OWN_CONV2D_WRW = os.environ.get('PF_OWN_CONV2D_WRW', '0') != '0'
+# backward-filter of the RxS convolutions on pf_wrw.hip (shared-tile kernel); PF_OWN_CONV2D_WRW=0: MIOpen, for A/B runs
+OWN_CONV2D_WRW = os.environ.get('PF_OWN_CONV2D_WRW', '1') != '0'
 OWN_CONV2D = os.environ.get('PF_OWN_CONV2D', '1') != '0'     # RxS convolutions on pf_igemm.hip (0: MIOpen, for A/B runs)
 
 
@@ -808,7 +807,9 @@ class _Conv2dIgemm(torch.autograd.Function):
       B_, _, H_, W_ = x.shape
       Ho_, Wo_ = dy.shape[2], dy.shape[3]
       M_ = B_ * Ho_ * Wo_
-      splits = hip.conv2d_wrw_splits(M_, N_, C_, R_ * S_) if OWN_CONV2D_WRW else 0
+      # C = 64: the [64 x 64] tile per tap is too small to feed the matrix cores (measured 256 vs 168 us against MIOpen on
+      # the 56x56 layer, tools/gpu/wrw_bench.py); from C = 128 up the shared-tile kernel is on par or ahead
+      splits = hip.conv2d_wrw_splits(M_, N_, C_, R_ * S_) if (OWN_CONV2D_WRW and C_ >= 128) else 0
       with region('conv2d_wrw', float((x.numel() + dy.numel()) * 2)):
         if splits > 0:
           # the kernel's gradient view inside the flat gradient buffer (KRSC memory): written directly, like the 1x1 path

@@ -114,9 +114,12 @@ def test_conv1x1_fwd_strided_and_ymap(hip, n, H, Wd):
                                             (4096, 64, 64, torch.float32), (10001, 128, 256, torch.bfloat16),
                                             (7777, 512, 128, torch.float32), (3000, 64, 128, torch.float32),
                                             (50176, 256, 1024, torch.float32)])
-@pytest.mark.parametrize('tr', ['0', '1'])
-def test_conv1x1_wrw(hip, monkeypatch, M, N, K, dw_dtype, tr):
-  monkeypatch.setenv('PF_WRW_TR', tr)            # 1: the transposed-LDS-read kernel where it applies (opt-in, see pf_wrw.hip)
+@pytest.mark.parametrize('impl', ['shared-tile', 'scatter', 'wave-private'])
+def test_conv1x1_wrw(hip, monkeypatch, M, N, K, dw_dtype, impl):
+  # the three backward-filter kernels: shared-tile transposed reads (pf_wrw.hip k_wrw2, default where it applies), the
+  # 2-byte-scatter kernel (pf_conv.hip, fallback), the wave-private transposed-read kernel (pf_wrw.hip k_wrw_tr, opt-in)
+  monkeypatch.setenv('PF_WRW2', '1' if impl == 'shared-tile' else '0')
+  monkeypatch.setenv('PF_WRW_TR', '1' if impl == 'wave-private' else '0')
   g = torch.Generator(device='cuda').manual_seed(M)
   X = _bf(torch.randn(M, K, device='cuda', generator=g))
   dY = _bf(torch.randn(M, N, device='cuda', generator=g) * 0.1)
@@ -148,9 +151,10 @@ def test_conv1x1_wrw(hip, monkeypatch, M, N, K, dw_dtype, tr):
 
 
 @pytest.mark.parametrize('n,H,Wd,K,N', [(2, 8, 12, 64, 64), (10, 30, 34, 128, 192)])
-@pytest.mark.parametrize('tr', ['0', '1'])
-def test_conv1x1_wrw_strided(hip, monkeypatch, n, H, Wd, K, N, tr):
-  monkeypatch.setenv('PF_WRW_TR', tr)
+@pytest.mark.parametrize('impl', ['shared-tile', 'scatter', 'wave-private'])
+def test_conv1x1_wrw_strided(hip, monkeypatch, n, H, Wd, K, N, impl):
+  monkeypatch.setenv('PF_WRW2', '1' if impl == 'shared-tile' else '0')
+  monkeypatch.setenv('PF_WRW_TR', '1' if impl == 'wave-private' else '0')
   s = 2
   Ho, Wo = H // s, Wd // s
   M = n * Ho * Wo

@@ -129,7 +129,9 @@ def test_conv2d_backward_data_through_flipped_kernel_with_bn_statistics(hip):
 @pytest.mark.parametrize('imgs,H,C,N,k,stride,dw_dtype', [(8, 28, 128, 128, 3, 1, torch.float32), (12, 14, 256, 256, 3, 1, torch.bfloat16),
                                                           (16, 56, 64, 64, 3, 1, torch.float32), (16, 28, 128, 128, 3, 2, torch.float32),
                                                           (10, 30, 64, 192, 1, 2, torch.float32)])
-def test_conv2d_wrw_matches_autograd(hip, imgs, H, C, N, k, stride, dw_dtype):
+@pytest.mark.parametrize('impl', ['shared-tile', 'wave-private'])
+def test_conv2d_wrw_matches_autograd(hip, monkeypatch, imgs, H, C, N, k, stride, dw_dtype, impl):
+  monkeypatch.setenv('PF_WRW2', '1' if impl == 'shared-tile' else '0')
   """Backward-filter on the transposed-LDS-read kernel (pf_conv2d_wrw): 3x3 stride 1 / 2 with zero padding at the borders
   (padding taps must contribute exactly 0), KRSC output, deterministic."""
   g = torch.Generator(device='cuda').manual_seed(C + N + H)

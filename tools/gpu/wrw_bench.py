@@ -20,7 +20,7 @@ def timeit(fn, n=10):
 
 
 B = int(os.environ.get('B', 256))
-print('1x1 (prologue, 8-bit):  HW,K,N | tr us | old us | floor us (6.3 TB/s) | max rel err tr vs old')
+print('1x1 (prologue, 8-bit):  HW,K,N | shared-tile us | scatter us | floor us (6.3 TB/s) | max rel err')
 for hw, K, N in [(56, 64, 64), (56, 64, 256), (56, 256, 64), (56, 256, 128), (28, 128, 512), (28, 512, 128), (28, 512, 256),
                  (14, 256, 1024), (14, 1024, 256), (14, 1024, 512), (7, 512, 2048), (7, 2048, 512)]:
   M = B * hw * hw
@@ -32,12 +32,12 @@ for hw, K, N in [(56, 64, 64), (56, 64, 256), (56, 256, 64), (56, 256, 128), (28
   hip.minmax_tensor(torch.relu(X.float() * ss[0] + ss[1]).contiguous(), slot)
   res = {}
   for mode in ('1', '0'):
-    os.environ['PF_WRW_TR'] = mode
+    os.environ['PF_WRW2'] = mode
     ws = torch.empty((hip.conv1x1_wrw_splits(M, N, K) + 32) * N * K, device='cuda')
     dW = torch.empty(N, K, device='cuda', dtype=torch.bfloat16)
     t = timeit(lambda: hip.conv1x1_wrw(dY, X, dW, ws, M, N, K, scale_shift=ss, act='Relu', slot=slot, bits=8))
     res[mode] = (t, dW.float().clone())
-  os.environ.pop('PF_WRW_TR')
+  os.environ.pop('PF_WRW2')
   err = float((res['1'][1] - res['0'][1]).abs().max() / (res['0'][1].abs().max() + 1e-9))
   print('%-14s | %7.0f | %7.0f | %6.0f | %.1e' % ('%d,%d,%d' % (hw, K, N), res['1'][0], res['0'][0], M * (K + N) * 2 / 6.3e12 * 1e6, err))
 print('3x3:  H,C,N,stride | tr us | miopen us | TF tr')
