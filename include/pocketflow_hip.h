@@ -280,6 +280,17 @@ int pf_conv2d_wrw_splits(int M, int N, int C, int taps);
 int pf_conv2d_wrw(const void* dY, const void* X, void* dW, int dw_dtype, float* workspace, int imgs, int H, int Wd, int C,
                   int N, int th, int tw, int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream);
 
+/* ---- backward-data layout of all convolution kernels in one launch -------------------------------------------------
+ * Conv2DBackpropInput needs W'[c][R-1-r][S-1-s][n] = W[n][r][s][c]; one 64 x 64 tile of one (kernel, tap) matrix per
+ * workgroup, described by a PfTransposeTile (built once on the host).  src / dst: flat buffers of `dtype`.            */
+typedef struct PfTransposeTile {
+  int64_t src_off, dst_off;   /* element offsets of the [O][I] source matrix / the [I][O] destination matrix        */
+  int32_t O, I, src_ld, dst_ld;
+  int32_t o0, i0;             /* tile origin                                                                        */
+  int32_t reserved0, reserved1;
+} PfTransposeTile;
+int pf_seg_transpose(const void* src_flat, void* dst_flat, int dtype, const void* tiles, int n_tiles, void* stream);
+
 /* ---- K13: max-pooling of the ResNet stem (tf.layers.max_pooling2d, padding SAME: utils/external/resnet_model.py:522-526)
  * and MaxPoolGrad, NHWC float32 / bf16, C % 8 == 0.  Padding is -inf (clipped windows).  idx[B][Ho][Wo][C] (uint8, may be
  * NULL in the forward call) holds r*k+s of the FIRST maximum of each window, the element the gradient is routed to.

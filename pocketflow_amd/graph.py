@@ -195,6 +195,9 @@ class VarStore:
     self.o_master = torch.zeros(max(self.o_size, ALIGN), dtype=torch.float32, device=dev)
     self.state = torch.zeros(max(self.s_size, ALIGN), dtype=torch.float32, device=dev)
     self.w_grad = torch.zeros_like(self.w_compute) if requires_grad else None
+    self.w_t = None                            # backward-data layout of the convolution kernels (lazily built)
+    self.w_t_fresh = False
+    self._t_tiles, self._n_t_tiles = None, 0
     self.o_grad = torch.zeros_like(self.o_master) if requires_grad else None
     for v in self.vars:
       n = v.numel
@@ -260,6 +263,37 @@ class VarStore:
     """compute copy <- master (plain cast); quantising learners overwrite it every step."""
     if self.separate_compute:
       self.w_compute.copy_(self.w_master)
+    self.w_t_fresh = False
+
+  # -- backward-data layout of the convolution kernels: W'[c][R-1-r][S-1-s][n] = W[n][r][s][c], all kernels, one launch ----
+  def _build_transpose_tiles(self) -> None:
+    rows = []
+    for v in self.vars:
+      if v.group != 'W' or v.kind != 'conv' or not v.trainable:
+        continue
+      kh, kw, cin, cout = v.ref_shape
+      RS = kh * kw
+      for rs in range(RS):
+        for o0 in range(0, cout, 64):
+          for i0 in range(0, cin, 64):
+            rows.append((v.offset + rs * cin, v.offset + (RS - 1 - rs) * cout, cout, cin, RS * cin, RS * cout, o0, i0, 0, 0))
+    from pocketflow_amd.hip import TILE_DTYPE      # (the `hip` module object may be a test double)
+    tiles = np.array(rows, dtype=TILE_DTYPE) if rows else np.zeros(0, dtype=TILE_DTYPE)
+    self._n_t_tiles = len(rows)
+    self._t_tiles = torch.from_numpy(tiles.view(np.uint8).copy()).to(self.device) if rows else None
+    self.w_t = torch.zeros_like(self.w_compute)
+
+  def transposed(self, v: 'Variable') -> torch.Tensor:
+    """Kernel `v` in backward-data layout, [C][R][S][N] (1x1: [K][N]), a view of the flat buffer `w_t`; refreshed for
+    ALL kernels by one pf_seg_transpose launch the first time it is asked for after the compute copy changed."""
+    if self.w_t is None:
+      self._build_transpose_tiles()
+    if not self.w_t_fresh:
+      if self._n_t_tiles:
+        hip.seg_transpose(self.w_compute, self.w_t, self._t_tiles, self._n_t_tiles)
+      self.w_t_fresh = True
+    kh, kw, cin, cout = v.ref_shape
+    return self.w_t[v.offset:v.offset + v.numel].view(cin, kh, kw, cout)
 
   def zero_grad(self) -> None:
     if self.w_grad is not None:
@@ -370,6 +404,7 @@ class Graph:
   def begin_step(self) -> None:
     """Reset the activation min/max slots (ONE memset for all activations of the step)."""
     hip.minmax_slots_init(self.act_slots)
+    self.store.w_t_fresh = False               # the quantiser rewrites the compute copy of the kernels every step
 
   def scratch(self, n_floats: int) -> torch.Tensor:
     if self._scratch is None or self._scratch.numel() < n_floats:
@@ -738,7 +773,11 @@ class _FusedConv1x1(torch.autograd.Function):
       if direct:
         graph.store.notify_grad(ctx.w_var)       # autograd sees no gradient for this leaf: report it ourselves
     if ctx.needs_input_grad[0]:
-      wt = w2d.t().contiguous()                                                # [K][N]
+      wv = getattr(ctx, 'w_var', None)
+      if USE_SEG_TRANSPOSE and wv is not None and wv.store is graph.store and wv.tensor is ctx.w_leaf:
+        wt = graph.store.transposed(wv).view(K, N)                             # [K][N], one launch for all kernels
+      else:
+        wt = w2d.t().contiguous()
       if geom is None:
         dx = torch.empty_like(x)
       else:
@@ -756,6 +795,7 @@ class _FusedConv1x1(torch.autograd.Function):
     return dx, dw, (dy if has_res else None), None, None, None, None, None, None
 
 
+USE_SEG_TRANSPOSE = os.environ.get('PF_SEG_TRANSPOSE', '1') != '0'   # backward-data kernel layouts in one launch (0: aten)
 OWN_POOL = os.environ.get('PF_OWN_POOL', '1') != '0'         # stem max-pooling on pf_pool.hip (0: aten, for A/B runs)
 # backward-filter of the RxS convolutions on pf_wrw.hip (shared-tile kernel); PF_OWN_CONV2D_WRW=0: MIOpen, for A/B runs
 OWN_CONV2D_WRW = os.environ.get('PF_OWN_CONV2D_WRW', '1') != '0'
@@ -830,7 +870,11 @@ class _Conv2dIgemm(torch.autograd.Function):
       N, C, R, S = w.shape
       if stride == 1:
         B, _, H, W = x.shape
-        wb = w.detach().permute(0, 2, 3, 1).flip(1, 2).permute(3, 1, 2, 0).contiguous()   # [C][R][S][N]
+        wv = ctx.w_var
+        if USE_SEG_TRANSPOSE and wv is not None and wv.store is graph.store and wv.tensor is w:
+          wb = graph.store.transposed(wv)                                                 # [C][R][S][N]
+        else:
+          wb = w.detach().permute(0, 2, 3, 1).flip(1, 2).permute(3, 1, 2, 0).contiguous()
         dx = torch.empty_like(x)
         M = B * H * W
         fuse = (FUSE_BN_BWD_STATS and bn_box is not None and bn_box.get('n_consumers') == 1

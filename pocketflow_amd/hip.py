@@ -42,7 +42,7 @@ SYMBOLS = [
     'pf_bn_act_quant_apply', 'pf_bn_bwd_stats', 'pf_bn_bwd_finalize', 'pf_bn_bwd_apply', 'pf_bn_bwd_apply_add',
     'pf_bn_eval_scale_shift', 'pf_gemm_bf16_nt', 'pf_gemm_bf16_nn', 'pf_gemm_bf16_tn',
     'pf_conv1x1_stats_groups', 'pf_conv1x1_stats_groups_k', 'pf_conv1x1_fwd', 'pf_conv1x1_bwd_data_bnstats', 'pf_conv1x1_wrw_splits',
-    'pf_conv1x1_wrw', 'pf_conv2d_stats_groups', 'pf_conv2d_fwd', 'pf_conv2d_wrw_splits', 'pf_conv2d_wrw', 'pf_maxpool_fwd', 'pf_maxpool_bwd',
+    'pf_conv1x1_wrw', 'pf_conv2d_stats_groups', 'pf_conv2d_fwd', 'pf_conv2d_wrw_splits', 'pf_conv2d_wrw', 'pf_maxpool_fwd', 'pf_maxpool_bwd', 'pf_seg_transpose',
     'pf_image_resize_bilinear',
 ]
 
@@ -387,6 +387,17 @@ def conv2d_wrw(dY, X, dW, workspace, imgs: int, H: int, Wd: int, C: int, N: int,
   _check(_lib.pf_conv2d_wrw(_ptr(dY), _ptr(X), _ptr(dW), c_int(dtype_code(dW)), _ptr(workspace), c_int(imgs), c_int(H),
                             c_int(Wd), c_int(C), c_int(N), c_int(th), c_int(tw), c_int(stride), c_int(pad_h),
                             c_int(pad_w), c_int(Ho), c_int(Wo), _stream()), 'pf_conv2d_wrw')
+
+
+TILE_DTYPE = np.dtype([('src_off', '<i8'), ('dst_off', '<i8'), ('O', '<i4'), ('I', '<i4'), ('src_ld', '<i4'),
+                       ('dst_ld', '<i4'), ('o0', '<i4'), ('i0', '<i4'), ('r0', '<i4'), ('r1', '<i4')])
+assert TILE_DTYPE.itemsize == 48          # struct PfTransposeTile: two int64 + eight int32
+
+
+def seg_transpose(src_flat, dst_flat, tiles, n_tiles: int) -> None:
+  _dev(src_flat)
+  _check(_lib.pf_seg_transpose(_ptr(src_flat), _ptr(dst_flat), c_int(dtype_code(src_flat)), _ptr(tiles), c_int(n_tiles),
+                               _stream()), 'pf_seg_transpose')
 
 
 # ------------------------------------------------------------------------------------------------

@@ -184,6 +184,16 @@ class FakeHip(object):
       xr = self._q_of(xr, scale_shift, act, slot, bits, slot is not None)
     dW.copy_(_rows(dY, N).float().t() @ xr)
 
+  def seg_transpose(self, src_flat, dst_flat, tiles, n_tiles):
+    import numpy as np
+    from pocketflow_amd import hip as real
+    t = np.frombuffer(tiles.numpy().tobytes(), dtype=real.TILE_DTYPE)
+    for r in t:
+      o1, i1 = min(int(r['o0']) + 64, int(r['O'])), min(int(r['i0']) + 64, int(r['I']))
+      for o in range(int(r['o0']), o1):
+        src = src_flat[int(r['src_off']) + o * int(r['src_ld']) + int(r['i0']):int(r['src_off']) + o * int(r['src_ld']) + i1]
+        dst_flat[int(r['dst_off']) + int(r['i0']) * int(r['dst_ld']) + o:int(r['dst_off']) + (i1 - 1) * int(r['dst_ld']) + o + 1:int(r['dst_ld'])] = src
+
   def conv2d_wrw_splits(self, M, N, C, taps):
     return 2
 

@@ -525,3 +525,26 @@ def test_maxpool_same_forward_and_gradient_match_torch(dtype, B, C, H, W, k, str
   y.backward(dy.to(dtype).contiguous(memory_format=torch.channels_last))
   ref.backward(dy)
   assert torch.equal(x.grad.float(), xr.grad)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_seg_transpose_gives_the_backward_data_layout_of_every_kernel(dtype):
+  """W'[c][R-1-r][S-1-s][n] = W[n][r][s][c] for all convolution kernels of a store in one launch (pf_seg_transpose)."""
+  from pocketflow_amd.graph import VarStore
+  st = VarStore('model')
+  shapes = [(1, 1, 64, 256), (3, 3, 64, 64), (1, 1, 72, 40), (3, 3, 130, 70), (7, 7, 3, 64), (5, 3, 16, 8)]
+  vs = [st.add('c%d/kernel' % i, s, 'conv') for i, s in enumerate(shapes)]
+  st.add('fc/kernel', (100, 10), 'dense')
+  st.finalize('cuda', dtype)
+  rng = np.random.RandomState(0)
+  st.load_numpy({v.name: rng.randn(*v.ref_shape).astype(np.float32) for v in st.vars if v.group == 'W'})
+  for v in vs:
+    got = st.transposed(v)
+    w_krsc = v.tensor.detach().permute(0, 2, 3, 1)                       # [N][R][S][C]
+    ref = w_krsc.flip(1, 2).permute(3, 1, 2, 0).contiguous()              # [C][R][S][N]
+    assert got.shape == ref.shape and torch.equal(got, ref), v.name
+  # stale after the compute copy changes, fresh again on the next request
+  st.w_master.mul_(2.0)
+  st.sync_compute()
+  assert not st.w_t_fresh
+  assert torch.equal(st.transposed(vs[1]), vs[1].tensor.detach().permute(0, 2, 3, 1).flip(1, 2).permute(3, 1, 2, 0).contiguous())
