@@ -46,7 +46,7 @@ def parse_args():
   ap.add_argument('--weight_bits', type=int, default=8)
   ap.add_argument('--roofline_kernel', default='conv1x1_fwd',
                   help='profiling region whose launches are timed with HIP events: conv1x1_fwd | conv1x1_wrw | '
-                       'conv1x1_bwd_data | bn_bwd_apply | bn_bwd_stats | bn_act_quant_apply | bn_stats')
+                       'conv1x1_bwd_data | conv2d_fwd | bn_bwd_apply | bn_bwd_stats | bn_act_quant_apply | bn_stats')
   ap.add_argument('--no_cpu_baseline', action='store_true')
   ap.add_argument('--cpu_batch', type=int, default=32, help='batch of the CPU baseline sample (SURVEY 8d: 32)')
   ap.add_argument('--cpu_steps', type=int, default=5, help='timed CPU steps after the warm-up (SURVEY 8d: >= 5)')
@@ -54,31 +54,41 @@ def parse_args():
   return ap.parse_args()
 
 
-# profiling region -> kernel-name prefix in the rocprofv3 PMC summaries under profiles/
-REGION_KERNELS = {'conv1x1_fwd': 'k_conv1x1_fwd<', 'conv1x1_wrw': 'k_conv1x1_wrw<', 'conv1x1_bwd_data': 'k_conv1x1_fwd<',
-                  'bn_bwd_apply': 'k_bn_bwd_apply<', 'bn_bwd_stats': 'k_bn_bwd_stats', 'bn_act_quant_apply': 'k_bn_apply<',
-                  'bn_stats': 'k_bn_stats'}
+# profiling region -> regular expressions of the kernels it launches (names as in the rocprofv3 summaries under profiles/).
+# The fused 1x1 forward (region conv1x1_fwd: producer BN + ReLU + fake-quant prologue, residual / statistics epilogue) is
+# dispatched per shape to three kernels: the resident-kernel variant (pf_conv_stream.hip), the direct-to-LDS staged
+# variant with the in-LDS prologue pass (pf_igemm.hip, MODE 2) and the register-staged tiles (pf_conv.hip).
+REGION_KERNELS = {'conv1x1_fwd': [r'^k_conv1x1_stream<\d+, true, ', r'^k_igemm<\d+, \d+, \d+, \d+, \d+, 2>',
+                                  r'^k_conv1x1_fwd<\d+, true, '],
+                  'conv1x1_wrw': [r'^k_wrw2<', r'^k_conv1x1_wrw<', r'^k_wrw_tr<'],
+                  'conv1x1_bwd_data': [r'^k_conv1x1_stream<\d+, false, ', r'^k_igemm<\d+, \d+, \d+, \d+, \d+, [01]>',
+                                       r'^k_conv1x1_fwd<\d+, false, '],
+                  'conv2d_fwd': [r'^k_igemm<\d+, \d+, \d+, \d+, \d+, 0>'],
+                  'bn_bwd_apply': [r'^k_bn_bwd_apply<'], 'bn_bwd_stats': [r'^k_bn_bwd_stats'],
+                  'bn_act_quant_apply': [r'^k_bn_apply<'], 'bn_stats': [r'^k_bn_stats']}
+PROFILE_TAG = 'r02'
 
 
-def pmc_traffic_per_launch(region, tag='r01'):
-  """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes of THIS command
+def pmc_traffic_per_launch(region, tag=PROFILE_TAG):
+  """HBM bytes per launch of the roofline region's kernels from the committed rocprofv3 PMC passes of THIS command
   (profiles/<tag>_pmc_FETCH_SIZE.csv / _WRITE_SIZE.csv; separate --pmc passes, values in KiB).  Per
   MI355X_MICROARCH.md (HBM section) FETCH_SIZE counts wide coalesced reads at half their size on gfx950
-  (x2 correction); WRITE_SIZE needs none (calibrated here on k_bn_apply, whose writes are exactly one
-  tensor).  Returns None when the summaries are absent."""
+  (x2 correction); WRITE_SIZE needs none (calibrated in round 1 on k_bn_apply, whose writes are exactly one
+  tensor).  Returns None when the summaries are absent or the region's kernels cannot be told apart by name."""
   import csv
-  prefix = REGION_KERNELS.get(region)
-  if region == 'conv1x1_bwd_data':
-    return None                                   # shares its kernel name with the forward: not separable
-  tot, n = 0.0, 0
+  import re
+  pats = REGION_KERNELS.get(region)
+  if pats is None or region in ('conv1x1_bwd_data', 'conv2d_fwd'):
+    return None                                   # these share kernel names with other regions: not separable
+  tot = 0.0
   for counter, mult in (('FETCH_SIZE', 2.0), ('WRITE_SIZE', 1.0)):
     path = os.path.join(ROOT, 'profiles', '%s_pmc_%s.csv' % (tag, counter))
-    if prefix is None or not os.path.exists(path):
+    if not os.path.exists(path):
       return None
     disp, kib = 0, 0.0
     with open(path) as f:
       for r in csv.DictReader(f):
-        if r['kernel'].startswith(prefix) and (region != 'conv1x1_fwd' or ', true, ' in r['kernel']):
+        if any(re.search(p, r['kernel']) for p in pats):
           disp += int(r['dispatches'])
           kib += float(r['mean_' + counter]) * int(r['dispatches'])
     if disp == 0:
@@ -130,7 +140,7 @@ def main():
       shutil.rmtree(tmp, ignore_errors=True)
       os.makedirs(tmp, exist_ok=True)
     dist.barrier()
-  torch.backends.cudnn.benchmark = True
+  torch.backends.cudnn.benchmark = os.environ.get('PF_CUDNN_BENCHMARK', '1') != '0'
 
   mh = ModelHelper()
   if rank == 0:
@@ -151,10 +161,16 @@ def main():
   profiling.enable(args.roofline_kernel)
   sync()
   t0 = time.perf_counter()
+  marks = []
   for _ in range(args.steps):
     learner.train_step()
+    marks.append(time.perf_counter())
   sync()
   dt = time.perf_counter() - t0
+  host_ms = (marks[-1] - t0) * 1e3 / max(1, args.steps)        # host-side submission time per step (GPU-bound when << ms_per_step)
+  if os.environ.get('PF_BENCH_TRACE_STEPS') and rank == 0:    # host-side submission time of every step (diagnostics)
+    sys.stderr.write('host ms/step: %s | tail sync %.1f ms\n' % (
+        ' '.join('%.1f' % ((b - a) * 1e3) for a, b in zip([t0] + marks[:-1], marks)), (t0 + dt - marks[-1]) * 1e3))
   if world > 1:
     t = torch.tensor([dt], dtype=torch.float64, device='cuda')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -166,7 +182,9 @@ def main():
     value = images / dt
     per_gpu = value / world
     ach = (work / (ms * 1e-3)) if ms > 0 else 0.0
-    roofline = {'bound': 'hbm', 'kernel': REGION_KERNELS.get(args.roofline_kernel, args.roofline_kernel).rstrip('<'),
+    roofline = {'bound': 'hbm',
+                'kernel': 'fused 1x1 convolution forward, student + teacher (k_conv1x1_stream / k_igemm<..,2> / k_conv1x1_fwd)'
+                          if args.roofline_kernel == 'conv1x1_fwd' else args.roofline_kernel,
                 'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9,
                 'unit': 'GB/s', 'frac': ach / HBM_PEAK, 'traffic': pmc_traffic_per_launch(args.roofline_kernel),
                 'algorithmic_bytes_per_launch': (work / n_launch) if n_launch else None, 'launches': n_launch,
@@ -194,7 +212,7 @@ def main():
         'value': value, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'bf16' if args.dtype.startswith('bf') else 'f32', 'data': 'synthetic',
-        'value_per_gpu': per_gpu,
+        'value_per_gpu': per_gpu, 'host_submit_ms_per_step': host_ms,
         'config': {'workload': 'ResNet-v2-%d@ILSVRC-12-synthetic %dx%dx3, UniformQuantLearner w%d/a%d + distillation, '
                                'Adam, batch %d/GPU (BASELINE.json configs[2])'
                                % (args.resnet_size, args.image_size, args.image_size, args.weight_bits,

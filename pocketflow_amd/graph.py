@@ -799,6 +799,7 @@ USE_SEG_TRANSPOSE = os.environ.get('PF_SEG_TRANSPOSE', '1') != '0'   # backward-
 OWN_POOL = os.environ.get('PF_OWN_POOL', '1') != '0'         # stem max-pooling on pf_pool.hip (0: aten, for A/B runs)
 # backward-filter of the RxS convolutions on pf_wrw.hip (shared-tile kernel); PF_OWN_CONV2D_WRW=0: MIOpen, for A/B runs
 OWN_CONV2D_WRW = os.environ.get('PF_OWN_CONV2D_WRW', '1') != '0'
+OWN_CONV2D_WRW_MIN_C = int(os.environ.get('PF_OWN_CONV2D_WRW_MIN_C', '128'))   # narrower inputs: MIOpen is faster (measured)
 OWN_CONV2D = os.environ.get('PF_OWN_CONV2D', '1') != '0'     # RxS convolutions on pf_igemm.hip (0: MIOpen, for A/B runs)
 
 
@@ -849,7 +850,7 @@ class _Conv2dIgemm(torch.autograd.Function):
       M_ = B_ * Ho_ * Wo_
       # C = 64: the [64 x 64] tile per tap is too small to feed the matrix cores (measured 256 vs 168 us against MIOpen on
       # the 56x56 layer, tools/gpu/wrw_bench.py); from C = 128 up the shared-tile kernel is on par or ahead
-      splits = hip.conv2d_wrw_splits(M_, N_, C_, R_ * S_) if (OWN_CONV2D_WRW and C_ >= 128) else 0
+      splits = hip.conv2d_wrw_splits(M_, N_, C_, R_ * S_) if (OWN_CONV2D_WRW and C_ >= OWN_CONV2D_WRW_MIN_C) else 0
       with region('conv2d_wrw', float((x.numel() + dy.numel()) * 2)):
         if splits > 0:
           # the kernel's gradient view inside the flat gradient buffer (KRSC memory): written directly, like the 1x1 path
