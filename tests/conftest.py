@@ -21,3 +21,19 @@ def _reset_flags():
     FLAGS.reset()
   except Exception:
     pass
+
+
+@pytest.fixture(autouse=True)
+def _dirty_allocator(request):
+  """GPU tests start with NaN patterns in the caching allocator's free blocks, as they would be after a long run:
+  a kernel that reads a `torch.empty` buffer it never wrote (or assumes a fresh allocation is zero) then fails in
+  every test order, not only when an earlier test happened to leave garbage behind.  PF_TEST_POISON=0 disables."""
+  if request.node.get_closest_marker('gpu') is not None and os.environ.get('PF_TEST_POISON', '1') != '0':
+    import torch
+    if torch.cuda.is_available():
+      small = [torch.full((1 << 16,), float('nan'), device='cuda') for _ in range(256)]      # 256 KiB blocks (small pool)
+      mid = [torch.full((1 << 20,), float('nan'), device='cuda') for _ in range(64)]         # 4 MiB blocks
+      big = [torch.full((1 << 26,), float('nan'), device='cuda') for _ in range(6)]          # 256 MiB blocks
+      torch.cuda.synchronize()
+      del small, mid, big
+  yield

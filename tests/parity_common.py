@@ -36,7 +36,7 @@ def _force_state(learner, ora):
     flat[v.offset:v.offset + v.numel] = torch.from_numpy(np.ascontiguousarray(acc)).to(flat.device)
 
 
-def run_cp_masked_finetune(FLAGS, tmp_path, optimizer, steps=3):
+def run_cp_masked_finetune(FLAGS, tmp_path, optimizer, steps=3, report=None):
   """BASELINE configs[3] shrunk: the masked fine-tune of the ChannelPrunedLearner (cp learner.py:381-471) on
   MobileNet-v1 x0.5 @64 with distillation.  The keep-masks are a seeded stand-in for the LASSO selector's output
   (which is pinned separately against the reference's own compute_pruned_kernel, tests/test_channel_pruner_host.py):
@@ -64,6 +64,18 @@ def run_cp_masked_finetune(FLAGS, tmp_path, optimizer, steps=3):
   convs = [op for op in learner.graph.matmul_ops if op.var.kind == 'conv']
   fake, by_var = {}, {}
   vals = learner.graph.store.export_numpy()
+  # Generic, NEGATIVE BN offsets instead of the initialiser's exact zeros.  About half of all channels of the freshly
+  # pruned network are dead (zero batch variance); with beta == 0 each of them sits EXACTLY on its ReLU6 gate (u = beta
+  # = 0), and a channel that is dead only because all of its inputs are <= 0 re-opens when ONE input lands at +1e-8
+  # instead of 0 in another float32 summation order -- BN then amplifies its gradient by 1/sqrt(eps) = 31.6 per layer.
+  # Measured: the oracle's OWN gradients change by factors up to 1e4 when every beta moves from 0 to +1e-20 (not at all
+  # for -1e-20); HIP vs oracle at step 0 came out at 2e-6 or at 3-10 % per variable depending on the run, and at 1e-5
+  # from step 1 on (beta != 0); random-sign betas keep dead channels open and the comparison at the 1e-2 level.  With
+  # beta < 0 a dead channel is robustly closed in every implementation, and a fine-tune never starts from exact zeros
+  # anyway (pre-trained betas are generic).
+  for name in list(vals):
+    if name.endswith('/beta'):
+      vals[name] = (-0.01 - np.abs(0.1 * rng.standard_normal(vals[name].shape))).astype(np.float32)
   for i, op in enumerate(convs):
     kh, kw, cin, cout = op.var.ref_shape
     keep_in = np.ones(cin, bool) if i == 0 else rng.rand(cin) < 0.5
@@ -97,19 +109,20 @@ def run_cp_masked_finetune(FLAGS, tmp_path, optimizer, steps=3):
     ref = ora.train_step(*pool[step % len(pool)], extra={'dropout_mask': dmask})
     assert abs(float(loss.detach()) - ref['loss']) <= 5e-4 * max(1.0, abs(ref['loss'])), (step, float(loss.detach()), ref['loss'])
     if optimizer == 'momentum':
-      # Momentum-SGD at the ILSVRC learning rate on a freshly pruned BN network is chaotic: a 1e-6 weight difference
-      # after one update flips single ReLU6 gates and moves per-channel gradients by 10 % at the next step (measured;
-      # with IDENTICAL weights the two gradient computations agree to 3e-4 absolute).  As in the weight-sparsification
-      # test, every step is therefore checked from a common state: compare, then teacher-force weights and slots.
       # One Momentum step from a common state IS a gradient comparison, so the bar is relative to the update:
-      # ||w_hip - w_oracle|| <= 5e-3 * ||w_oracle - w_before|| per variable (float32 reductions over 10^4..10^6 terms with
-      # inputs of magnitude 10^2 on the GPU; a wrong mask, a missing L2 term or a wrong accumulator is O(1) on this scale).
+      # ||w_hip - w_oracle|| <= 5e-3 * ||w_oracle - w_before|| per variable; every step is checked from a common state
+      # (compare, then teacher-force weights and slots, as in the weight-sparsification test).  Measured on MI355X with
+      # the generic BN offsets above (tools/gpu/cp_parity_report.py): 1e-5 over all variables together, <= 4.4e-4 for the
+      # worst variable; a wrong mask, learning rate or accumulator is O(1) on this scale.
       got_now, ref_now = st.export_numpy(), ora.export()
       for name, ref_v in ref_now.items():
         if 'moving_' in name:
           continue
         upd = float(np.linalg.norm((ref_v - prev[name]).astype(np.float64)))
         err = float(np.linalg.norm((got_now[name] - ref_v).astype(np.float64)))
+        if report is not None:                       # diagnostics (tools/gpu/cp_parity_report.py): collect instead of assert
+          report.append((step, name, err, upd))
+          continue
         assert err <= 5e-3 * upd + 1e-6 * float(np.linalg.norm(ref_v)) + 1e-9, \
             'step %d: %s: |hip - oracle| = %.3e vs |update| = %.3e' % (step, name, err, upd)
       _force_state(learner, ora)
