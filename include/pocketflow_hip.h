@@ -300,6 +300,13 @@ int pf_maxpool_fwd(const void* x, void* y, void* idx, int dtype, int B, int H, i
 int pf_maxpool_bwd(const void* dy, const void* idx, void* dx, int dtype, int B, int H, int W, int C, int k, int stride,
                    int pad_h, int pad_w, int Ho, int Wo, void* stream);
 
+/* ---- the ResNet stem: 7x7 / stride 2 / pad 3 convolution of a 3-channel image to 64 channels --------------------
+ * replaces the initial conv2d_fixed_padding of utils/external/resnet_model.py:478-486 (tf.pad + tf.layers.conv2d VALID).
+ * X [imgs][H][Wd][3] bf16 (NHWC), W [64][7][7][3] bf16 (KRSC), Y [imgs][H/2][Wd/2][64] bf16.  H even, Wd % 32 == 0:
+ * pf_conv_stem_supported tells whether a (H, Wd, C, N, k, stride, pad) convolution is this one.                        */
+int pf_conv_stem_supported(int H, int Wd, int C, int N, int k, int stride, int pad);
+int pf_conv_stem_fwd(const void* X, const void* W, void* Y, int imgs, int H, int Wd, void* stream);
+
 /* ---- K13: input pipeline tail -----------------------------------------------------------
  * replaces, per image, the preprocessing chain of utils/external/imagenet_preprocessing.py:226-260 behind the JPEG
  * decoder: training  random_flip_left_right -> tf.image.resize_images(BILINEAR, align_corners=False) -> - means;

@@ -801,6 +801,7 @@ OWN_POOL = os.environ.get('PF_OWN_POOL', '1') != '0'         # stem max-pooling 
 OWN_CONV2D_WRW = os.environ.get('PF_OWN_CONV2D_WRW', '1') != '0'
 OWN_CONV2D_WRW_MIN_C = int(os.environ.get('PF_OWN_CONV2D_WRW_MIN_C', '128'))   # narrower inputs: MIOpen is faster (measured)
 OWN_CONV2D = os.environ.get('PF_OWN_CONV2D', '1') != '0'     # RxS convolutions on pf_igemm.hip (0: MIOpen, for A/B runs)
+OWN_STEM = os.environ.get('PF_OWN_STEM', '1') != '0'         # the 7x7/2 stem on pf_stem.hip (0: MIOpen, for A/B runs)
 
 
 def _run_conv2d(x, w_krsc, stride, pad, want_stats):
@@ -895,6 +896,39 @@ class _Conv2dIgemm(torch.autograd.Function):
           dx = torch.ops.aten.convolution_backward(dy, x, w.detach(), None, [stride, stride], list(pad), [1, 1], False,
                                                    [0, 0], 1, [True, False, False])[0]
     return dx, dw, None, None, None, None, None, None, None
+
+
+class _StemConv(torch.autograd.Function):
+  """The ResNet stem (7x7 / stride 2 / pad 3, 3 -> 64 channels) on pf_conv_stem_fwd; the image needs no gradient, the
+  backward-filter goes through MIOpen."""
+
+  @staticmethod
+  def forward(ctx, x, w):
+    B, _, H, Wd = x.shape
+    y = torch.empty((B, w.shape[0], H // 2, Wd // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    with region('conv_stem_fwd', float((x.numel() + y.numel()) * 2)):
+      hip.conv_stem_fwd(x, w.detach().permute(0, 2, 3, 1), y, B, H, Wd)
+    ctx.save_for_backward(x, w)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    x, w = ctx.saved_tensors
+    dx = dw = None
+    if ctx.needs_input_grad[1]:
+      dw = torch.ops.aten.convolution_backward(_nhwc(dy), x, w.detach(), None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
+                                               [False, True, False])[1]
+    if ctx.needs_input_grad[0]:
+      dx = torch.ops.aten.convolution_backward(_nhwc(dy), x, w.detach(), None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
+                                               [True, False, False])[0]
+    return dx, dw
+
+
+def own_stem_ok(x, conv, pad) -> bool:
+  return (OWN_STEM and conv.bias is None and isinstance(x, torch.Tensor) and fusable_tensor(x) and x.dim() == 4
+          and pad is not None and pad[0] == pad[1] and conv.graph.fuse_conv1x1
+          and x.is_contiguous(memory_format=torch.channels_last)
+          and hip.conv_stem_supported(x.shape[2], x.shape[3], x.shape[1], conv.kernel.ref_shape[3], conv.k, conv.stride, pad[0]))
 
 
 def own_conv2d_ok(x, conv, pad) -> bool:
@@ -1007,6 +1041,13 @@ class Conv2D:
         sym = (0, 0)
     elif self.padding == 'VALID':
       sym = (0, 0)
+    if residual is None and own_stem_ok(x, self, sym):
+      if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+        return _StemConv.apply(x, w)
+      y = torch.empty((x.shape[0], w.shape[0], x.shape[2] // 2, x.shape[3] // 2), dtype=x.dtype, device=x.device,
+                      memory_format=torch.channels_last)
+      hip.conv_stem_fwd(x, w.detach().permute(0, 2, 3, 1), y, x.shape[0], x.shape[2], x.shape[3])
+      return y
     if own_conv2d_ok(x, self, sym):
       bn_box = getattr(x, '_pf_bn', None)
       if bn_box is not None:

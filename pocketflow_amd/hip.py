@@ -42,7 +42,7 @@ SYMBOLS = [
     'pf_bn_act_quant_apply', 'pf_bn_bwd_stats', 'pf_bn_bwd_finalize', 'pf_bn_bwd_apply', 'pf_bn_bwd_apply_add',
     'pf_bn_eval_scale_shift', 'pf_gemm_bf16_nt', 'pf_gemm_bf16_nn', 'pf_gemm_bf16_tn',
     'pf_conv1x1_stats_groups', 'pf_conv1x1_stats_groups_k', 'pf_conv1x1_fwd', 'pf_conv1x1_bwd_data_bnstats', 'pf_conv1x1_wrw_splits',
-    'pf_conv1x1_wrw', 'pf_conv2d_stats_groups', 'pf_conv2d_fwd', 'pf_conv2d_wrw_splits', 'pf_conv2d_wrw', 'pf_maxpool_fwd', 'pf_maxpool_bwd', 'pf_seg_transpose',
+    'pf_conv1x1_wrw', 'pf_conv2d_stats_groups', 'pf_conv2d_fwd', 'pf_conv2d_wrw_splits', 'pf_conv2d_wrw', 'pf_maxpool_fwd', 'pf_maxpool_bwd', 'pf_seg_transpose', 'pf_conv_stem_supported', 'pf_conv_stem_fwd',
     'pf_image_resize_bilinear',
 ]
 
@@ -398,6 +398,20 @@ def seg_transpose(src_flat, dst_flat, tiles, n_tiles: int) -> None:
   _dev(src_flat)
   _check(_lib.pf_seg_transpose(_ptr(src_flat), _ptr(dst_flat), c_int(dtype_code(src_flat)), _ptr(tiles), c_int(n_tiles),
                                _stream()), 'pf_seg_transpose')
+
+
+# ------------------------------------------------------------------------------------------------
+# the ResNet stem (7x7 / 2, 3 -> 64 channels)
+# ------------------------------------------------------------------------------------------------
+
+def conv_stem_supported(H: int, Wd: int, C: int, N: int, k: int, stride: int, pad: int) -> bool:
+  return bool(_lib.pf_conv_stem_supported(c_int(H), c_int(Wd), c_int(C), c_int(N), c_int(k), c_int(stride), c_int(pad)))
+
+
+def conv_stem_fwd(X, W, Y, imgs: int, H: int, Wd: int) -> None:
+  """X: NHWC memory [imgs][H][Wd][3] bf16, W: KRSC memory [64][7][7][3] bf16, Y: [imgs][H/2][Wd/2][64] bf16."""
+  _dev(X)
+  _check(_lib.pf_conv_stem_fwd(_ptr(X), _ptr(W), _ptr(Y), c_int(imgs), c_int(H), c_int(Wd), _stream()), 'pf_conv_stem_fwd')
 
 
 # ------------------------------------------------------------------------------------------------

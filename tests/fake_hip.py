@@ -233,6 +233,15 @@ class FakeHip(object):
       partial[:, 3] = float('-inf')
       partial[1, 0], partial[1, 1], partial[1, 2], partial[1, 3] = yr.sum(0), (yr * yr).sum(0), yr.min(0).values, yr.max(0).values
 
+  # -- the ResNet stem (pf_stem.hip) --------------------------------------------------------------------------------------
+  def conv_stem_supported(self, H, Wd, C, N, k, stride, pad):
+    return C == 3 and N == 64 and k == 7 and stride == 2 and pad == 3 and H % 2 == 0 and Wd % 32 == 0 and 32 <= Wd <= 1024
+
+  def conv_stem_fwd(self, X, W, Y, imgs, H, Wd):
+    self._n('conv_stem_fwd')
+    import torch.nn.functional as F
+    y = F.conv2d(X.float(), W.float().permute(0, 3, 1, 2), stride=2, padding=3)
+    _rows(Y, 64).copy_(y.permute(0, 2, 3, 1).reshape(-1, 64))
 
 
 

@@ -153,3 +153,26 @@ def test_conv2d_wrw_matches_autograd(hip, monkeypatch, imgs, H, C, N, k, stride,
   dw2 = torch.empty_like(dw)
   hip.conv2d_wrw(dy, x, dw2, ws, imgs, H, H, C, N, k, k, stride, pad, pad, Ho, Ho)
   assert torch.equal(dw, dw2)
+
+
+# ---- the ResNet stem (pf_stem.hip) ------------------------------------------------------------------------------------
+@pytest.mark.parametrize('imgs,H,Wd', [(3, 64, 64), (2, 224, 224), (1, 38, 96), (5, 18, 32), (130, 32, 64)])
+def test_conv_stem_fwd_matches_torch(hip, imgs, H, Wd):
+  """7x7 / stride 2 / pad 3, 3 -> 64 channels: borders on all four sides (zero padding), a partial last strip of output
+  rows (H/2 not a multiple of 8), more (image, strip) items than persistent workgroups, an ASYMMETRIC random kernel (a
+  transposed window, a wrong tap or channel order would show), several calls into the same output buffer."""
+  assert hip.conv_stem_supported(H, Wd, 3, 64, 7, 2, 3) and not hip.conv_stem_supported(H, Wd, 4, 64, 7, 2, 3)
+  g = torch.Generator(device='cuda').manual_seed(H + Wd + imgs)
+  x = _bf(torch.randn(imgs, H, Wd, 3, device='cuda', generator=g))
+  w = _bf(torch.randn(64, 7, 7, 3, device='cuda', generator=g) * 0.1)
+  ref = _bf(_ref(x, w, 2, (3, 3)))
+  for rep in range(2):
+    y = torch.full((imgs, H // 2, Wd // 2, 64), float('nan'), device='cuda', dtype=torch.bfloat16)
+    hip.conv_stem_fwd(x, w, y, imgs, H, Wd)
+    _close(y, ref, 'stem %dx%dx%d call %d' % (imgs, H, Wd, rep))
+  # one-hot probes: every (tap, channel) weight must meet exactly its input element
+  x1 = torch.zeros(1, 32, 32, 3, device='cuda', dtype=torch.bfloat16)
+  x1[0, 10, 13, 1] = 1.0
+  y1 = torch.empty(1, 16, 16, 64, device='cuda', dtype=torch.bfloat16)
+  hip.conv_stem_fwd(x1, w, y1, 1, 32, 32)
+  assert torch.equal(y1, _bf(_ref(x1, w, 2, (3, 3))))
