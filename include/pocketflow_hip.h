@@ -306,6 +306,12 @@ int pf_maxpool_bwd(const void* dy, const void* idx, void* dx, int dtype, int B, 
  * pf_conv_stem_supported tells whether a (H, Wd, C, N, k, stride, pad) convolution is this one.                        */
 int pf_conv_stem_supported(int H, int Wd, int C, int N, int k, int stride, int pad);
 int pf_conv_stem_fwd(const void* X, const void* W, void* Y, int imgs, int H, int Wd, void* stream);
+/* backward-filter of the same convolution (Conv2DBackpropFilter): dW [64][7][7][3] in dw_dtype (PF_F32 / PF_BF16) from
+ * dY [imgs][H/2][Wd/2][64] bf16 and X; deterministic (fixed-order slab reduction).  Wd <= 256.  workspace:
+ * (pf_conv_stem_wrw_slabs(imgs, H, Wd) + 32) * 64 * 147 floats (pf_conv_stem_wrw_slabs returns 0 for unsupported shapes). */
+int pf_conv_stem_wrw_slabs(int imgs, int H, int Wd);
+int pf_conv_stem_wrw(const void* dY, const void* X, void* dW, int dw_dtype, float* workspace, int imgs, int H, int Wd,
+                     void* stream);
 
 /* ---- K13: input pipeline tail -----------------------------------------------------------
  * replaces, per image, the preprocessing chain of utils/external/imagenet_preprocessing.py:226-260 behind the JPEG

@@ -345,11 +345,11 @@ struct Wrw2Args {
 
 template <int TN, int TK, int WTN, int WTK, bool PRO, bool MAP>
 __global__ __launch_bounds__(64 * (TN / WTN) * (TK / WTK)) void k_wrw2(const Wrw2Args a) {
-  constexpr int WN = TN / WTN, WK = TK / WTK, NWAVE = WN * WK, T = 64 * NWAVE;
+  constexpr int WN = TN / WTN, WK = TK / WTK, NWAVE = WN * WK;
   constexpr int NI = WTN / 16, NJ = WTK / 16;        // 16x16 accumulator blocks of one wavefront
   constexpr int NBN = TN / 16, NBK = TK / 16;        // 16-channel blocks of the staged tiles
   constexpr int DY_BYTES = 4 * NBN * 256, X_BYTES = 4 * NBK * 256, STAGE = DY_BYTES + X_BYTES;
-  constexpr int IDY = 4 * (TN / 64), IX = 4 * (TK / 64), INS = IDY + IX;      // LDS-DMA instructions per stage
+  constexpr int IDY = 4 * (TN / 64), IX = 4 * (TK / 64);                     // LDS-DMA instructions per stage
   static_assert(IDY % NWAVE == 0, "dY instructions must split evenly over the wavefronts (slot kinds are static)");
   constexpr int KDY = IDY / NWAVE;                   // slots 0..KDY-1 of every wavefront stage dY, the rest stage X
   constexpr int XS = (IX + NWAVE - 1) / NWAVE;       // X slots per wavefront (slot x is live iff wave + x*NWAVE < IX)

@@ -899,29 +899,46 @@ class _Conv2dIgemm(torch.autograd.Function):
 
 
 class _StemConv(torch.autograd.Function):
-  """The ResNet stem (7x7 / stride 2 / pad 3, 3 -> 64 channels) on pf_conv_stem_fwd; the image needs no gradient, the
-  backward-filter goes through MIOpen."""
+  """The ResNet stem (7x7 / stride 2 / pad 3, 3 -> 64 channels) on pf_conv_stem_fwd / pf_conv_stem_wrw (the image needs
+  no gradient; if it does, backward-data goes through MIOpen)."""
 
   @staticmethod
-  def forward(ctx, x, w):
+  def forward(ctx, x, w, graph, w_var):
     B, _, H, Wd = x.shape
     y = torch.empty((B, w.shape[0], H // 2, Wd // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     with region('conv_stem_fwd', float((x.numel() + y.numel()) * 2)):
       hip.conv_stem_fwd(x, w.detach().permute(0, 2, 3, 1), y, B, H, Wd)
     ctx.save_for_backward(x, w)
+    ctx.meta = (graph, w_var)
     return y
 
   @staticmethod
   def backward(ctx, dy):
     x, w = ctx.saved_tensors
+    graph, w_var = ctx.meta
+    dy = _nhwc(dy)
     dx = dw = None
     if ctx.needs_input_grad[1]:
-      dw = torch.ops.aten.convolution_backward(_nhwc(dy), x, w.detach(), None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
-                                               [False, True, False])[1]
+      B, _, H, Wd = x.shape
+      S = hip.conv_stem_wrw_slabs(B, H, Wd) if OWN_CONV2D_WRW else 0
+      with region('conv_stem_wrw', float((x.numel() + dy.numel()) * 2)):
+        if S > 0:
+          gw = getattr(w, 'grad', None)
+          direct = (gw is not None and gw.shape == w.shape and gw.permute(0, 2, 3, 1).is_contiguous()
+                    and gw.dtype in (torch.float32, torch.bfloat16))
+          dwk = gw.permute(0, 2, 3, 1) if direct else torch.empty((w.shape[0], 7, 7, 3), dtype=w.dtype, device=x.device)
+          hip.conv_stem_wrw(dy, x, dwk, graph.scratch((S + 32) * 64 * 147), B, H, Wd)
+          if direct:
+            graph.store.notify_grad(w_var)
+          else:
+            dw = dwk.permute(0, 3, 1, 2)
+        else:
+          dw = torch.ops.aten.convolution_backward(dy, x, w.detach(), None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
+                                                   [False, True, False])[1]
     if ctx.needs_input_grad[0]:
-      dx = torch.ops.aten.convolution_backward(_nhwc(dy), x, w.detach(), None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
+      dx = torch.ops.aten.convolution_backward(dy, x, w.detach(), None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
                                                [True, False, False])[0]
-    return dx, dw
+    return dx, dw, None, None
 
 
 def own_stem_ok(x, conv, pad) -> bool:
@@ -1043,7 +1060,7 @@ class Conv2D:
       sym = (0, 0)
     if residual is None and own_stem_ok(x, self, sym):
       if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
-        return _StemConv.apply(x, w)
+        return _StemConv.apply(x, w, self.graph, self.kernel)
       y = torch.empty((x.shape[0], w.shape[0], x.shape[2] // 2, x.shape[3] // 2), dtype=x.dtype, device=x.device,
                       memory_format=torch.channels_last)
       hip.conv_stem_fwd(x, w.detach().permute(0, 2, 3, 1), y, x.shape[0], x.shape[2], x.shape[3])

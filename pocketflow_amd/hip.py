@@ -42,7 +42,7 @@ SYMBOLS = [
     'pf_bn_act_quant_apply', 'pf_bn_bwd_stats', 'pf_bn_bwd_finalize', 'pf_bn_bwd_apply', 'pf_bn_bwd_apply_add',
     'pf_bn_eval_scale_shift', 'pf_gemm_bf16_nt', 'pf_gemm_bf16_nn', 'pf_gemm_bf16_tn',
     'pf_conv1x1_stats_groups', 'pf_conv1x1_stats_groups_k', 'pf_conv1x1_fwd', 'pf_conv1x1_bwd_data_bnstats', 'pf_conv1x1_wrw_splits',
-    'pf_conv1x1_wrw', 'pf_conv2d_stats_groups', 'pf_conv2d_fwd', 'pf_conv2d_wrw_splits', 'pf_conv2d_wrw', 'pf_maxpool_fwd', 'pf_maxpool_bwd', 'pf_seg_transpose', 'pf_conv_stem_supported', 'pf_conv_stem_fwd',
+    'pf_conv1x1_wrw', 'pf_conv2d_stats_groups', 'pf_conv2d_fwd', 'pf_conv2d_wrw_splits', 'pf_conv2d_wrw', 'pf_maxpool_fwd', 'pf_maxpool_bwd', 'pf_seg_transpose', 'pf_conv_stem_supported', 'pf_conv_stem_fwd', 'pf_conv_stem_wrw_slabs', 'pf_conv_stem_wrw',
     'pf_image_resize_bilinear',
 ]
 
@@ -412,6 +412,18 @@ def conv_stem_fwd(X, W, Y, imgs: int, H: int, Wd: int) -> None:
   """X: NHWC memory [imgs][H][Wd][3] bf16, W: KRSC memory [64][7][7][3] bf16, Y: [imgs][H/2][Wd/2][64] bf16."""
   _dev(X)
   _check(_lib.pf_conv_stem_fwd(_ptr(X), _ptr(W), _ptr(Y), c_int(imgs), c_int(H), c_int(Wd), _stream()), 'pf_conv_stem_fwd')
+
+
+def conv_stem_wrw_slabs(imgs: int, H: int, Wd: int) -> int:
+  return int(_lib.pf_conv_stem_wrw_slabs(c_int(imgs), c_int(H), c_int(Wd)))
+
+
+def conv_stem_wrw(dY, X, dW, workspace, imgs: int, H: int, Wd: int) -> None:
+  """dY: [imgs][H/2][Wd/2][64] bf16, X: [imgs][H][Wd][3] bf16, dW: KRSC memory [64][7][7][3] float32 / bf16;
+  workspace: float32, (conv_stem_wrw_slabs(...) + 32) * 64 * 147 elements."""
+  _dev(dY)
+  _check(_lib.pf_conv_stem_wrw(_ptr(dY), _ptr(X), _ptr(dW), c_int(dtype_code(dW)), _ptr(workspace), c_int(imgs), c_int(H),
+                               c_int(Wd), _stream()), 'pf_conv_stem_wrw')
 
 
 # ------------------------------------------------------------------------------------------------

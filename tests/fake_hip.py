@@ -237,6 +237,16 @@ class FakeHip(object):
   def conv_stem_supported(self, H, Wd, C, N, k, stride, pad):
     return C == 3 and N == 64 and k == 7 and stride == 2 and pad == 3 and H % 2 == 0 and Wd % 32 == 0 and 32 <= Wd <= 1024
 
+  def conv_stem_wrw_slabs(self, imgs, H, Wd):
+    return 2 if self.conv_stem_supported(H, Wd, 3, 64, 7, 2, 3) and Wd <= 256 else 0
+
+  def conv_stem_wrw(self, dY, X, dW, workspace, imgs, H, Wd):
+    self._n('conv_stem_wrw')
+    w0 = torch.zeros(64, 3, 7, 7)
+    g = torch.ops.aten.convolution_backward(dY.float(), X.float(), w0, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
+                                            [False, True, False])[1]
+    dW.copy_(g.permute(0, 2, 3, 1))
+
   def conv_stem_fwd(self, X, W, Y, imgs, H, Wd):
     self._n('conv_stem_fwd')
     import torch.nn.functional as F

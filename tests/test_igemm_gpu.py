@@ -176,3 +176,28 @@ def test_conv_stem_fwd_matches_torch(hip, imgs, H, Wd):
   y1 = torch.empty(1, 16, 16, 64, device='cuda', dtype=torch.bfloat16)
   hip.conv_stem_fwd(x1, w, y1, 1, 32, 32)
   assert torch.equal(y1, _bf(_ref(x1, w, 2, (3, 3))))
+
+
+@pytest.mark.parametrize('dw_dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('imgs,H,Wd', [(3, 64, 64), (2, 224, 224), (1, 38, 96), (5, 18, 32), (130, 32, 64)])
+def test_conv_stem_wrw_matches_autograd(hip, imgs, H, Wd, dw_dtype):
+  """Backward-filter of the stem against aten's float32 convolution_backward on the same bf16 operands: an odd number of
+  output rows (a half-empty last strip), more (image, strip) items than persistent workgroups, border taps; float32 and
+  bf16 gradient buffers; bit-reproducible (fixed-order slab reduction)."""
+  S = hip.conv_stem_wrw_slabs(imgs, H, Wd)
+  assert S > 0 and hip.conv_stem_wrw_slabs(imgs, H, 512) == 0
+  g = torch.Generator(device='cuda').manual_seed(H * 3 + Wd + imgs)
+  x = _bf(torch.randn(imgs, H, Wd, 3, device='cuda', generator=g))
+  dy = _bf(torch.randn(imgs, H // 2, Wd // 2, 64, device='cuda', generator=g) * 0.1)
+  ref = torch.ops.aten.convolution_backward(dy.float().permute(0, 3, 1, 2), x.float().permute(0, 3, 1, 2),
+                                            torch.zeros(64, 3, 7, 7, device='cuda'), None, [2, 2], [3, 3], [1, 1], False,
+                                            [0, 0], 1, [False, True, False])[1].permute(0, 2, 3, 1)
+  outs = []
+  for rep in range(2):
+    ws = torch.full(((S + 32) * 64 * 147,), float('nan'), device='cuda')
+    dw = torch.full((64, 7, 7, 3), float('nan'), device='cuda', dtype=dw_dtype)
+    hip.conv_stem_wrw(dy, x, dw, ws, imgs, H, Wd)
+    outs.append(dw)
+  assert torch.equal(outs[0], outs[1])
+  err = float((outs[0].float() - ref).abs().max() / ref.abs().max())
+  assert err <= (1e-4 if dw_dtype == torch.float32 else 6e-3), err

@@ -34,3 +34,18 @@ err = float((y.float() - ref).abs().max() / ref.abs().max())
 nbytes = (x.numel() + y.numel()) * 2
 print('stem %dx%dx%d: own %.0f us (%.2f TB/s of in+out bytes, %.0f TFLOP/s useful)  MIOpen %.0f us  max rel err %.1e  floor(6.3 TB/s) %.0f us' % (
     B, H, H, t_own, nbytes / t_own / 1e6, 2 * B * (H // 2) ** 2 * 64 * 147 / t_own / 1e6, t_mi, err, nbytes / 6.3e6))
+
+# backward-filter
+dy = (torch.randn(B, H // 2, H // 2, 64, device='cuda', generator=g) * 0.1).bfloat16()
+S = hip.conv_stem_wrw_slabs(B, H, H)
+if S > 0:
+  ws = torch.empty((S + 32) * 64 * 147, device='cuda')
+  dw = torch.empty(64, 7, 7, 3, device='cuda', dtype=torch.bfloat16)
+  dyn = dy.permute(0, 3, 1, 2)
+  t_own = timeit(lambda: hip.conv_stem_wrw(dy, x, dw, ws, B, H, H))
+  t_mi = timeit(lambda: torch.ops.aten.convolution_backward(dyn, xn, wn, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [False, True, False]))
+  ref = torch.ops.aten.convolution_backward(dyn.float(), xn.float(), wn.float(), None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
+                                            [False, True, False])[1].permute(0, 2, 3, 1)
+  err = float((dw.float() - ref).abs().max() / ref.abs().max())
+  print('stem wrw: own %.0f us (incl. slab reduction; %d slabs)  MIOpen %.0f us  max rel err %.1e  floor %.0f us' % (
+      t_own, S, t_mi, err, (x.numel() + dy.numel()) * 2 / 6.3e6))
