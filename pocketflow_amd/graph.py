@@ -567,6 +567,8 @@ class LazyAct(object):
     self.mean_invstd = mean_invstd            # training mode only: lets a consumer fuse the BN-backward statistics
     self.n_consumers = 0                      # fused convolutions that read this activation
     self.bwd_stats = None                     # (partial, n_blocks, data_ptr of dq) left by the single consumer
+    self.n_grad_consumers = 0                 # ... of which take part in the backward pass
+    self.pending = None                       # dq of the first of TWO consumers, waiting to be joined by the second
     self._q = None
 
   @property
@@ -784,17 +786,36 @@ class _FusedConv1x1(torch.autograd.Function):
         dx = torch.zeros_like(x)
       fuse_stats = (FUSE_BN_BWD_STATS and lazy is not None and lazy.n_consumers == 1 and geom is None
                     and lazy.mean_invstd is not None and lazy.act in ('Relu', 'Relu6'))
-      with region('conv1x1_bwd_data', float((M * K * (2 if fuse_stats else 1) + M * N) * 2)):
+      # An activation with exactly TWO fused consumers (bn1 of a projection block: shortcut convolution + conv1): the
+      # consumer whose backward runs first parks its dq on the LazyAct and reports no gradient; the second takes it as the
+      # residual operand of its backward-data kernel -- the sum autograd would form with a separate add kernel (two reads
+      # and one write of the 4C-channel tensor) costs one extra read.  The block calls conv1 BEFORE the shortcut
+      # convolution, so the (possibly strided, zero-filled) shortcut gradient comes first and the dense one joins it.
+      join = (JOIN_TWO_CONSUMERS and lazy is not None and lazy.n_consumers == 2 and lazy.n_grad_consumers == 2)
+      second = join and lazy.pending is not None
+      res = lazy.pending if (second and geom is None) else None
+      with region('conv1x1_bwd_data', float((M * K * (2 if (fuse_stats or res is not None) else 1) + M * N) * 2)):
         if fuse_stats:
           G = hip.conv1x1_stats_groups(M, K, N)
           partial = torch.empty((G, 2, K), dtype=torch.float32, device=x.device)
           hip.conv1x1_bwd_data_bnstats(dy, wt, dx, x, lazy.scale_shift, lazy.mean_invstd, lazy.act, partial, M, N, K)
           lazy.bwd_stats = (partial, G, dx.data_ptr())
+        elif res is not None:
+          hip.conv1x1_fwd(dy, wt, dx, M, K, N, R=res)
         else:
           hip.conv1x1_fwd(dy, wt, dx, M, K, N, geom=geom, ymap=geom is not None)
+      if join:
+        if not second:
+          lazy.pending, dx = dx, None           # parked: the second consumer delivers the sum
+        else:
+          if res is None:
+            dx = dx + lazy.pending              # the second one is the strided one: no residual operand under a row map
+          lazy.pending = None
     return dx, dw, (dy if has_res else None), None, None, None, None, None, None
 
 
+# two fused consumers of one activation: join their input gradients inside the second backward-data kernel (0: autograd add)
+JOIN_TWO_CONSUMERS = os.environ.get('PF_JOIN_TWO_CONSUMERS', '1') != '0'
 USE_SEG_TRANSPOSE = os.environ.get('PF_SEG_TRANSPOSE', '1') != '0'   # backward-data kernel layouts in one launch (0: aten)
 OWN_POOL = os.environ.get('PF_OWN_POOL', '1') != '0'         # stem max-pooling on pf_pool.hip (0: aten, for A/B runs)
 # backward-filter of the RxS convolutions on pf_wrw.hip (shared-tile kernel); PF_OWN_CONV2D_WRW=0: MIOpen, for A/B runs
@@ -1033,6 +1054,8 @@ class Conv2D:
       xin = lazy.x if lazy is not None else _nhwc(x)
       if torch.is_grad_enabled() and (xin.requires_grad or w.requires_grad):
         box = []
+        if lazy is not None and xin.requires_grad:
+          lazy.n_grad_consumers += 1
         y = _FusedConv1x1.apply(xin, w, residual, lazy, want_stats, self.stride, self.graph, box, self.kernel)
         if box and box[0] is not None:
           y._pf_stats = box[0]

@@ -77,6 +77,43 @@ def test_fused_plumbing_is_exact_on_cpu(monkeypatch, act_bits, filters):
     assert cos > 0.995, cos
 
 
+def test_two_consumer_join_in_backward_data(monkeypatch):
+  """bn1 of a projection block has two fused consumers (shortcut convolution + conv1).  With the join, the consumer whose
+  backward runs first parks its input gradient and the second one adds it as the residual operand of its backward-data
+  launch (no autograd add): same gradients as without the join, one plain launch per projection block replaced by one
+  with a residual operand, and the order is the one the block arranges (the dense conv1 joins the strided shortcut)."""
+  from pocketflow_amd import graph as G
+  results = {}
+  for join in (False, True):
+    fake = FakeHip()
+    monkeypatch.setattr(G, 'hip', fake)
+    monkeypatch.setattr(G, 'fusable_tensor', lambda t: True)
+    monkeypatch.setattr(G, 'JOIN_TWO_CONSUMERS', join)
+    seen = []
+    orig = fake.conv1x1_fwd
+
+    def spy(X, W, Y, M, N, K, R=None, scale_shift=None, **kw):
+      if scale_shift is None and R is not None:
+        seen.append((kw.get('geom') is not None, M, N, K))
+      return orig(X, W, Y, M, N, K, R=R, scale_shift=scale_shift, **kw)
+    fake.conv1x1_fwd = spy
+    g, net = _build(True, fake, None, 8)
+    torch.manual_seed(0)
+    x = torch.randn(4, 3, 12, 12).contiguous(memory_format=torch.channels_last)
+    g.begin_step = lambda: None
+    fake.minmax_slots_init(g.act_slots)
+    with g.as_default():
+      logits = net(x, True)
+    n_fwd_res = len(seen)                                  # plain launches with a residual in the forward pass: none
+    (logits * torch.randn(4, 7)).sum().backward()
+    results[join] = dict(w_grad=g.store.w_grad.clone(), o_grad=g.store.o_grad.clone(), joins=seen[n_fwd_res:])
+  assert results[False]['joins'] == [] and len(results[True]['joins']) == 2          # two projection blocks in this net
+  assert all(not strided for strided, _, _, _ in results[True]['joins'])            # the DENSE consumer does the join
+  for k in ('w_grad', 'o_grad'):
+    a, b = results[False][k], results[True][k]
+    assert float((a - b).abs().max() / (a.abs().max() + 1e-12)) <= 2e-6, k
+
+
 def test_mobilenet_pointwise_fusion_is_exact_on_cpu(monkeypatch):
   """MobileNet-v1: the depthwise BN+ReLU6 is applied inside the pointwise 1x1 convolution, which leaves the
   statistics for its own BN; same exactness check as above (no quantisers)."""
