@@ -569,6 +569,7 @@ class LazyAct(object):
     self.bwd_stats = None                     # (partial, n_blocks, data_ptr of dq) left by the single consumer
     self.n_grad_consumers = 0                 # ... of which take part in the backward pass
     self.pending = None                       # dq of the first of TWO consumers, waiting to be joined by the second
+    self.join_ok = False                      # set by the caller that KNOWS both consumers reach the loss (see _FusedConv1x1)
     self._q = None
 
   @property
@@ -791,7 +792,10 @@ class _FusedConv1x1(torch.autograd.Function):
       # residual operand of its backward-data kernel -- the sum autograd would form with a separate add kernel (two reads
       # and one write of the 4C-channel tensor) costs one extra read.  The block calls conv1 BEFORE the shortcut
       # convolution, so the (possibly strided, zero-filled) shortcut gradient comes first and the dense one joins it.
-      join = (JOIN_TWO_CONSUMERS and lazy is not None and lazy.n_consumers == 2 and lazy.n_grad_consumers == 2)
+      # Opt-in (`lazy.join_ok`, set by the bottleneck block): a parked gradient is only delivered by the second consumer's
+      # backward, so both consumers must be known to reach the loss.
+      join = (JOIN_TWO_CONSUMERS and lazy is not None and lazy.join_ok and lazy.n_consumers == 2
+              and lazy.n_grad_consumers == 2)
       second = join and lazy.pending is not None
       res = lazy.pending if (second and geom is None) else None
       with region('conv1x1_bwd_data', float((M * K * (2 if (fuse_stats or res is not None) else 1) + M * N) * 2)):
