@@ -6,11 +6,12 @@ of one agent update of the reference (paths relative to /root/reference):
   rl_agents/ddpg/agent.py:71-117, 216-247, 280-300, 372-408   target update, parameter noise, train(), losses
 
 PARITY.  The forward passes are pinned against the reference's own `Actor` / `Critic` classes executed over
-oracle/tf_stub.py (tests/golden/make_reference_rl_golden.py -> tests/golden/reference_rl.npz; checked in
-tests/test_rl_golden.py).  The update step cannot be executed from the reference here (it is TF graph code:
-placeholders, optimizer.minimize, sessions); it is restated from agent.py and the published semantics of
-tf.train.AdamOptimizer / tf.nn.l2_loss, and the product (torch autograd) is checked against this independent
-analytic implementation -- "parity unpinned" for that step, said so here and in DESIGN.md.
+oracle/tf_stub.py, and the UPDATE STEP against the reference's own `Agent` class (__build, init, record, finalize_rlout,
+train) executed over the deferred-execution stand-in oracle/tf_graph_stub.py (placeholders, optimizer.minimize,
+tf.assign, sess.run) -- tests/golden/make_reference_rl_golden.py -> tests/golden/reference_rl.npz; checked in
+tests/test_rl_golden.py: losses and every variable of the main and target networks after each of three updates.
+What stays a restatement is TensorFlow's own kernels (tf.layers.dense, layer_norm, AdamOptimizer arithmetic), as for
+every other fixture of this repository: TF never ran here.
 
 Only tests/ may import this module.
 """

@@ -18,8 +18,10 @@ Lifted (paths relative to /root/reference):
                                                  __compute_model_flops, finallayer  (RL state table, strategy table and the
                                                  FLOP-target action constraint, run on a stand-in model wrapper that
                                                  describes two small topologies; pandas is the real one)
-Not executable here (TF graph construction / sessions): Agent.__build / train, BitOptimizer, PROptimizer roll-out
-loops; they are restated in oracle/ddpg_oracle.py and pocketflow_amd and anchored on the pieces above.
+  rl_agents/ddpg/agent.py                        Agent (whole class: __build, init, record, finalize_rlout, train) over the
+                                                 deferred-execution stand-in oracle/tf_graph_stub.py -> the update step
+Not executable here (TF graph construction / sessions inside learner loops): BitOptimizer, PROptimizer roll-out loops;
+they are restated in pocketflow_amd and anchored on the pieces above.
 """
 import json
 import os
@@ -325,9 +327,80 @@ def gen_cp_states(out, meta):
   meta['cp_topologies'] = {k: {'ops': [list(o) for o in v[0]], 'fathers': v[1]} for k, v in CP_TOPOLOGIES.items()}
 
 
+def gen_agent_update(out, meta):
+  """The reference's `Agent.__build / init / record / finalize_rlout / train` EXECUTED as they are written, over the
+  deferred-execution stand-in oracle/tf_graph_stub.py (placeholders, optimizer.minimize, tf.assign, sess.run): initial
+  variables, the mini-batches `train()` drew, and every variable (main + target networks, Adam slots) after each of three
+  updates.  This is what pins the update step of the product agent and of oracle/ddpg_oracle.py."""
+  sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+  import oracle.tf_graph_stub as tfg
+  cases = []
+  for name, s_dims, a_dims, a_min, a_max, width, depth, w_dcy, bsln, batch in (
+      ('default', 5, 2, 0.0, 1.0, 64, 2, 0.0, True, 16), ('decay_narrow', 7, 3, -1.0, 2.0, 16, 3, 1e-3, False, 8)):
+    set_flags(**DDPG_DEFAULTS)
+    set_flags(ddpg_actor_depth=depth, ddpg_actor_width=width, ddpg_critic_depth=depth, ddpg_critic_width=width,
+              ddpg_tau=0.01, ddpg_gamma=0.9, ddpg_lrn_rate=1e-3, ddpg_loss_w_dcy=w_dcy, ddpg_batch_size=batch,
+              ddpg_enbl_bsln_func=bsln)
+    tfg.reset_default_graph()
+    tfg.seed(11 + len(cases))
+    ac = G.lift('rl_agents/ddpg/actor_critic.py', ['dense_block', 'Model', 'Actor', 'Critic'], {'tf': tfg, 'ENBL_LAYER_NORM': True})
+    rb = G.lift('rl_agents/ddpg/replay_buffer.py', ['ReplayBuffer'])
+    nz = G.lift('rl_agents/ddpg/noise.py', ['AdaptiveNoiseSpec', 'TimeDecayNoiseSpec'])
+    ag_ns = G.lift('rl_agents/ddpg/agent.py',
+                   ['normalize', 'denormalize', 'calc_loss_dcy', 'get_target_model_ops', 'get_perturb_op', 'Agent'],
+                   {'tf': tfg, 'Actor': ac['Actor'], 'Critic': ac['Critic'], 'ReplayBuffer': rb['ReplayBuffer'],
+                    'AdaptiveNoiseSpec': nz['AdaptiveNoiseSpec'], 'TimeDecayNoiseSpec': nz['TimeDecayNoiseSpec'],
+                    'RunningMeanStd': None})
+    agent = ag_ns['Agent'](tfg.Session(), s_dims, a_dims, 10, 64, a_min, a_max)
+    agent.init()
+    nets = {'actor_mn': agent.actor, 'actor_tr': agent.actor_tr, 'critic_mn': agent.critic, 'critic_tr': agent.critic_tr}
+    model_vars = {k: [v for v in tfg.get_collection(tfg.GraphKeys.TRAINABLE_VARIABLES, scope=m.scope)] for k, m in nets.items()}
+
+    def snapshot(tag):
+      for k, vs in model_vars.items():
+        for v in vs:
+          out['agent/%s/%s/%s' % (name, tag, v.name[:-2])] = v.value.numpy().copy()
+    snapshot('init')
+    # the target networks start as copies of the main networks (ops['target_init'])
+    for a, b in ((agent.actor, agent.actor_tr), (agent.critic, agent.critic_tr)):
+      for va, vb in zip(model_vars['actor_mn' if a is agent.actor else 'critic_mn'], model_vars['actor_tr' if a is agent.actor else 'critic_tr']):
+        assert np.array_equal(va.value.numpy(), vb.value.numpy())
+    rng = np.random.RandomState(40 + len(cases))
+    n = 70                                              # > buf_size: the buffer is "ready" only when full (and wraps once)
+    trans = [rng.randn(n, s_dims).astype(np.float32), rng.uniform(a_min, a_max, (n, a_dims)).astype(np.float32),
+             rng.randn(n).astype(np.float32), (rng.rand(n) > 0.8).astype(np.float32), rng.randn(n, s_dims).astype(np.float32)]
+    for j, t in enumerate(trans):
+      out['agent/%s/transitions/%d' % (name, j)] = t
+    agent.record(*trans)
+    agent.finalize_rlout(trans[2])
+    drawn = []
+    sample = agent.memory.sample
+
+    def logging_sample(batch_size):
+      mb = sample(batch_size)
+      drawn.append(mb)
+      return mb
+    agent.memory.sample = logging_sample
+    np.random.seed(3 + len(cases))
+    steps = []
+    for it in range(3):
+      a_loss, c_loss, std = agent.train()
+      steps.append(dict(actor_loss=float(a_loss), critic_loss=float(c_loss), noise_std=float(std)))
+      snapshot('after%d' % it)
+      for k, v in drawn[-1].items():                      # as FED: the baseline is already subtracted from the rewards
+        out['agent/%s/batch%d/%s' % (name, it, k)] = np.asarray(v, dtype=np.float32).copy()
+    cases.append(dict(name=name, s_dims=s_dims, a_dims=a_dims, a_min=a_min, a_max=a_max, width=width, depth=depth,
+                      w_dcy=w_dcy, bsln=bsln, batch=batch, tau=0.01, gamma=0.9, lrn_rate=1e-3, np_seed=3 + len(cases),
+                      reward_ema=None if agent.reward_ema is None else float(agent.reward_ema), steps=steps,
+                      vars={k: [v.name[:-2] for v in vs] for k, vs in model_vars.items()}))
+  meta['agent_update'] = cases
+  set_flags(**DDPG_DEFAULTS)
+
+
 def main():
   arrays, meta = {}, {}
   gen_actor_critic(arrays, meta)
+  gen_agent_update(arrays, meta)
   gen_replay(arrays, meta)
   gen_noise(meta)
   gen_agent_host(arrays, meta)

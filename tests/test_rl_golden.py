@@ -181,3 +181,102 @@ def test_pruning_ratio_helper(flags):
     assert np.array_equal(np.stack(states), A['%s/case%d/states' % (tag, row['case'])])
     assert ratios == row['prune_ratios'], row
     assert float(h.calc_overall_prune_ratio()) == row['overall'] and float(h.calc_reward(0.8)) == row['reward']
+
+
+# -- the agent's update step, pinned by the reference's own Agent class executed over oracle/tf_graph_stub.py ------------------
+def _agent_case_arrays(case, tag, key):
+  return {n: A['agent/%s/%s/%s' % (case['name'], tag, n)] for n in case['vars'][key]}
+
+
+@pytest.fixture
+def ddpg_flags():
+  import pocketflow_amd.rl_agents.ddpg.agent  # noqa: F401
+  from pocketflow_amd.flags import FLAGS
+  names = ('ddpg_actor_depth', 'ddpg_actor_width', 'ddpg_critic_depth', 'ddpg_critic_width', 'ddpg_tau', 'ddpg_gamma',
+           'ddpg_lrn_rate', 'ddpg_loss_w_dcy', 'ddpg_batch_size', 'ddpg_enbl_bsln_func', 'ddpg_noise_type', 'ddpg_noise_prtl')
+  saved = {k: getattr(FLAGS, k) for k in names}
+  yield FLAGS
+  for k, v in saved.items():
+    setattr(FLAGS, k, v)
+
+
+def _set_case_flags(FLAGS, case):
+  FLAGS.ddpg_actor_depth = FLAGS.ddpg_critic_depth = case['depth']
+  FLAGS.ddpg_actor_width = FLAGS.ddpg_critic_width = case['width']
+  FLAGS.ddpg_tau, FLAGS.ddpg_gamma, FLAGS.ddpg_lrn_rate = case['tau'], case['gamma'], case['lrn_rate']
+  FLAGS.ddpg_loss_w_dcy, FLAGS.ddpg_batch_size, FLAGS.ddpg_enbl_bsln_func = case['w_dcy'], case['batch'], case['bsln']
+  FLAGS.ddpg_noise_type, FLAGS.ddpg_noise_prtl = 'param', 'tdecy'
+
+
+@pytest.mark.parametrize('case', M['agent_update'], ids=lambda c: c['name'])
+def test_product_agent_update_matches_the_executed_reference(ddpg_flags, case):
+  """`Agent.train()` of the reference (agent.py:216-247 over the graph built in :249-408), executed by
+  tests/golden/make_reference_rl_golden.py, against the product agent fed the SAME initial variables and the SAME
+  mini-batches: losses, main networks, target networks after each of three updates."""
+  from pocketflow_amd.rl_agents.ddpg.agent import Agent
+  _set_case_flags(ddpg_flags, case)
+  ag = Agent(5, case['s_dims'], case['a_dims'], 10, 64, case['a_min'], case['a_max'])
+  ag.init()
+  nets = {'actor_mn': ag.actor, 'actor_tr': ag.actor_tr, 'critic_mn': ag.critic, 'critic_tr': ag.critic_tr}
+  for key, net in nets.items():
+    assert net.var_names == case['vars'][key]
+    net.load_numpy(_agent_case_arrays(case, 'init', key))
+  worst = 0.0
+  for it, ref in enumerate(case['steps']):
+    mb = {k: A['agent/%s/batch%d/%s' % (case['name'], it, k)] for k in ('states', 'actions', 'rewards', 'terminals', 'states_next')}
+    _, a_loss, c_loss = ag.train_on_batch(mb)
+    assert abs(a_loss - ref['actor_loss']) <= 2e-5 * max(1.0, abs(ref['actor_loss'])), (it, a_loss, ref['actor_loss'])
+    assert abs(c_loss - ref['critic_loss']) <= 2e-5 * max(1.0, abs(ref['critic_loss'])), (it, c_loss, ref['critic_loss'])
+    for key, net in nets.items():
+      want = _agent_case_arrays(case, 'after%d' % it, key)
+      for n, p in net.params.items():
+        worst = max(worst, float(np.max(np.abs(p.detach().numpy() - want[n]))))
+  # Adam moves an element by ~lr = 1e-3 per step; agreement is at float32 round-off of the gradients
+  assert worst <= 2e-5, worst
+
+
+@pytest.mark.parametrize('case', M['agent_update'], ids=lambda c: c['name'])
+def test_oracle_agent_update_matches_the_executed_reference(case):
+  from oracle.ddpg_oracle import DdpgOracle
+  init = {k: _agent_case_arrays(case, 'init', k) for k in case['vars']}
+  ora = DdpgOracle(list(init['actor_mn'].values()), list(init['critic_mn'].values()), case['a_min'], case['a_max'],
+                   depth=case['depth'], gamma=case['gamma'], tau=case['tau'], lr=case['lrn_rate'], w_dcy=case['w_dcy'])
+  worst = 0.0
+  for it, ref in enumerate(case['steps']):
+    mb = {k: A['agent/%s/batch%d/%s' % (case['name'], it, k)] for k in ('states', 'actions', 'rewards', 'terminals', 'states_next')}
+    _, a_loss, c_loss = ora.train_on_batch(mb)
+    assert abs(a_loss - ref['actor_loss']) <= 2e-5 * max(1.0, abs(ref['actor_loss']))
+    assert abs(c_loss - ref['critic_loss']) <= 2e-5 * max(1.0, abs(ref['critic_loss']))
+    for key, got in (('actor_mn', ora.actor), ('critic_mn', ora.critic), ('actor_tr', ora.actor_tr), ('critic_tr', ora.critic_tr)):
+      for g, w in zip(got, _agent_case_arrays(case, 'after%d' % it, key).values()):
+        worst = max(worst, float(np.max(np.abs(g - w))))
+  assert worst <= 2e-5, worst
+
+
+@pytest.mark.parametrize('case', M['agent_update'], ids=lambda c: c['name'])
+def test_product_agent_train_draws_the_reference_minibatches(ddpg_flags, case):
+  """The whole host path: record -> finalize_rlout (reward baseline) -> train() three times under the same NumPy seed
+  draws the mini-batches the reference drew (baseline already subtracted) and ends in the same variables."""
+  from pocketflow_amd.rl_agents.ddpg.agent import Agent
+  _set_case_flags(ddpg_flags, case)
+  ag = Agent(5, case['s_dims'], case['a_dims'], 10, 64, case['a_min'], case['a_max'])
+  ag.init()
+  nets = {'actor_mn': ag.actor, 'actor_tr': ag.actor_tr, 'critic_mn': ag.critic, 'critic_tr': ag.critic_tr}
+  for key, net in nets.items():
+    net.load_numpy(_agent_case_arrays(case, 'init', key))
+  trans = [A['agent/%s/transitions/%d' % (case['name'], j)] for j in range(5)]
+  ag.record(*trans)
+  ag.finalize_rlout(trans[2])
+  if case['bsln']:
+    assert abs(ag.reward_ema - case['reward_ema']) <= 1e-6
+  np.random.seed(case['np_seed'])
+  ag.memory.rng = np.random                               # the reference samples with the global NumPy generator
+  for it, ref in enumerate(case['steps']):
+    a_loss, c_loss, std = ag.train()
+    assert abs(a_loss - ref['actor_loss']) <= 2e-5 * max(1.0, abs(ref['actor_loss'])), (it, a_loss, ref)
+    assert abs(c_loss - ref['critic_loss']) <= 2e-5 * max(1.0, abs(ref['critic_loss'])), (it, c_loss, ref)
+    assert std == ref['noise_std']
+  for key, net in nets.items():
+    want = _agent_case_arrays(case, 'after2', key)
+    for n, p in net.params.items():
+      assert float(np.max(np.abs(p.detach().numpy() - want[n]))) <= 2e-5, n
