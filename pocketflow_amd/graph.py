@@ -26,6 +26,7 @@ from __future__ import annotations
 
 import math
 import os
+import weakref
 import threading
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
@@ -638,7 +639,13 @@ class _BnLazy(torch.autograd.Function):
     ctx.save_for_backward(x, scale_shift, mean_invstd)
     ctx.meta = (layer.act, graph, rows, C)
     ctx.params = (gamma, beta)
-    ctx.box = box                             # [scale_shift, mean_invstd, LazyAct (appended by the caller)]
+    # [scale_shift, mean_invstd, weakref to the LazyAct (appended by the caller)].  WEAK: the LazyAct holds this node's
+    # output alias, so a strong reference would close a cycle ctx -> LazyAct -> alias -> grad_fn -> ctx that only Python's
+    # cyclic collector can free -- one step's 4C-channel activations (~10 GB at B = 256) would then live until the
+    # collector happens to run, the caching allocator would keep growing (measured: 26 GB reserved after 5 steps, 52 GB
+    # after 13) and, at the memory ceiling, fall into malloc-retry mode (torch.empty at 185 us: the host-bound bench
+    # processes of DESIGN.md section 6).  The consumers' autograd nodes hold the LazyAct strongly until backward is over.
+    ctx.box = box
     ctx.set_materialize_grads(False)          # an unused shortcut alias must arrive as None, not as a zeros tensor
     box.append(scale_shift)
     box.append(mean_invstd)
@@ -654,7 +661,7 @@ class _BnLazy(torch.autograd.Function):
     if dq is None:
       return dskip, None, None, None, None, None, None, None, None
     pre = None
-    lazy = ctx.box[2] if len(ctx.box) > 2 else None
+    lazy = ctx.box[2]() if len(ctx.box) > 2 else None      # None if every consumer is gone: only the fusion below is lost
     if lazy is not None and lazy.bwd_stats is not None and lazy.bwd_stats[2] == dq.data_ptr():
       pre = lazy.bwd_stats[:2]                # the single consumer's backward-data kernel already reduced dy
     dx, dgamma, dbeta = _bn_backward(dq, x, scale_shift, mean_invstd, act, graph, rows, C, addend=dskip,
@@ -1250,7 +1257,7 @@ class BatchNormAct:
         box = []
         alias, skip = _BnLazy.apply(_nhwc(x), self.gamma.tensor, self.beta.tensor, self, g, slot, bits, box, stats)
         lazy_out = LazyAct(alias, box[0], self.act, slot, bits, x.numel() // self.C, self.C, mean_invstd=box[1])
-        box.append(lazy_out)
+        box.append(weakref.ref(lazy_out))
         return (lazy_out, skip) if getattr(self, '_want_skip', False) else lazy_out
       box = {}
       q = _BnActQuant.apply(x, self.gamma.tensor, self.beta.tensor, self, g, True, slot, bits, stats, box)

@@ -77,6 +77,46 @@ def test_fused_plumbing_is_exact_on_cpu(monkeypatch, act_bits, filters):
     assert cos > 0.995, cos
 
 
+@pytest.mark.parametrize('fuse', [False, True])
+def test_a_step_leaves_no_reference_cycles(monkeypatch, fuse):
+  """Every tensor a training step allocates must die by REFERENCE COUNTING when the step ends.  A cycle through an autograd
+  node (ctx -> LazyAct -> output alias -> grad_fn -> ctx) is only freed when Python's cyclic collector happens to run: on
+  the GPU one step's activations (tens of GB at batch 256) then stay allocated for a random number of further steps, the
+  caching allocator grows to the memory ceiling and every allocation turns into a malloc retry (measured: the host-bound
+  bench processes of round 2).  Here: collector disabled, several steps, and the set of live tensors must not grow."""
+  import gc
+  from pocketflow_amd import graph as G
+  fake = FakeHip()
+  monkeypatch.setattr(G, 'hip', fake)
+  monkeypatch.setattr(G, 'fusable_tensor', lambda t: True)
+  g, net = _build(fuse, fake, 6, 8)
+  g.begin_step = lambda: None
+  fake.minmax_slots_init(g.act_slots)
+  x = torch.randn(4, 3, 12, 12).contiguous(memory_format=torch.channels_last)
+  wts = torch.randn(4, 7)
+
+  def step():
+    with g.as_default():
+      logits = net(x, True)
+    (logits * wts).sum().backward()
+    g.store.zero_grad()
+
+  def live_tensor_bytes():
+    return sum(o.numel() * o.element_size() for o in gc.get_objects() if isinstance(o, torch.Tensor))
+  step()
+  gc.collect()
+  gc.disable()
+  try:
+    step()
+    base = live_tensor_bytes()
+    for _ in range(3):
+      step()
+    grown = live_tensor_bytes() - base
+  finally:
+    gc.enable()
+  assert grown <= 0, 'tensors of finished steps are still alive without the cyclic collector: +%d bytes' % grown
+
+
 def test_two_consumer_join_in_backward_data(monkeypatch):
   """bn1 of a projection block has two fused consumers (shortcut convolution + conv1).  With the join, the consumer whose
   backward runs first parks its input gradient and the second one adds it as the residual operand of its backward-data

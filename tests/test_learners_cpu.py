@@ -121,6 +121,44 @@ def test_uq_resnet20_distillation_on_cpu(cpu_learners):
   assert _max_rel(lrn.graph.store.export_numpy(), ora.export()) <= 2 * 2 * lrn.lrn_rate(0) + 1e-5
 
 
+@pytest.mark.parametrize('fused', [False, True])
+def test_learner_steps_free_their_tensors_by_refcount(cpu_learners, monkeypatch, fused):
+  """Whole learner steps (teacher forward, quantisers, forward, losses, backward, optimiser) with Python's cyclic collector
+  DISABLED: the bytes held by live tensors must not grow from step to step (see test_a_step_leaves_no_reference_cycles in
+  tests/test_fused_plumbing_cpu.py for what a cycle costs on the GPU).  ResNet-50 bottlenecks, fused and unfused plumbing."""
+  import gc
+  import torch
+  import pocketflow_amd.graph as G
+  FLAGS, fake, tmp = cpu_learners
+  from pocketflow_amd.nets.resnet_at_ilsvrc12 import ModelHelper
+  from pocketflow_amd.learners.uniform_quantization.learner import UniformQuantLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  if fused:
+    monkeypatch.setattr(G, 'fusable_tensor', lambda t: True)
+  FLAGS.batch_size, FLAGS.batch_size_eval, FLAGS.nb_classes, FLAGS.resnet_size, FLAGS.image_size = 2, 2, 11, 50, 32
+  FLAGS.uql_weight_bits, FLAGS.uql_activation_bits = 8, 8
+  FLAGS.enbl_dst, FLAGS.dst_eval_teacher = True, False
+  FLAGS.uql_save_quant_model_path = str(tmp / 'uql' / 'm.ckpt')
+  mh = ModelHelper()
+  create_synthetic_checkpoint(mh)
+  lrn = UniformQuantLearner(None, mh)
+
+  def live_tensor_bytes():
+    return sum(o.numel() * o.element_size() for o in gc.get_objects() if isinstance(o, torch.Tensor))
+  lrn.train_step()
+  gc.collect()
+  gc.disable()
+  try:
+    lrn.train_step()
+    base = live_tensor_bytes()
+    for _ in range(3):
+      lrn.train_step()
+    grown = live_tensor_bytes() - base
+  finally:
+    gc.enable()
+  assert grown <= 0, 'tensors of finished steps survive without the cyclic collector: +%d bytes over 3 steps' % grown
+
+
 @pytest.mark.parametrize('use_buckets,bucket_type,opt_mode', [(False, 'split', 'weights'), (True, 'split', 'both'),
                                                               (True, 'channel', 'cluster')])
 def test_nuq_resnet20_on_cpu(cpu_learners, use_buckets, bucket_type, opt_mode):
