@@ -203,7 +203,7 @@ def main():
   h2 = time.perf_counter()
   probe_warm['host_share_of_two_steps'] = (h1 - h0) / max(h2 - h0, 1e-9)
   mem_warm = memory_snapshot(torch)
-  if rank == 0 and (probe_warm['us_per_dispatch'] > 40.0 or probe_warm['host_share_of_two_steps'] > 0.9):
+  if world == 1 and (probe_warm['us_per_dispatch'] > 40.0 or probe_warm['host_share_of_two_steps'] > 0.9):   # (an extra step on one rank only would dead-lock the all-reduce)
     import cProfile
     import io
     import pstats
