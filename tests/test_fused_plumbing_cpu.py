@@ -77,8 +77,8 @@ def test_fused_plumbing_is_exact_on_cpu(monkeypatch, act_bits, filters):
     assert cos > 0.995, cos
 
 
-@pytest.mark.parametrize('fuse', [False, True])
-def test_a_step_leaves_no_reference_cycles(monkeypatch, fuse):
+@pytest.mark.parametrize('fuse,filters,size', [(False, 8, 12), (True, 8, 12), (True, 64, 32)])
+def test_a_step_leaves_no_reference_cycles(monkeypatch, fuse, filters, size):
   """Every tensor a training step allocates must die by REFERENCE COUNTING when the step ends.  A cycle through an autograd
   node (ctx -> LazyAct -> output alias -> grad_fn -> ctx) is only freed when Python's cyclic collector happens to run: on
   the GPU one step's activations (tens of GB at batch 256) then stay allocated for a random number of further steps, the
@@ -89,10 +89,10 @@ def test_a_step_leaves_no_reference_cycles(monkeypatch, fuse):
   fake = FakeHip()
   monkeypatch.setattr(G, 'hip', fake)
   monkeypatch.setattr(G, 'fusable_tensor', lambda t: True)
-  g, net = _build(fuse, fake, 6, 8)
+  g, net = _build(fuse, fake, 6, filters)                 # filters = 64: + the implicit-GEMM 3x3 path with its BN box
   g.begin_step = lambda: None
   fake.minmax_slots_init(g.act_slots)
-  x = torch.randn(4, 3, 12, 12).contiguous(memory_format=torch.channels_last)
+  x = torch.randn(4, 3, size, size).contiguous(memory_format=torch.channels_last)
   wts = torch.randn(4, 7)
 
   def step():
@@ -115,6 +115,8 @@ def test_a_step_leaves_no_reference_cycles(monkeypatch, fuse):
   finally:
     gc.enable()
   assert grown <= 0, 'tensors of finished steps are still alive without the cyclic collector: +%d bytes' % grown
+  if filters == 64:
+    assert fake.calls.get('conv2d_fwd', 0) > 0 and fake.calls.get('conv2d_bwd_data_bnstats', 0) > 0
 
 
 def test_two_consumer_join_in_backward_data(monkeypatch):
