@@ -158,6 +158,47 @@ def gen_nonuniform(out):
         out['nuq/%s/b%d/%s/clusters' % (cname, bits, mode_name)] = cb.a.astype(np.float32)
 
 
+def gen_quantiser_gradients(out):
+  """The quantisers' BACKWARD rules, by executing the same reference functions over oracle/tf_eager_grad_stub.py (torch
+  autograd honouring gradient_override_map / stop_gradient): d(sum(y * G))/dx and, for NUQ, d/d(clusters)."""
+  sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+  import torch
+  import oracle.tf_eager_grad_stub as tg
+  rng = np.random.RandomState(20240701)
+  cases = weight_cases(np.random.RandomState(20240601))
+  cases = {k: cases[k] for k in ('conv3x3x5x7', 'conv1x1x16x32')}
+  cases['dense37x5'] = (rng.randn(37, 5) * 0.3).astype(np.float32)
+  UQ = lift('learners/uniform_quantization/utils.py', ['UniformQuantization'], {'tf': tg, 'ge': None})['UniformQuantization']
+  NQ = lift('learners/nonuniform_quantization/utils.py', ['NonUniformQuantization'], {'tf': tg, 'ge': None})['NonUniformQuantization']
+  for cname, w in cases.items():
+    G = rng.randn(*w.shape).astype(np.float32)
+    out['qgrad/%s/in' % cname], out['qgrad/%s/upstream' % cname] = w, G
+    for mode_name, use_b, btype, bsize in (('tensor', False, 'split', 0), ('channel', True, 'channel', 0), ('split64', True, 'split', 64)):
+      x = tg.T(torch.tensor(w, requires_grad=True))
+      q = UQ(tg.Session(), bsize, use_b, btype)
+      y = q._UniformQuantization__uniform_quantize(x, tg.T(np.int64(4)), 'weight', 'm/c')
+      (dx,) = tg.gradients(tg.reduce_sum(y * tg.T(G)), [x])
+      out['qgrad/%s/uq4/%s/out' % (cname, mode_name)] = y.numpy().astype(np.float32)
+      out['qgrad/%s/uq4/%s/dx' % (cname, mode_name)] = dx.numpy().astype(np.float32)
+      tg.created_variables.clear()
+      x = tg.T(torch.tensor(w, requires_grad=True))
+      q = NQ(tg.Session(), bsize, use_b, 'quantile', btype)
+      y = q.quant_fn(x, tg.T(np.int64(3)), 'weight', 'm/c')
+      (cb,) = list(tg.created_variables.values())
+      dx, dc = tg.gradients(tg.reduce_sum(y * tg.T(G)), [x, cb])
+      out['qgrad/%s/nuq3/%s/out' % (cname, mode_name)] = y.numpy().astype(np.float32)
+      out['qgrad/%s/nuq3/%s/clusters' % (cname, mode_name)] = cb.numpy().astype(np.float32)
+      out['qgrad/%s/nuq3/%s/dx' % (cname, mode_name)] = dx.numpy().astype(np.float32)
+      out['qgrad/%s/nuq3/%s/dclusters' % (cname, mode_name)] = dc.numpy().astype(np.float32)
+  # activation quantiser (per-tensor range under stop_gradient, Round -> Identity): gradient = identity
+  a = np.maximum(rng.randn(2, 4, 4, 3), 0).astype(np.float32)
+  Ga = rng.randn(*a.shape).astype(np.float32)
+  x = tg.T(torch.tensor(a, requires_grad=True))
+  y = UQ(tg.Session(), 256, True, 'channel')._UniformQuantization__uniform_quantize(x, tg.T(np.int64(8)), 'activation', 'm/a')
+  (dx,) = tg.gradients(tg.reduce_sum(y * tg.T(Ga)), [x])
+  out['qgrad/act/in'], out['qgrad/act/upstream'], out['qgrad/act/dx'] = a, Ga, dx.numpy().astype(np.float32)
+
+
 def gen_distill(out):
   ns = lift('learners/distillation_helper.py', ['DistillationHelper.calc_loss'])
   calc_loss = ns['DistillationHelper'].calc_loss
@@ -406,6 +447,7 @@ def main():
   builtins.print = lambda *a, **k: None      # the reference prints "Quantized: <scope>" per op
   gen_uniform(arrays)
   gen_nonuniform(arrays)
+  gen_quantiser_gradients(arrays)
   gen_distill(arrays)
   gen_ws(arrays)
   gen_channel_pruner(arrays)

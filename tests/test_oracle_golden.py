@@ -95,6 +95,38 @@ def test_nonuniform_quantize_and_cluster_init_bit_exact(arrays):
   assert n == 7 * 3 * 4
 
 
+def test_quantiser_gradients_match_the_executed_reference_graph_code(arrays):
+  """Backward rules of the quantisers.  The reference rewires TF's gradient registry while it builds them
+  (gradient_override_map {'Round':'Identity'} / {'Mul':'Add','Sign':'Identity'}, tf.stop_gradient on the ranges);
+  tests/golden/make_reference_golden.py executes those very functions over oracle/tf_eager_grad_stub.py (torch autograd
+  honouring the override map) and records d(sum(y*G))/dx and d/d(clusters).  The oracle's hand-stated rules
+  (uniform_quantize_grad, nuq_backward) must reproduce them; the two stand-ins must agree on the forward values."""
+  cases = sorted({k.split('/')[1] for k in arrays if k.startswith("qgrad/") and k.split('/')[1] != 'act'})
+  assert cases == ['conv1x1x16x32', 'conv3x3x5x7', 'dense37x5']
+  for c in cases:
+    w, G = arrays['qgrad/%s/in' % c], arrays['qgrad/%s/upstream' % c]
+    gmax = float(np.abs(G).max())
+    for mode, use_b, btype, bsize in (('tensor', False, 'split', 0), ('channel', True, 'channel', 0), ('split64', True, 'split', 64)):
+      # uniform, 4 bits: straight-through identity (TF computes g * alpha / alpha: 1-2 ulp)
+      y, _ = O.uniform_quantize(w, 4, 'weight', use_b, btype, bsize)
+      assert np.max(np.abs(y - arrays['qgrad/%s/uq4/%s/out' % (c, mode)])) <= 1e-6
+      assert np.max(np.abs(O.uniform_quantize_grad(G) - arrays['qgrad/%s/uq4/%s/dx' % (c, mode)])) <= 4e-7 * gmax
+      if 'uq/%s/b4/%s' % (c, mode) in arrays:                # the NumPy stand-in's forward fixture of the same call
+        assert np.max(np.abs(arrays['uq/%s/b4/%s' % (c, mode)] - arrays['qgrad/%s/uq4/%s/out' % (c, mode)])) <= 1e-6
+      # non-uniform, 3 bits: dx = g, d(clusters)[j, b] = sum over the elements assigned to j of alpha_b * g
+      pre = 'qgrad/%s/nuq3/%s/' % (c, mode)
+      y, info = O.nuq_quantize(w, 3, None, use_b, btype, bsize, 'quantile')
+      assert np.array_equal(info['codebook'].reshape(arrays[pre + 'clusters'].shape), arrays[pre + 'clusters'])
+      assert np.max(np.abs(y - arrays[pre + 'out'])) <= 1e-6
+      gw, dc = O.nuq_backward(G, info, use_b, btype, bsize)
+      assert np.max(np.abs(gw - arrays[pre + 'dx'])) <= 4e-7 * gmax
+      ref_dc = arrays[pre + 'dclusters']
+      assert dc.shape == ref_dc.shape
+      assert np.max(np.abs(dc - ref_dc)) <= 2e-5 * max(1.0, float(np.abs(ref_dc).max())), (c, mode)
+  a, Ga = arrays['qgrad/act/in'], arrays['qgrad/act/upstream']
+  assert np.max(np.abs(O.uniform_quantize_grad(Ga) - arrays['qgrad/act/dx'])) <= 4e-7 * float(np.abs(Ga).max())
+
+
 def test_distillation_loss_bit_exact(arrays):
   for name in ('b4c10', 'b3c1001', 'b5c7_T1'):
     T, w = arrays['dst/%s/cfg' % name]
