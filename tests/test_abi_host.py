@@ -35,6 +35,28 @@ def test_library_exports_every_declared_symbol():
   assert b'invalid' in hip._lib.pf_error_string(1).lower() or len(hip._lib.pf_error_string(1)) > 0
 
 
+def test_host_side_shape_rules_of_the_convolution_entry_points():
+  """The pure host functions of the C ABI that tell a caller whether / how an entry point takes a shape (no device work):
+  what the layer executor relies on when it chooses between our kernels and the library fallback."""
+  from pocketflow_amd import hip
+  # the stem kernel is exactly the 7x7 / stride 2 / pad 3, 3 -> 64 convolution with an even height and Wd % 32 == 0
+  assert hip.conv_stem_supported(224, 224, 3, 64, 7, 2, 3) and hip.conv_stem_supported(38, 96, 3, 64, 7, 2, 3)
+  for bad in ((224, 224, 4, 64, 7, 2, 3), (224, 224, 3, 32, 7, 2, 3), (224, 224, 3, 64, 3, 2, 3), (224, 224, 3, 64, 7, 1, 3),
+              (224, 224, 3, 64, 7, 2, 2), (225, 224, 3, 64, 7, 2, 3), (224, 200, 3, 64, 7, 2, 3), (224, 2048, 3, 64, 7, 2, 3)):
+    assert not hip.conv_stem_supported(*bad), bad
+  # its backward-filter: one slab per persistent workgroup (<= 768), none for rows wider than 256 pixels
+  assert hip.conv_stem_wrw_slabs(256, 224, 224) == 768 and hip.conv_stem_wrw_slabs(1, 32, 32) == 8
+  assert hip.conv_stem_wrw_slabs(4, 224, 512) == 0 and hip.conv_stem_wrw_slabs(0, 224, 224) == 0
+  # RxS backward-filter: C, N multiples of 64 and at least 2048 output pixels; 0 = "use the fallback"
+  assert hip.conv2d_wrw_splits(256 * 56 * 56, 64, 64, 9) > 0 and hip.conv2d_wrw_splits(256 * 14 * 14, 256, 256, 9) > 0
+  assert hip.conv2d_wrw_splits(1024, 64, 64, 9) == 0 and hip.conv2d_wrw_splits(256 * 56 * 56, 64, 48, 9) == 0
+  # statistics groups of the fused forward kernels: at least one, bounded (the consumer BN reduces [G][4][N])
+  for M, N, K in ((256 * 56 * 56, 256, 64), (256 * 7 * 7, 2048, 512), (4096, 64, 64)):
+    for pro in (False, True):
+      assert 1 <= hip.conv1x1_stats_groups(M, N, K, prologue=pro) <= 1024
+    assert 1 <= hip.conv2d_stats_groups(M, N) <= 1024
+
+
 def test_header_is_plain_c_and_struct_sizes_match(tmp_path):
   from pocketflow_amd import hip
   src = tmp_path / 'sz.c'
