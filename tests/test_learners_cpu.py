@@ -173,7 +173,7 @@ def test_other_learners_free_their_tensors_by_refcount(cpu_learners, kind):
   assert grown <= 0, '%s: tensors of finished steps survive without the cyclic collector: +%d bytes over 3 steps' % (kind, grown)
 
 
-@pytest.mark.parametrize('fused', [False, True])
+@pytest.mark.parametrize('fused', [True])          # (the unfused executor: test_other_learners_... and tests/test_fused_plumbing_cpu.py)
 def test_learner_steps_free_their_tensors_by_refcount(cpu_learners, monkeypatch, fused):
   """Whole learner steps (teacher forward, quantisers, forward, losses, backward, optimiser) with Python's cyclic collector
   DISABLED: the bytes held by live tensors must not grow from step to step (see test_a_step_leaves_no_reference_cycles in
