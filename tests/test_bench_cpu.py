@@ -1,0 +1,49 @@
+"""bench.py's control flow end to end WITHOUT a GPU: the HIP entry points are replaced by the float32 emulations of
+tests/fake_hip.py and the few torch.cuda calls bench.py makes are stubbed, so that every line of `main()` runs -- argument
+handling, learner construction, warm-up, the self-diagnosis (here forced into its host-bound branch), the timed region and
+the JSON line with every key of the driver's contract.  (What it measures is meaningless; the GPU runs measure.)"""
+import json
+import sys
+
+import torch
+
+from fake_hip import FakeHipFull
+
+
+def test_bench_main_runs_end_to_end_on_emulated_kernels(monkeypatch, capsys, tmp_path):
+  import pocketflow_amd.graph as G
+  import pocketflow_amd.plan as P
+  import pocketflow_amd.losses as L
+  import pocketflow_amd.optim as Opt
+  import pocketflow_amd.profiling as PR
+  import pocketflow_amd.learners.abstract_learner as AL
+  import pocketflow_amd.learners.nonuniform_quantization.utils as NU
+  import pocketflow_amd.learners.weight_sparsification.learner as WS
+  import pocketflow_amd.learners.layerwise as LW
+  import bench
+  fake = FakeHipFull()
+  for mod in (G, P, L, Opt, WS, NU, LW):
+    monkeypatch.setattr(mod, 'hip', fake)
+  monkeypatch.setattr(AL, 'require_gpu', lambda: torch.device('cpu'))
+  monkeypatch.setattr(torch.cuda, 'synchronize', lambda *a, **k: None)
+  # pretend the process is host-bound: the diagnostic branch (one more step under cProfile) must work when it is needed
+  monkeypatch.setattr(bench, 'launch_probe', lambda torch, n=1000: {'host_us_per_launch': 1.0, 'us_per_dispatch': 99.0})
+  monkeypatch.setattr(bench, 'memory_snapshot', lambda torch: {'reserved_gb': 0.0, 'segments_allocated': 0})
+  monkeypatch.setattr(PR, 'enable', lambda name: None)
+  monkeypatch.setattr(PR, 'summary', lambda name: (72, 7.2, 72 * 3.0e8))
+  monkeypatch.setenv('TMPDIR', str(tmp_path))
+  monkeypatch.setattr(sys, 'argv', ['bench.py', '--steps', '1', '--warmup', '1', '--batch', '2', '--image_size', '32',
+                                    '--dtype', 'float32', '--no_cpu_baseline'])
+  bench.main()
+  out, err = capsys.readouterr()
+  line = json.loads([ln for ln in out.splitlines() if ln.startswith('{')][-1])
+  for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+    assert key in line, key
+  assert line['n_gpus'] == 1 and line['steps'] == 1 and line['warmup'] == 1 and line['scaling'] == 'weak'
+  assert line['higher_is_better'] is True and line['vs_baseline'] is None and line['data'] == 'synthetic'
+  assert line['unit'] == 'images/s' and line['value'] > 0 and 'workload' in line['config'] and 'model' not in line['config']
+  r = line['roofline']
+  assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and r['launches'] == 72
+  assert line['launch_probe']['after_warmup']['us_per_dispatch'] == 99.0 and 'memory' in line
+  assert 'host-bound process' in err and 'tottime' in err          # the self-diagnosis printed its profile
