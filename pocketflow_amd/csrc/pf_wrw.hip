@@ -581,7 +581,7 @@ int pf_wrw2_launch(const void* dY, const void* X, float* slabs, const float* sca
                    int bits, int M, int N, int C, int th, int tw, int H, int Wd, int Ho, int Wo, int stride, int pad_h,
                    int pad_w, int S, int64_t x_rows, hipStream_t st) {
   if (S <= 0) return -1;
-  if (x_rows * C >= ((int64_t)1 << 30)) return -1;
+  if (x_rows * C >= ((int64_t)1 << 30) || (int64_t)M * N >= ((int64_t)1 << 30)) return -1;   // 31-bit byte offsets inside the kernel
   Wrw2Args a;
   a.dY = (const bf16_t*)dY; a.X = (const bf16_t*)X; a.slabs = slabs; a.ss = scale_shift; a.slot = slot;
   a.kq = uq_k_of_bits(slot ? bits : 8);
