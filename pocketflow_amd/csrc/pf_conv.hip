@@ -67,12 +67,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a)
   const int lrow = tid >> 3, kp = tid & 7;          // staging: 8 lanes cover 128 contiguous bytes of a row
 
   Pro pro;
-  pro.lo = a.act_lo; pro.hi = a.act_hi; pro.quant = 0; pro.beta = 0.f; pro.c1 = 1.f; pro.c2 = 1.f;
-  if (PRO && a.slot != nullptr) {
-    float alpha, beta;
-    slot_alpha_beta(a.slot, alpha, beta);
-    pro.quant = 1; pro.beta = beta; pro.c1 = a.kq / alpha; pro.c2 = alpha / a.kq;
-  }
+  pro_init(pro, a.act_lo, a.act_hi, a.kq, PRO ? a.slot : nullptr);
 
   f32x4 acc[4][JM];
   // input tiles are prefetched TWO k-steps ahead in two register sets (ra0 / ra1, used alternately): with
@@ -142,7 +137,8 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a)
   const int wvec = tid % VPR, wrow = tid / VPR;
 
   if (PRO) {                                        // scale | shift of all K input channels, once per workgroup
-    for (int i = tid; i < 2 * a.K; i += PF_THREADS) ssl[i] = a.ss[i];
+    for (int i = tid; i < 2 * a.K; i += PF_THREADS)     // staged FOLDED (pf_conv_common.h)
+      ssl[i] = (i < a.K) ? pro_fold_scale(pro, a.ss[i]) : pro_fold_shift(pro, a.ss[i]);
   }
   constexpr bool bwd_stats = BWD;                    // backward-data + BN-backward statistics (PRO == false)
   if (bwd_stats) {
@@ -322,6 +318,7 @@ extern "C" int pf_conv1x1_stats_groups(int M, int N) {
 // [M][K] x [N][K] problem (depends on which kernel the shape is dispatched to)
 // pf_igemm.hip: direct-to-LDS staged GEMM for the prologue-free shapes with a deep contraction
 extern "C" int pf_conv2d_stats_groups(int M, int N);
+int pf_igemm_stats_groups(int M, int N, int pro);           // the launcher's own tile decision (prologue variant or not)
 int pf_igemm_conv1x1(const void* X, const void* W, void* Y, const void* R, float* partial, const void* bn_x,
                      const float* bss, const float* bmi, float b_lo, float b_hi, const float* scale_shift,
                      const uint32_t* slot, float kq, float act_lo, float act_hi, int M, int N, int K, int Ho, int Wo,
@@ -339,7 +336,7 @@ extern "C" int pf_conv1x1_stats_groups_k(int M, int N, int K, int prologue) {
   int nw = 0;
   const int nsplit = pf_conv_stream_plan(M, N, K, &nw);
   if (nsplit > 0) return pf_conv_stream_groups(nsplit);
-  if (conv_use_igemm(prologue != 0, K)) return pf_conv2d_stats_groups(M, N);
+  if (conv_use_igemm(prologue != 0, K)) return pf_igemm_stats_groups(M, N, prologue != 0);
   return pf_conv1x1_stats_groups(M, N);
 }
 
@@ -461,12 +458,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_wrw(const ConvArgs a)
   const int frow = lane & 15, fm = lane >> 4;               // fragment: channel row, 8-pixel group
 
   Pro pro;
-  pro.lo = a.act_lo; pro.hi = a.act_hi; pro.quant = 0; pro.beta = 0.f; pro.c1 = 1.f; pro.c2 = 1.f;
-  if (PRO && a.slot != nullptr) {
-    float alpha, beta;
-    slot_alpha_beta(a.slot, alpha, beta);
-    pro.quant = 1; pro.beta = beta; pro.c1 = a.kq / alpha; pro.c2 = alpha / a.kq;
-  }
+  pro_init(pro, a.act_lo, a.act_hi, a.kq, PRO ? a.slot : nullptr);
   // staging maps: dY tile 64 x 128 = 1024 vectors (4 / thread): pixel = p >> 4, channel group = p & 15
   //               X  tile 64 x 64  =  512 vectors (2 / thread): pixel = p >> 3, channel group = p & 7
   const int qkp = tid & 7;
@@ -474,7 +466,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_wrw(const ConvArgs a)
     const int k = k0 + qkp * 8;
     if (k < a.K) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { pro.sc[j] = a.ss[k + j]; pro.sh[j] = a.ss[a.K + k + j]; }
+      for (int j = 0; j < 8; ++j) { pro.sc[j] = pro_fold_scale(pro, a.ss[k + j]); pro.sh[j] = pro_fold_shift(pro, a.ss[a.K + k + j]); }
     }
   }
   f32x4 acc[2][4];

@@ -62,24 +62,78 @@ __device__ __forceinline__ int64_t map_row(const ConvArgs& a, int m) {
   return ((int64_t)n * a.H + (int64_t)ho * a.stride) * a.Wd + (int64_t)wo * a.stride;
 }
 
-// prologue on one 16-byte vector (8 consecutive input channels of one pixel)
+// prologue on one 16-byte vector (8 consecutive input channels of one pixel): BN affine -> activation clamp ->
+// activation fake-quant of the producer layer (uq utils.py:51-79,163-199), bf16 throughput mode.
+//
+// All per-tensor and per-channel constants are FOLDED once (pro_fold_*), so that an element costs
+//   t = med3(fma(sc', x, sh'), lo', hi');  q = fma(rint(t), alpha/k, beta)          (4 VALU + unpack / pack)
+// with sc' = scale * k/alpha, sh' = (shift - beta) * k/alpha, lo' = (lo - beta) * k/alpha, hi' likewise: t is the grid
+// coordinate (y - beta) * k/alpha of the reference chain with the BN affine and the quantiser affine contracted into
+// ONE fma (round 2 spent 7 VALU here: fma, max, min, sub, mul, rint, fma).  t differs from the chain's value by a few
+// float32 ulps of its terms, so q differs from the five-rounding chain of uq_point() only where t sits within that
+// distance of a rounding boundary n + 1/2 -- enumerated by tests/test_conv_gpu.py (tie test).  Without fake-quant
+// (quant == 0) the fold is the identity (k/alpha = 1, beta = 0): t = act(fma(scale, x, shift)) exactly as before.
 struct Pro {
-  float sc[8], sh[8];
-  float lo, hi, beta, c1, c2;
+  float sc[8], sh[8];   // FOLDED scale / shift of this lane's 8 channels (pro_fold_scale / pro_fold_shift)
+  float lo, hi;         // FOLDED activation window (pro_fold_window)
+  float beta, c1, c2;   // range minimum, k/alpha, alpha/k
   int quant;
 };
+// a: activation window (act_lo, act_hi), kq = 2^bits - 1, slot = min/max slot of the activation or null
+__device__ __forceinline__ void pro_init(Pro& p, float act_lo, float act_hi, float kq, const uint32_t* slot) {
+  p.quant = 0; p.beta = 0.f; p.c1 = 1.f; p.c2 = 1.f;
+  if (slot != nullptr) {
+    float alpha, beta;
+    slot_alpha_beta(slot, alpha, beta);
+    p.quant = 1; p.beta = beta; p.c1 = kq / alpha; p.c2 = alpha / kq;
+  }
+  p.lo = (act_lo - p.beta) * p.c1;
+  p.hi = (act_hi - p.beta) * p.c1;
+}
+__device__ __forceinline__ float pro_fold_scale(const Pro& p, float scale) { return scale * p.c1; }
+__device__ __forceinline__ float pro_fold_shift(const Pro& p, float shift) { return (shift - p.beta) * p.c1; }
+__device__ __forceinline__ float pro_point(const Pro& p, float sc, float sh, float x) {
+  const float t = __builtin_amdgcn_fmed3f(fmaf(sc, x, sh), p.lo, p.hi);
+  return p.quant ? fmaf(rintf(t), p.c2, p.beta) : t;
+}
 __device__ __forceinline__ uint4 pro_apply(const Pro& p, const uint4& v) {
   float f[8];
   unpack8(v, f);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float y = fminf(fmaxf(fmaf(p.sc[j], f[j], p.sh[j]), p.lo), p.hi);
-    // fake-quant with the per-tensor constants folded: rint((y - beta) * k/alpha) * alpha/k + beta.
-    // Differs from the five-rounding chain of uq_point() only on exact rounding ties (bf16 throughput
-    // mode; the float32 parity mode never takes this path).
-    if (p.quant) y = fmaf(rintf((y - p.beta) * p.c1), p.c2, p.beta);
-    f[j] = y;
-  }
+  for (int j = 0; j < 8; ++j) f[j] = pro_point(p, p.sc[j], p.sh[j], f[j]);
   return pack8(f);
 }
 
+// ---- LDS accesses the compiler must NOT order against LDS-DMA ------------------------------------------------------
+// hipcc (ROCm 7.2) treats a pending `buffer_load ... lds` as a store to LDS that any ordinary LDS store -- and any LDS load
+// it cannot tell apart -- may alias, and emits `s_waitcnt vmcnt(0)` in front of it: one such access per k-step drains a
+// multi-stage LDS-DMA ring every step (seen in the ISA of the 3-stage prologue kernel: the wait sat in front of the
+// in-place ds_write of the prologue pass and in front of the scale / shift reads).  These helpers issue the access from
+// inline asm, which the wait-count pass does not model; the CALLER guarantees the ordering (own counted vmcnt for the
+// vectors a lane staged itself; s_waitcnt lgkmcnt(0) + barrier before anybody else reads what was written here).
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)p; }
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4v_t __attribute__((ext_vector_type(4)));
+// loads and their wait in ONE statement (outputs early-clobber): the destinations are valid when the statement ends
+__device__ __forceinline__ void lds_read_b128x4(uint32_t p0, uint32_t p1, float4& a, float4& b, float4& c, float4& d) {
+  f32x4v_t ra, rb, rc, rd;
+  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:16\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(ra), "=&v"(rb), "=&v"(rc), "=&v"(rd) : "v"(p0), "v"(p1) : "memory");
+  a = make_float4(ra[0], ra[1], ra[2], ra[3]); b = make_float4(rb[0], rb[1], rb[2], rb[3]);
+  c = make_float4(rc[0], rc[1], rc[2], rc[3]); d = make_float4(rd[0], rd[1], rd[2], rd[3]);
+}
+__device__ __forceinline__ uint4 lds_read_b128(uint32_t p) {
+  u32x4_t v;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void lds_read_b128x2(uint32_t p0, uint32_t p1, uint4& a, uint4& b) {
+  u32x4_t ra, rb;
+  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(ra), "=&v"(rb) : "v"(p0), "v"(p1) : "memory");
+  a = make_uint4(ra[0], ra[1], ra[2], ra[3]); b = make_uint4(rb[0], rb[1], rb[2], rb[3]);
+}
+__device__ __forceinline__ void lds_write_b128(uint32_t p, const uint4& v) {
+  const u32x4_t r = {v.x, v.y, v.z, v.w};
+  asm volatile("ds_write_b128 %0, %1" : : "v"(p), "v"(r) : "memory");
+}

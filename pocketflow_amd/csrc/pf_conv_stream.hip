@@ -69,6 +69,8 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
   const int cnt = (s_first < NS) ? (NS - s_first + sstep - 1) / sstep : 0;
   const int T = cnt * KC;
 
+  Pro pro;
+  pro_init(pro, a.act_lo, a.act_hi, a.kq, PRO ? a.slot : nullptr);
   // ---- stage the kernel slice (and the per-channel vectors) once ------------------------------------------------
   {
     const int swz_mask = (KV >= 16) ? 15 : 7;
@@ -78,7 +80,8 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
       if (n0 + n < a.N) w = *reinterpret_cast<const uint4*>(a.W + (int64_t)(n0 + n) * K + c * 8);
       *reinterpret_cast<uint4*>(Wl + ((int64_t)n * KV + (c ^ (n & swz_mask))) * 8) = w;
     }
-    if (PRO) for (int i = tid; i < 2 * K; i += ST_THREADS) aux[i] = a.ss[i];
+    if (PRO) for (int i = tid; i < 2 * K; i += ST_THREADS)   // FOLDED scale | shift (pf_conv_common.h)
+      aux[i] = (i < K) ? pro_fold_scale(pro, a.ss[i]) : pro_fold_shift(pro, a.ss[i]);
     if (BWD) for (int i = tid; i < 4 * NW; i += ST_THREADS) {
       const int qq = i / NW, c = n0 + (i - qq * NW);
       float v = 0.f;
@@ -88,13 +91,6 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
   }
   __syncthreads();
 
-  Pro pro;
-  pro.lo = a.act_lo; pro.hi = a.act_hi; pro.quant = 0; pro.beta = 0.f; pro.c1 = 1.f; pro.c2 = 1.f;
-  if (PRO && a.slot != nullptr) {
-    float alpha, beta;
-    slot_alpha_beta(a.slot, alpha, beta);
-    pro.quant = 1; pro.beta = beta; pro.c1 = a.kq / alpha; pro.c2 = alpha / a.kq;
-  }
   const int wswz = (KV >= 16) ? l15 : (l15 & 7);                          // this lane's weight-row swizzle
   const bf16_t* __restrict__ side = BWD ? a.bx : a.R;                    // second [M][N] operand of the epilogue
   const int wvec = lane % VPR, wrow = lane / VPR;

@@ -69,7 +69,11 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 template <int BM, int BN, int WM, int WN, int NS, int MODE>
 __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
   constexpr bool BWD = (MODE == IG_BWD), PRO = (MODE == IG_PRO);
-  static_assert(!PRO || NS == 2, "the in-LDS prologue pass is written for the 2-stage ring");
+  static_assert(!PRO || NS == 2 || NS == 3, "the in-LDS prologue pass is written for the 2- and 3-stage rings");
+  // PRO with three stages: the loads of step ks+2 travel, the lanes transform their own vectors of step ks+1 in LDS and the
+  // matrix cores multiply step ks -- all inside ONE barrier interval (round 2's two-stage form ran them back to back:
+  // wait for the loads, transform, barrier, multiply; measured 5.5 k cycles per step against 0.5 k of MFMA issue).
+  constexpr bool PRO3 = PRO && NS == 3;
   constexpr int T = 64 * WM * WN;
   constexpr int WR = BM / WM, WC = BN / WN;         // wavefront tile: pixels x channels
   constexpr int JM = WR / 16, NI = WC / 16;
@@ -84,6 +88,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
   float* red = reinterpret_cast<float*>(smem);
   constexpr int RING_B = NS * STAGE, CT_B = BM * CS_LD_B * 2;
   float* bpl = reinterpret_cast<float*>(smem + (RING_B > CT_B ? RING_B : CT_B));   // BWD: scale | shift | mean | invstd [4][BN]
+  float* ssl = bpl;                                                                // PRO3: FOLDED scale | shift [2][C] of the producer BN
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);              // scalar: LDS-DMA bases stay in SGPRs
@@ -116,11 +121,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
   const int wvec = tid % VPR, wrw = tid / VPR;
   const bf16_t* __restrict__ side = BWD ? a.bx : a.R;
   Pro pro;
-  pro.lo = a.act_lo; pro.hi = a.act_hi; pro.quant = 0; pro.beta = 0.f; pro.c1 = 1.f; pro.c2 = 1.f;
-  if (PRO && a.slot != nullptr) {
-    float alpha, beta;
-    slot_alpha_beta(a.slot, alpha, beta);
-    pro.quant = 1; pro.beta = beta; pro.c1 = a.kq / alpha; pro.c2 = alpha / a.kq;
+  pro_init(pro, a.act_lo, a.act_hi, a.kq, PRO ? a.slot : nullptr);
+  if (PRO3) {
+    // ordinary loads, BEFORE any LDS-DMA is in flight: beside a pending buffer_load ... lds the compiler waits vmcnt(0) for
+    // every register-destination load, which would drain the ring once per step
+    for (int i = tid; i < 2 * a.C; i += T) ssl[i] = (i < a.C) ? pro_fold_scale(pro, a.ss[i]) : pro_fold_shift(pro, a.ss[i]);
+    __syncthreads();
   }
 
   // Buffer descriptors (wave-uniform): LDS-DMA through buffer_load ... lds takes a 32-bit per-lane byte offset plus a
@@ -196,11 +202,39 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
       ps0 = *reinterpret_cast<const float4*>(p); ps1 = *reinterpret_cast<const float4*>(p + 4);
       ph0 = *reinterpret_cast<const float4*>(p + a.C); ph1 = *reinterpret_cast<const float4*>(p + a.C + 4);
     };
+    auto transform3 = [&](int buf, int cc, int i0, int i1) {            // PRO3: vectors [i0, i1) of this lane, constants from LDS
+      // every LDS access of the pass through the asm helpers (pf_conv_common.h): an ordinary ds_write / ds_read here makes
+      // the compiler drain the LDS-DMA ring (vmcnt(0)) once per step
+      const uint32_t pss = lds_addr(ssl + cc * 64 + schunk * 8);
+      float4 s0, s1, h0, h1;
+      lds_read_b128x4(pss, pss + (uint32_t)a.C * 4u, s0, s1, h0, h1);
+      pro.sc[0] = s0.x; pro.sc[1] = s0.y; pro.sc[2] = s0.z; pro.sc[3] = s0.w;
+      pro.sc[4] = s1.x; pro.sc[5] = s1.y; pro.sc[6] = s1.z; pro.sc[7] = s1.w;
+      pro.sh[0] = h0.x; pro.sh[1] = h0.y; pro.sh[2] = h0.z; pro.sh[3] = h0.w;
+      pro.sh[4] = h1.x; pro.sh[5] = h1.y; pro.sh[6] = h1.z; pro.sh[7] = h1.w;
+      const uint32_t pv = lds_addr(smem + buf * STAGE + srow * 128 + (lane & 7) * 16);
+      static_assert(!PRO3 || AS == 1 || AS == 2 || AS == 4, "vector count per lane");
+#pragma unroll
+      for (int i = 0; i < AS; i += 2) {
+        if (i >= i0 && i < i1) {
+          if (i + 1 < i1) {
+            uint4 v0, v1;
+            lds_read_b128x2(pv + i * (T / 8) * 128, pv + (i + 1) * (T / 8) * 128, v0, v1);
+            lds_write_b128(pv + i * (T / 8) * 128, pro_apply(pro, v0));
+            lds_write_b128(pv + (i + 1) * (T / 8) * 128, pro_apply(pro, v1));
+          } else {
+            lds_write_b128(pv + i * (T / 8) * 128, pro_apply(pro, lds_read_b128(pv + i * (T / 8) * 128)));
+          }
+        } else if (i + 1 >= i0 && i + 1 < i1) {
+          lds_write_b128(pv + (i + 1) * (T / 8) * 128, pro_apply(pro, lds_read_b128(pv + (i + 1) * (T / 8) * 128)));
+        }
+      }
+    };
     auto transform = [&](int buf) {
-      pro.sc[0] = ps0.x; pro.sc[1] = ps0.y; pro.sc[2] = ps0.z; pro.sc[3] = ps0.w;
-      pro.sc[4] = ps1.x; pro.sc[5] = ps1.y; pro.sc[6] = ps1.z; pro.sc[7] = ps1.w;
-      pro.sh[0] = ph0.x; pro.sh[1] = ph0.y; pro.sh[2] = ph0.z; pro.sh[3] = ph0.w;
-      pro.sh[4] = ph1.x; pro.sh[5] = ph1.y; pro.sh[6] = ph1.z; pro.sh[7] = ph1.w;
+      const float rs[8] = {ps0.x, ps0.y, ps0.z, ps0.w, ps1.x, ps1.y, ps1.z, ps1.w};
+      const float rh[8] = {ph0.x, ph0.y, ph0.z, ph0.w, ph1.x, ph1.y, ph1.z, ph1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { pro.sc[j] = pro_fold_scale(pro, rs[j]); pro.sh[j] = pro_fold_shift(pro, rh[j]); }
       unsigned char* As = smem + buf * STAGE;
 #pragma unroll
       for (int i = 0; i < AS; ++i) {
@@ -211,25 +245,30 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
 #pragma unroll
     for (int d = 0; d < NS - 1; ++d)
       if (d < nk) {
-        if (PRO) fetch_ss(s_cc);
+        if (PRO && !PRO3) fetch_ss(s_cc);
         stage(ibuf);
         ibuf = (ibuf + 1 == NS) ? 0 : ibuf + 1;
       }
     if (nk >= NS - 1) wait_vm<(NS - 2) * LPS>(); else wait_vm<0>();
-    if (PRO) { transform(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    if (PRO3) { transform3(0, 0, 0, AS); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    else if (PRO) { transform(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
     __builtin_amdgcn_s_barrier();
     int cbuf = 0;
     for (int ks = 0; ks < nk; ++ks) {
       const bool more = ks + NS - 1 < nk;
       const int tbuf = ibuf;                                                // buffer the stage issued now lands in
       if (more) {
-        if (PRO) fetch_ss(s_cc);
+        if (PRO && !PRO3) fetch_ss(s_cc);
         stage(ibuf);
         ibuf = (ibuf + 1 == NS) ? 0 : ibuf + 1;
       }
       const unsigned char* As = smem + cbuf * STAGE;
       const unsigned char* Bs = As + A_BYTES;
       cbuf = (cbuf + 1 == NS) ? 0 : cbuf + 1;
+      const bool tnext = PRO3 && (ks + 1 < nk);                             // PRO3: step ks+1 is transformed beside the MFMAs of ks
+      if (PRO3) {                                                           // own part of stage ks+1 (issued one step ago) has landed
+        if (more) wait_vm<LPS>(); else wait_vm<0>();
+      }
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int coff = (((kk * 4 + q) ^ (l15 & 7)) << 4);
@@ -245,9 +284,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
 #pragma unroll
           for (int j = 0; j < JM; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        // half of this lane's vectors of step ks+1 behind each half of the MFMAs: the VALU work has matrix work to hide in
+        if (tnext) transform3(cbuf, ks + 1, kk * (AS / 2), (kk == 1) ? AS : (AS / 2));
       }
-      if (more) wait_vm<(NS - 2) * LPS>(); else wait_vm<0>();             // the NEXT step's stage has landed (own part)
-      if (PRO && more) transform(tbuf);
+      if (!PRO3) {
+        if (more) wait_vm<(NS - 2) * LPS>(); else wait_vm<0>();           // the NEXT step's stage has landed (own part)
+      }
+      if (PRO && !PRO3 && more) transform(tbuf);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // own fragment reads / prologue writes are done
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -351,27 +394,41 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
-struct IgCfg { int bm, bn; };
+struct IgCfg { int bm, bn, slots; bool pro3; };    // slots: resident workgroups on the chip (256 CUs x workgroups per CU)
 
-static IgCfg ig_pick(int M, int N) {
+static bool ig_pro3_enabled() {
+  const char* e = getenv("PF_IGEMM_PRO3");                 // =0: round 2's two-stage prologue kernel (A/B runs)
+  return e == nullptr || atoi(e) != 0;
+}
+
+// ONE decision for the launcher and for the statistics-group query (the [G][.][N] partial array is sized from it)
+static IgCfg ig_pick(int M, int N, bool pro) {
+  (void)M;
+  if (pro) {
+    // prologue variant.  Three stages, 8 wavefronts, one workgroup per CU: 128 x 256 tiles where N allows (the in-LDS
+    // prologue pass over the input tile is amortised over 256 output channels), 256 x 128 otherwise.
+    if (ig_pro3_enabled()) {
+      if (N % 256 == 0) return IgCfg{128, 256, 256, true};
+      if (N % 128 == 0) return IgCfg{256, 128, 256, true};
+    }
+    return IgCfg{128, (N % 128 == 0) ? 128 : 64, 512, false};
+  }
   const char* e = getenv("PF_IGEMM_TILE");                 // tuning override: "256x128" | "128x128" | "256x64" | "128x64"
   if (e != nullptr) {
     int bm = 0, bn = 0;
     if (sscanf(e, "%dx%d", &bm, &bn) == 2 && (bm == 128 || bm == 256) && (bn == 64 || bn == 128 || (bn == 256 && bm == 256)) &&
         (N % bn == 0 || bn == 64))
-      return IgCfg{bm, bn};
+      return IgCfg{bm, bn, (bm == 256) ? 256 : 512, false};
   }
   const int bn = (N % 128 == 0) ? 128 : 64;
   // measured on the ResNet-50 shapes at batch 256 (tools/gpu/igemm_bench.py): 128-row tiles with two workgroups per CU
   // (2 LDS stages each) beat 256-row tiles with one workgroup per CU and 3 stages on every shape (e.g. 3x3 C = 256 at
   // 14x14: 85 vs 96 us; 3x3 C = 64 at 56x56: 127 vs 165 us): the second workgroup hides the barrier / DMA waits of the
   // first better than a deeper pipeline does
-  (void)M;
-  return IgCfg{128, bn};
+  return IgCfg{128, bn, 512, false};
 }
 
-static int ig_grid(int bm, int tiles_m, int tiles_n, int* G_out) {
-  const int slots = (bm == 256) ? 256 : 512;               // resident workgroups: 1 (512 threads) or 2 (256 threads) per CU
+static int ig_grid(int slots, int tiles_m, int tiles_n, int* G_out) {
   int G = slots / tiles_n;
   G = (G / 8) * 8;
   if (G < 8) G = 8;
@@ -381,26 +438,31 @@ static int ig_grid(int bm, int tiles_m, int tiles_n, int* G_out) {
   return G * tiles_n;
 }
 
-extern "C" int pf_conv2d_stats_groups(int M, int N) {
-  const IgCfg c = ig_pick(M, N);
+int pf_igemm_stats_groups(int M, int N, int pro) {
+  const IgCfg c = ig_pick(M, N, pro != 0);
   int G;
-  ig_grid(c.bm, (M + c.bm - 1) / c.bm, (N + c.bn - 1) / c.bn, &G);
+  ig_grid(c.slots, (M + c.bm - 1) / c.bm, (N + c.bn - 1) / c.bn, &G);
   return G;
 }
 
+extern "C" int pf_conv2d_stats_groups(int M, int N) { return pf_igemm_stats_groups(M, N, 0); }
+
 template <int BM, int BN, int WM, int WN, int NS, int MODE>
-static int ig_launch_t(IgArgs& a, hipStream_t st) {
-  constexpr bool BWD = (MODE == IG_BWD);
+static int ig_launch_t(IgArgs& a, int slots, hipStream_t st) {
+  constexpr bool BWD = (MODE == IG_BWD), PRO3 = (MODE == IG_PRO && NS == 3);
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
-  const int grid = ig_grid(BM, a.tiles_m, a.tiles_n, &a.G);
-  // stage ring and (aliased on it) the C tile; the BWD vectors sit behind whichever is larger
+  const int grid = ig_grid(slots, a.tiles_m, a.tiles_n, &a.G);
+  // stage ring and (aliased on it) the C tile; the BWD vectors / the folded prologue constants sit behind whichever is larger
   constexpr size_t ring = NS * (size_t)(BM + BN) * 128, ctile = (size_t)BM * (BN + 8) * 2;
-  size_t lds = (ring > ctile ? ring : ctile) + (BWD ? 4 * BN * 4 : 0);
+  constexpr size_t base = (ring > ctile ? ring : ctile);
+  const size_t lds = base + (BWD ? 4 * BN * 4 : 0) + (PRO3 ? 2 * (size_t)a.C * 4 : 0);
+  if (PRO3 && a.C > CV_MAXK) return (int)hipErrorInvalidValue;
   static bool configured = false;
   if (!configured) {
+    const size_t lds_max = base + (BWD ? 4 * BN * 4 : 0) + (PRO3 ? 2 * (size_t)CV_MAXK * 4 : 0);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<BM, BN, WM, WN, NS, MODE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
@@ -410,15 +472,15 @@ static int ig_launch_t(IgArgs& a, hipStream_t st) {
 }
 
 static int ig_launch(IgArgs& a, hipStream_t st) {
-  const IgCfg c = ig_pick(a.M, a.N);
   const bool bwd = a.bx != nullptr, pro = a.ss != nullptr;
-  if (pro) {                                             // prologue variant: 128-row tiles, 2 stages (the only instantiation)
+  const IgCfg c = ig_pick(a.M, a.N, pro);
+  if (pro) {
     if (a.th * a.tw != 1 || bwd) return (int)hipErrorInvalidValue;
-    // (256 x 256 prologue tiles were tried for N >= 512 -- half as many column tiles repeat the prologue pass -- and lost:
-    // 116 vs 100 us on 14x14 256 -> 1024; the 57 spilled registers of that instantiation dominate)
-    return (a.N % 128 == 0) ? ig_launch_t<128, 128, 2, 2, 2, IG_PRO>(a, st) : ig_launch_t<128, 64, 2, 2, 2, IG_PRO>(a, st);
+    if (c.pro3) return (c.bn == 256) ? ig_launch_t<128, 256, 2, 4, 3, IG_PRO>(a, c.slots, st)
+                                     : ig_launch_t<256, 128, 4, 2, 3, IG_PRO>(a, c.slots, st);
+    return (c.bn == 128) ? ig_launch_t<128, 128, 2, 2, 2, IG_PRO>(a, c.slots, st) : ig_launch_t<128, 64, 2, 2, 2, IG_PRO>(a, c.slots, st);
   }
-#define PF_IG(BMV, BNV, WMV, WNV, NSV) (bwd ? ig_launch_t<BMV, BNV, WMV, WNV, NSV, IG_BWD>(a, st) : ig_launch_t<BMV, BNV, WMV, WNV, NSV, IG_PLAIN>(a, st))
+#define PF_IG(BMV, BNV, WMV, WNV, NSV) (bwd ? ig_launch_t<BMV, BNV, WMV, WNV, NSV, IG_BWD>(a, c.slots, st) : ig_launch_t<BMV, BNV, WMV, WNV, NSV, IG_PLAIN>(a, c.slots, st))
   if (c.bm == 256 && c.bn == 256) return PF_IG(256, 256, 4, 2, 2);    // 8 wavefronts (64 x 128 each), 1 workgroup / CU, 2 stages (128 KiB)
   if (c.bm == 256 && c.bn == 128) return PF_IG(256, 128, 4, 2, 3);    // 8 wavefronts, 1 workgroup / CU, 3 stages (144 KiB)
   if (c.bm == 128 && c.bn == 128) return PF_IG(128, 128, 2, 2, 2);    // 4 wavefronts, 2 workgroups / CU, 2 stages each

@@ -80,15 +80,13 @@ __global__ __launch_bounds__(256) void k_wrw_tr(const WrwArgs a) {
 
   // prologue constants: this lane's channels are c0 + j*16 + l15 in every X fragment
   float psc[4], psh[4];
-  float p_beta = 0.f, p_c1 = 1.f, p_c2 = 1.f;
-  bool p_quant = false;
+  Pro pro;
+  pro_init(pro, a.act_lo, a.act_hi, a.kq, PRO ? a.slot : nullptr);
   if (PRO) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { psc[j] = a.ss[c0 + j * 16 + l15]; psh[j] = a.ss[a.C + c0 + j * 16 + l15]; }
-    if (a.slot != nullptr) {
-      float alpha, beta;
-      slot_alpha_beta(a.slot, alpha, beta);
-      p_quant = true; p_beta = beta; p_c1 = a.kq / alpha; p_c2 = alpha / a.kq;
+    for (int j = 0; j < 4; ++j) {
+      psc[j] = pro_fold_scale(pro, a.ss[c0 + j * 16 + l15]);
+      psh[j] = pro_fold_shift(pro, a.ss[a.C + c0 + j * 16 + l15]);
     }
   }
 
@@ -167,11 +165,7 @@ __global__ __launch_bounds__(256) void k_wrw_tr(const WrwArgs a) {
         float f[8];
         unpack8(u, f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float y = fminf(fmaxf(fmaf(psc[j], f[e], psh[j]), a.act_lo), a.act_hi);
-          if (p_quant) y = fmaf(rintf((y - p_beta) * p_c1), p_c2, p_beta);   // folded constants, as pro_apply()
-          f[e] = y;
-        }
+        for (int e = 0; e < 8; ++e) f[e] = pro_point(pro, psc[j], psh[j], f[e]);
         u = pack8(f);
       }
       xf[j] = *reinterpret_cast<const bf16x8*>(&u);
@@ -386,13 +380,8 @@ __global__ __launch_bounds__(64 * (TN / WTN) * (TK / WTK)) void k_wrw2(const Wrw
   // this wavefront's instruction slots: id = wave + k * NWAVE; id < IDY: dY piece (pg, g4), else X piece (pg, g4)
   float psc[XS][8], psh[XS][8];
   Pro pro;
-  pro.lo = a.act_lo; pro.hi = a.act_hi; pro.quant = 0; pro.beta = 0.f; pro.c1 = 1.f; pro.c2 = 1.f;
+  pro_init(pro, a.act_lo, a.act_hi, a.kq, PRO ? a.slot : nullptr);
   if (PRO) {
-    if (a.slot != nullptr) {
-      float alpha, beta;
-      slot_alpha_beta(a.slot, alpha, beta);
-      pro.quant = 1; pro.beta = beta; pro.c1 = a.kq / alpha; pro.c2 = alpha / a.kq;
-    }
 #pragma unroll
     for (int x = 0; x < XS; ++x) {
       const int xi = wave + x * NWAVE;
@@ -400,7 +389,7 @@ __global__ __launch_bounds__(64 * (TN / WTN) * (TK / WTK)) void k_wrw2(const Wrw
         const int g4 = xi % (TK / 64);
         const int c = c0 + (g4 * 4 + sb) * 16 + sch * 8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { psc[x][j] = a.ss[c + j]; psh[x][j] = a.ss[a.C + c + j]; }
+        for (int j = 0; j < 8; ++j) { psc[x][j] = pro_fold_scale(pro, a.ss[c + j]); psh[x][j] = pro_fold_shift(pro, a.ss[a.C + c + j]); }
       }
     }
   }

@@ -270,8 +270,8 @@ class VarStore:
   def _build_transpose_tiles(self) -> None:
     rows = []
     for v in self.vars:
-      if v.group != 'W' or v.kind != 'conv' or not v.trainable:
-        continue
+      if v.group != 'W' or v.kind != 'conv':      # every convolution kernel, trainable or not: a frozen kernel whose
+        continue                                   # INPUT needs a gradient is read in this layout too
       kh, kw, cin, cout = v.ref_shape
       RS = kh * kw
       for rs in range(RS):
@@ -902,7 +902,8 @@ class _Conv2dIgemm(torch.autograd.Function):
                                                    [0, 0], 1, [False, True, False])[1]
     if ctx.needs_input_grad[0]:
       N, C, R, S = w.shape
-      if stride == 1:
+      # backward-data = the same kernel with the roles of C and N swapped: its contraction runs over N in steps of 64
+      if stride == 1 and N % 64 == 0 and C % 8 == 0 and igemm_limits_ok(dy.numel(), w.numel(), R * S):
         B, _, H, W = x.shape
         wv = ctx.w_var
         if USE_SEG_TRANSPOSE and wv is not None and wv.store is graph.store and wv.tensor is w:
@@ -980,10 +981,16 @@ def own_stem_ok(x, conv, pad) -> bool:
           and hip.conv_stem_supported(x.shape[2], x.shape[3], x.shape[1], conv.kernel.ref_shape[3], conv.k, conv.stride, pad[0]))
 
 
+def igemm_limits_ok(n_in_elems: int, n_kernel_elems: int, taps: int) -> bool:
+  """Mirror of the argument checks of pf_conv2d_fwd (pf_igemm.hip): 31-bit byte offsets, 32-bit tap mask."""
+  return n_in_elems < (1 << 30) and n_kernel_elems < (1 << 30) and taps <= 32
+
+
 def own_conv2d_ok(x, conv, pad) -> bool:
+  kh, kw, cin, cout = conv.kernel.ref_shape
   return (OWN_CONV2D and conv.k > 1 and conv.bias is None and isinstance(x, torch.Tensor) and fusable_tensor(x)
-          and x.dim() == 4 and conv.kernel.ref_shape[2] % 64 == 0 and conv.kernel.ref_shape[3] % 8 == 0
-          and pad is not None and conv.graph.fuse_conv1x1)
+          and x.dim() == 4 and cin % 64 == 0 and cout % 8 == 0
+          and pad is not None and conv.graph.fuse_conv1x1 and igemm_limits_ok(x.numel(), kh * kw * cin * cout, kh * kw))
 
 
 def fusable_tensor(t: torch.Tensor) -> bool:
@@ -1327,12 +1334,12 @@ class _MaxPool(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, x, k, stride, ph, pw):
+    need_grad = ctx.needs_input_grad[0]          # of the ARGUMENT: a channels_last copy made in here never requires grad
     x = _nhwc(x)
     B, C, H, W = x.shape
     Ho = (H + ph[0] + ph[1] - k) // stride + 1
     Wo = (W + pw[0] + pw[1] - k) // stride + 1
     y = torch.empty((B, C, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-    need_grad = x.requires_grad
     idx = torch.empty((B, Ho, Wo, C), dtype=torch.uint8, device=x.device) if need_grad else None
     with region('maxpool_fwd', float((x.numel() + y.numel()) * x.element_size())):
       hip.maxpool_fwd(x, y, idx, B, H, W, C, k, stride, ph[0], pw[0], Ho, Wo)

@@ -176,7 +176,7 @@ class ChannelPrunedGpuLearner(AbstractLearner):  # pylint: disable=too-many-inst
       loss, metrics = self.calc_loss(y, logits, self.vars_prnd['trainable'])
       if FLAGS.enbl_dst:
         loss = loss + self.helper_dst.calc_loss(logits, logits_dst)
-    loss.backward()
+    self.optimizer.backward(loss)
     lr = self.lrn_rate(self.global_step)
     self.optimizer.weight_decay = g.store.weight_decay
     self.optimizer.compute_gradients()

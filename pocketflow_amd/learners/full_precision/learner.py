@@ -67,7 +67,7 @@ class FullPrecLearner(AbstractLearner):  # pylint: disable=too-many-instance-att
       loss, metrics = self.calc_loss(y, logits, self.trainable_vars)
       if self.enbl_dst:
         loss = loss + self.helper_dst.calc_loss(logits, logits_dst)
-    loss.backward()
+    self.optimizer.backward(loss)
     lr = self.lrn_rate(self.global_step)
     self.optimizer.weight_decay = g.store.weight_decay
     self.optimizer.compute_gradients()

@@ -101,7 +101,7 @@ class NonUniformQuantLearner(AbstractLearner):
       if FLAGS.enbl_dst:
         dst_loss = self.helper_dst.calc_loss(logits, logits_dst)
         loss = loss + dst_loss
-    loss.backward()
+    optimizer.backward(loss)
     if FLAGS.nuql_opt_mode in ('cluster', 'both'):
       self.nonuni_quant.codebook_grads()
     lr = self.lrn_rate(self.ft_step)

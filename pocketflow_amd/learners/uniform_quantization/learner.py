@@ -108,7 +108,7 @@ class UniformQuantLearner(AbstractLearner):
       if FLAGS.enbl_dst:
         dst_loss = self.helper_dst.calc_loss(logits, logits_dst)
         loss = loss + dst_loss
-    loss.backward()
+    self.optimizer.backward(loss)
     lr = self.lrn_rate(self.ft_step)
     self.optimizer.weight_decay = g.store.weight_decay
     self.optimizer.compute_gradients()

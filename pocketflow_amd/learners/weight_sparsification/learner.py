@@ -87,7 +87,7 @@ class WeightSparseLearner(AbstractLearner):  # pylint: disable=too-many-instance
       loss, metrics = self.calc_loss(y, logits, self.trainable_vars)
       if FLAGS.enbl_dst:
         loss = loss + self.helper_dst.calc_loss(logits, logits_dst)
-    loss.backward()
+    self.optimizer.backward(loss)
     lr = self.lrn_rate(self.global_step)
     self.optimizer.weight_decay = g.store.weight_decay
     self.optimizer.compute_gradients()

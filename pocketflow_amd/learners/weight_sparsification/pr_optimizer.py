@@ -292,7 +292,7 @@ class PROptimizer(object):  # pylint: disable=too-many-instance-attributes
     x_prnd = self.__forward_tapped(self.graph_prnd, images, layer_p)[layer_p][0]
     diff = layer_p.plain(x_prnd.detach()).float() - y_full.float()
     loss = (diff * diff).sum() / 2
-    loss.backward()
+    self.opt_rg.backward(loss)
     self.opt_rg.weight_decay = 0.0
     self.opt_rg.compute_gradients()
     self.opt_rg.apply_gradients(FLAGS.ws_lrn_rate_rg)
@@ -307,7 +307,7 @@ class PROptimizer(object):  # pylint: disable=too-many-instance-attributes
     with g.as_default():
       logits = self.model_helper.forward_eval(to_device_images(images, g))
       loss, __ = self.model_helper.calc_loss(labels.to(self.device), logits, self.vars_prnd['trainable'])
-    loss.backward()
+    self.opt_ft.backward(loss)
     self.opt_ft.weight_decay = g.store.weight_decay
     self.opt_ft.compute_gradients()
     self.opt_ft.apply_gradients(FLAGS.ws_lrn_rate_ft)

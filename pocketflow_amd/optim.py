@@ -49,6 +49,13 @@ class FlatOptimizer(object):
     self.beta1_power = np.float32(self.beta1)
     self.beta2_power = np.float32(self.beta2)
 
+  def backward(self, loss: torch.Tensor) -> None:
+    """The backward pass of a training step.  Learners call this (not `loss.backward()`) for the backward that is
+    followed by compute_gradients() / apply_gradients(): the distributed wrapper overrides it to let the gradient
+    exchange start from inside the pass.  Any OTHER backward (layer-wise tuning on rank 0, regression-gradient
+    helpers) stays a plain `loss.backward()` and never touches the process group."""
+    loss.backward()
+
   def compute_gradients(self) -> None:
     """Gradients already sit in store.w_grad / store.o_grad after backward (single process)."""
     self.g_scale = 1.0
@@ -76,6 +83,7 @@ class FlatOptimizer(object):
       if st.o_size:
         hip.momentum_flat(st.o_master, o_grad, self.slots_o[0], self.o_mask, st.o_decay, wd, self.g_scale,
                           lrn_rate, self.momentum)
+    st.w_t_fresh = False          # the backward-data layout of the kernels is stale when w_master aliases w_compute
     st.zero_grad()
 
 
@@ -113,6 +121,7 @@ class GradReducer(object):
     self._stage_w: Optional[torch.Tensor] = None
     self._stage_o: Optional[torch.Tensor] = None
     self._reset_cycle()
+    self.armed = False         # in-backward launching is OPT-IN per step: arm() ... backward ... disarm() / finish()
     store.grad_hook = self._on_grad
     self.n_overlapped = 0      # buckets launched from inside backward in the last cycle (diagnostics / tests)
 
@@ -160,8 +169,28 @@ class GradReducer(object):
     self.handles.append(dist.all_reduce(stage[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
     self.launched[b] = True
 
+  def arm(self) -> None:
+    """Allow bucket all-reduces to be launched from inside the NEXT backward pass.  Every rank must run that backward
+    (it is the one followed by finish()); a backward that only some ranks run -- LayerwiseTuner on the primary worker
+    while the others sit in a barrier, regression-gradient helpers that do their own all-reduce -- must stay unarmed,
+    or its collectives would pair with the other ranks' barrier.  Arming starts a fresh cycle: whatever an unarmed or
+    abandoned backward left behind (seen-set, pending counts) is dropped."""
+    for h in self.handles:       # an armed backward that never reached finish(): its launches are complete collectives
+      h.wait()
+    self._reset_cycle()
+    self.armed = True
+
+  def disarm(self) -> None:
+    self.armed = False
+
   def _on_grad(self, var) -> None:
     if not (self.overlap and self._active()) or var.group != 'W':
+      return
+    if not self.armed:
+      # a gradient produced OUTSIDE the armed pass while buckets of this cycle are already in flight (a second,
+      # accumulating backward before the update): the overlapped results are stale -> finish() re-reduces, blocking
+      if any(self.launched):
+        self.dirty = True
       return
     b = self.var_bucket.get(var.name)
     if b is None:
@@ -178,6 +207,7 @@ class GradReducer(object):
   def finish(self):
     """-> (w_grad tensor, o_grad tensor, g_scale) the optimiser kernel must use for this update."""
     st = self.store
+    self.armed = False
     if not self._active():
       self._reset_cycle()
       return st.w_grad, st.o_grad, 1.0
@@ -241,6 +271,14 @@ class DistributedFlatOptimizer(object):
       object.__setattr__(self, name, value)
     else:
       setattr(self.opt, name, value)
+
+  def backward(self, loss: torch.Tensor) -> None:
+    """loss.backward() with the in-backward bucket launches of the GradReducer enabled for exactly this pass."""
+    self.reducer.arm()
+    try:
+      loss.backward()
+    finally:
+      self.reducer.disarm()
 
   def compute_gradients(self) -> None:
     w_src, o_src, scale = self.reducer.finish()

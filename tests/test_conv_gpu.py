@@ -86,6 +86,48 @@ def test_conv1x1_fwd_prologue_matches_standalone_bn_act_quant(hip, act, bits, sh
   _close_bf16(Y, ref, frac_tol=2e-3 if bits is not None else 0.0, what='prologue %s/%s' % (act, bits))
 
 
+# the three-stage prologue kernel of pf_igemm.hip (k_igemm<128,256,..,3,PRO> for N % 256 == 0, <256,128,..,3,PRO> for
+# N % 128 == 0): deep contractions (up to the 2048 channels whose folded constants fill the LDS to its last byte), row tails,
+# persistent workgroups that walk several row tiles, residual + statistics in the epilogue, and PF_IGEMM_PRO3=0 (round 2's
+# two-stage kernel) on the same inputs -- the two must agree to the last bit (same prologue arithmetic, same k order)
+@pytest.mark.parametrize('M,N,K', [(3000, 256, 1024), (5003, 512, 192), (2600, 128, 2048), (4133, 1024, 256), (40000, 256, 576),
+                                   (1, 256, 64), (129, 128, 64), (36000, 128, 640)])
+@pytest.mark.parametrize('act,bits', [('Relu', 8), ('Relu', None)])
+def test_conv1x1_fwd_prologue_three_stage_kernel(hip, M, N, K, act, bits, monkeypatch):
+  g = torch.Generator(device='cuda').manual_seed(M + N + K)
+  X = _bf(torch.randn(M, K, device='cuda', generator=g) * 2)
+  W = _bf(torch.randn(N, K, device='cuda', generator=g) * (K ** -0.5))
+  R = _bf(torch.randn(M, N, device='cuda', generator=g))
+  ss = torch.stack([torch.rand(K, device='cuda', generator=g) + 0.5, torch.randn(K, device='cuda', generator=g)])
+  slot = torch.empty(2, dtype=torch.int32, device='cuda')
+  hip.minmax_slots_init(slot)
+  if bits is not None:
+    y = torch.relu(X.float() * ss[0] + ss[1])
+    hip.minmax_tensor(y.contiguous(), slot)
+  sl = slot if bits is not None else None
+  Q = torch.empty_like(X)
+  hip.bn_act_quant_apply(X, Q, M, K, ss, act, sl, bits or 8, bits is not None)
+  out = {}
+  for mode in ('1', '0'):
+    monkeypatch.setenv('PF_IGEMM_PRO3', mode)
+    G = hip.conv1x1_stats_groups(M, N, K, prologue=True)
+    partial = torch.full((G, 4, N), float('nan'), device='cuda')
+    Y = torch.full((M, N), float('nan'), device='cuda', dtype=torch.bfloat16)
+    hip.conv1x1_fwd(X, W, Y, M, N, K, R=R, scale_shift=ss, act=act, slot=sl, bits=bits or 8, partial=partial)
+    out[mode] = (Y, partial)
+  Y, partial = out['1']
+  acc = Q.float() @ W.float().t()
+  ref = _bf(_bf(acc).float() + R.float())
+  _close_bf16(Y, ref, frac_tol=2e-3 if bits is not None else 1e-6, what='3-stage prologue', scale=acc)
+  y = Y.float()
+  assert not torch.isnan(partial).any()
+  torch.testing.assert_close(partial[:, 0].sum(0), y.sum(0), rtol=1e-4, atol=1e-2)
+  torch.testing.assert_close(partial[:, 1].sum(0), (y * y).sum(0), rtol=1e-4, atol=1e-2)
+  assert torch.equal(partial[:, 2].min(0).values, y.min(0).values)
+  assert torch.equal(partial[:, 3].max(0).values, y.max(0).values)
+  assert torch.equal(Y, out['0'][0]), 'two-stage and three-stage prologue kernels differ'
+
+
 @pytest.mark.parametrize('n,H,Wd', [(3, 14, 10), (9, 46, 50)])
 def test_conv1x1_fwd_strided_and_ymap(hip, n, H, Wd):
   K, N, s = 64, 128, 2
@@ -295,7 +337,10 @@ def test_prologue_fake_quant_equals_oracle_except_enumerated_ties(hip, M, C, act
   k = float(2 ** bits - 1)
   t = (y - beta) / alpha * k
   dist = np.abs(t - (np.floor(t) + 0.5))                       # distance to the nearest rounding boundary
-  near = dist <= 8 * np.spacing(np.float32(k)) + 2e-6 * k      # a few float32 ulps of t (incl. fma vs mul+add in y)
+  # a few float32 ulps of the TERMS of t: round 3 contracts the BN affine and the quantiser affine into one fma,
+  # t = fma(scale * k/alpha, x, (shift - beta) * k/alpha), whose rounding error scales with |scale * x| * k/alpha, not with t
+  mag = np.abs(X.float().cpu().numpy().astype(np.float64) * ss[0].cpu().numpy()) + np.abs(ss[1].cpu().numpy()) + abs(float(y.min()))
+  near = dist <= 8 * np.spacing(np.float32(k)) + 2e-6 * k + 6e-7 * mag / alpha * k
   # second (tiny) class: the float32 results of the two chains differ in their last bits (alpha * (r / k) + beta vs
   # fma(r, alpha / k, beta)), which shows after the bf16 rounding only if the float32 value sits within a few ulps
   # of a bf16 rounding boundary (low 16 bits ~ 0x8000): then the stored values are adjacent bf16 numbers
@@ -307,7 +352,7 @@ def test_prologue_fake_quant_equals_oracle_except_enumerated_ties(hip, M, C, act
   d_grid, d_16 = diff & near, diff & ~near & near16
   assert np.all(np.abs(got[d_grid] - ref[d_grid]) <= step * 1.02 + np.abs(ref[d_grid]) * 2 ** -7)   # neighbouring grid point
   assert np.all(np.abs(got[d_16] - ref[d_16]) <= np.abs(ref[d_16]) * 2 ** -7 + 1e-30)               # adjacent bf16 number
-  assert near.mean() < 1e-3                                    # grid ties are rare
+  assert near.mean() < 2e-3                                    # grid ties are rare
   # (near16 is a property of the <= 2^bits distinct grid VALUES, not of the elements: a grid value whose float32 image sits
   # next to a bf16 boundary is shared by many elements; what is asserted above is that nothing ELSE differs)
   assert d_16.sum() <= near16.sum()

@@ -87,10 +87,21 @@ def _worker(rank, world, port, out_dir):
   assert len(red.buckets) >= 2 and red.buckets[0][0] == 0 and red.buckets[-1][1] == st.w_size
   wvars = sorted([v for v in st.vars if v.group == 'W'], key=lambda v: -v.offset)
   for dirty in (False, True):
+    # between two training steps rank 0 alone runs a backward pass (LayerwiseTuner under
+    # *_enbl_rl_layerwise_tune, regression-gradient helpers) while the others wait in a barrier.  In-backward launching
+    # is opt-in per step, so those reports must launch NOTHING -- a lone all-reduce would pair with the barrier -- and
+    # must not leak seen / pending state into the next armed cycle.
+    if rank == 0:
+      for v in wvars:
+        st.notify_grad(v)
+      assert not any(red.launched) and not red.handles and not red.armed
+    dist.barrier()
     st.w_grad.copy_(torch.arange(st.w_grad.numel(), dtype=torch.float32) * (rank + 2))
     st.o_grad.fill_(float(rank + 2))
+    red.arm()                                              # what DistributedFlatOptimizer.backward() does around loss.backward()
     for v in wvars:
       st.notify_grad(v)
+    red.disarm()
     if dirty:
       st.w_grad.mul_(2.0)                                  # a second backward pass accumulated into the buffer
       st.notify_grad(wvars[0])
