@@ -38,13 +38,17 @@ def parse_args():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=20)
   ap.add_argument('--warmup', type=int, default=5)
-  ap.add_argument('--batch', type=int, default=256, help='per-GPU batch (north star: 256)')
-  ap.add_argument('--resnet_size', type=int, default=50)
-  ap.add_argument('--image_size', type=int, default=224)
+  ap.add_argument('--config', default='c2', choices=sorted(CONFIGS),
+                  help='which concrete run of SURVEY 8(d): c2 = BASELINE.json configs[2] (the headline line, default); '
+                       'c2a32 = the same with the reference default of 32-bit activations; c1 = configs[1]; c3 = configs[3]; '
+                       'c4 = configs[4] (each at its per-GPU batch on N GPUs)')
+  ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the configuration\'s; north star: 256)')
+  ap.add_argument('--resnet_size', type=int, default=None)
+  ap.add_argument('--image_size', type=int, default=None)
   ap.add_argument('--dtype', default='bfloat16')
-  ap.add_argument('--act_bits', type=int, default=8)
-  ap.add_argument('--weight_bits', type=int, default=8)
-  ap.add_argument('--roofline_kernel', default='conv1x1_fwd',
+  ap.add_argument('--act_bits', type=int, default=None)
+  ap.add_argument('--weight_bits', type=int, default=None)
+  ap.add_argument('--roofline_kernel', default=None,
                   help='profiling region whose launches are timed with HIP events: conv1x1_fwd | conv1x1_wrw | '
                        'conv1x1_bwd_data | conv2d_fwd | bn_bwd_apply | bn_bwd_stats | bn_act_quant_apply | bn_stats')
   ap.add_argument('--no_cpu_baseline', action='store_true')
@@ -53,7 +57,135 @@ def parse_args():
   ap.add_argument('--cpu_batch', type=int, default=32, help='batch of the CPU baseline sample (SURVEY 8d: 32)')
   ap.add_argument('--cpu_steps', type=int, default=5, help='timed CPU steps after the warm-up (SURVEY 8d: >= 5)')
   ap.add_argument('--cpu_budget_s', type=float, default=200.0, help='wall-clock bound of the CPU baseline sample')
-  return ap.parse_args()
+  args = ap.parse_args()
+  cfg = CONFIGS[args.config]
+  for k in ('batch', 'resnet_size', 'image_size', 'act_bits', 'weight_bits', 'roofline_kernel'):
+    if getattr(args, k) is None:
+      setattr(args, k, cfg[k])
+  return args
+
+
+# The concrete runs of SURVEY.md section 8(d) ("Configs -> concrete runs"); every one prints the same JSON contract.
+#   flops: fwd + bwd-data + bwd-filter of the student (+ the teacher's forward with distillation) per image, SURVEY App. C
+CONFIGS = {
+    'c2': dict(model='resnet', learner='uniform', resnet_size=50, image_size=224, batch=256, weight_bits=8, act_bits=8, dst=True,
+               roofline_kernel='conv1x1_fwd', flops=32.71e9, nb_classes=1001,
+               workload='ResNet-v2-{resnet_size}@ILSVRC-12-synthetic {image_size}x{image_size}x3, UniformQuantLearner w{weight_bits}/a{act_bits} + '
+                        'distillation, Adam, batch {batch}/GPU (BASELINE.json configs[2])',
+               metric='images/sec ResNet-50 INT8 quant-aware fine-tune (whole job; per GPU = value / n_gpus)'),
+    'c2a32': dict(model='resnet', learner='uniform', resnet_size=50, image_size=224, batch=256, weight_bits=8, act_bits=32, dst=True,
+                  roofline_kernel='conv1x1_fwd', flops=32.71e9, nb_classes=1001,
+                  workload='ResNet-v2-{resnet_size}@ILSVRC-12-synthetic {image_size}x{image_size}x3, UniformQuantLearner w{weight_bits}/a{act_bits} '
+                           '(the reference default uql_activation_bits) + distillation, Adam, batch {batch}/GPU (configs[2] variant)',
+                  metric='images/sec ResNet-50 8-bit-weight quant-aware fine-tune, 32-bit activations (whole job)'),
+    'c1': dict(model='resnet_cifar', learner='weight-sparse', resnet_size=20, image_size=32, batch=128, weight_bits=8, act_bits=32, dst=False,
+               roofline_kernel='bn_bwd_apply', flops=3 * 82.15e6, nb_classes=10,
+               workload='ResNet-v2-{resnet_size}@CIFAR-10-synthetic 32x32x3, WeightSparseLearner 50 % sparsity (uniform), Momentum, '
+                        'batch {batch}/GPU (BASELINE.json configs[1])',
+               metric='images/sec ResNet-20 weight-sparsification fine-tune (whole job)'),
+    'c3': dict(model='mobilenet', learner='channel', resnet_size=0, image_size=224, batch=256, weight_bits=8, act_bits=32, dst=True,
+               roofline_kernel='conv1x1_fwd', flops=4 * 1.137e9, nb_classes=1001,
+               workload='MobileNet-v1@ILSVRC-12-synthetic {image_size}x{image_size}x3, ChannelPrunedLearner masked fine-tune at preserve '
+                        'ratio 0.5 (seeded keep-masks; the LASSO selection is host work outside the step) + distillation, Adam, '
+                        'batch {batch}/GPU (BASELINE.json configs[3])',
+               metric='images/sec MobileNet-v1 channel-pruned fine-tune (whole job)'),
+    'c4': dict(model='resnet', learner='non-uniform', resnet_size=50, image_size=224, batch=256, weight_bits=4, act_bits=32, dst=True,
+               roofline_kernel='conv1x1_fwd', flops=32.71e9, nb_classes=1001,
+               workload='ResNet-v2-{resnet_size}@ILSVRC-12-synthetic {image_size}x{image_size}x3, NonUniformQuantLearner {weight_bits}-bit codebooks + '
+                        'distillation, Adam, batch {batch}/GPU (BASELINE.json configs[4])',
+               metric='images/sec ResNet-50 4-bit non-uniform quant-aware fine-tune (whole job)'),
+}
+
+
+def build_learner(args, FLAGS, tmp, rank, world, barrier):
+  """(learner, step function) of the configuration: the learner classes, flags and entry points are the ones
+  nets/*_run.py would use; only the data are synthetic and the start checkpoint is seeded."""
+  import numpy as np
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  cfg = CONFIGS[args.config]
+  kind = cfg['learner']
+  # importing the modules DEFINES their flags (as in the reference); values are assigned afterwards
+  import pocketflow_amd.learners.distillation_helper  # noqa: F401
+  if cfg['model'] == 'resnet':
+    from pocketflow_amd.nets.resnet_at_ilsvrc12 import ModelHelper
+  elif cfg['model'] == 'resnet_cifar':
+    from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
+  else:
+    from pocketflow_amd.nets.mobilenet_at_ilsvrc12 import ModelHelper
+  if kind == 'uniform':
+    from pocketflow_amd.learners.uniform_quantization.learner import UniformQuantLearner as Learner
+  elif kind == 'non-uniform':
+    from pocketflow_amd.learners.nonuniform_quantization.learner import NonUniformQuantLearner as Learner
+  elif kind == 'weight-sparse':
+    from pocketflow_amd.learners.weight_sparsification.learner import WeightSparseLearner as Learner
+  else:
+    from pocketflow_amd.learners.channel_pruning.learner import ChannelPrunedLearner as Learner
+  FLAGS.nb_classes = cfg['nb_classes']
+  FLAGS.image_size = args.image_size
+  FLAGS.batch_size = args.batch
+  FLAGS.compute_dtype = args.dtype
+  FLAGS.enbl_dst = cfg['dst']
+  FLAGS.dst_eval_teacher = False            # the teacher's one-off evaluation is not part of a step
+  FLAGS.synthetic_pool = 2
+  FLAGS.save_path = os.path.join(tmp, 'models', 'model.ckpt')
+  FLAGS.save_path_dst = os.path.join(tmp, 'models_dst', 'model.ckpt')
+  if cfg['model'] != 'mobilenet':
+    FLAGS.resnet_size = args.resnet_size
+  if kind == 'uniform':
+    FLAGS.uql_weight_bits, FLAGS.uql_activation_bits = args.weight_bits, args.act_bits
+    FLAGS.uql_save_quant_model_path = os.path.join(tmp, 'uql', 'model.ckpt')
+  elif kind == 'non-uniform':
+    FLAGS.nuql_weight_bits, FLAGS.nuql_activation_bits = args.weight_bits, args.act_bits
+    FLAGS.nuql_save_quant_model_path = os.path.join(tmp, 'nuql', 'model.ckpt')
+  elif kind == 'weight-sparse':
+    FLAGS.ws_prune_ratio, FLAGS.ws_prune_ratio_prtl = 0.5, 'uniform'
+    FLAGS.ws_save_path = os.path.join(tmp, 'ws', 'model.ckpt')
+  else:
+    FLAGS.cp_channel_pruned_path = os.path.join(tmp, 'models', 'pruned_model.ckpt')
+    FLAGS.cp_best_path = os.path.join(tmp, 'models', 'best_model.ckpt')
+    FLAGS.cp_original_path = os.path.join(tmp, 'models', 'original_model.ckpt')
+    FLAGS.cp_lrn_rate_ft = 1e-4
+  mh = ModelHelper()
+  if rank == 0:
+    create_synthetic_checkpoint(mh)
+  barrier()
+  learner = Learner(None, mh)
+  if kind == 'non-uniform':
+    learner.init_clusters()
+  if kind == 'channel':
+    # the masked fine-tune of cp learner.py:381-471 with seeded keep-masks at preserve ratio 0.5: every Conv2D but the first
+    # (inputs) and the last (outputs) loses half of its input / output channels; depthwise kernels are never masked
+    from pocketflow_amd.utils import checkpoint
+    rng = np.random.RandomState(11)
+    convs = [op for op in learner.graph.matmul_ops if op.var.kind == 'conv']
+    vals = learner.graph.store.export_numpy()
+    fake = {}
+    for i, op in enumerate(convs):
+      kh, kw, cin, cout = op.var.ref_shape
+      keep_in = np.ones(cin, bool) if i == 0 else rng.rand(cin) < 0.5
+      keep_out = np.ones(cout, bool) if i == len(convs) - 1 else rng.rand(cout) < 0.5
+      keep_in[0] = keep_out[0] = True
+      fake[op.name] = [keep_in.tolist(), keep_out.tolist()]
+      m = np.zeros(op.var.ref_shape, np.float32)
+      m[:, :, keep_in, :] = 1.0
+      m[:, :, :, ~keep_out] = 0.0
+      vals[op.var.name] = vals[op.var.name] * m
+    pruned = None
+    if rank == 0:
+      pruned = checkpoint.save(vals, FLAGS.cp_channel_pruned_path, None)
+    barrier()
+    pruned = pruned or checkpoint.latest_checkpoint(os.path.dirname(FLAGS.cp_channel_pruned_path))
+    learner.setup_finetune(pruned, finetune=True, fake_pruning_dict=fake)
+  if kind == 'weight-sparse':
+    # the step the second half of the run executes: masks at their final ratio (ws learner.py:296-312 reaches it at
+    # 0.5 * nb_iters), gradient * mask + Momentum fused in the optimiser kernel
+    learner.global_step = int(FLAGS.ws_iter_ratio_end * learner.nb_iters_train) + 1
+    learner.prune_step()
+  if world > 1 and kind != 'channel':
+    bcast = getattr(learner, 'ops', {}).get('bcast') or getattr(learner, 'bcast_op', None)
+    if bcast is not None:
+      bcast()
+  return learner, learner.train_step
 
 
 # profiling region -> regular expressions of the kernels it launches (names as in the rocprofv3 summaries under profiles/).
@@ -136,9 +268,6 @@ def main():
       raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
   from pocketflow_amd.flags import FLAGS
   from pocketflow_amd import profiling
-  from pocketflow_amd.nets.resnet_at_ilsvrc12 import ModelHelper
-  from pocketflow_amd.learners.uniform_quantization.learner import UniformQuantLearner
-  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
   from pocketflow_amd.utils.multi_gpu_wrapper import MultiGpuWrapper as mgw
 
   # one scratch directory for ALL ranks (rank 0 writes the synthetic "pre-trained" checkpoint and the teacher's
@@ -149,19 +278,6 @@ def main():
   else:
     tmp = tempfile.mkdtemp(prefix='pf_bench_')
   FLAGS.enbl_multi_gpu = world > 1
-  FLAGS.resnet_size = args.resnet_size
-  FLAGS.nb_classes = 1001
-  FLAGS.image_size = args.image_size
-  FLAGS.batch_size = args.batch
-  FLAGS.compute_dtype = args.dtype
-  FLAGS.enbl_dst = True
-  FLAGS.dst_eval_teacher = False            # the teacher's one-off evaluation is not part of a step
-  FLAGS.uql_weight_bits = args.weight_bits
-  FLAGS.uql_activation_bits = args.act_bits
-  FLAGS.synthetic_pool = 2
-  FLAGS.save_path = os.path.join(tmp, 'models', 'model.ckpt')
-  FLAGS.save_path_dst = os.path.join(tmp, 'models_dst', 'model.ckpt')
-  FLAGS.uql_save_quant_model_path = os.path.join(tmp, 'uql', 'model.ckpt')
   if world > 1:
     mgw.init()
     if rank == 0:
@@ -170,14 +286,11 @@ def main():
     dist.barrier()
   torch.backends.cudnn.benchmark = os.environ.get('PF_CUDNN_BENCHMARK', '1') != '0'
 
-  mh = ModelHelper()
-  if rank == 0:
-    create_synthetic_checkpoint(mh)
-  if world > 1:
-    dist.barrier()
-  learner = UniformQuantLearner(None, mh)
-  if world > 1:
-    learner.ops['bcast']()
+  def barrier():
+    if world > 1:
+      dist.barrier()
+  learner, train_step = build_learner(args, FLAGS, tmp, rank, world, barrier)
+  cfg = CONFIGS[args.config]
 
   def sync():
     if world > 1:
@@ -185,7 +298,7 @@ def main():
     torch.cuda.synchronize()
 
   for _ in range(args.warmup):
-    learner.train_step()
+    train_step()
   # Self-diagnosis of a host-bound process.  Seven bench processes of round 2 ran at 150 ms instead of
   # 29 ms per step with the same kernels: the caching allocator was going to the driver for every tensor (torch.empty at
   # 185 us) because a reference cycle in the layer executor kept each step's activations alive until Python's cyclic
@@ -196,8 +309,8 @@ def main():
   torch.cuda.synchronize()
   probe_warm = launch_probe(torch)
   h0 = time.perf_counter()
-  learner.train_step()
-  learner.train_step()
+  train_step()
+  train_step()
   h1 = time.perf_counter()
   torch.cuda.synchronize()
   h2 = time.perf_counter()
@@ -209,7 +322,7 @@ def main():
     import pstats
     prof = cProfile.Profile()
     prof.enable()
-    learner.train_step()
+    train_step()
     prof.disable()
     torch.cuda.synchronize()
     buf = io.StringIO()
@@ -226,7 +339,7 @@ def main():
   t0 = time.perf_counter()
   marks = []
   for _ in range(args.steps):
-    learner.train_step()
+    train_step()
     marks.append(time.perf_counter())
   sync()
   dt = time.perf_counter() - t0
@@ -237,10 +350,25 @@ def main():
   if os.environ.get('PF_BENCH_TRACE_STEPS') and rank == 0:    # host-side submission time of every step (diagnostics)
     sys.stderr.write('host ms/step: %s | tail sync %.1f ms\n' % (
         ' '.join('%.1f' % ((b - a) * 1e3) for a, b in zip([t0] + marks[:-1], marks)), (t0 + dt - marks[-1]) * 1e3))
+  multi_gpu = None
   if world > 1:
     t = torch.tensor([dt], dtype=torch.float64, device='cuda')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    # data-parallel invariants, outside the timed region: after the broadcast and K all-reduced updates every rank must
+    # hold bit-identical parameters (deterministic kernels + one summed gradient); how much of the exchange was launched
+    # from inside backward; bytes on the links per step (utils/multi_gpu_wrapper.py:83-98 of the reference = Horovod)
+    st = learner.graph.store
+    sig = torch.stack([b.double().sum() for b in (st.w_master, st.o_master)] +
+                      [b.double().abs().sum() for b in (st.w_master, st.o_master)]).to('cuda')
+    sigs = [torch.zeros_like(sig) for _ in range(world)]
+    dist.all_gather(sigs, sig)
+    red = getattr(st, 'reducer', None)
+    el = 4 if (red is not None and red.reduce_dtype is not None) else st.w_grad.element_size()
+    multi_gpu = {'backend': dist.get_backend(), 'params_identical_across_ranks': all(bool(torch.equal(sigs[0], x)) for x in sigs),
+                 'buckets': len(red.buckets) if red is not None else None,
+                 'buckets_launched_inside_backward': red.n_overlapped if red is not None else None,
+                 'allreduce_bytes_per_step': int(st.w_size * el + st.o_size * 4)}
   n_launch, ms, work = profiling.summary(args.roofline_kernel)
 
   if rank == 0:
@@ -255,9 +383,9 @@ def main():
                 'unit': 'GB/s', 'frac': ach / HBM_PEAK, 'traffic': pmc_traffic_per_launch(args.roofline_kernel),
                 'algorithmic_bytes_per_launch': (work / n_launch) if n_launch else None, 'launches': n_launch,
                 'avg_launch_ms': (ms / n_launch) if n_launch else None,
-                'step_mfma_frac': per_gpu * R50_FLOPS_PER_IMAGE_STEP_DST / MFMA_BF16_PEAK}
+                'step_mfma_frac': per_gpu * cfg['flops'] / MFMA_BF16_PEAK}
     cpu_baseline = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and cfg['learner'] == 'uniform':   # the oracle timer restates the UQ step
       # the reference path restated on the host cores (oracle/learner_oracle.py), in a child process with a
       # hard wall-clock limit so that the default run always finishes within minutes
       import subprocess
@@ -274,7 +402,7 @@ def main():
       except subprocess.TimeoutExpired:
         cpu_baseline = None
     line = {
-        'metric': 'images/sec ResNet-50 INT8 quant-aware fine-tune (whole job; per GPU = value / n_gpus)',
+        'metric': cfg['metric'],
         'value': value, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'bf16' if args.dtype.startswith('bf') else 'f32', 'data': 'synthetic',
@@ -282,12 +410,9 @@ def main():
         'host_submit_ms_min_median_max': [host_steps[0], host_steps[len(host_steps) // 2], host_steps[-1]],
         'launch_probe': {'after_warmup': probe_warm, 'after_timed_region': probe_after, 'extra_untimed_steps': 2},
         'memory': {'after_warmup': mem_warm, 'after_timed_region': mem_after},
-        'config': {'workload': 'ResNet-v2-%d@ILSVRC-12-synthetic %dx%dx3, UniformQuantLearner w%d/a%d + distillation, '
-                               'Adam, batch %d/GPU (BASELINE.json configs[2])'
-                               % (args.resnet_size, args.image_size, args.image_size, args.weight_bits,
-                                  args.act_bits, args.batch),
+        'config': {'workload': cfg['workload'].format(**vars(args)), 'name': args.config,
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world},
-        'roofline': roofline, 'cpu_baseline': cpu_baseline}
+        'roofline': roofline, 'cpu_baseline': cpu_baseline, 'multi_gpu': multi_gpu}
     print(json.dumps(line))
   if world > 1:
     dist.barrier()

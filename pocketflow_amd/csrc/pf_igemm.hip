@@ -59,6 +59,13 @@ struct IgArgs {
   int tiles_m, tiles_n, G;
 };
 
+// Ablation builds for tools/gpu/igemm_ablate.py ONLY (never in libpocketflow_hip.so): -DPF_IG_ABLATE=1 drops the MFMAs and
+// their fragment reads (what is left is the LDS-DMA fill + barriers), =2 drops the LDS-DMA (matrix work + fragment reads +
+// barriers), =3 drops both the LDS-DMA and the fragment reads (matrix work + barriers).  Results are garbage by design.
+#ifndef PF_IG_ABLATE
+#define PF_IG_ABLATE 0
+#endif
+
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // MODE 0: plain (+ residual / statistics), 1: backward-data with BN-backward sums, 2: producer's BN + act + fake-quant
@@ -170,6 +177,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
       unsigned char* As = smem + buf * STAGE;
       unsigned char* Bs = As + A_BYTES;
       const uint32_t tapoff = (uint32_t)(((s_r * a.Wd + s_s) * a.C + s_cc * 64) * 2);   // wave-uniform
+#if PF_IG_ABLATE < 2
 #pragma unroll
       for (int i = 0; i < AS; ++i) {
         const uint32_t voff = ((pmask[i] >> s_tap) & 1u) ? (pbase[i] + tapoff) : OOB;
@@ -178,6 +186,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
 #pragma unroll
       for (int i = 0; i < BS; ++i)
         PF_BUFFER_LOAD_LDS16(rsW, Bs + (i * (T / 8) + wave * 8) * 128, boff[i], s_ks * 128);
+#else
+      (void)As; (void)Bs; (void)tapoff;
+#endif
       ++s_ks;
       if (++s_cc == cch) { s_cc = 0; ++s_tap; if (++s_s == a.tw) { s_s = 0; ++s_r; } }
     };
@@ -273,17 +284,29 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
       for (int kk = 0; kk < 2; ++kk) {
         const int coff = (((kk * 4 + q) ^ (l15 & 7)) << 4);
         bf16x8 wf[NI], xf[JM];
+#if PF_IG_ABLATE != 1
+#if PF_IG_ABLATE == 3
+#pragma unroll
+        for (int i = 0; i < NI; ++i) { uint4 u = make_uint4(lane, i, kk, 0x3f803f80u); asm volatile("" : "+v"(u.x)); wf[i] = *reinterpret_cast<const bf16x8*>(&u); }
+#pragma unroll
+        for (int j = 0; j < JM; ++j) { uint4 u = make_uint4(lane, j, kk, 0x3f803f80u); asm volatile("" : "+v"(u.x)); xf[j] = *reinterpret_cast<const bf16x8*>(&u); }
+        (void)coff;
+#else
 #pragma unroll
         for (int i = 0; i < NI; ++i)
           wf[i] = *reinterpret_cast<const bf16x8*>(Bs + (wn * WC + i * 16 + l15) * 128 + coff);
 #pragma unroll
         for (int j = 0; j < JM; ++j)
           xf[j] = *reinterpret_cast<const bf16x8*>(As + (wm * WR + j * 16 + l15) * 128 + coff);
+#endif
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
           for (int j = 0; j < JM; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+#else
+        (void)coff; (void)wf; (void)xf;
+#endif
         // half of this lane's vectors of step ks+1 behind each half of the MFMAs: the VALU work has matrix work to hide in
         if (tnext) transform3(cbuf, ks + 1, kk * (AS / 2), (kk == 1) ? AS : (AS / 2));
       }

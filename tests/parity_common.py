@@ -23,6 +23,75 @@ def _max_rel(a, b, skip=()):
   return worst, where
 
 
+def product_gradients(learner, step_fn=None):
+  """One forward + backward of the learner's own train_step WITHOUT the parameter update: the optimiser's
+  apply_gradients is replaced, for this one call, by a capture of the flat gradient buffers.  Returns
+  {variable name: d(loss without the L2 term)/d(variable) in the reference layout, float32}: the coupled weight decay of
+  ModelHelper.calc_loss lives inside the optimiser kernel (optim.py), so the buffers hold the data-loss gradient."""
+  opt = getattr(learner.optimizer, 'opt', learner.optimizer)
+  st = learner.graph.store
+  captured = {}
+
+  def capture(lr):
+    wg = opt.w_grad_src if opt.w_grad_src is not None else st.w_grad
+    og = opt.o_grad_src if opt.o_grad_src is not None else st.o_grad
+    captured['w'], captured['o'] = wg.detach().float().cpu().numpy().copy(), og.detach().float().cpu().numpy().copy()
+    st.zero_grad()
+  orig = opt.apply_gradients
+  opt.apply_gradients = capture
+  try:
+    out = (step_fn or learner.train_step)()
+  finally:
+    opt.apply_gradients = orig
+  grads = {}
+  for v in st.vars:
+    if not v.trainable:
+      continue
+    flat = captured['w'] if v.group == 'W' else captured['o']
+    grads[v.name] = v.to_ref(flat[v.offset:v.offset + v.numel])
+  return out, grads
+
+
+def compare_gradients(hip_grads, ora, ora_grads, what=''):
+  """Per-variable comparison of the product's gradients with the oracle learner's: the oracle differentiates the WHOLE
+  loss (incl. loss_w_dcy * l2), so loss_w_dcy * w is added to the product's data-loss gradient of every regularised
+  variable.  Returns {name: (relative L2 error, cosine)} and the same two numbers for the concatenated gradient."""
+  wd = float(ora.cfg.get('loss_w_dcy', 0.0))
+  l2 = set(ora._l2_names())
+  vals = ora.export()
+  per = {}
+  dots = np.zeros(3)
+  for name, ref in ora_grads.items():
+    if name not in hip_grads:
+      continue
+    got = hip_grads[name].astype(np.float64).reshape(-1)
+    if name in l2:
+      got = got + wd * vals[name].astype(np.float64).reshape(-1)
+    r = ref.astype(np.float64).reshape(-1)
+    nr, ng = np.linalg.norm(r), np.linalg.norm(got)
+    per[name] = (float(np.linalg.norm(got - r) / (nr + 1e-30)), float(got @ r / (nr * ng + 1e-300)))
+    dots += (got @ r, ng * ng, nr * nr)
+  whole_cos = float(dots[0] / np.sqrt(dots[1] * dots[2] + 1e-300))
+  whole_ratio = float(np.sqrt(dots[1] / (dots[2] + 1e-300)))
+  return per, whole_cos, whole_ratio
+
+
+def gradient_report(per, whole_cos, whole_ratio, what):
+  worst_l2 = max(per.items(), key=lambda kv: kv[1][0])
+  worst_cos = min(per.items(), key=lambda kv: kv[1][1])
+  cosv = sorted(v[1] for v in per.values())
+  line = ('%s: %d variables | relative L2 error: worst %.3e (%s) | cosine: worst %.5f (%s), median %.5f | whole gradient: '
+          'cosine %.6f, norm ratio %.4f' % (what, len(per), worst_l2[1][0], worst_l2[0], worst_cos[1][1], worst_cos[0],
+                                            cosv[len(cosv) // 2], whole_cos, whole_ratio))
+  print(line)
+  import os
+  out = os.environ.get('PF_PARITY_REPORT')              # tools/gpu/r03_call.sh collects these lines under profiles/
+  if out:
+    with open(out, 'a') as f:
+      f.write(line + '\n')
+  return worst_l2, worst_cos
+
+
 def _force_state(learner, ora):
   """HIP learner <- oracle: variables (incl. BN moving statistics) and the Momentum accumulators."""
   st = learner.graph.store
@@ -135,3 +204,88 @@ def run_cp_masked_finetune(FLAGS, tmp_path, optimizer, steps=3, report=None):
     assert worst <= min(tol, 1e-3), 'variable %s differs by %.3e (tolerance %.1e)' % (where, worst, tol)
   worst, where = _max_rel({k: v for k, v in got.items() if 'moving_' in k}, {k: v for k, v in ora.export().items() if 'moving_' in k})
   assert worst <= 1e-3, (where, worst)
+
+
+def run_bf16_fused_parity(FLAGS, tmp_path, steps=10, expect_bf16=True):
+  """Body of tests/test_parity_gpu.py::test_uq_resnet50_bf16_fused_path_matches_oracle_within_bf16_noise (see its
+  docstring); `expect_bf16=False` runs the same body in float32 (CPU emulation: tests/test_learners_cpu.py)."""
+
+  from oracle.learner_oracle import OracleLearner
+  import oracle.learner_oracle as LO
+  from bf16_noise_probe import conditioned_resnet50_state, moved_student, _R16, cosines
+  from pocketflow_amd.nets.resnet_at_ilsvrc12 import ModelHelper
+  from pocketflow_amd.learners.uniform_quantization.learner import UniformQuantLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  from pocketflow_amd.utils import checkpoint
+  import os
+  for k, v in dict(batch_size=16, batch_size_eval=16, uql_weight_bits=8, uql_activation_bits=8,
+                   enbl_dst=True, dst_eval_teacher=False, save_path_dst=str(tmp_path / 'models_dst' / 'model.ckpt'),
+                   uql_save_quant_model_path=str(tmp_path / 'uql' / 'm.ckpt'), nb_eval_batches_override=1,
+                   resnet_size=50, nb_classes=1001, image_size=64, uql_use_buckets=False,
+                   compute_dtype='bfloat16' if expect_bf16 else 'float32').items():
+    setattr(FLAGS, k, v)
+  mh = ModelHelper()
+  create_synthetic_checkpoint(mh)
+  prefix = checkpoint.latest_checkpoint(os.path.dirname(FLAGS.save_path))
+  rng = np.random.RandomState(5)
+  calib = rng.randn(16, 64, 64, 3).astype(np.float32)
+  cond = conditioned_resnet50_state(checkpoint.load(prefix), calib, branch_scale=0.1, dense_scale=0.2)
+  checkpoint.save(cond, FLAGS.save_path, 0)
+  learner = UniformQuantLearner(None, mh)                 # student AND teacher restore the conditioned checkpoint
+  if expect_bf16:
+    assert learner.graph.compute_dtype == torch.bfloat16 and learner.graph.fuse_conv1x1
+  learner.graph.store.load_numpy(moved_student(cond, 0.05))
+  init = learner.graph.store.export_numpy()
+  tvals = learner.helper_dst.learner.graph.store.export_numpy()
+  assert all(k.startswith('distilled_model/') for k in tvals)
+  cfg = dict(model='resnet', dataset='ilsvrc_12', resnet_size=50, nb_classes=1001, loss_w_dcy=FLAGS.loss_w_dcy, enbl_dst=True,
+             loss_w_dst=FLAGS.loss_w_dst, tempr_dst=FLAGS.tempr_dst, momentum=FLAGS.momentum, image_shape=(64, 64, 3),
+             learner='uniform', uql_weight_bits=8, uql_activation_bits=8, uql_use_buckets=False)
+  ora = OracleLearner(init, cfg, learner.lrn_rate, teacher_values=tvals)
+  pool = _pool(learner.iter_train)
+  # (1) float32 oracle, (2) the oracle with bf16 storage emulated, (3) the product: one backward each, same state and batch
+  ref, g32 = ora.compute_grads(*pool[0])
+  o_conv, o_act, o_qw = LO.Scope.conv2d, LO.Scope.activation, LO.Scope._quant_weight
+  LO.Scope.conv2d = lambda self, *a, **k: _R16.apply(o_conv(self, *a, **k))
+  LO.Scope.activation = lambda self, *a, **k: _R16.apply(o_act(self, *a, **k))
+  LO.Scope._quant_weight = lambda self, w, name: _R16.apply(o_qw(self, w, name))
+  try:
+    ora16 = OracleLearner(init, cfg, learner.lrn_rate, teacher_values=tvals)
+    ref16, g16 = ora16.compute_grads(*pool[0])
+  finally:
+    LO.Scope.conv2d, LO.Scope.activation, LO.Scope._quant_weight = o_conv, o_act, o_qw
+  floor = cosines(g16, g32)                                # {name: (cosine, relative L2)} of the emulation vs float32
+  out, hg = product_gradients(learner)
+  loss0 = float(out['loss'].detach())
+  assert abs(loss0 - ref['loss']) <= 5e-3 * abs(ref['loss']), (loss0, ref['loss'], ref16['loss'])
+  per, wc, wr = compare_gradients(hg, ora, g32)
+  gradient_report(per, wc, wr, 'ResNet-50 UQ w8/a8 + dst @64 B=16, bf16 FUSED path vs float32 oracle')
+  fl_k = sorted(v[0] for k, v in floor.items() if k.endswith('kernel'))
+  pr_k = sorted(v[1] for k, v in per.items() if k.endswith('kernel'))
+  line = ('   bf16 noise floor (oracle with bf16 storage vs float32 oracle), kernels: min cos %.4f median %.4f | product: min cos '
+          '%.4f median %.4f | loss: oracle %.6f, bf16-emulated oracle %.6f, product %.6f' % (
+              fl_k[0], fl_k[len(fl_k) // 2], pr_k[0], pr_k[len(pr_k) // 2], ref['loss'], ref16['loss'], loss0))
+  print(line)
+  if os.environ.get('PF_PARITY_REPORT'):
+    with open(os.environ['PF_PARITY_REPORT'], 'a') as f:
+      f.write(line + '\n')
+  assert len(per) == len(g32)
+  behind = {k: (per[k][1], floor[k][0]) for k in per if per[k][1] < floor[k][0] - 0.05}
+  assert not behind, 'gradients further from the float32 oracle than bf16 storage explains: %s' % sorted(behind.items())[:5]
+  assert min(v[1] for v in per.values()) >= 0.80
+  assert wc >= 0.99 and abs(wr - 1.0) <= 0.05, (wc, wr)
+  # (4) loss trajectory: 10 fine-tune steps on both sides
+  traj = []
+  for step in range(1, steps + 1):
+    o = learner.train_step()
+    r = ora.train_step(*pool[step % len(pool)])
+    traj.append((float(o['loss']), r['loss']))
+    assert abs(traj[-1][0] - traj[-1][1]) <= 1e-2 * abs(traj[-1][1]), (step, traj[-1])
+    assert abs(float(o['dst_loss']) - r['dst_loss']) <= 1e-2 * abs(r['dst_loss']) + 1e-3
+  line = '   %d-step loss trajectory, product vs oracle: max relative difference %.2e' % (steps, max(abs(a - b) / abs(b) for a, b in traj))
+  print(line)
+  if os.environ.get('PF_PARITY_REPORT'):
+    with open(os.environ['PF_PARITY_REPORT'], 'a') as f:
+      f.write(line + '\n')
+
+

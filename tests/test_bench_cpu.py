@@ -10,8 +10,14 @@ import torch
 from fake_hip import FakeHipFull
 
 
-def test_bench_main_runs_end_to_end_on_emulated_kernels(monkeypatch, capsys, tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize('config,extra', [('c2', []), ('c2a32', []), ('c1', []), ('c4', ['--resnet_size', '18']),
+                                          ('c3', ['--image_size', '64'])])
+def test_bench_main_runs_end_to_end_on_emulated_kernels(monkeypatch, capsys, tmp_path, config, extra):
   import pocketflow_amd.graph as G
+  import pocketflow_amd.learners.channel_pruning.learner as CP
   import pocketflow_amd.plan as P
   import pocketflow_amd.losses as L
   import pocketflow_amd.optim as Opt
@@ -22,7 +28,7 @@ def test_bench_main_runs_end_to_end_on_emulated_kernels(monkeypatch, capsys, tmp
   import pocketflow_amd.learners.layerwise as LW
   import bench
   fake = FakeHipFull()
-  for mod in (G, P, L, Opt, WS, NU, LW):
+  for mod in (G, P, L, Opt, WS, NU, LW, CP):
     monkeypatch.setattr(mod, 'hip', fake)
   monkeypatch.setattr(AL, 'require_gpu', lambda: torch.device('cpu'))
   monkeypatch.setattr(torch.cuda, 'synchronize', lambda *a, **k: None)
@@ -32,9 +38,13 @@ def test_bench_main_runs_end_to_end_on_emulated_kernels(monkeypatch, capsys, tmp
   monkeypatch.setattr(PR, 'enable', lambda name: None)
   monkeypatch.setattr(PR, 'summary', lambda name: (72, 7.2, 72 * 3.0e8))
   monkeypatch.setenv('TMPDIR', str(tmp_path))
-  monkeypatch.setattr(sys, 'argv', ['bench.py', '--steps', '1', '--warmup', '1', '--batch', '2', '--image_size', '32',
-                                    '--dtype', 'float32', '--no_cpu_baseline'])
-  bench.main()
+  monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', config, '--steps', '1', '--warmup', '1', '--batch', '2',
+                                    '--image_size', '32', '--dtype', 'float32', '--no_cpu_baseline'] + extra)
+  from pocketflow_amd.flags import FLAGS
+  try:
+    bench.main()
+  finally:
+    FLAGS.reset()
   out, err = capsys.readouterr()
   line = json.loads([ln for ln in out.splitlines() if ln.startswith('{')][-1])
   for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
@@ -43,6 +53,10 @@ def test_bench_main_runs_end_to_end_on_emulated_kernels(monkeypatch, capsys, tmp
   assert line['n_gpus'] == 1 and line['steps'] == 1 and line['warmup'] == 1 and line['scaling'] == 'weak'
   assert line['higher_is_better'] is True and line['vs_baseline'] is None and line['data'] == 'synthetic'
   assert line['unit'] == 'images/s' and line['value'] > 0 and 'workload' in line['config'] and 'model' not in line['config']
+  assert line['config']['name'] == config
+  want = {'c2': 'UniformQuantLearner w8/a8', 'c2a32': 'w8/a32', 'c1': 'WeightSparseLearner', 'c3': 'ChannelPrunedLearner',
+          'c4': 'NonUniformQuantLearner 4-bit'}[config]
+  assert want in line['config']['workload'], line['config']['workload']
   r = line['roofline']
   assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and r['launches'] == 72
   assert line['launch_probe']['after_warmup']['us_per_dispatch'] == 99.0 and 'memory' in line

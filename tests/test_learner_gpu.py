@@ -164,3 +164,32 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
   line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
   rec = json.loads(line)
   assert rec['n_gpus'] == 2 and rec['config']['global_batch'] == 16 and rec['value'] > 0
+  mg = rec['multi_gpu']
+  assert mg['backend'] == 'gloo' and mg['params_identical_across_ranks'] is True, mg
+  assert mg['buckets_launched_inside_backward'] > 0, mg      # the in-backward launches are armed by optimizer.backward()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs: the RCCL path of utils/multi_gpu_wrapper.py')
+def test_bench_two_gpus_over_rccl(tmp_path):
+  """bench.py --gpus 2 on the nccl (= RCCL) backend, one rank per GPU (VERDICT r2 "next" 8): after the broadcast and three
+  all-reduced Adam steps both ranks hold bit-identical parameters, and the bucketed all-reduce was launched from inside
+  backward.  Skipped on the 1-GPU boxes of the build loop; the driver's multi-GPU box runs it."""
+  import json
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, TMPDIR=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY='0', PF_ALLREDUCE_BUCKET=str(4 << 20))
+  env.pop('PF_DIST_BACKEND', None)
+  env.pop('PF_SINGLE_DEVICE', None)
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+         '127.0.0.1', '--master-port', '29541', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3',
+         '--warmup', '1', '--batch', '16', '--image_size', '64', '--no_cpu_baseline']
+  out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+  assert out.returncode == 0, out.stderr[-3000:]
+  rec = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+  mg = rec['multi_gpu']
+  print('2 x MI355X over %s: %.0f images/s, %d of %d buckets launched inside backward, %.1f MB all-reduced per step' % (
+      mg['backend'], rec['value'], mg['buckets_launched_inside_backward'], mg['buckets'], mg['allreduce_bytes_per_step'] / 1e6))
+  assert rec['n_gpus'] == 2 and mg['backend'] == 'nccl'
+  assert mg['params_identical_across_ranks'] is True
+  assert mg['buckets'] >= 2 and mg['buckets_launched_inside_backward'] > 0

@@ -27,6 +27,28 @@ TOL_BAR = 1e-3          # north_star tolerance
 TOL_WORK = 2e-5         # working tolerance for a handful of float32 steps (Momentum / frozen codebooks)
 
 
+GRAD_TOL = 1e-4         # float32 gradients, per variable, relative L2 (VERDICT r2 "next" 2a)
+
+
+def _check_gradients(learner, ora, batch, what, tol=GRAD_TOL, min_cos=None):
+  """One backward pass on both sides from the SAME state and batch, no update: d(loss)/d(variable) of the HIP learner
+  against the oracle's, variable by variable.  This is the gradient-level bar the Adam-bounded weight comparison below
+  cannot give (Adam moves every element by ~lr whatever its gradient: a backward pass with wrong signs would pass it)."""
+  from parity_common import product_gradients, compare_gradients, gradient_report
+  out, hg = product_gradients(learner)
+  ref, og = ora.compute_grads(*batch)
+  loss = float(out['loss'] if isinstance(out, dict) else out[1])
+  assert abs(loss - ref['loss']) <= 2e-4 * max(1.0, abs(ref['loss'])), (what, loss, ref['loss'])
+  per, wc, wr = compare_gradients(hg, ora, og, what)
+  worst_l2, worst_cos = gradient_report(per, wc, wr, what)
+  assert len(per) >= len(og) - len(getattr(ora.student.quant, 'codebooks', {})), 'variables without a gradient comparison'
+  assert worst_l2[1][0] <= tol, '%s: gradient of %s differs by %.3e (relative L2)' % (what, worst_l2[0], worst_l2[1][0])
+  if min_cos is not None:
+    assert worst_cos[1][1] >= min_cos
+  assert abs(wr - 1.0) <= 10 * tol
+  return per
+
+
 def adam_tol(steps, lr):
   """Adam moves every element by ~lr per step whatever the gradient's scale, so an element whose true
   gradient is ~0 follows the SIGN of float32 summation noise: two correct implementations may differ by
@@ -99,7 +121,10 @@ def test_uq_lenet_steps_match_oracle(tmp_path, use_buckets, bucket_type, bits):
   ora = OracleLearner(init, cfg, learner.lrn_rate)
   assert ora.n_matmul == 4 and ora.n_act == 3
   pool = _pool(learner.iter_train)
-  for step in range(4):
+  # 8-bit activations: a rounding-boundary flip changes a gradient element by a whole STE gate; LeNet is shallow enough
+  # that the flips of one batch stay below 1e-3 of a variable's gradient norm
+  _check_gradients(learner, ora, pool[0], 'LeNet UQ w%d/a8 %s' % (bits, bucket_type if use_buckets else 'per-tensor'), tol=2e-3)
+  for step in range(1, 5):
     out = learner.train_step()
     ref = ora.train_step(*pool[step % len(pool)])
     assert abs(float(out['loss']) - ref['loss']) <= 1e-4 * max(1.0, abs(ref['loss'])), step
@@ -133,7 +158,11 @@ def test_uq_resnet20_distillation_matches_oracle(tmp_path, a_bits, loss_tol, bul
   ora = OracleLearner(init, cfg, learner.lrn_rate)
   assert ora.n_matmul == 23 and ora.n_act == 19
   pool = _pool(learner.iter_train)
-  for step in range(3):
+  if a_bits == 32:                               # the continuous path: float32 gradients variable by variable
+    _check_gradients(learner, ora, pool[0], 'ResNet-20 UQ w8/a32 + dst')
+  else:
+    learner.iter_train.get_next()                # keep both branches on the same batch sequence
+  for step in range(1, 4):
     out = learner.train_step()
     ref = ora.train_step(*pool[step % len(pool)])
     assert abs(float(out['loss']) - ref['loss']) <= loss_tol * max(1.0, abs(ref['loss'])), (step, float(out['loss']), ref['loss'])
@@ -277,7 +306,11 @@ def test_uq_resnet50_distillation_matches_oracle(tmp_path, image_size, a_bits, s
   assert ora.n_matmul == 54 and ora.n_act == 49          # 54 -> 52 quantised matmuls, 49 ReLUs
   assert sum(b is not None for b in ora.student.quant.w_bits) == 52
   pool = _pool(learner.iter_train)
-  for step in range(steps):
+  if a_bits == 32:
+    _check_gradients(learner, ora, pool[0], 'ResNet-50 UQ w8/a32 + dst @%d B=32' % image_size)
+  else:
+    learner.iter_train.get_next()
+  for step in range(1, steps + 1):
     out = learner.train_step()
     ref = ora.train_step(*pool[step % len(pool)])
     assert abs(float(out['loss']) - ref['loss']) <= loss_tol * max(1.0, abs(ref['loss'])), (step, float(out['loss']), ref['loss'])
@@ -295,6 +328,23 @@ def test_uq_resnet50_distillation_matches_oracle(tmp_path, image_size, a_bits, s
       if e > worst:
         worst, where = e, k
   assert worst <= moving_tol, (where, worst)
+
+
+def test_uq_resnet50_bf16_fused_path_matches_oracle_within_bf16_noise(tmp_path):
+  """The mode bench.py measures -- bf16 storage, BN / ReLU / fake-quant prologues and residual / statistics epilogues fused
+  into the in-tree convolution kernels (k_igemm*, k_conv1x1_stream, k_wrw2, k_stem7x7*) -- against the float32 oracle
+  learner at STEP level (VERDICT r2 "weak" #1, "next" 2b): BASELINE configs[2] shrunk to 64x64, batch 16, w8/a8 +
+  distillation, from a conditioned state (tests/bf16_noise_probe.py: damped residual branches and classifier, BN moving
+  statistics calibrated, the student moved 5 % away from its teacher).
+
+  What can be asked of ANY bf16 implementation is measured in the same test: the oracle is run a second time with every
+  tensor the bf16 mode keeps in HBM rounded to bf16 on the way (forward and backward).  Its per-variable gradient cosine
+  against the float32 oracle is the noise floor (0.93-0.98 per kernel: tests/bf16_noise_probe.py on the CPU); the product
+  has to stay within 0.05 of it variable by variable, the concatenated gradient within cosine 0.99 and 5 % in norm, the
+  step-0 loss within 5e-3 and a 10-step loss trajectory within 1 %.  The numbers are appended to $PF_PARITY_REPORT."""
+  from parity_common import run_bf16_fused_parity
+  FLAGS = _setup(tmp_path)
+  run_bf16_fused_parity(FLAGS, tmp_path, steps=10, expect_bf16=True)
 
 
 def test_nuq_resnet50_4bit_distillation_matches_oracle(tmp_path):

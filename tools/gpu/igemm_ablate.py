@@ -1,0 +1,64 @@
+"""Where does the time of the implicit-GEMM kernel go?  pf_conv2d_fwd of the product library next to three ABLATION builds of
+pf_igemm.hip (tools/gpu/build_ablate.sh -> tools/gpu/_build/libig_ablate{1,2,3}.so):
+  full  the product kernel
+  fill  -DPF_IG_ABLATE=1: LDS-DMA + barriers only (no fragment reads, no MFMAs)
+  comp  -DPF_IG_ABLATE=2: fragment reads + MFMAs + barriers (no LDS-DMA)
+  mfma  -DPF_IG_ABLATE=3: MFMAs + barriers (no LDS-DMA, no fragment reads)
+per ResNet-50 shape (B = 256) and tile (PF_IGEMM_TILE).  LDS-fill traffic per launch = tiles x k-steps x stage bytes is printed
+beside the times: 'fill TB/s' = that traffic / the fill-only time."""
+import ctypes, os, sys
+from ctypes import c_int, c_void_p
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from pocketflow_amd import hip
+
+here = os.path.dirname(os.path.abspath(__file__))
+libs = {'full': hip._lib}
+for n, name in ((1, 'fill'), (2, 'comp'), (3, 'mfma')):
+  libs[name] = ctypes.CDLL(os.path.join(here, '_build', 'libig_ablate%d.so' % n))
+
+
+def timeit(fn, n=10):
+  for _ in range(3): fn()
+  torch.cuda.synchronize()
+  a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+  a.record()
+  for _ in range(n): fn()
+  b.record(); torch.cuda.synchronize()
+  return a.elapsed_time(b) / n * 1e3
+
+
+def call(lib, x, w, y, z, B, H, C, N, k, s, pad, Ho):
+  st = c_void_p(torch.cuda.current_stream().cuda_stream)
+  p = lambda t: c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+  r = lib.pf_conv2d_fwd(p(x), p(w), p(y), p(z), p(None), p(None), p(None), p(None), p(None), c_int(0), c_int(B), c_int(H), c_int(H),
+                        c_int(C), c_int(N), c_int(k), c_int(k), c_int(s), c_int(pad), c_int(pad), c_int(Ho), c_int(Ho), st)
+  assert r == 0, r
+
+
+B = int(os.environ.get('B', 256))
+shapes = [(56, 64, 64, 3, 1), (28, 128, 128, 3, 1), (14, 256, 256, 3, 1), (7, 512, 512, 3, 1), (14, 1024, 256, 1, 1), (14, 256, 1024, 1, 1)]
+tiles = os.environ.get('TILES', '128x128,256x128,256x256,128x64').split(',')
+print('%-18s %-8s | %8s %8s %8s %8s | %9s %9s | %s' % ('H,C,N,k,s', 'tile', 'full us', 'fill us', 'comp us', 'mfma us', 'fill MB', 'fill TB/s', 'TF full'))
+for H, C, N, k, s in shapes:
+  g = torch.Generator(device='cuda').manual_seed(H + C + N)
+  x = torch.randn(B, H, H, C, device='cuda', generator=g).bfloat16()
+  w = (torch.randn(N, k, k, C, device='cuda', generator=g) * 0.05).bfloat16()
+  pad = (k - 1) // 2
+  Ho = (H + 2 * pad - k) // s + 1
+  y = torch.empty(B, Ho, Ho, N, device='cuda', dtype=torch.bfloat16)
+  z = hip.zero_page(x.device)
+  M = B * Ho * Ho
+  for t in tiles:
+    bm, bn = (int(v) for v in t.split('x'))
+    if N % bn:
+      continue
+    os.environ['PF_IGEMM_TILE'] = t
+    ts = {name: timeit(lambda: call(lib, x, w, y, z, B, H, C, N, k, s, pad, Ho)) for name, lib in libs.items()}
+    ntile = ((M + bm - 1) // bm) * (N // bn)
+    steps = k * k * C // 64
+    mb = ntile * steps * (bm + bn) * 128 / 1e6
+    print('%-18s %-8s | %8.0f %8.0f %8.0f %8.0f | %9.0f %9.1f | %5.0f' % (
+        '%d,%d,%d,%d,%d' % (H, C, N, k, s), t, ts['full'], ts['fill'], ts['comp'], ts['mfma'], mb, mb / ts['fill'],
+        2.0 * M * N * C * k * k / ts['full'] * 1e-6))
+os.environ.pop('PF_IGEMM_TILE', None)

@@ -1,0 +1,29 @@
+# gpurun payloads of round 3, by name:  gpurun --timeout N -- 'bash tools/gpu/r03_call.sh <name>'
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+# bench.py JSON line (file $2) -> one summary line tagged $1
+bench_line() { python -c "
+import json, sys
+for ln in open(sys.argv[2]):
+    if not ln.startswith('{'): continue
+    d = json.loads(ln)
+    print(sys.argv[1], round(d['value']), 'img/s', round(d['ms_per_step'], 2), 'ms/step | host submit', d.get('host_submit_ms_min_median_max'), '| roofline frac', d.get('roofline', {}).get('frac'))
+" "$1" "$2"; }
+run_bench() {  # $1 tag, rest: bench.py arguments
+  tag=$1; shift
+  timeout 400 python bench.py "$@" > gpurun_out/r03_bench_$tag.json 2> gpurun_out/r03_bench_$tag.err || tail -5 gpurun_out/r03_bench_$tag.err
+  bench_line $tag gpurun_out/r03_bench_$tag.json
+}
+case "$1" in
+c1)
+  # new prologue arithmetic + 3-stage prologue kernel: numerics, per-layer A/B, ablation of the plain kernel, step A/B
+  timeout 900 python -m pytest tests/test_conv_gpu.py tests/test_igemm_gpu.py -m gpu -q --tb=short -x 2>&1 | tail -25 | cut -c1-400 > gpurun_out/r03_c1_pytest.log
+  tail -8 gpurun_out/r03_c1_pytest.log
+  timeout 300 python tools/gpu/pro_bench.py > gpurun_out/r03_c1_pro_bench.log 2>&1; cat gpurun_out/r03_c1_pro_bench.log
+  timeout 400 python tools/gpu/igemm_ablate.py > gpurun_out/r03_c1_ablate.log 2>&1; cat gpurun_out/r03_c1_ablate.log
+  PF_IGEMM_PRO3=1 run_bench c1_pro3 --steps 10 --warmup 5 --no_cpu_baseline
+  PF_IGEMM_PRO3=0 run_bench c1_pro2 --steps 10 --warmup 5 --no_cpu_baseline
+  ;;
+*) echo "unknown payload $1"; exit 2;;
+esac
