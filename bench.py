@@ -97,13 +97,16 @@ CONFIGS = {
 }
 
 
-def build_learner(args, FLAGS, tmp, rank, world, barrier):
-  """(learner, step function) of the configuration: the learner classes, flags and entry points are the ones
-  nets/*_run.py would use; only the data are synthetic and the start checkpoint is seeded."""
-  import numpy as np
-  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+def set_flags(args, tmp, world):
+  """Import the modules of the configuration (importing DEFINES their flags, as in the reference) and assign the flag
+  values of the run.  Needs no GPU: tests/test_bench_cpu.py runs it in a fresh interpreter for every configuration.
+  Returns (ModelHelper class, Learner class)."""
+  from pocketflow_amd.flags import FLAGS
+  import pocketflow_amd.learners.abstract_learner  # noqa: F401
+  import pocketflow_amd.learners.learner_utils  # noqa: F401
   cfg = CONFIGS[args.config]
   kind = cfg['learner']
+  FLAGS.enbl_multi_gpu = world > 1
   # importing the modules DEFINES their flags (as in the reference); values are assigned afterwards
   import pocketflow_amd.learners.distillation_helper  # noqa: F401
   if cfg['model'] == 'resnet':
@@ -121,7 +124,8 @@ def build_learner(args, FLAGS, tmp, rank, world, barrier):
   else:
     from pocketflow_amd.learners.channel_pruning.learner import ChannelPrunedLearner as Learner
   FLAGS.nb_classes = cfg['nb_classes']
-  FLAGS.image_size = args.image_size
+  if cfg['model'] != 'resnet_cifar':
+    FLAGS.image_size = args.image_size        # (the CIFAR-10 pipeline has a fixed 32 x 32 input and no such flag)
   FLAGS.batch_size = args.batch
   FLAGS.compute_dtype = args.dtype
   FLAGS.enbl_dst = cfg['dst']
@@ -145,6 +149,17 @@ def build_learner(args, FLAGS, tmp, rank, world, barrier):
     FLAGS.cp_best_path = os.path.join(tmp, 'models', 'best_model.ckpt')
     FLAGS.cp_original_path = os.path.join(tmp, 'models', 'original_model.ckpt')
     FLAGS.cp_lrn_rate_ft = 1e-4
+  return ModelHelper, Learner
+
+
+def build_learner(args, FLAGS, tmp, rank, world, barrier):
+  """(learner, step function) of the configuration: the learner classes, flags and entry points are the ones
+  nets/*_run.py would use; only the data are synthetic and the start checkpoint is seeded."""
+  import numpy as np
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  cfg = CONFIGS[args.config]
+  kind = cfg['learner']
+  ModelHelper, Learner = set_flags(args, tmp, world)
   mh = ModelHelper()
   if rank == 0:
     create_synthetic_checkpoint(mh)
@@ -277,8 +292,8 @@ def main():
     tmp = os.path.join(tempfile.gettempdir(), 'pf_bench_' + ''.join(c if c.isalnum() else '_' for c in tag))
   else:
     tmp = tempfile.mkdtemp(prefix='pf_bench_')
-  FLAGS.enbl_multi_gpu = world > 1
   if world > 1:
+    import pocketflow_amd.learners.abstract_learner  # noqa: F401  (defines enbl_multi_gpu & co. before mgw reads flags)
     mgw.init()
     if rank == 0:
       shutil.rmtree(tmp, ignore_errors=True)

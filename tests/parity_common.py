@@ -206,10 +206,10 @@ def run_cp_masked_finetune(FLAGS, tmp_path, optimizer, steps=3, report=None):
   assert worst <= 1e-3, (where, worst)
 
 
-def run_bf16_fused_parity(FLAGS, tmp_path, steps=10, expect_bf16=True):
-  """Body of tests/test_parity_gpu.py::test_uq_resnet50_bf16_fused_path_matches_oracle_within_bf16_noise (see its
-  docstring); `expect_bf16=False` runs the same body in float32 (CPU emulation: tests/test_learners_cpu.py)."""
-
+def conditioned_uq_resnet50(FLAGS, tmp_path, a_bits=8, compute_dtype='bfloat16'):
+  """UniformQuantLearner on ResNet-v2-50 (64x64, batch 16, w8 / a`a_bits` + distillation) from the conditioned state of
+  tests/bf16_noise_probe.py -- damped residual branches and classifier, calibrated BN moving statistics, the student moved
+  5 % off its teacher -- plus the oracle learner on the same state.  Returns (learner, oracle, batch pool)."""
   from oracle.learner_oracle import OracleLearner
   import oracle.learner_oracle as LO
   from bf16_noise_probe import conditioned_resnet50_state, moved_student, _R16, cosines
@@ -218,11 +218,11 @@ def run_bf16_fused_parity(FLAGS, tmp_path, steps=10, expect_bf16=True):
   from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
   from pocketflow_amd.utils import checkpoint
   import os
-  for k, v in dict(batch_size=16, batch_size_eval=16, uql_weight_bits=8, uql_activation_bits=8,
+  for k, v in dict(batch_size=16, batch_size_eval=16, uql_weight_bits=8, uql_activation_bits=a_bits,
                    enbl_dst=True, dst_eval_teacher=False, save_path_dst=str(tmp_path / 'models_dst' / 'model.ckpt'),
                    uql_save_quant_model_path=str(tmp_path / 'uql' / 'm.ckpt'), nb_eval_batches_override=1,
                    resnet_size=50, nb_classes=1001, image_size=64, uql_use_buckets=False,
-                   compute_dtype='bfloat16' if expect_bf16 else 'float32').items():
+                   compute_dtype=compute_dtype).items():
     setattr(FLAGS, k, v)
   mh = ModelHelper()
   create_synthetic_checkpoint(mh)
@@ -232,17 +232,29 @@ def run_bf16_fused_parity(FLAGS, tmp_path, steps=10, expect_bf16=True):
   cond = conditioned_resnet50_state(checkpoint.load(prefix), calib, branch_scale=0.1, dense_scale=0.2)
   checkpoint.save(cond, FLAGS.save_path, 0)
   learner = UniformQuantLearner(None, mh)                 # student AND teacher restore the conditioned checkpoint
-  if expect_bf16:
-    assert learner.graph.compute_dtype == torch.bfloat16 and learner.graph.fuse_conv1x1
   learner.graph.store.load_numpy(moved_student(cond, 0.05))
   init = learner.graph.store.export_numpy()
   tvals = learner.helper_dst.learner.graph.store.export_numpy()
   assert all(k.startswith('distilled_model/') for k in tvals)
   cfg = dict(model='resnet', dataset='ilsvrc_12', resnet_size=50, nb_classes=1001, loss_w_dcy=FLAGS.loss_w_dcy, enbl_dst=True,
              loss_w_dst=FLAGS.loss_w_dst, tempr_dst=FLAGS.tempr_dst, momentum=FLAGS.momentum, image_shape=(64, 64, 3),
-             learner='uniform', uql_weight_bits=8, uql_activation_bits=8, uql_use_buckets=False)
+             learner='uniform', uql_weight_bits=8, uql_activation_bits=a_bits, uql_use_buckets=False)
   ora = OracleLearner(init, cfg, learner.lrn_rate, teacher_values=tvals)
   pool = _pool(learner.iter_train)
+  return learner, ora, pool, init, tvals, cfg
+
+
+def run_bf16_fused_parity(FLAGS, tmp_path, steps=10, expect_bf16=True):
+  """Body of tests/test_parity_gpu.py::test_uq_resnet50_bf16_fused_path_matches_oracle_within_bf16_noise (see its
+  docstring); `expect_bf16=False` runs the same body in float32 (CPU emulation: tests/test_learners_cpu.py)."""
+
+  from oracle.learner_oracle import OracleLearner
+  import oracle.learner_oracle as LO
+  from bf16_noise_probe import _R16, cosines
+  import os
+  learner, ora, pool, init, tvals, cfg = conditioned_uq_resnet50(FLAGS, tmp_path, 8, 'bfloat16' if expect_bf16 else 'float32')
+  if expect_bf16:
+    assert learner.graph.compute_dtype == torch.bfloat16 and learner.graph.fuse_conv1x1
   # (1) float32 oracle, (2) the oracle with bf16 storage emulated, (3) the product: one backward each, same state and batch
   ref, g32 = ora.compute_grads(*pool[0])
   o_conv, o_act, o_qw = LO.Scope.conv2d, LO.Scope.activation, LO.Scope._quant_weight

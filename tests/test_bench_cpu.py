@@ -61,3 +61,19 @@ def test_bench_main_runs_end_to_end_on_emulated_kernels(monkeypatch, capsys, tmp
   assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and r['launches'] == 72
   assert line['launch_probe']['after_warmup']['us_per_dispatch'] == 99.0 and 'memory' in line
   assert 'host-bound process' in err and 'tottime' in err          # the self-diagnosis printed its profile
+
+
+@pytest.mark.parametrize('config', ['c1', 'c2', 'c2a32', 'c3', 'c4'])
+def test_bench_flag_setup_in_a_fresh_interpreter(config, tmp_path):
+  """bench.py assigns reference flags that only exist once the module defining them was imported; in a fresh process
+  (how the driver runs it) nothing else has imported them.  (Round 3, GPU call 2: `Unknown command line flag
+  'enbl_multi_gpu'` -- the in-process test above had passed because other tests' imports had defined the flag.)"""
+  import os
+  import subprocess
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  code = ('import sys; sys.argv = ["bench.py", "--config", %r]; sys.path.insert(0, %r); import bench; '
+          'a = bench.parse_args(); mh, ln = bench.set_flags(a, %r, 1); '
+          'from pocketflow_amd.flags import FLAGS; print("OK", mh.__name__, ln.__name__, FLAGS.batch_size, FLAGS.enbl_multi_gpu)'
+          % (config, root, str(tmp_path)))
+  out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+  assert out.returncode == 0 and 'OK ModelHelper' in out.stdout, out.stderr[-2000:]

@@ -25,5 +25,24 @@ c1)
   PF_IGEMM_PRO3=1 run_bench c1_pro3 --steps 10 --warmup 5 --no_cpu_baseline
   PF_IGEMM_PRO3=0 run_bench c1_pro2 --steps 10 --warmup 5 --no_cpu_baseline
   ;;
+c2)
+  # full GPU suite (new gradient-level parity tests; report lines -> gpurun_out/r03_parity_report.txt), the headline bench with
+  # the 3-stage prologue kernel on and off, and the other concrete runs of SURVEY 8(d)
+  rm -f gpurun_out/r03_parity_report.txt
+  PF_PARITY_REPORT=$GRAFT_REPO_ROOT/gpurun_out/r03_parity_report.txt timeout 2400 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -40 | cut -c1-600 > gpurun_out/r03_c2_pytest.log
+  tail -12 gpurun_out/r03_c2_pytest.log; cat gpurun_out/r03_parity_report.txt
+  PF_IGEMM_PRO3=1 run_bench c2_pro3 --steps 15 --warmup 5 --no_cpu_baseline
+  PF_IGEMM_PRO3=0 run_bench c2_pro2 --steps 15 --warmup 5 --no_cpu_baseline
+  for c in c2a32 c4 c3 c1; do run_bench cfg_$c --config $c --steps 10 --warmup 4 --no_cpu_baseline; done
+  ;;
+c3)
+  # the step-level parity tests (gradient level) + the 2-rank bench test, then the benches of all configurations
+  rm -f gpurun_out/r03_parity_report.txt
+  PF_PARITY_REPORT=$GRAFT_REPO_ROOT/gpurun_out/r03_parity_report.txt timeout 1800 python -m pytest tests/test_parity_gpu.py tests/test_learner_gpu.py -m gpu -q --tb=short 2>&1 | tail -30 | cut -c1-600 > gpurun_out/r03_c3_pytest.log
+  tail -8 gpurun_out/r03_c3_pytest.log; cat gpurun_out/r03_parity_report.txt
+  PF_IGEMM_PRO3=1 run_bench c2_pro3 --steps 15 --warmup 5 --no_cpu_baseline
+  PF_IGEMM_PRO3=0 run_bench c2_pro2 --steps 15 --warmup 5 --no_cpu_baseline
+  for c in c2a32 c4 c3 c1; do run_bench cfg_$c --config $c --steps 10 --warmup 4 --no_cpu_baseline; done
+  ;;
 *) echo "unknown payload $1"; exit 2;;
 esac
