@@ -313,6 +313,22 @@ int pf_conv_stem_wrw_slabs(int imgs, int H, int Wd);
 int pf_conv_stem_wrw(const void* dY, const void* X, void* dW, int dw_dtype, float* workspace, int imgs, int H, int Wd,
                      void* stream);
 
+/* ---- K12 (MobileNet): depthwise 3x3 convolutions, NHWC float32 / bf16, kernel [C][3][3] in the activation dtype ----------
+ * replaces DepthwiseConv2dNative / ...BackpropInput / ...BackpropFilter behind slim.separable_conv2d(num_outputs=None)
+ * (utils/external/mobilenet_v1.py:264-292).  stride 1 | 2; pad_h / pad_w are TensorFlow's FRONT pads of 'SAME'
+ * (floor(total / 2); the rest behind is implied by Ho / Wo).  C % 8 == 0 and 256 % (C / 8) == 0 (pf_depthwise_supported).
+ * pf_depthwise_fwd: partial (may be NULL) receives the per-channel {sum, sum of squares, min, max} of the stored outputs,
+ * [G][4][C] with G = pf_depthwise_groups(B, Ho, Wo, C) -- the statistics of the BatchNorm behind the layer (pf_bn_finalize).
+ * pf_depthwise_wrw: slabs = workspace of pf_depthwise_groups(B, Ho, Wo, C) * C * 9 floats; fixed-order reduction.        */
+int pf_depthwise_supported(int C, int k, int stride);
+int pf_depthwise_groups(int B, int Ho, int Wo, int C);
+int pf_depthwise_fwd(const void* X, const void* W, void* Y, int dtype, float* partial, int B, int H, int Wd, int C, int k,
+                     int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream);
+int pf_depthwise_bwd_data(const void* dY, const void* W, void* dX, int dtype, int B, int H, int Wd, int C, int k,
+                          int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream);
+int pf_depthwise_wrw(const void* dY, const void* X, void* dW, int dtype, int dw_dtype, float* slabs, int B, int H, int Wd,
+                     int C, int k, int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream);
+
 /* ---- K13: input pipeline tail -----------------------------------------------------------
  * replaces, per image, the preprocessing chain of utils/external/imagenet_preprocessing.py:226-260 behind the JPEG
  * decoder: training  random_flip_left_right -> tf.image.resize_images(BILINEAR, align_corners=False) -> - means;

@@ -1,0 +1,359 @@
+// K12 for MobileNet-v1: the depthwise 3x3 convolutions (DepthwiseConv2dNative, utils/external/mobilenet_v1.py:264-292 =
+// slim.separable_conv2d(num_outputs=None)), forward, backward-data and backward-filter, NHWC activations, kernels stored
+// [C][kh][kw] (graph.Variable 'depthwise': CRS).  The reference pads 'SAME' the TensorFlow way: total = max((out-1)*stride
+// + k - in, 0), floor(total / 2) in FRONT and the rest behind -- asymmetric for stride 2 on even sizes (0 in front, 1 behind),
+// so the kernels take the front pads and bound-check both sides.
+//
+//   y [b][ho][wo][c] = sum_{r,s} x[b][ho*st + r - ph][wo*st + s - pw][c] * w[c][r][s]
+//   dx[b][hi][wi][c] = sum_{r,s : (hi + ph - r) % st == 0, (wi + pw - s) % st == 0} dy[b][(hi+ph-r)/st][(wi+pw-s)/st][c] * w[c][r][s]
+//   dw[c][r][s]      = sum_{b,ho,wo} dy[b][ho][wo][c] * x[b][ho*st + r - ph][wo*st + s - pw][c]
+//
+// MI355X mapping.  One multiply-add per loaded element: these are HBM-bound layers (1 read + 1 write of the activation per
+// pass; MobileNet-v1 at batch 256 moves 5.0 M elements per image through them), there is nothing for the matrix cores.
+// A lane owns 8 consecutive channels (one 16-byte vector) and walks STRIPS of 4 output pixels of one row, so that
+// consecutive lanes read consecutive 16-byte groups of one pixel (coalesced 64 B .. 2 KiB runs) and the 3 x (3 + 3*st)
+// input vectors of a strip are loaded once for its 4 outputs; the vertical re-use between rows and the horizontal halo
+// between strips are served by the L1 / L2 (the input tensor is read once from HBM).  The 72 kernel taps of the lane's
+// channels live in registers for the whole launch.  The forward kernel leaves the per-channel {sum, sum of squares, min,
+// max} of the values it stored (the statistics the BatchNorm behind every depthwise layer needs, mobilenet_v1.py:279-292)
+// in partial[G][4][C], reduced in a fixed order: one pass over the tensor less per layer, deterministic.  Backward-filter
+// keeps 9 x 8 float32 accumulators per lane, combines the lanes of a workgroup through LDS and writes one [C][9] slab per
+// workgroup; a second launch adds the slabs in a fixed order (bit-reproducible, like pf_wrw_reduce).
+#include "pf_common.h"
+
+#define DW_T 256
+#define DW_PW 4
+
+struct DwArgs {
+  const void* x;       // fwd: input; bwd-data: dy; wrw: x
+  const void* w;       // [C][3][3] in the activation dtype (bwd-data: the caller passes the kernel FLIPPED for stride 1)
+  void* y;             // fwd: output; bwd-data: dx
+  const void* dy;      // wrw only
+  float* partial;      // fwd: [G][4][C] statistics or null; wrw: [G][C][9] slabs
+  int B, H, W, C, Ho, Wo, stride, ph, pw;
+  int flip;            // forward kernel used as stride-1 backward-data: taps read in reverse order
+  int strips_w;        // strips per output row
+  int64_t total;       // strips in the tensor
+};
+
+template <typename T> __device__ __forceinline__ float dw_round(float v);
+template <> __device__ __forceinline__ float dw_round<float>(float v) { return v; }
+template <> __device__ __forceinline__ float dw_round<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+
+// forward (and stride-1 backward-data, which is the same sum over the flipped kernel with front pads k-1-p)
+template <typename T, int ST>
+__global__ __launch_bounds__(DW_T) void k_dw_fwd(const DwArgs a) {
+  __shared__ float red[4 * DW_T * 8];
+  const int C8 = a.C >> 3, SPB = DW_T / C8;
+  const int cg = threadIdx.x % C8, sl = threadIdx.x / C8;
+  const T* __restrict__ x = (const T*)a.x;
+  const T* __restrict__ w = (const T*)a.w;
+  T* __restrict__ y = (T*)a.y;
+  float wr[9][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[t][j] = load_one<T>(w + (int64_t)(cg * 8 + j) * 9 + (a.flip ? 8 - t : t));
+  float st_s[8], st_q[8], st_mn[8], st_mx[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; st_mn[j] = INFINITY; st_mx[j] = -INFINITY; }
+  constexpr int NV = (DW_PW - 1) * ST + 3;
+  for (int64_t strip = (int64_t)blockIdx.x * SPB + sl; strip < a.total; strip += (int64_t)gridDim.x * SPB) {
+    const int sw = (int)(strip % a.strips_w);
+    const int64_t t = strip / a.strips_w;
+    const int ho = (int)(t % a.Ho), b = (int)(t / a.Ho);
+    const int wo0 = sw * DW_PW;
+    float acc[DW_PW][8];
+#pragma unroll
+    for (int p = 0; p < DW_PW; ++p)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[p][j] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int hi = ho * ST + r - a.ph;
+      if ((unsigned)hi >= (unsigned)a.H) continue;
+      const T* row = x + ((int64_t)(b * a.H + hi) * a.W) * a.C + cg * 8;
+      float v[NV][8];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int wi = wo0 * ST - a.pw + i;
+        if ((unsigned)wi < (unsigned)a.W) load8<T>(row + (int64_t)wi * a.C, v[i]);
+        else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < DW_PW; ++p)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[p][j] = fmaf(v[p * ST + s][j], wr[r * 3 + s][j], acc[p][j]);
+    }
+#pragma unroll
+    for (int p = 0; p < DW_PW; ++p) {
+      if (wo0 + p >= a.Wo) continue;
+      store8<T>(y + ((int64_t)(b * a.Ho + ho) * a.Wo + wo0 + p) * a.C + cg * 8, acc[p]);
+      if (a.partial != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = dw_round<T>(acc[p][j]);                 // statistics see the stored values
+          st_s[j] += f;
+          st_q[j] = fmaf(f, f, st_q[j]);
+          st_mn[j] = fminf(st_mn[j], f);
+          st_mx[j] = fmaxf(st_mx[j], f);
+        }
+      }
+    }
+  }
+  if (a.partial != nullptr) {
+    // lanes with equal channel group (sl = 0 .. SPB-1) -> one row of partial, fixed order
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[(0 * SPB + sl) * a.C + cg * 8 + j] = st_s[j];
+      red[(1 * SPB + sl) * a.C + cg * 8 + j] = st_q[j];
+      red[(2 * SPB + sl) * a.C + cg * 8 + j] = st_mn[j];
+      red[(3 * SPB + sl) * a.C + cg * 8 + j] = st_mx[j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4 * a.C; i += DW_T) {
+      const int stat = i / a.C, c = i - stat * a.C;
+      float v = red[(stat * SPB) * a.C + c];
+      for (int k = 1; k < SPB; ++k) {
+        const float u = red[(stat * SPB + k) * a.C + c];
+        v = (stat < 2) ? (v + u) : (stat == 2 ? fminf(v, u) : fmaxf(v, u));
+      }
+      a.partial[((int64_t)blockIdx.x * 4 + stat) * a.C + c] = v;
+    }
+  }
+}
+
+// backward-data for any stride (gather form): one lane = 8 channels of one INPUT pixel
+template <typename T>
+__global__ __launch_bounds__(DW_T) void k_dw_bwd_data(const DwArgs a) {
+  const int C8 = a.C >> 3, SPB = DW_T / C8;
+  const int cg = threadIdx.x % C8, sl = threadIdx.x / C8;
+  const T* __restrict__ dy = (const T*)a.x;
+  const T* __restrict__ w = (const T*)a.w;
+  T* __restrict__ dx = (T*)a.y;
+  float wr[9][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[t][j] = load_one<T>(w + (int64_t)(cg * 8 + j) * 9 + t);
+  const int64_t npix = (int64_t)a.B * a.H * a.W;
+  for (int64_t pix = (int64_t)blockIdx.x * SPB + sl; pix < npix; pix += (int64_t)gridDim.x * SPB) {
+    const int wi = (int)(pix % a.W);
+    const int64_t t = pix / a.W;
+    const int hi = (int)(t % a.H), b = (int)(t / a.H);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int th = hi + a.ph - r;
+      if (th < 0 || th % a.stride) continue;
+      const int ho = th / a.stride;
+      if (ho >= a.Ho) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int tw = wi + a.pw - s;
+        if (tw < 0 || tw % a.stride) continue;
+        const int wo = tw / a.stride;
+        if (wo >= a.Wo) continue;
+        float g[8];
+        load8<T>(dy + ((int64_t)(b * a.Ho + ho) * a.Wo + wo) * a.C + cg * 8, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(g[j], wr[r * 3 + s][j], acc[j]);
+      }
+    }
+    store8<T>(dx + pix * a.C + cg * 8, acc);
+  }
+}
+
+// backward-filter: strips of 4 output pixels as in the forward kernel; slab [G][C][9]
+template <typename T, int ST>
+__global__ __launch_bounds__(DW_T) void k_dw_wrw(const DwArgs a) {
+  __shared__ float red[DW_T * 8];                       // one tap at a time: [SPB][C]
+  const int C8 = a.C >> 3, SPB = DW_T / C8;
+  const int cg = threadIdx.x % C8, sl = threadIdx.x / C8;
+  const T* __restrict__ x = (const T*)a.x;
+  const T* __restrict__ dy = (const T*)a.dy;
+  float acc[9][8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+  constexpr int NV = (DW_PW - 1) * ST + 3;
+  for (int64_t strip = (int64_t)blockIdx.x * SPB + sl; strip < a.total; strip += (int64_t)gridDim.x * SPB) {
+    const int sw = (int)(strip % a.strips_w);
+    const int64_t t = strip / a.strips_w;
+    const int ho = (int)(t % a.Ho), b = (int)(t / a.Ho);
+    const int wo0 = sw * DW_PW;
+    float g[DW_PW][8];
+#pragma unroll
+    for (int p = 0; p < DW_PW; ++p) {
+      if (wo0 + p < a.Wo) load8<T>(dy + ((int64_t)(b * a.Ho + ho) * a.Wo + wo0 + p) * a.C + cg * 8, g[p]);
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[p][j] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int hi = ho * ST + r - a.ph;
+      if ((unsigned)hi >= (unsigned)a.H) continue;
+      const T* row = x + ((int64_t)(b * a.H + hi) * a.W) * a.C + cg * 8;
+      float v[NV][8];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int wi = wo0 * ST - a.pw + i;
+        if ((unsigned)wi < (unsigned)a.W) load8<T>(row + (int64_t)wi * a.C, v[i]);
+        else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < DW_PW; ++p)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[r * 3 + s][j] = fmaf(g[p][j], v[p * ST + s][j], acc[r * 3 + s][j]);
+    }
+  }
+  float* slab = a.partial + (int64_t)blockIdx.x * a.C * 9;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[sl * a.C + cg * 8 + j] = acc[t][j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < a.C; c += DW_T) {
+      float v = red[c];
+      for (int k = 1; k < SPB; ++k) v += red[k * a.C + c];
+      slab[(int64_t)c * 9 + t] = v;
+    }
+    __syncthreads();
+  }
+}
+
+template <typename TO>
+__global__ __launch_bounds__(DW_T) void k_dw_wrw_reduce(const float* __restrict__ slabs, int G, int n, TO* __restrict__ dw) {
+  const int e = blockIdx.x * DW_T + threadIdx.x;
+  if (e >= n) return;
+  float v = 0.f;
+  for (int g = 0; g < G; ++g) v += slabs[(int64_t)g * n + e];
+  store_one<TO>(dw + e, v);
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+static bool dw_shape_ok(int C, int k) { return k == 3 && C >= 8 && (C % 8) == 0 && C <= 2048 && (DW_T % (C / 8)) == 0; }
+
+extern "C" int pf_depthwise_supported(int C, int k, int stride) { return (dw_shape_ok(C, k) && (stride == 1 || stride == 2)) ? 1 : 0; }
+
+static int dw_groups(int64_t total, int C) {
+  const int spb = DW_T / (C / 8);
+  int64_t g = (total + spb - 1) / spb;
+  if (g > 1024) g = 1024;                                   // ~4 workgroups per CU, grid-stride beyond
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// rows of the statistics array pf_depthwise_fwd writes ([G][4][C]) / slabs of pf_depthwise_wrw ([G][C][9] floats)
+extern "C" int pf_depthwise_groups(int B, int Ho, int Wo, int C) {
+  if (C < 8 || (C % 8)) return 0;
+  const int64_t total = (int64_t)B * Ho * ((Wo + DW_PW - 1) / DW_PW);
+  return dw_groups(total, C);
+}
+
+static int dw_fill(DwArgs& a, int B, int H, int W, int C, int Ho, int Wo, int stride, int ph, int pw) {
+  if (B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || ph < 0 || pw < 0 || ph > 2 || pw > 2) return (int)hipErrorInvalidValue;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.ph = ph; a.pw = pw;
+  a.flip = 0;
+  a.strips_w = (Wo + DW_PW - 1) / DW_PW;
+  a.total = (int64_t)B * Ho * a.strips_w;
+  return 0;
+}
+
+extern "C" int pf_depthwise_fwd(const void* X, const void* W, void* Y, int dtype, float* partial, int B, int H, int Wd, int C,
+                                int k, int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream) {
+  if (!pf_depthwise_supported(C, k, stride)) return (int)hipErrorInvalidValue;
+  if (!pf_aligned16(X) || !pf_aligned16(Y) || X == nullptr || W == nullptr || Y == nullptr) return (int)hipErrorInvalidValue;
+  DwArgs a;
+  const int r = dw_fill(a, B, H, Wd, C, Ho, Wo, stride, pad_h, pad_w);
+  if (r) return r;
+  a.x = X; a.w = W; a.y = Y; a.dy = nullptr; a.partial = partial;
+  const int grid = dw_groups(a.total, C);
+  hipStream_t st = (hipStream_t)stream;
+#define PF_DW(TT)                                                                     \
+  do {                                                                                \
+    if (stride == 1) k_dw_fwd<TT, 1><<<grid, DW_T, 0, st>>>(a);                       \
+    else k_dw_fwd<TT, 2><<<grid, DW_T, 0, st>>>(a);                                   \
+  } while (0)
+  if (dtype == PF_F32) PF_DW(float);
+  else if (dtype == PF_BF16) PF_DW(bf16_t);
+  else return (int)hipErrorInvalidValue;
+#undef PF_DW
+  PF_LAUNCH_CHECK();
+  return 0;
+}
+
+// dX [B][H][Wd][C] from dY [B][Ho][Wo][C]; W is the forward kernel [C][3][3] (not flipped), pad_h / pad_w the forward front pads
+extern "C" int pf_depthwise_bwd_data(const void* dY, const void* W, void* dX, int dtype, int B, int H, int Wd, int C, int k,
+                                     int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream) {
+  if (!pf_depthwise_supported(C, k, stride)) return (int)hipErrorInvalidValue;
+  if (!pf_aligned16(dY) || !pf_aligned16(dX) || dY == nullptr || W == nullptr || dX == nullptr) return (int)hipErrorInvalidValue;
+  DwArgs a;
+  hipStream_t st = (hipStream_t)stream;
+  if (stride == 1) {
+    // the same strip kernel on the flipped taps: dx[hi][wi] = sum_{r',s'} dy[hi + r' - (2-ph)][wi + s' - (2-pw)] * w[2-r'][2-s']
+    const int r1 = dw_fill(a, B, Ho, Wo, C, H, Wd, 1, 2 - pad_h, 2 - pad_w);
+    if (r1) return r1;
+    a.x = dY; a.w = W; a.y = dX; a.dy = nullptr; a.partial = nullptr; a.flip = 1;
+    const int grid1 = dw_groups(a.total, C);
+    if (dtype == PF_F32) k_dw_fwd<float, 1><<<grid1, DW_T, 0, st>>>(a);
+    else if (dtype == PF_BF16) k_dw_fwd<bf16_t, 1><<<grid1, DW_T, 0, st>>>(a);
+    else return (int)hipErrorInvalidValue;
+    PF_LAUNCH_CHECK();
+    return 0;
+  }
+  const int r = dw_fill(a, B, H, Wd, C, Ho, Wo, stride, pad_h, pad_w);
+  if (r) return r;
+  a.x = dY; a.w = W; a.y = dX; a.dy = nullptr; a.partial = nullptr;
+  const int64_t npix = (int64_t)B * H * Wd;
+  const int grid = dw_groups(npix, C);
+  if (dtype == PF_F32) k_dw_bwd_data<float><<<grid, DW_T, 0, st>>>(a);
+  else if (dtype == PF_BF16) k_dw_bwd_data<bf16_t><<<grid, DW_T, 0, st>>>(a);
+  else return (int)hipErrorInvalidValue;
+  PF_LAUNCH_CHECK();
+  return 0;
+}
+
+// dW [C][3][3] (dw_dtype) from dY and X; slabs: pf_depthwise_groups(B, Ho, Wo, C) * C * 9 floats of workspace
+extern "C" int pf_depthwise_wrw(const void* dY, const void* X, void* dW, int dtype, int dw_dtype, float* slabs, int B, int H,
+                                int Wd, int C, int k, int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream) {
+  if (!pf_depthwise_supported(C, k, stride)) return (int)hipErrorInvalidValue;
+  if (!pf_aligned16(dY) || !pf_aligned16(X) || dY == nullptr || X == nullptr || dW == nullptr || slabs == nullptr)
+    return (int)hipErrorInvalidValue;
+  DwArgs a;
+  const int r = dw_fill(a, B, H, Wd, C, Ho, Wo, stride, pad_h, pad_w);
+  if (r) return r;
+  a.x = X; a.w = nullptr; a.y = nullptr; a.dy = dY; a.partial = slabs;
+  const int grid = dw_groups(a.total, C);
+  hipStream_t st = (hipStream_t)stream;
+#define PF_DWW(TT)                                                                    \
+  do {                                                                                \
+    if (stride == 1) k_dw_wrw<TT, 1><<<grid, DW_T, 0, st>>>(a);                       \
+    else k_dw_wrw<TT, 2><<<grid, DW_T, 0, st>>>(a);                                   \
+  } while (0)
+  if (dtype == PF_F32) PF_DWW(float);
+  else if (dtype == PF_BF16) PF_DWW(bf16_t);
+  else return (int)hipErrorInvalidValue;
+#undef PF_DWW
+  const int n = C * 9;
+  if (dw_dtype == PF_F32) k_dw_wrw_reduce<float><<<(n + DW_T - 1) / DW_T, DW_T, 0, st>>>(slabs, grid, n, (float*)dW);
+  else if (dw_dtype == PF_BF16) k_dw_wrw_reduce<bf16_t><<<(n + DW_T - 1) / DW_T, DW_T, 0, st>>>(slabs, grid, n, (bf16_t*)dW);
+  else return (int)hipErrorInvalidValue;
+  PF_LAUNCH_CHECK();
+  return 0;
+}

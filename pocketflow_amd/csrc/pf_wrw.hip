@@ -324,6 +324,12 @@ typedef int pf_wrsrc_t;                               // host pass: the kernel b
 #define PF_W_BUFFER_LOAD_LDS16(rs, lds, voff) ((void)(rs), (void)(lds), (void)(voff))
 #endif
 
+// Ablation builds for tools/gpu/wrw_ablate.py ONLY (never in libpocketflow_hip.so): PF_W2_ABLATE bit 0 drops the fragment reads
+// and MFMAs of k_wrw2, bit 1 the LDS-DMA, bit 2 the slab stores of the epilogue.  Results are garbage by design.
+#ifndef PF_W2_ABLATE
+#define PF_W2_ABLATE 0
+#endif
+
 struct Wrw2Args {
   const bf16_t* dY;
   const bf16_t* X;
@@ -418,7 +424,7 @@ __global__ __launch_bounds__(64 * (TN / WTN) * (TK / WTK)) void k_wrw2(const Wrw
       const int m = mb + pg * 8 + srow;
       const int n = n0 + (g4 * 4 + sb) * 16 + sch * 8;
       const uint32_t voff = (m < mend && n < a.N) ? (uint32_t)(m * a.N + n) * 2u : OOB;
-      PF_W_BUFFER_LOAD_LDS16(rsY, dst + (pg * NBN + g4 * 4) * 256, voff);
+      if (!(PF_W2_ABLATE & 2)) PF_W_BUFFER_LOAD_LDS16(rsY, dst + (pg * NBN + g4 * 4) * 256, voff);
     }
 #pragma unroll
     for (int x = 0; x < XS; ++x) {
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(64 * (TN / WTN) * (TK / WTK)) void k_wrw2(const Wrw
           while (px_ho[x] >= a.Ho) { px_ho[x] -= a.Ho; ++px_img[x]; }
         }
         const uint32_t voff = ok ? (uint32_t)(row * a.C + c0 + (g4 * 4 + sb) * 16 + sch * 8) * 2u : OOB;
-        PF_W_BUFFER_LOAD_LDS16(rsX, dst + DY_BYTES + (pg * NBK + g4 * 4) * 256, voff);
+        if (!(PF_W2_ABLATE & 2)) PF_W_BUFFER_LOAD_LDS16(rsX, dst + DY_BYTES + (pg * NBK + g4 * 4) * 256, voff);
       }
     }
   };
@@ -475,6 +481,7 @@ __global__ __launch_bounds__(64 * (TN / WTN) * (TK / WTK)) void k_wrw2(const Wrw
     if (more) stage(t + 1, buf ^ 1);
     const unsigned char* sbase = smem + buf * STAGE;
     bf16x8 xf[NJ];
+    if (!(PF_W2_ABLATE & 1)) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int cb = wk * NJ + j;
@@ -502,6 +509,7 @@ __global__ __launch_bounds__(64 * (TN / WTN) * (TK / WTK)) void k_wrw2(const Wrw
       for (int j = 0; j < NJ; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, xf[j], acc[i][j], 0, 0, 0);
     }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // own pieces of the next stage have landed
     if (PRO && more) transform(buf ^ 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -519,7 +527,7 @@ __global__ __launch_bounds__(64 * (TN / WTN) * (TK / WTK)) void k_wrw2(const Wrw
       const int n = n0 + wn * WTN + i * 16 + q * 4;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (n + r < a.N) out[(int64_t)(n + r) * ktot + k] = acc[i][j][r];
+        if (n + r < a.N && (!(PF_W2_ABLATE & 4) || acc[i][j][r] == 12345.678f)) out[(int64_t)(n + r) * ktot + k] = acc[i][j][r];
     }
 }
 

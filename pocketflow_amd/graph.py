@@ -834,6 +834,8 @@ OWN_CONV2D_WRW = os.environ.get('PF_OWN_CONV2D_WRW', '1') != '0'
 OWN_CONV2D_WRW_MIN_C = int(os.environ.get('PF_OWN_CONV2D_WRW_MIN_C', '128'))   # narrower inputs: MIOpen is faster (measured)
 OWN_CONV2D = os.environ.get('PF_OWN_CONV2D', '1') != '0'     # RxS convolutions on pf_igemm.hip (0: MIOpen, for A/B runs)
 OWN_STEM = os.environ.get('PF_OWN_STEM', '1') != '0'         # the 7x7/2 stem on pf_stem.hip (0: MIOpen, for A/B runs)
+OWN_DEPTHWISE = os.environ.get('PF_OWN_DEPTHWISE', '1') != '0'   # depthwise 3x3 on pf_depthwise.hip (0: MIOpen, for A/B runs)
+DEPTHWISE_ANY_DEVICE = False     # tests: run the depthwise plumbing on CPU tensors (the HIP entry points are emulated there)
 
 
 def _run_conv2d(x, w_krsc, stride, pad, want_stats):
@@ -1157,6 +1159,64 @@ def _pass_tag(x, y):
   return y
 
 
+class _NoCtx(object):
+  """Stand-in for an autograd context when a Function's forward is called directly (no gradient needed)."""
+  needs_input_grad = (False,) * 16
+
+  def save_for_backward(self, *a):
+    pass
+
+
+class _Depthwise(torch.autograd.Function):
+  """y = depthwise_conv3x3(x, W) on pf_depthwise_* (float32 or bf16 NHWC), TF 'SAME' front pads; the forward kernel leaves
+  the statistics of y for the BatchNorm behind it (`want_stats`)."""
+
+  @staticmethod
+  def forward(ctx, x, w, stride, ph, pw, Ho, Wo, want_stats, graph, box, w_var):
+    x = _nhwc(x)
+    B, C, H, W = x.shape
+    k = w.shape[2]
+    y = torch.empty((B, C, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    wk = w.detach().reshape(C, k, k)
+    partial = None
+    if want_stats:
+      G = hip.depthwise_groups(B, Ho, Wo, C)
+      partial = torch.empty((G, 4, C), dtype=torch.float32, device=x.device)
+      box.append((partial, G))
+    with region('depthwise_fwd', float((x.numel() + y.numel()) * x.element_size())):
+      hip.depthwise_fwd(x, wk, y, B, H, W, C, k, stride, ph, pw, Ho, Wo, partial=partial)
+    ctx.save_for_backward(x, w)
+    ctx.meta = (stride, ph, pw, Ho, Wo, graph, w_var)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    x, w = ctx.saved_tensors
+    stride, ph, pw, Ho, Wo, graph, w_var = ctx.meta
+    dy = _nhwc(dy)
+    if dy.dtype != x.dtype:
+      dy = dy.to(x.dtype)
+    B, C, H, W = x.shape
+    k = w.shape[2]
+    dx = dw = None
+    if ctx.needs_input_grad[1]:
+      gw = getattr(w, 'grad', None)
+      direct = gw is not None and gw.shape == w.shape and gw.is_contiguous() and gw.dtype in (torch.float32, torch.bfloat16)
+      dwk = gw if direct else torch.empty(w.shape, dtype=w.dtype, device=x.device)
+      G = hip.depthwise_groups(B, Ho, Wo, C)
+      with region('depthwise_wrw', float((x.numel() + dy.numel()) * x.element_size())):
+        hip.depthwise_wrw(dy, x, dwk, graph.scratch(G * C * k * k), B, H, W, C, k, stride, ph, pw, Ho, Wo)
+      if direct:
+        graph.store.notify_grad(w_var)             # written straight into the flat gradient buffer
+      else:
+        dw = dwk
+    if ctx.needs_input_grad[0]:
+      dx = torch.empty_like(x)
+      with region('depthwise_bwd_data', float((x.numel() + dy.numel()) * x.element_size())):
+        hip.depthwise_bwd_data(dy, w.detach().reshape(C, k, k), dx, B, H, W, C, k, stride, ph, pw, Ho, Wo)
+    return dx, dw, None, None, None, None, None, None, None, None, None
+
+
 class DepthwiseConv2D:
   """slim.separable_conv2d(num_outputs=None, depth_multiplier=1): DepthwiseConv2dNative."""
 
@@ -1175,12 +1235,28 @@ class DepthwiseConv2D:
     finally:
       self.graph.taps = taps
 
-  def __call__(self, x) -> torch.Tensor:
+  def __call__(self, x, want_stats: bool = False) -> torch.Tensor:
+    """`want_stats`: the consumer is a BatchNormAct -- leave the per-channel statistics of the output on the tensor."""
     x = materialize(x)
     if self.graph.taps is not None:
       return _tapped(self, x)
     ph = _same_pads(x.shape[2], self.k, self.stride)
     pw = _same_pads(x.shape[3], self.k, self.stride)
+    w = self.kernel.tensor
+    if (OWN_DEPTHWISE and (x.is_cuda or DEPTHWISE_ANY_DEVICE) and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and w.dtype == x.dtype
+        and hip.depthwise_supported(self.channels, self.k, self.stride)):
+      Ho, Wo = -(-x.shape[2] // self.stride), -(-x.shape[3] // self.stride)
+      bn_box = getattr(x, '_pf_bn', None)
+      if bn_box is not None:
+        bn_box['n_consumers'] += 2                 # a consumer that does not fuse the BN-backward sums of its producer
+      box = []
+      if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+        y = _Depthwise.apply(x, w, self.stride, ph[0], pw[0], Ho, Wo, want_stats, self.graph, box, self.kernel)
+      else:
+        y = _Depthwise.forward(_NoCtx(), x, w, self.stride, ph[0], pw[0], Ho, Wo, want_stats, self.graph, box, self.kernel)
+      if box:
+        y._pf_stats = box[0]
+      return y
     pad = 0
     if ph[0] == ph[1] and pw[0] == pw[1]:
       pad = (ph[0], pw[0])

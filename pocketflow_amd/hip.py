@@ -43,7 +43,8 @@ SYMBOLS = [
     'pf_bn_eval_scale_shift', 'pf_gemm_bf16_nt', 'pf_gemm_bf16_nn', 'pf_gemm_bf16_tn',
     'pf_conv1x1_stats_groups', 'pf_conv1x1_stats_groups_k', 'pf_conv1x1_fwd', 'pf_conv1x1_bwd_data_bnstats', 'pf_conv1x1_wrw_splits',
     'pf_conv1x1_wrw', 'pf_conv2d_stats_groups', 'pf_conv2d_fwd', 'pf_conv2d_wrw_splits', 'pf_conv2d_wrw', 'pf_maxpool_fwd', 'pf_maxpool_bwd', 'pf_seg_transpose', 'pf_conv_stem_supported', 'pf_conv_stem_fwd', 'pf_conv_stem_wrw_slabs', 'pf_conv_stem_wrw',
-    'pf_image_resize_bilinear',
+    'pf_image_resize_bilinear', 'pf_depthwise_supported', 'pf_depthwise_groups', 'pf_depthwise_fwd', 'pf_depthwise_bwd_data',
+    'pf_depthwise_wrw',
 ]
 
 
@@ -387,6 +388,40 @@ def conv2d_wrw(dY, X, dW, workspace, imgs: int, H: int, Wd: int, C: int, N: int,
   _check(_lib.pf_conv2d_wrw(_ptr(dY), _ptr(X), _ptr(dW), c_int(dtype_code(dW)), _ptr(workspace), c_int(imgs), c_int(H),
                             c_int(Wd), c_int(C), c_int(N), c_int(th), c_int(tw), c_int(stride), c_int(pad_h),
                             c_int(pad_w), c_int(Ho), c_int(Wo), _stream()), 'pf_conv2d_wrw')
+
+
+def depthwise_supported(C: int, k: int, stride: int) -> bool:
+  return bool(_lib.pf_depthwise_supported(c_int(C), c_int(k), c_int(stride)))
+
+
+def depthwise_groups(B: int, Ho: int, Wo: int, C: int) -> int:
+  return int(_lib.pf_depthwise_groups(c_int(B), c_int(Ho), c_int(Wo), c_int(C)))
+
+
+def depthwise_fwd(X, W, Y, B: int, H: int, Wd: int, C: int, k: int, stride: int, pad_h: int, pad_w: int, Ho: int, Wo: int,
+                  partial=None) -> None:
+  """X: NHWC memory [B][H][Wd][C], W: [C][k][k] in X's dtype, Y: [B][Ho][Wo][C]; partial: [G][4][C] float32 or None."""
+  _dev(X)
+  _check(_lib.pf_depthwise_fwd(_ptr(X), _ptr(W), _ptr(Y), c_int(dtype_code(X)), _ptr(partial), c_int(B), c_int(H), c_int(Wd),
+                               c_int(C), c_int(k), c_int(stride), c_int(pad_h), c_int(pad_w), c_int(Ho), c_int(Wo),
+                               _stream()), 'pf_depthwise_fwd')
+
+
+def depthwise_bwd_data(dY, W, dX, B: int, H: int, Wd: int, C: int, k: int, stride: int, pad_h: int, pad_w: int, Ho: int,
+                       Wo: int) -> None:
+  _dev(dY)
+  _check(_lib.pf_depthwise_bwd_data(_ptr(dY), _ptr(W), _ptr(dX), c_int(dtype_code(dY)), c_int(B), c_int(H), c_int(Wd), c_int(C),
+                                    c_int(k), c_int(stride), c_int(pad_h), c_int(pad_w), c_int(Ho), c_int(Wo), _stream()),
+         'pf_depthwise_bwd_data')
+
+
+def depthwise_wrw(dY, X, dW, slabs, B: int, H: int, Wd: int, C: int, k: int, stride: int, pad_h: int, pad_w: int, Ho: int,
+                  Wo: int) -> None:
+  """dW: [C][k][k], float32 or bf16; slabs: depthwise_groups(B, Ho, Wo, C) * C * k * k floats."""
+  _dev(X)
+  _check(_lib.pf_depthwise_wrw(_ptr(dY), _ptr(X), _ptr(dW), c_int(dtype_code(X)), c_int(dtype_code(dW)), _ptr(slabs), c_int(B),
+                               c_int(H), c_int(Wd), c_int(C), c_int(k), c_int(stride), c_int(pad_h), c_int(pad_w), c_int(Ho),
+                               c_int(Wo), _stream()), 'pf_depthwise_wrw')
 
 
 TILE_DTYPE = np.dtype([('src_off', '<i8'), ('dst_off', '<i8'), ('O', '<i4'), ('I', '<i4'), ('src_ld', '<i4'),

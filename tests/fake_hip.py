@@ -233,6 +233,49 @@ class FakeHip(object):
       partial[:, 3] = float('-inf')
       partial[1, 0], partial[1, 1], partial[1, 2], partial[1, 3] = yr.sum(0), (yr * yr).sum(0), yr.min(0).values, yr.max(0).values
 
+  # -- depthwise 3x3 (pf_depthwise.hip): the tensors arrive as logical NCHW / physical NHWC torch views ------------------------
+  def depthwise_supported(self, C, k, stride):
+    return k == 3 and C % 8 == 0 and C >= 8 and 256 % (C // 8) == 0 and stride in (1, 2)
+
+  def depthwise_groups(self, B, Ho, Wo, C):
+    return 2
+
+  @staticmethod
+  def _dw_pad(x, H, Wd, k, stride, ph, pw, Ho, Wo):
+    import torch.nn.functional as F
+    pb_h, pb_w = max((Ho - 1) * stride + k - H - ph, 0), max((Wo - 1) * stride + k - Wd - pw, 0)
+    return F.pad(x, (pw, pb_w, ph, pb_h))
+
+  def depthwise_fwd(self, X, W, Y, B, H, Wd, C, k, stride, pad_h, pad_w, Ho, Wo, partial=None):
+    self._n('depthwise_fwd')
+    import torch.nn.functional as F
+    y = F.conv2d(self._dw_pad(X.float(), H, Wd, k, stride, pad_h, pad_w, Ho, Wo), W.float().reshape(C, 1, k, k), stride=stride, groups=C)
+    Y.copy_(y.to(Y.dtype))
+    if partial is not None:
+      yr = Y.float().permute(0, 2, 3, 1).reshape(-1, C)
+      partial[:, 0:2] = 0
+      partial[:, 2] = float('inf')
+      partial[:, 3] = float('-inf')
+      partial[1, 0], partial[1, 1], partial[1, 2], partial[1, 3] = yr.sum(0), (yr * yr).sum(0), yr.min(0).values, yr.max(0).values
+
+  def depthwise_bwd_data(self, dY, W, dX, B, H, Wd, C, k, stride, pad_h, pad_w, Ho, Wo):
+    self._n('depthwise_bwd_data')
+    import torch.nn.functional as F
+    with torch.enable_grad():                    # (called from inside a backward pass, where grad mode is off)
+      x = torch.zeros(B, C, H, Wd, requires_grad=True)
+      y = F.conv2d(self._dw_pad(x, H, Wd, k, stride, pad_h, pad_w, Ho, Wo), W.detach().float().reshape(C, 1, k, k), stride=stride, groups=C)
+      (g,) = torch.autograd.grad(y, x, dY.float())
+    dX.copy_(g.to(dX.dtype))
+
+  def depthwise_wrw(self, dY, X, dW, slabs, B, H, Wd, C, k, stride, pad_h, pad_w, Ho, Wo):
+    self._n('depthwise_wrw')
+    import torch.nn.functional as F
+    with torch.enable_grad():
+      w = torch.zeros(C, 1, k, k, requires_grad=True)
+      y = F.conv2d(self._dw_pad(X.detach().float(), H, Wd, k, stride, pad_h, pad_w, Ho, Wo), w, stride=stride, groups=C)
+      (g,) = torch.autograd.grad(y, w, dY.float())
+    dW.copy_(g.reshape(dW.shape).to(dW.dtype))
+
   # -- the ResNet stem (pf_stem.hip) --------------------------------------------------------------------------------------
   def conv_stem_supported(self, H, Wd, C, N, k, stride, pad):
     return C == 3 and N == 64 and k == 7 and stride == 2 and pad == 3 and H % 2 == 0 and Wd % 32 == 0 and 32 <= Wd <= 1024

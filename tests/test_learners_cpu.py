@@ -34,6 +34,7 @@ def cpu_learners(monkeypatch, tmp_path):
   for mod in (G, P, L, Opt, WS, NU, LW):
     monkeypatch.setattr(mod, 'hip', fake)
   monkeypatch.setattr(AL, 'require_gpu', lambda: torch.device('cpu'))
+  monkeypatch.setattr(G, 'DEPTHWISE_ANY_DEVICE', True)      # MobileNet: the depthwise plumbing on the emulated entry points
   FLAGS.save_path = str(tmp_path / 'models' / 'model.ckpt')
   FLAGS.save_path_eval = str(tmp_path / 'models_eval' / 'model.ckpt')
   FLAGS.enbl_dst = False
