@@ -196,7 +196,14 @@ class GradReducer(object):
     if b is None:
       return
     if var.name in self.seen:
-      self.dirty = True
+      # Inside ONE armed backward pass a variable reports twice when its producer writes the flat buffer directly: once
+      # through VarStore.notify_grad from the kernel launcher, once through the leaf's post-accumulate hook, which torch
+      # (2.10) fires even when the autograd function returned None for that leaf.  Both come after the gradient was
+      # enqueued, so the second is a no-op.  (Round 2 marked the cycle dirty here: on the fused bf16 path EVERY kernel
+      # reported twice, every overlapped launch was thrown away and re-done blocking in finish() -- found by the
+      # `buckets_launched_inside_backward > 0` assertion of tests/test_learner_gpu.py, round 3.)  A second, accumulating
+      # backward pass is outside the armed window and still invalidates the launches (branch above).  Limitation: a kernel
+      # shared by two ops of one graph would report after its FIRST consumer; no network of the path shares kernels.
       return
     self.seen.add(var.name)
     self.pending[b] -= 1

@@ -44,5 +44,18 @@ c3)
   PF_IGEMM_PRO3=0 run_bench c2_pro2 --steps 15 --warmup 5 --no_cpu_baseline
   for c in c2a32 c4 c3 c1; do run_bench cfg_$c --config $c --steps 10 --warmup 4 --no_cpu_baseline; done
   ;;
+c4)
+  # depthwise kernels + the 2-rank control flow, backward-filter ablation, per-step kernel table, MobileNet bench with own depthwise
+  timeout 900 python -m pytest tests/test_depthwise_gpu.py tests/test_learner_gpu.py -m gpu -q --tb=short -k "depthwise or two_ranks or mobilenet" 2>&1 | tail -15 | cut -c1-500 > gpurun_out/r03_c4_pytest.log
+  tail -6 gpurun_out/r03_c4_pytest.log
+  timeout 400 python tools/gpu/wrw_ablate.py > gpurun_out/r03_wrw_ablation.txt 2>&1; cat gpurun_out/r03_wrw_ablation.txt
+  run_bench cfg_c3 --config c3 --steps 10 --warmup 4 --no_cpu_baseline
+  PF_OWN_DEPTHWISE=0 run_bench cfg_c3_miopen --config c3 --steps 10 --warmup 4 --no_cpu_baseline
+  cd /tmp
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r3a -o r3a -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 4 --no_cpu_baseline > $GRAFT_REPO_ROOT/gpurun_out/r03_prof.log 2>&1
+  cd $GRAFT_REPO_ROOT
+  python tools/prof_summary.py $(find /tmp/prof_r3a -name '*kernel_trace.csv' | head -1) --steps 4 --out gpurun_out/r03_step_kernels_b256.csv | head -40 | cut -c1-170
+  cp $(find /tmp/prof_r3a -name '*kernel_stats.csv' | head -1) gpurun_out/r03_rocprofv3_stats_b256.csv
+  ;;
 *) echo "unknown payload $1"; exit 2;;
 esac
