@@ -73,21 +73,34 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 #define IG_PLAIN 0
 #define IG_BWD 1
 #define IG_PRO 2
+// MODE 3 = IG_PRO with WAVE SPECIALISATION: WM x WN consumer wavefronts (fragment reads + MFMAs only) plus as many PRODUCER
+// wavefronts that issue all LDS-DMA and run the BN / ReLU / fake-quant pass over the input tile of step ks+1 in LDS while
+// the consumers multiply step ks.  Two consumers and one producer per SIMD: the prologue's VALU work (5.5 instructions per
+// element, as long as the MFMAs of the step when one wavefront has to do both -- measured: +23 us on 14x14 1024 -> 256) runs
+// in the shadow of the matrix pipe instead of in its way.  Three stages, one barrier per step, 64 x 64 accumulators per
+// consumer, 12 wavefronts = 3 per SIMD = 168 registers each.
+#define IG_PROW 3
+#define IG_NWP 4                                    // producer wavefronts of the wave-specialised variant (one per SIMD)
 template <int BM, int BN, int WM, int WN, int NS, int MODE>
-__global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
-  constexpr bool BWD = (MODE == IG_BWD), PRO = (MODE == IG_PRO);
+__global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) void k_igemm(const IgArgs a) {
+  constexpr bool WS = (MODE == IG_PROW);
+  constexpr bool BWD = (MODE == IG_BWD), PRO = (MODE == IG_PRO || WS);
+  static_assert(!WS || NS == 3, "the wave-specialised variant is written for the 3-stage ring");
   static_assert(!PRO || NS == 2 || NS == 3, "the in-LDS prologue pass is written for the 2- and 3-stage rings");
   // PRO with three stages: the loads of step ks+2 travel, the lanes transform their own vectors of step ks+1 in LDS and the
   // matrix cores multiply step ks -- all inside ONE barrier interval (round 2's two-stage form ran them back to back:
   // wait for the loads, transform, barrier, multiply; measured 5.5 k cycles per step against 0.5 k of MFMA issue).
   constexpr bool PRO3 = PRO && NS == 3;
-  constexpr int T = 64 * WM * WN;
+  constexpr int NWC = WM * WN;                      // consumer wavefronts (all of them unless WS)
+  constexpr int T = 64 * (NWC + (WS ? IG_NWP : 0)); // threads of the workgroup
+  constexpr int TS = WS ? 64 * IG_NWP : 64 * NWC;   // threads that STAGE (WS: the producer wavefronts)
+  constexpr int TE = 64 * NWC;                      // threads of the epilogue row stores (WS: the consumers)
   constexpr int WR = BM / WM, WC = BN / WN;         // wavefront tile: pixels x channels
   constexpr int JM = WR / 16, NI = WC / 16;
-  constexpr int AS = BM * 8 / T, BS = BN * 8 / T;   // 16-byte loads per lane and step (input / kernel tile)
+  constexpr int AS = BM * 8 / TS, BS = BN * 8 / TS; // 16-byte loads per staging lane and step (input / kernel tile)
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int CS_LD = BN + 8, CS_LD_B = BN + 8;
-  constexpr int VPR = BN / 8, RPP = T / VPR, NP = BM / RPP;
+  constexpr int VPR = BN / 8, RPP = TE / VPR, NP = BM / RPP;
   static_assert(AS >= 1 && BS >= 1 && NP >= 1, "tile too small for the block");
   constexpr int LPS = AS + BS;                      // LDS-DMA instructions per lane and stage
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NS stages; aliased: C tile, statistics scratch
@@ -99,9 +112,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);              // scalar: LDS-DMA bases stay in SGPRs
-  const int wm = wave / WN, wn = wave % WN;
+  const bool prod = WS && wave >= NWC;                                    // WS: producer wavefront (scalar condition)
+  const int swave = prod ? wave - NWC : wave;                             // index among the staging wavefronts
+  const int cwave = wave % NWC;
+  const int wm = cwave / WN, wn = cwave % WN;
   const int l15 = lane & 15, q = lane >> 4;
-  const int srow = tid >> 3;                                              // staging row of this lane (per 16-byte slot)
+  const int srow = (swave * 64 + lane) >> 3;                              // staging row of this lane (per 16-byte slot)
   const int schunk = (lane & 7) ^ ((lane >> 3) & 7);                      // source 16-byte group for its LDS position
 
   const int xcd = blockIdx.x & 7, L = blockIdx.x >> 3;
@@ -146,7 +162,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
   uint32_t boff[BS];
 #pragma unroll
   for (int i = 0; i < BS; ++i) {
-    const int n = n0 + i * (T / 8) + srow;
+    const int n = n0 + i * (TS / 8) + srow;
     boff[i] = (n < a.N) ? (uint32_t)(((int64_t)n * wrow + schunk * 8) * 2) : OOB;
   }
 
@@ -157,9 +173,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
     uint32_t pbase[AS], pmask[AS];
 #pragma unroll
     for (int i = 0; i < AS; ++i) {
-      const int m = m0 + i * (T / 8) + srow;
+      const int m = m0 + i * (TS / 8) + srow;
       pbase[i] = 0; pmask[i] = 0;
-      if (m < a.M) {
+      if (m < a.M && (!WS || prod)) {
         const int img = m / hw_o, rem = m - img * hw_o;
         const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
         const int h0 = ho * a.stride - a.pad_h, w0 = wo * a.stride - a.pad_w;
@@ -181,11 +197,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
 #pragma unroll
       for (int i = 0; i < AS; ++i) {
         const uint32_t voff = ((pmask[i] >> s_tap) & 1u) ? (pbase[i] + tapoff) : OOB;
-        PF_BUFFER_LOAD_LDS16(rsX, As + (i * (T / 8) + wave * 8) * 128, voff, 0);
+        PF_BUFFER_LOAD_LDS16(rsX, As + (i * (TS / 8) + swave * 8) * 128, voff, 0);
       }
 #pragma unroll
       for (int i = 0; i < BS; ++i)
-        PF_BUFFER_LOAD_LDS16(rsW, Bs + (i * (T / 8) + wave * 8) * 128, boff[i], s_ks * 128);
+        PF_BUFFER_LOAD_LDS16(rsW, Bs + (i * (TS / 8) + swave * 8) * 128, boff[i], s_ks * 128);
 #else
       (void)As; (void)Bs; (void)tapoff;
 #endif
@@ -224,20 +240,20 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
       pro.sh[0] = h0.x; pro.sh[1] = h0.y; pro.sh[2] = h0.z; pro.sh[3] = h0.w;
       pro.sh[4] = h1.x; pro.sh[5] = h1.y; pro.sh[6] = h1.z; pro.sh[7] = h1.w;
       const uint32_t pv = lds_addr(smem + buf * STAGE + srow * 128 + (lane & 7) * 16);
-      static_assert(!PRO3 || AS == 1 || AS == 2 || AS == 4, "vector count per lane");
+      static_assert(!PRO3 || AS == 1 || AS == 2 || AS == 4 || AS == 8, "vector count per lane");
 #pragma unroll
       for (int i = 0; i < AS; i += 2) {
         if (i >= i0 && i < i1) {
           if (i + 1 < i1) {
             uint4 v0, v1;
-            lds_read_b128x2(pv + i * (T / 8) * 128, pv + (i + 1) * (T / 8) * 128, v0, v1);
-            lds_write_b128(pv + i * (T / 8) * 128, pro_apply(pro, v0));
-            lds_write_b128(pv + (i + 1) * (T / 8) * 128, pro_apply(pro, v1));
+            lds_read_b128x2(pv + i * (TS / 8) * 128, pv + (i + 1) * (TS / 8) * 128, v0, v1);
+            lds_write_b128(pv + i * (TS / 8) * 128, pro_apply(pro, v0));
+            lds_write_b128(pv + (i + 1) * (TS / 8) * 128, pro_apply(pro, v1));
           } else {
-            lds_write_b128(pv + i * (T / 8) * 128, pro_apply(pro, lds_read_b128(pv + i * (T / 8) * 128)));
+            lds_write_b128(pv + i * (TS / 8) * 128, pro_apply(pro, lds_read_b128(pv + i * (TS / 8) * 128)));
           }
         } else if (i + 1 >= i0 && i + 1 < i1) {
-          lds_write_b128(pv + (i + 1) * (T / 8) * 128, pro_apply(pro, lds_read_b128(pv + (i + 1) * (T / 8) * 128)));
+          lds_write_b128(pv + (i + 1) * (TS / 8) * 128, pro_apply(pro, lds_read_b128(pv + (i + 1) * (TS / 8) * 128)));
         }
       }
     };
@@ -249,10 +265,77 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
       unsigned char* As = smem + buf * STAGE;
 #pragma unroll
       for (int i = 0; i < AS; ++i) {
-        uint4* p = reinterpret_cast<uint4*>(As + (i * (T / 8) + srow) * 128 + (lane & 7) * 16);
+        uint4* p = reinterpret_cast<uint4*>(As + (i * (TS / 8) + srow) * 128 + (lane & 7) * 16);
         *p = pro_apply(pro, *p);
       }
     };
+    if constexpr (WS) {
+      // ---- wave-specialised ring: producers stage + transform one step ahead, consumers multiply.  TWO loops with the same
+      // barrier count (not one loop with a role branch inside): register live ranges then end at the role boundary -- the
+      // consumers' accumulators are not live in the producer loop, the producers' staging state not in the consumer loop
+      // (a single loop needed 212 spilled registers at the 168-register budget of 12 wavefronts per CU).
+      if (prod) {
+        stage(0);
+        if (nk > 1) { stage(1); wait_vm<LPS>(); } else wait_vm<0>();
+        transform3(0, 0, 0, AS);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int tb = 1;                                                         // buffer of step ks+1
+        ibuf = (nk > 1) ? 2 : 1;
+        for (int ks = 0; ks < nk; ++ks) {
+          const bool more = ks + 2 < nk;
+          if (more) { stage(ibuf); ibuf = (ibuf + 1 == NS) ? 0 : ibuf + 1; }
+          if (ks + 1 < nk) {
+            if (more) wait_vm<LPS>(); else wait_vm<0>();                    // own pieces of step ks+1 have landed
+            transform3(tb, ks + 1, 0, AS);
+            tb = (tb + 1 == NS) ? 0 : tb + 1;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the prologue writes of this wavefront are done
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        f32x4 cacc[NI][JM];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < JM; ++j) cacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_s_barrier();
+        int cbuf = 0;
+        for (int ks = 0; ks < nk; ++ks) {
+          const unsigned char* As = smem + cbuf * STAGE;
+          const unsigned char* Bs = As + A_BYTES;
+          cbuf = (cbuf + 1 == NS) ? 0 : cbuf + 1;
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const int coff = (((kk * 4 + q) ^ (l15 & 7)) << 4);
+            bf16x8 wf[NI], xf[JM];
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+              wf[i] = *reinterpret_cast<const bf16x8*>(Bs + (wn * WC + i * 16 + l15) * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < JM; ++j)
+              xf[j] = *reinterpret_cast<const bf16x8*>(As + (wm * WR + j * 16 + l15) * 128 + coff);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+              for (int j = 0; j < JM; ++j)
+                cacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], cacc[i][j], 0, 0, 0);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the fragment reads of this wavefront are done
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // C tile staging (aliases the ring: every fragment read of the tile is behind the last barrier)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < JM; ++j) {
+            const uint2 v = make_uint2(pack_bf16x2(cacc[i][j][0], cacc[i][j][1]), pack_bf16x2(cacc[i][j][2], cacc[i][j][3]));
+            *reinterpret_cast<uint2*>(Cs + (wm * WR + j * 16 + l15) * CS_LD + wn * WC + i * 16 + q * 4) = v;
+          }
+      }
+    } else {
 #pragma unroll
     for (int d = 0; d < NS - 1; ++d)
       if (d < nk) {
@@ -318,8 +401,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     }
+    }
 
     // ---- epilogue of one [BM][BN] tile (C staging aliases the stage buffers: all reads of them are complete) ----
+    if (!WS) {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -327,9 +412,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
         const uint2 v = make_uint2(pack_bf16x2(acc[i][j][0], acc[i][j][1]), pack_bf16x2(acc[i][j][2], acc[i][j][3]));
         *reinterpret_cast<uint2*>(Cs + (wm * WR + j * 16 + l15) * CS_LD + wn * WC + i * 16 + q * 4) = v;
       }
+    }
+    if constexpr (WS) {                                                     // per-tile statistics: (re)defined HERE, dead in the role loops
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; st_mn[j] = INFINITY; st_mx[j] = -INFINITY; }
+    }
     // epilogue passes in groups of <= 8 rows per thread: the side vectors (residual / BN input) of a group are all in
     // flight before the group is processed (and before the LDS hand-off for the first group)
-    constexpr int PG = (NP > 8) ? 8 : NP;
+    constexpr int PG = (NP > 8) ? 8 : (WS && NP > 4 ? 4 : NP);
     uint4 rres[PG];
     auto load_side = [&](int p0) {
 #pragma unroll
@@ -339,7 +429,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
         if (m < a.M && n < a.N) rres[p] = *reinterpret_cast<const uint4*>(side + (int64_t)m * a.N + n);
       }
     };
-    if (side != nullptr) load_side(0);
+    const bool etid = !WS || tid < TE;                                      // WS: the producers only keep the barriers company
+    if (side != nullptr && etid) load_side(0);
     __syncthreads();
 #pragma unroll
     for (int p0 = 0; p0 < NP; p0 += PG) {
@@ -348,7 +439,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
         const int p = p0 + pp;
         const int rl = wrw + p * RPP;
         const int m = m0 + rl, n = n0 + wvec * 8;
-        if (m < a.M && n < a.N) {
+        if (m < a.M && n < a.N && etid) {
           uint4 c = *reinterpret_cast<const uint4*>(Cs + rl * CS_LD + wvec * 8);
           if (BWD) {
             float f[8], xv[8];
@@ -386,13 +477,47 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
           *reinterpret_cast<uint4*>(a.Y + (int64_t)m * a.N + n) = c;
         }
       }
-      if (side != nullptr && p0 + PG < NP) load_side(p0 + PG);
+      if (side != nullptr && p0 + PG < NP && etid) load_side(p0 + PG);
     }
     __syncthreads();
+    if constexpr (WS) {
+      // statistics of THIS tile -> partial[g][4][N] at once (first tile of the workgroup: store, later tiles: combine, in
+      // tile order: deterministic): the 32 accumulator registers are dead while the next tile's main loop runs (the
+      // 64 x 128 accumulators of a consumer leave no room for them)
+      if (a.partial != nullptr) {
+        if (etid) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          red[(0 * RPP + wrw) * BN + wvec * 8 + j] = st_s[j];
+          red[(1 * RPP + wrw) * BN + wvec * 8 + j] = st_q[j];
+          red[(2 * RPP + wrw) * BN + wvec * 8 + j] = st_mn[j];
+          red[(3 * RPP + wrw) * BN + wvec * 8 + j] = st_mx[j];
+        }
+        }
+        __syncthreads();
+        for (int c = tid; c < 4 * BN; c += T) {
+          const int stat = c / BN, col = c - stat * BN;
+          float r = red[(stat * RPP) * BN + col];
+          for (int rr = 1; rr < RPP; ++rr) {
+            const float w = red[(stat * RPP + rr) * BN + col];
+            r = (stat < 2) ? (r + w) : (stat == 2 ? fminf(r, w) : fmaxf(r, w));
+          }
+          if (n0 + col < a.N) {
+            float* dst = a.partial + ((int64_t)g * 4 + stat) * a.N + n0 + col;
+            if (tm != g) {
+              const float o = *dst;
+              r = (stat < 2) ? (o + r) : (stat == 2 ? fminf(o, r) : fmaxf(o, r));
+            }
+            *dst = r;
+          }
+        }
+        __syncthreads();
+      }
+    }
   }
 
   // ---- per-workgroup statistics -> partial[g][stat][N] (fixed order: deterministic) ---------------------------
-  if (a.partial != nullptr) {
+  if (!WS && a.partial != nullptr) {
     // threads with equal column group: RPP row lanes.  Two-level: registers -> LDS [stat][RPP][BN] in chunks that fit
     constexpr int nstat_max = 4;
     const int nstat = BWD ? 2 : 4;
@@ -417,7 +542,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
-struct IgCfg { int bm, bn, slots; bool pro3; };    // slots: resident workgroups on the chip (256 CUs x workgroups per CU)
+struct IgCfg { int bm, bn, slots; bool pro3, prow; };    // slots: resident workgroups on the chip (256 CUs x workgroups per CU)
+
+static bool ig_prow_enabled() {
+  const char* e = getenv("PF_IGEMM_PROW");                 // =0: the single-role three-stage kernel (A/B runs)
+  return e == nullptr || atoi(e) != 0;
+}
 
 static bool ig_pro3_enabled() {
   const char* e = getenv("PF_IGEMM_PRO3");                 // =0: round 2's two-stage prologue kernel (A/B runs)
@@ -431,24 +561,25 @@ static IgCfg ig_pick(int M, int N, bool pro) {
     // prologue variant.  Three stages, 8 wavefronts, one workgroup per CU: 128 x 256 tiles where N allows (the in-LDS
     // prologue pass over the input tile is amortised over 256 output channels), 256 x 128 otherwise.
     if (ig_pro3_enabled()) {
-      if (N % 256 == 0) return IgCfg{128, 256, 256, true};
-      if (N % 128 == 0) return IgCfg{256, 128, 256, true};
+      const bool prow = ig_prow_enabled();
+      if (N % 256 == 0) return IgCfg{128, 256, 256, true, prow};
+      if (N % 128 == 0) return IgCfg{256, 128, 256, true, prow};
     }
-    return IgCfg{128, (N % 128 == 0) ? 128 : 64, 512, false};
+    return IgCfg{128, (N % 128 == 0) ? 128 : 64, 512, false, false};
   }
   const char* e = getenv("PF_IGEMM_TILE");                 // tuning override: "256x128" | "128x128" | "256x64" | "128x64"
   if (e != nullptr) {
     int bm = 0, bn = 0;
     if (sscanf(e, "%dx%d", &bm, &bn) == 2 && (bm == 128 || bm == 256) && (bn == 64 || bn == 128 || (bn == 256 && bm == 256)) &&
         (N % bn == 0 || bn == 64))
-      return IgCfg{bm, bn, (bm == 256) ? 256 : 512, false};
+      return IgCfg{bm, bn, (bm == 256) ? 256 : 512, false, false};
   }
   const int bn = (N % 128 == 0) ? 128 : 64;
   // measured on the ResNet-50 shapes at batch 256 (tools/gpu/igemm_bench.py): 128-row tiles with two workgroups per CU
   // (2 LDS stages each) beat 256-row tiles with one workgroup per CU and 3 stages on every shape (e.g. 3x3 C = 256 at
   // 14x14: 85 vs 96 us; 3x3 C = 64 at 56x56: 127 vs 165 us): the second workgroup hides the barrier / DMA waits of the
   // first better than a deeper pipeline does
-  return IgCfg{128, bn, 512, false};
+  return IgCfg{128, bn, 512, false, false};
 }
 
 static int ig_grid(int slots, int tiles_m, int tiles_n, int* G_out) {
@@ -472,7 +603,8 @@ extern "C" int pf_conv2d_stats_groups(int M, int N) { return pf_igemm_stats_grou
 
 template <int BM, int BN, int WM, int WN, int NS, int MODE>
 static int ig_launch_t(IgArgs& a, int slots, hipStream_t st) {
-  constexpr bool BWD = (MODE == IG_BWD), PRO3 = (MODE == IG_PRO && NS == 3);
+  constexpr bool BWD = (MODE == IG_BWD), PRO3 = ((MODE == IG_PRO || MODE == IG_PROW) && NS == 3);
+  constexpr int THREADS = 64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0));
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
   const int grid = ig_grid(slots, a.tiles_m, a.tiles_n, &a.G);
@@ -489,7 +621,7 @@ static int ig_launch_t(IgArgs& a, int slots, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
-  k_igemm<BM, BN, WM, WN, NS, MODE><<<grid, 64 * WM * WN, lds, st>>>(a);
+  k_igemm<BM, BN, WM, WN, NS, MODE><<<grid, THREADS, lds, st>>>(a);
   PF_LAUNCH_CHECK();
   return 0;
 }
@@ -499,6 +631,8 @@ static int ig_launch(IgArgs& a, hipStream_t st) {
   const IgCfg c = ig_pick(a.M, a.N, pro);
   if (pro) {
     if (a.th * a.tw != 1 || bwd) return (int)hipErrorInvalidValue;
+    if (c.pro3 && c.prow) return (c.bn == 256) ? ig_launch_t<128, 256, 2, 4, 3, IG_PROW>(a, c.slots, st)
+                                               : ig_launch_t<256, 128, 4, 2, 3, IG_PROW>(a, c.slots, st);
     if (c.pro3) return (c.bn == 256) ? ig_launch_t<128, 256, 2, 4, 3, IG_PRO>(a, c.slots, st)
                                      : ig_launch_t<256, 128, 4, 2, 3, IG_PRO>(a, c.slots, st);
     return (c.bn == 128) ? ig_launch_t<128, 128, 2, 2, 2, IG_PRO>(a, c.slots, st) : ig_launch_t<128, 64, 2, 2, 2, IG_PRO>(a, c.slots, st);

@@ -86,8 +86,8 @@ def test_conv1x1_fwd_prologue_matches_standalone_bn_act_quant(hip, act, bits, sh
   _close_bf16(Y, ref, frac_tol=2e-3 if bits is not None else 0.0, what='prologue %s/%s' % (act, bits))
 
 
-# the three-stage prologue kernel of pf_igemm.hip (k_igemm<128,256,..,3,PRO> for N % 256 == 0, <256,128,..,3,PRO> for
-# N % 128 == 0): deep contractions (up to the 2048 channels whose folded constants fill the LDS to its last byte), row tails,
+# the three-stage prologue kernels of pf_igemm.hip (wave-specialised k_igemm<..,IG_PROW> and single-role k_igemm<..,3,IG_PRO>;
+# 128 x 256 tiles for N % 256 == 0, 256 x 128 for N % 128 == 0): deep contractions (up to the 2048 channels whose folded constants fill the LDS to its last byte), row tails,
 # persistent workgroups that walk several row tiles, residual + statistics in the epilogue, and PF_IGEMM_PRO3=0 (round 2's
 # two-stage kernel) on the same inputs -- the two must agree to the last bit (same prologue arithmetic, same k order)
 @pytest.mark.parametrize('M,N,K', [(3000, 256, 1024), (5003, 512, 192), (2600, 128, 2048), (4133, 1024, 256), (40000, 256, 576),
@@ -108,14 +108,16 @@ def test_conv1x1_fwd_prologue_three_stage_kernel(hip, M, N, K, act, bits, monkey
   Q = torch.empty_like(X)
   hip.bn_act_quant_apply(X, Q, M, K, ss, act, sl, bits or 8, bits is not None)
   out = {}
-  for mode in ('1', '0'):
-    monkeypatch.setenv('PF_IGEMM_PRO3', mode)
+  # 'ws': wave-specialised (4 producer + 8 consumer wavefronts), '3': single-role three-stage kernel, '2': round 2's two-stage kernel
+  for mode, (pro3, prow) in (('ws', ('1', '1')), ('3', ('1', '0')), ('2', ('0', '0'))):
+    monkeypatch.setenv('PF_IGEMM_PRO3', pro3)
+    monkeypatch.setenv('PF_IGEMM_PROW', prow)
     G = hip.conv1x1_stats_groups(M, N, K, prologue=True)
     partial = torch.full((G, 4, N), float('nan'), device='cuda')
     Y = torch.full((M, N), float('nan'), device='cuda', dtype=torch.bfloat16)
     hip.conv1x1_fwd(X, W, Y, M, N, K, R=R, scale_shift=ss, act=act, slot=sl, bits=bits or 8, partial=partial)
     out[mode] = (Y, partial)
-  Y, partial = out['1']
+  Y, partial = out['ws']
   acc = Q.float() @ W.float().t()
   ref = _bf(_bf(acc).float() + R.float())
   _close_bf16(Y, ref, frac_tol=2e-3 if bits is not None else 1e-6, what='3-stage prologue', scale=acc)
@@ -125,7 +127,10 @@ def test_conv1x1_fwd_prologue_three_stage_kernel(hip, M, N, K, act, bits, monkey
   torch.testing.assert_close(partial[:, 1].sum(0), (y * y).sum(0), rtol=1e-4, atol=1e-2)
   assert torch.equal(partial[:, 2].min(0).values, y.min(0).values)
   assert torch.equal(partial[:, 3].max(0).values, y.max(0).values)
-  assert torch.equal(Y, out['0'][0]), 'two-stage and three-stage prologue kernels differ'
+  assert torch.equal(Y, out['2'][0]) and torch.equal(Y, out['3'][0]), 'the three prologue kernels differ'
+  for mode in ('3', '2'):                                      # and so do their statistics (different partial layouts, same sums)
+    torch.testing.assert_close(out[mode][1][:, 0].sum(0), partial[:, 0].sum(0), rtol=1e-5, atol=1e-3)
+    assert torch.equal(out[mode][1][:, 2].min(0).values, partial[:, 2].min(0).values)
 
 
 @pytest.mark.parametrize('n,H,Wd', [(3, 14, 10), (9, 46, 50)])

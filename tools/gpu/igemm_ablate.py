@@ -18,22 +18,17 @@ for n, name in ((1, 'fill'), (2, 'comp'), (3, 'mfma')):
   libs[name] = ctypes.CDLL(os.path.join(here, '_build', 'libig_ablate%d.so' % n))
 
 
-def timeit(fn, n=10):
-  for _ in range(3): fn()
-  torch.cuda.synchronize()
-  a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
-  a.record()
-  for _ in range(n): fn()
-  b.record(); torch.cuda.synchronize()
-  return a.elapsed_time(b) / n * 1e3
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _timing import gpu_time_us as timeit   # hipGraph replay: no host launch overhead in the numbers
 
 
-def call(lib, x, w, y, z, B, H, C, N, k, s, pad, Ho):
+def make_args(x, w, y, z, B, H, C, N, k, s, pad, Ho):
+  """ctypes argument objects, built ONCE per shape: a call then costs ~2 us of host time (rebuilding them per call makes
+  the loop host-bound at 30-45 us and every column reads the same)"""
   st = c_void_p(torch.cuda.current_stream().cuda_stream)
   p = lambda t: c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
-  r = lib.pf_conv2d_fwd(p(x), p(w), p(y), p(z), p(None), p(None), p(None), p(None), p(None), c_int(0), c_int(B), c_int(H), c_int(H),
-                        c_int(C), c_int(N), c_int(k), c_int(k), c_int(s), c_int(pad), c_int(pad), c_int(Ho), c_int(Ho), st)
-  assert r == 0, r
+  return (p(x), p(w), p(y), p(z), p(None), p(None), p(None), p(None), p(None), c_int(0), c_int(B), c_int(H), c_int(H),
+          c_int(C), c_int(N), c_int(k), c_int(k), c_int(s), c_int(pad), c_int(pad), c_int(Ho), c_int(Ho), st)
 
 
 B = int(os.environ.get('B', 256))
@@ -54,7 +49,12 @@ for H, C, N, k, s in shapes:
     if N % bn:
       continue
     os.environ['PF_IGEMM_TILE'] = t
-    ts = {name: timeit(lambda: call(lib, x, w, y, z, B, H, C, N, k, s, pad, Ho)) for name, lib in libs.items()}
+    args = make_args(x, w, y, z, B, H, C, N, k, s, pad, Ho)
+    ts = {}
+    for name, lib in libs.items():
+      fn = lib.pf_conv2d_fwd
+      assert fn(*args) == 0
+      ts[name] = timeit(lambda: fn(*args))
     ntile = ((M + bm - 1) // bm) * (N // bn)
     steps = k * k * C // 64
     mb = ntile * steps * (bm + bn) * 128 / 1e6

@@ -57,5 +57,15 @@ c4)
   python tools/prof_summary.py $(find /tmp/prof_r3a -name '*kernel_trace.csv' | head -1) --steps 4 --out gpurun_out/r03_step_kernels_b256.csv | head -40 | cut -c1-170
   cp $(find /tmp/prof_r3a -name '*kernel_stats.csv' | head -1) gpurun_out/r03_rocprofv3_stats_b256.csv
   ;;
+c5)
+  # wave-specialised prologue kernel: numerics, per-layer A/B (graph-replay timing), ablations re-timed without host overhead, step A/B
+  timeout 900 python -m pytest tests/test_conv_gpu.py -m gpu -q --tb=short -x -k "three_stage or prologue" 2>&1 | tail -12 | cut -c1-400 > gpurun_out/r03_c5_pytest.log
+  tail -5 gpurun_out/r03_c5_pytest.log
+  timeout 300 python tools/gpu/pro_bench.py > gpurun_out/r03_pro_bench.txt 2>&1; cat gpurun_out/r03_pro_bench.txt
+  timeout 400 python tools/gpu/wrw_ablate.py > gpurun_out/r03_wrw_ablation.txt 2>&1; cat gpurun_out/r03_wrw_ablation.txt
+  timeout 400 python tools/gpu/igemm_ablate.py > gpurun_out/r03_igemm_ablation.txt 2>&1; cat gpurun_out/r03_igemm_ablation.txt
+  PF_IGEMM_PROW=1 run_bench c2_ws --steps 15 --warmup 5 --no_cpu_baseline
+  PF_IGEMM_PROW=0 run_bench c2_pro3 --steps 15 --warmup 5 --no_cpu_baseline
+  ;;
 *) echo "unknown payload $1"; exit 2;;
 esac

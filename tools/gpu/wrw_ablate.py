@@ -19,14 +19,8 @@ LAUNCH = '_Z14pf_wrw2_launchPKvS0_PfPKfiPKjiiiiiiiiiiiiiilP12ihipStream_t'
 SPLITS = '_Z14pf_wrw2_splitsiiii'
 
 
-def timeit(fn, n=10):
-  for _ in range(3): fn()
-  torch.cuda.synchronize()
-  a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
-  a.record()
-  for _ in range(n): fn()
-  b.record(); torch.cuda.synchronize()
-  return a.elapsed_time(b) / n * 1e3
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _timing import gpu_time_us as timeit   # hipGraph replay: no host launch overhead in the numbers
 
 
 B = int(os.environ.get('B', 256))
@@ -50,14 +44,18 @@ for H, C, N, k, pro in shapes:
   p = lambda t: c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
   st = c_void_p(torch.cuda.current_stream().cuda_stream)
 
-  def run(lib):
-    f = getattr(lib, LAUNCH)
-    r = f(p(dy), p(x), p(ws), p(ss if pro else None), c_int(1), p(slot if pro else None), c_int(8), c_int(M), c_int(N), c_int(C), c_int(k), c_int(k),
+  # ctypes argument objects are built ONCE: a call then costs ~2 us of host time, well below the kernels (the first version
+  # of this tool rebuilt 22 c_int objects per call and measured the HOST: every column read ~45 us)
+  args = (p(dy), p(x), p(ws), p(ss if pro else None), c_int(1), p(slot if pro else None), c_int(8), c_int(M), c_int(N), c_int(C), c_int(k), c_int(k),
           c_int(H), c_int(H), c_int(H), c_int(H), c_int(1), c_int(pad), c_int(pad), c_int(S), c_int64(M), st)
-    assert r == 0, r
-  ts = {name: timeit(lambda: run(lib)) for name, lib in libs.items()}
+  ts = {}
+  for name, lib in libs.items():
+    fn = getattr(lib, LAUNCH)
+    assert fn(*args) == 0
+    ts[name] = timeit(lambda: fn(*args))
   red = getattr(prod, '_Z13pf_wrw_reducePfilPviP12ihipStream_t')
-  t_red = timeit(lambda: red(p(ws), c_int(S), c_int64(N * taps * C), p(dw), c_int(0), st))
+  rargs = (p(ws), c_int(S), c_int64(N * taps * C), p(dw), c_int(0), st)
+  t_red = timeit(lambda: red(*rargs))
   slab = S * N * taps * C * 4 / 1e6
   inp = (M * C + M * N) * 2 / 1e6
   print('%-16s %-4d | %7.0f %7.0f %7.0f %7.0f %8.0f | %9.0f | %8.0f %6.0f | %5.0f' % (
