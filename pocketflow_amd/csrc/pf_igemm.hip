@@ -166,6 +166,13 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
     boff[i] = (n < a.N) ? (uint32_t)(((int64_t)n * wrow + schunk * 8) * 2) : OOB;
   }
 
+  if (WS && a.partial != nullptr && g >= a.tiles_m) {
+    // a workgroup without a row tile still owns its row of the statistics array (WS writes partial[g] tile by tile)
+    for (int c = tid; c < 4 * BN; c += T) {
+      const int stat = c / BN, col = c - stat * BN;
+      if (n0 + col < a.N) a.partial[((int64_t)g * 4 + stat) * a.N + n0 + col] = (stat < 2) ? 0.f : (stat == 2 ? INFINITY : -INFINITY);
+    }
+  }
   for (int tm = g; tm < a.tiles_m; tm += a.G) {
     const int m0 = tm * BM;
     // input rows of this lane: byte offset of the top-left input pixel of the receptive field (may lie outside the

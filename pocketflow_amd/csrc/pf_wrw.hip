@@ -329,6 +329,53 @@ typedef int pf_wrsrc_t;                               // host pass: the kernel b
 #ifndef PF_W2_ABLATE
 #define PF_W2_ABLATE 0
 #endif
+// -DPF_W2_TIMING (tools/gpu/wrw_timeline.py only): lane 0 of every wavefront of the middle workgroup records s_memtime at 7
+// points of steps 4..11 into the first words of the slab workspace; the kernel returns before its epilogue then.
+// (plain global stores: they ride on vmcnt like the LDS-DMA, which can only lengthen the counted wait a little)
+#ifdef PF_W2_TIMING
+#define PF_W2_STAMP(k) do { if (blockIdx.x == (unsigned)tm_blk && t >= 4 && t < 12 && lane == 0) \
+    tm_out[(t - 4) * 8 + (k)] = (uint32_t)__builtin_readcyclecounter(); } while (0)
+#else
+#define PF_W2_STAMP(k) do { } while (0)
+#endif
+
+// MFMA fragments (8 consecutive pixels of one channel each: two transposing reads, `lo` at p + off and `hi` at
+// p + off + HI) through INLINE ASM.  Reason: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the first
+// __builtin_amdgcn_ds_read_tr16_b64 it meets while an LDS-DMA is pending (it treats the DMA as a store the read may alias):
+// in k_wrw2 that wait sat right behind the issue of the NEXT stage's loads, i.e. every step waited for the prefetch it had
+// just started -- no overlap of loads and matrix work at all.  The asm reads are invisible to that pass; the statement
+// carries its own lgkmcnt(0), so the results are valid when it ends.  The caller guarantees the stage has landed (own
+// counted vmcnt + barrier).
+__device__ __forceinline__ bf16x8 tr_join(const v4s& lo, const v4s& hi) {
+  v8s x8;
+  x8[0] = lo[0]; x8[1] = lo[1]; x8[2] = lo[2]; x8[3] = lo[3];
+  x8[4] = hi[0]; x8[5] = hi[1]; x8[6] = hi[2]; x8[7] = hi[3];
+  return *reinterpret_cast<const bf16x8*>(&x8);
+}
+template <int HI>
+__device__ __forceinline__ void tr_read_frags(uint32_t p, bf16x8 (&f)[4]) {
+  v4s l0, l1, l2, l3, h0, h1, h2, h3;
+  asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %4, %8 offset:%9\n\t"
+               "ds_read_b64_tr_b16 %1, %8 offset:256\n\tds_read_b64_tr_b16 %5, %8 offset:%10\n\t"
+               "ds_read_b64_tr_b16 %2, %8 offset:512\n\tds_read_b64_tr_b16 %6, %8 offset:%11\n\t"
+               "ds_read_b64_tr_b16 %3, %8 offset:768\n\tds_read_b64_tr_b16 %7, %8 offset:%12\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3), "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3)
+               : "v"(p), "n"(HI), "n"(HI + 256), "n"(HI + 512), "n"(HI + 768)
+               : "memory");
+  f[0] = tr_join(l0, h0); f[1] = tr_join(l1, h1); f[2] = tr_join(l2, h2); f[3] = tr_join(l3, h3);
+}
+template <int HI>
+__device__ __forceinline__ void tr_read_frags(uint32_t p, bf16x8 (&f)[2]) {
+  v4s l0, l1, h0, h1;
+  asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %2, %4 offset:%5\n\t"
+               "ds_read_b64_tr_b16 %1, %4 offset:256\n\tds_read_b64_tr_b16 %3, %4 offset:%6\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(l0), "=&v"(l1), "=&v"(h0), "=&v"(h1)
+               : "v"(p), "n"(HI), "n"(HI + 256)
+               : "memory");
+  f[0] = tr_join(l0, h0); f[1] = tr_join(l1, h1);
+}
 
 struct Wrw2Args {
   const bf16_t* dY;
@@ -343,7 +390,10 @@ struct Wrw2Args {
   int tiles_n, tiles, rows_per_split;
 };
 
-template <int TN, int TK, int WTN, int WTK, bool PRO, bool MAP>
+// MAPM: how an output pixel m maps to the X row it multiplies -- 0: identity (1x1, stride 1); 1: "same-size shift": an RxS
+// tap of a stride-1 convolution whose output has the input's size: row = m + (r - pad_h) * Wd + (s - pad_w) inside the image,
+// nothing outside (all address arithmetic incremental: one add per LDS-DMA and step); 2: general (strided) map.
+template <int TN, int TK, int WTN, int WTK, bool PRO, int MAPM>
 __global__ __launch_bounds__(64 * (TN / WTN) * (TK / WTK)) void k_wrw2(const Wrw2Args a) {
   constexpr int WN = TN / WTN, WK = TK / WTK, NWAVE = WN * WK;
   constexpr int NI = WTN / 16, NJ = WTK / 16;        // 16x16 accumulator blocks of one wavefront
@@ -377,8 +427,10 @@ __global__ __launch_bounds__(64 * (TN / WTN) * (TK / WTK)) void k_wrw2(const Wrw
   const int mend = (mbeg + a.rows_per_split < a.M) ? (mbeg + a.rows_per_split) : a.M;
   const int nsteps = (mend > mbeg) ? (mend - mbeg + 31) / 32 : 0;
 
-  const pf_wrsrc_t rsY = PF_W_MAKE_RSRC(a.dY, a.dy_bytes);
-  const pf_wrsrc_t rsX = PF_W_MAKE_RSRC(a.X, a.x_bytes);
+  // dY (and X under the identity map) are bounded at THIS workgroup's last pixel row: rows past it read zeros through the
+  // descriptor's range check, the tail needs no per-lane compare
+  const pf_wrsrc_t rsY = PF_W_MAKE_RSRC(a.dY, (uint32_t)mend * (uint32_t)a.N * 2u);
+  const pf_wrsrc_t rsX = PF_W_MAKE_RSRC(a.X, (MAPM == 0) ? (uint32_t)mend * (uint32_t)a.C * 2u : a.x_bytes);
   constexpr uint32_t OOB = 0x80000000u;
   const int sb = lane >> 4, srow = (lane & 15) >> 1, sch = lane & 1;       // role inside one LDS-DMA instruction
   const int hw_o = a.Ho * a.Wo;
@@ -400,19 +452,37 @@ __global__ __launch_bounds__(64 * (TN / WTN) * (TK / WTK)) void k_wrw2(const Wrw
     }
   }
 
-  // MAP: output pixel -> (img, ho, wo) of this lane's X rows, advanced by 32 pixels per step WITHOUT divisions (the
-  // stages are issued in step order; two index divisions per lane and step cost more VALU time than the MFMAs of the step)
+  // Source offsets of this lane's LDS-DMA slots, kept INCREMENTALLY: one add per slot and step (round 2 recomputed every
+  // offset from the pixel index with two 32-bit multiplies, the strided map with two more and a divergent while loop --
+  // the cycle stamps of round 3 showed ~900 of a step's 2700 cycles in that arithmetic, tools/gpu/wrw_timeline.py).
+  uint32_t yoff[KDY], xoff[XS];
+  const uint32_t ystep = 32u * (uint32_t)a.N * 2u, xstep = 32u * (uint32_t)a.C * 2u;
+#pragma unroll
+  for (int k = 0; k < KDY; ++k) {
+    const int id = wave + k * NWAVE;
+    const int pg = id / (TN / 64), g4 = id % (TN / 64);
+    const int n = n0 + (g4 * 4 + sb) * 16 + sch * 8;
+    yoff[k] = (n < a.N) ? (uint32_t)((mbeg + pg * 8 + srow) * a.N + n) * 2u : OOB;   // (OOB + steps stays out of range)
+  }
+  // MAPM == 1: (ho, wo) of the lane's pixel per X slot, advanced by 32 pixels per step with ONE conditional wrap each (the
+  // launcher selects this mode only when 32 / Wo + 1 <= Ho); MAPM == 2: (img, ho, wo), general
   int px_img[XS], px_ho[XS], px_wo[XS];
   const int adv_q = 32 / a.Wo, adv_r = 32 - adv_q * a.Wo;
-  if (MAP) {
+  const int tap_dr = tap_r - a.pad_h, tap_ds = tap_s - a.pad_w;
 #pragma unroll
-    for (int x = 0; x < XS; ++x) {
-      const int xi = wave + x * NWAVE;
-      const int pg = (xi < IX) ? xi / (TK / 64) : 0;
-      const int m = mbeg + pg * 8 + srow;
+  for (int x = 0; x < XS; ++x) {
+    const int xi = (wave + x * NWAVE) % IX;
+    const int pg = xi / (TK / 64), g4 = xi % (TK / 64);
+    const int m = mbeg + pg * 8 + srow;
+    const int cofs = c0 + (g4 * 4 + sb) * 16 + sch * 8;
+    px_img[x] = 0; px_ho[x] = 0; px_wo[x] = 0;
+    if (MAPM != 0) {
       const int img = m / hw_o, rem = m - img * hw_o;
       px_img[x] = img; px_ho[x] = rem / a.Wo; px_wo[x] = rem - px_ho[x] * a.Wo;
     }
+    // identity: row m; shift: row m + dr * Wd + ds (may be "negative" for masked taps: the offset is only used when valid)
+    const int row0 = (MAPM == 1) ? m + tap_dr * a.Wd + tap_ds : m;
+    xoff[x] = (uint32_t)(row0 * a.C + cofs) * 2u;
   }
   auto stage = [&](int step, int buf) {
     unsigned char* dst = smem + buf * STAGE;
@@ -421,31 +491,41 @@ __global__ __launch_bounds__(64 * (TN / WTN) * (TK / WTK)) void k_wrw2(const Wrw
     for (int k = 0; k < KDY; ++k) {
       const int id = wave + k * NWAVE;                                      // wave-uniform
       const int pg = id / (TN / 64), g4 = id % (TN / 64);
-      const int m = mb + pg * 8 + srow;
-      const int n = n0 + (g4 * 4 + sb) * 16 + sch * 8;
-      const uint32_t voff = (m < mend && n < a.N) ? (uint32_t)(m * a.N + n) * 2u : OOB;
-      if (!(PF_W2_ABLATE & 2)) PF_W_BUFFER_LOAD_LDS16(rsY, dst + (pg * NBN + g4 * 4) * 256, voff);
+      if (!(PF_W2_ABLATE & 2)) PF_W_BUFFER_LOAD_LDS16(rsY, dst + (pg * NBN + g4 * 4) * 256, yoff[k]);
+      yoff[k] += ystep;
     }
 #pragma unroll
     for (int x = 0; x < XS; ++x) {
-      const int xi = wave + x * NWAVE;
-      if (xi < IX) {
-        const int pg = xi / (TK / 64), g4 = xi % (TK / 64);
+      // every wavefront issues exactly XS X-pieces per stage (the counted vmcnt needs one number for all of them): a
+      // wavefront without a piece of its own loads zeros (out-of-range offset) into a 1 KiB sink behind the ring
+      const bool own = wave + x * NWAVE < IX;                               // wave-uniform
+      const int xi = (wave + x * NWAVE) % IX;
+      const int pg = xi / (TK / 64), g4 = xi % (TK / 64);
+      uint32_t voff;
+      if (MAPM == 0) {
+        voff = xoff[x];                                                      // tail rows: descriptor range check
+        xoff[x] += xstep;
+      } else if (MAPM == 1) {
         const int m = mb + pg * 8 + srow;
-        bool ok = m < mend;
-        int row = m;
-        if (MAP) {
-          const int hi = px_ho[x] * a.stride + tap_r - a.pad_h, wi = px_wo[x] * a.stride + tap_s - a.pad_w;
-          ok = ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.Wd;
-          row = (px_img[x] * a.H + hi) * a.Wd + wi;
-          // advance to the pixel of the next step
-          px_wo[x] += adv_r; px_ho[x] += adv_q;
-          if (px_wo[x] >= a.Wo) { px_wo[x] -= a.Wo; ++px_ho[x]; }
-          while (px_ho[x] >= a.Ho) { px_ho[x] -= a.Ho; ++px_img[x]; }
-        }
-        const uint32_t voff = ok ? (uint32_t)(row * a.C + c0 + (g4 * 4 + sb) * 16 + sch * 8) * 2u : OOB;
-        if (!(PF_W2_ABLATE & 2)) PF_W_BUFFER_LOAD_LDS16(rsX, dst + DY_BYTES + (pg * NBK + g4 * 4) * 256, voff);
+        const bool ok = m < mend && (unsigned)(px_ho[x] + tap_dr) < (unsigned)a.H && (unsigned)(px_wo[x] + tap_ds) < (unsigned)a.Wd;
+        voff = ok ? xoff[x] : OOB;
+        xoff[x] += xstep;
+        px_wo[x] += adv_r; px_ho[x] += adv_q;
+        if (px_wo[x] >= a.Wo) { px_wo[x] -= a.Wo; ++px_ho[x]; }
+        if (px_ho[x] >= a.Ho) px_ho[x] -= a.Ho;
+      } else {
+        const int m = mb + pg * 8 + srow;
+        const int hi = px_ho[x] * a.stride + tap_r - a.pad_h, wi = px_wo[x] * a.stride + tap_s - a.pad_w;
+        const bool ok = m < mend && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.Wd;
+        const int row = (px_img[x] * a.H + hi) * a.Wd + wi;
+        voff = ok ? (uint32_t)(row * a.C + c0 + (g4 * 4 + sb) * 16 + sch * 8) * 2u : OOB;
+        px_wo[x] += adv_r; px_ho[x] += adv_q;
+        if (px_wo[x] >= a.Wo) { px_wo[x] -= a.Wo; ++px_ho[x]; }
+        while (px_ho[x] >= a.Ho) { px_ho[x] -= a.Ho; ++px_img[x]; }
       }
+      if (!own) voff = OOB;
+      unsigned char* xdst = own ? dst + DY_BYTES + (pg * NBK + g4 * 4) * 256 : smem + 3 * STAGE;
+      if (!(PF_W2_ABLATE & 2)) PF_W_BUFFER_LOAD_LDS16(rsX, xdst, voff);
     }
   };
   auto transform = [&](int buf) {                                            // own X pieces, in place
@@ -457,8 +537,8 @@ __global__ __launch_bounds__(64 * (TN / WTN) * (TK / WTK)) void k_wrw2(const Wrw
         const int pg = xi / (TK / 64), g4 = xi % (TK / 64);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { pro.sc[j] = psc[x][j]; pro.sh[j] = psh[x][j]; }
-        uint4* p = reinterpret_cast<uint4*>(dst + DY_BYTES + (pg * NBK + g4 * 4) * 256 + lane * 16);
-        *p = pro_apply(pro, *p);
+        const uint32_t p = lds_addr(dst + DY_BYTES + (pg * NBK + g4 * 4) * 256 + lane * 16);   // asm accesses: see pf_conv_common.h
+        lds_write_b128(p, pro_apply(pro, lds_read_b128(p)));
       }
     }
   };
@@ -471,51 +551,58 @@ __global__ __launch_bounds__(64 * (TN / WTN) * (TK / WTK)) void k_wrw2(const Wrw
   const int tr_off = (q & 1) * 128 + (l15 >> 2) * 32 + (l15 & 3) * 8;
   const int pg_lo = q >> 1;
 
+  // Three-stage ring with COUNTED waits: the loads of step t+2 are issued at the top of step t and have two steps to land;
+  // a wavefront waits for its own pieces of step t+1 (vmcnt(LPS): the youngest stage stays in flight across the barrier),
+  // transforms them in place (PRO), and the barrier publishes them.  One barrier per step.
+  constexpr int NSTG = 3, LPS = KDY + XS;
   if (nsteps > 0) stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (PRO && nsteps > 0) { transform(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+  if (nsteps > 1) { stage(1, 1); wrw_wait_vm<LPS>(); } else wrw_wait_vm<0>();
+  if (PRO && nsteps > 0) transform(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  int buf = 0, ibuf = 2;
+#ifdef PF_W2_TIMING
+  const int tm_blk = gridDim.x / 2;
+  uint32_t* tm_out = reinterpret_cast<uint32_t*>(a.slabs) + wave * 64;
+#endif
   for (int t = 0; t < nsteps; ++t) {
-    const int buf = t & 1;
-    const bool more = t + 1 < nsteps;
-    if (more) stage(t + 1, buf ^ 1);
+    const bool more2 = t + 2 < nsteps;
+    PF_W2_STAMP(0);
+    if (more2) { stage(t + 2, ibuf); ibuf = (ibuf + 1 == NSTG) ? 0 : ibuf + 1; }
+    PF_W2_STAMP(1);
     const unsigned char* sbase = smem + buf * STAGE;
-    bf16x8 xf[NJ];
+    buf = (buf + 1 == NSTG) ? 0 : buf + 1;                                  // now: the buffer of step t+1
     if (!(PF_W2_ABLATE & 1)) {
+      // fragments by transposing LDS reads issued from inline asm (tr_read_frags): the compiler must not see them, or it
+      // drains the LDS-DMA of the younger stages (vmcnt(0)) in front of the first one
+      bf16x8 xf[NJ], df[NI];
+      tr_read_frags<2 * NBK * 256>(lds_addr(sbase + DY_BYTES + (pg_lo * NBK + wk * NJ) * 256 + tr_off), xf);
+      tr_read_frags<2 * NBN * 256>(lds_addr(sbase + (pg_lo * NBN + wn * NI) * 256 + tr_off), df);
+      PF_W2_STAMP(2);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int cb = wk * NJ + j;
-      const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (__attribute__((address_space(3))) v4s*)(sbase + DY_BYTES + (pg_lo * NBK + cb) * 256 + tr_off));
-      const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (__attribute__((address_space(3))) v4s*)(sbase + DY_BYTES + ((pg_lo + 2) * NBK + cb) * 256 + tr_off));
-      v8s x8;
-      x8[0] = lo[0]; x8[1] = lo[1]; x8[2] = lo[2]; x8[3] = lo[3];
-      x8[4] = hi[0]; x8[5] = hi[1]; x8[6] = hi[2]; x8[7] = hi[3];
-      xf[j] = *reinterpret_cast<const bf16x8*>(&x8);
-    }
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int nb = wn * NI + i;
-      const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (__attribute__((address_space(3))) v4s*)(sbase + (pg_lo * NBN + nb) * 256 + tr_off));
-      const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (__attribute__((address_space(3))) v4s*)(sbase + ((pg_lo + 2) * NBN + nb) * 256 + tr_off));
-      v8s d8;
-      d8[0] = lo[0]; d8[1] = lo[1]; d8[2] = lo[2]; d8[3] = lo[3];
-      d8[4] = hi[0]; d8[5] = hi[1]; d8[6] = hi[2]; d8[7] = hi[3];
-      const bf16x8 df = *reinterpret_cast<const bf16x8*>(&d8);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, xf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[i], xf[j], acc[i][j], 0, 0, 0);
     }
+    // the MFMAs are register-only: without this fence the compiler sinks them BELOW the wait (inline asm's "memory" clobber
+    // orders memory operations only), and the wavefront would sit out the load latency before starting its matrix work
+    __builtin_amdgcn_sched_barrier(0);
+    PF_W2_STAMP(3);
+    if (t + 1 < nsteps) {
+      if (more2) wrw_wait_vm<LPS>(); else wrw_wait_vm<0>();                 // own pieces of step t+1 have landed
+      PF_W2_STAMP(4);
+      if (PRO) transform(buf);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // own pieces of the next stage have landed
-    if (PRO && more) transform(buf ^ 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PF_W2_STAMP(5);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    PF_W2_STAMP(6);
   }
+#ifdef PF_W2_TIMING
+  return;
+#endif
 
   float* out = a.slabs + (int64_t)split * a.N * ktot;
   const int kcol = tap * a.C + c0 + wk * WTK;
@@ -559,17 +646,17 @@ int pf_wrw2_splits(int M, int N, int C, int taps) {
   return (M + rows - 1) / rows;
 }
 
-template <int TN, int TK, int WTN, int WTK, bool PRO, bool MAP>
+template <int TN, int TK, int WTN, int WTK, bool PRO, int MAPM>
 static int wrw2_launch_t(const Wrw2Args& a, int grid, hipStream_t st) {
-  const size_t lds = 2 * (size_t)(4 * (TN / 16) * 256 + 4 * (TK / 16) * 256);
+  const size_t lds = 3 * (size_t)(4 * (TN / 16) * 256 + 4 * (TK / 16) * 256) + 1024;   // three stages + the 1 KiB sink
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wrw2<TN, TK, WTN, WTK, PRO, MAP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wrw2<TN, TK, WTN, WTK, PRO, MAPM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
-  k_wrw2<TN, TK, WTN, WTK, PRO, MAP><<<grid, 64 * (TN / WTN) * (TK / WTK), lds, st>>>(a);
+  k_wrw2<TN, TK, WTN, WTK, PRO, MAPM><<<grid, 64 * (TN / WTN) * (TK / WTK), lds, st>>>(a);
   PF_LAUNCH_CHECK();
   return 0;
 }
@@ -596,14 +683,19 @@ int pf_wrw2_launch(const void* dY, const void* X, float* slabs, const float* sca
   a.rows_per_split = rows;
   const int grid = a.tiles * S;
   const bool pro = scale_shift != nullptr;
-  const bool map = stride != 1 || th * tw > 1;
+  // 0: identity; 1: stride-1 tap of a same-size convolution (incremental shift addressing; one wrap per step must be
+  // enough: 32 / Wo + 1 <= Ho); 2: general
+  int mapm = 0;
+  if (stride != 1 || th * tw > 1) mapm = (stride == 1 && Ho == H && Wo == Wd && 32 / Wo + 1 <= Ho) ? 1 : 2;
   if (pro && th * tw > 1) return -1;
+  if (pro && mapm == 1) mapm = 2;                       // (prologue variants: identity and general only)
 #define PF_W2(TNV, TKV, WTNV, WTKV)                                                                           \
   do {                                                                                                        \
-    if (pro) return map ? wrw2_launch_t<TNV, TKV, WTNV, WTKV, true, true>(a, grid, st)                         \
-                        : wrw2_launch_t<TNV, TKV, WTNV, WTKV, true, false>(a, grid, st);                       \
-    return map ? wrw2_launch_t<TNV, TKV, WTNV, WTKV, false, true>(a, grid, st)                                 \
-               : wrw2_launch_t<TNV, TKV, WTNV, WTKV, false, false>(a, grid, st);                               \
+    if (pro) return mapm ? wrw2_launch_t<TNV, TKV, WTNV, WTKV, true, 2>(a, grid, st)                           \
+                         : wrw2_launch_t<TNV, TKV, WTNV, WTKV, true, 0>(a, grid, st);                          \
+    if (mapm == 1) return wrw2_launch_t<TNV, TKV, WTNV, WTKV, false, 1>(a, grid, st);                          \
+    return mapm ? wrw2_launch_t<TNV, TKV, WTNV, WTKV, false, 2>(a, grid, st)                                   \
+                : wrw2_launch_t<TNV, TKV, WTNV, WTKV, false, 0>(a, grid, st);                                  \
   } while (0)
   if (c.tn == 256 && c.tk == 128) PF_W2(256, 128, 64, 64);
   if (c.tn == 128 && c.tk == 128) PF_W2(128, 128, 64, 64);

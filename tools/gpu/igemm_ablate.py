@@ -54,7 +54,7 @@ for H, C, N, k, s in shapes:
     for name, lib in libs.items():
       fn = lib.pf_conv2d_fwd
       assert fn(*args) == 0
-      ts[name] = timeit(lambda: fn(*args))
+      ts[name] = timeit(lambda: fn(*(args[:-1] + (c_void_p(torch.cuda.current_stream().cuda_stream),))))
     ntile = ((M + bm - 1) // bm) * (N // bn)
     steps = k * k * C // 64
     mb = ntile * steps * (bm + bn) * 128 / 1e6

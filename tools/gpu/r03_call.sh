@@ -67,5 +67,21 @@ c5)
   PF_IGEMM_PROW=1 run_bench c2_ws --steps 15 --warmup 5 --no_cpu_baseline
   PF_IGEMM_PROW=0 run_bench c2_pro3 --steps 15 --warmup 5 --no_cpu_baseline
   ;;
+c6)
+  timeout 900 python -m pytest tests/test_conv_gpu.py -m gpu -q --tb=short -k "three_stage" 2>&1 | tail -6 | cut -c1-300
+  timeout 300 python tools/gpu/pro_bench.py > gpurun_out/r03_pro_bench.txt 2>&1; cat gpurun_out/r03_pro_bench.txt
+  timeout 400 python tools/gpu/wrw_ablate.py > gpurun_out/r03_wrw_ablation.txt 2>&1; cat gpurun_out/r03_wrw_ablation.txt
+  timeout 400 python tools/gpu/igemm_ablate.py > gpurun_out/r03_igemm_ablation.txt 2>&1; cat gpurun_out/r03_igemm_ablation.txt
+  ;;
+c7)
+  # three-stage backward-filter kernel (asm transposing reads, counted vmcnt): numerics, ablation, step
+  timeout 900 python -m pytest tests/test_conv_gpu.py tests/test_igemm_gpu.py -m gpu -q --tb=short -k "wrw or backward_filter" 2>&1 | tail -6 | cut -c1-300
+  timeout 400 python tools/gpu/wrw_ablate.py > gpurun_out/r03_wrw_ablation.txt 2>&1; cat gpurun_out/r03_wrw_ablation.txt
+  run_bench c2_wrw3 --steps 15 --warmup 5 --no_cpu_baseline
+  ;;
+c8)
+  timeout 900 python -m pytest tests/test_conv_gpu.py tests/test_igemm_gpu.py -m gpu -q --tb=short -k "wrw or backward_filter" 2>&1 | tail -4 | cut -c1-300
+  timeout 300 python tools/gpu/wrw_timeline.py 2>&1 | tee gpurun_out/r03_wrw_timeline.txt
+  ;;
 *) echo "unknown payload $1"; exit 2;;
 esac

@@ -11,7 +11,7 @@ import torch
 from pocketflow_amd import hip
 
 here = os.path.dirname(os.path.abspath(__file__))
-prod = ctypes.CDLL(hip.lib_path(), mode=ctypes.RTLD_GLOBAL)
+prod = ctypes.CDLL(hip.lib_path())      # NOT RTLD_GLOBAL: the ablation builds' template kernels would bind to the product's
 libs = {'full': prod}
 for n, name in ((1, 'nomma'), (2, 'nodma'), (4, 'nost'), (6, 'mmaonly')):
   libs[name] = ctypes.CDLL(os.path.join(here, '_build', 'libwrw_ablate%d.so' % n))
@@ -52,10 +52,10 @@ for H, C, N, k, pro in shapes:
   for name, lib in libs.items():
     fn = getattr(lib, LAUNCH)
     assert fn(*args) == 0
-    ts[name] = timeit(lambda: fn(*args))
+    ts[name] = timeit(lambda: fn(*(args[:-1] + (c_void_p(torch.cuda.current_stream().cuda_stream),))))
   red = getattr(prod, '_Z13pf_wrw_reducePfilPviP12ihipStream_t')
   rargs = (p(ws), c_int(S), c_int64(N * taps * C), p(dw), c_int(0), st)
-  t_red = timeit(lambda: red(*rargs))
+  t_red = timeit(lambda: red(*(rargs[:-1] + (c_void_p(torch.cuda.current_stream().cuda_stream),))))
   slab = S * N * taps * C * 4 / 1e6
   inp = (M * C + M * N) * 2 / 1e6
   print('%-16s %-4d | %7.0f %7.0f %7.0f %7.0f %8.0f | %9.0f | %8.0f %6.0f | %5.0f' % (
