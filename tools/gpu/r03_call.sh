@@ -83,5 +83,11 @@ c8)
   timeout 900 python -m pytest tests/test_conv_gpu.py tests/test_igemm_gpu.py -m gpu -q --tb=short -k "wrw or backward_filter" 2>&1 | tail -4 | cut -c1-300
   timeout 300 python tools/gpu/wrw_timeline.py 2>&1 | tee gpurun_out/r03_wrw_timeline.txt
   ;;
+c12)
+  timeout 900 python -m pytest tests/test_conv_gpu.py tests/test_igemm_gpu.py -m gpu -q --tb=short -k "wrw or backward_filter" 2>&1 | tail -4 | cut -c1-300
+  timeout 300 python tools/gpu/wrw_timeline.py 2>&1 | tee gpurun_out/r03_wrw_timeline.txt
+  timeout 400 python tools/gpu/wrw_ablate.py 2>&1 | tee gpurun_out/r03_wrw_ablation.txt
+  run_bench c2_wrw3b --steps 15 --warmup 5 --no_cpu_baseline
+  ;;
 *) echo "unknown payload $1"; exit 2;;
 esac
