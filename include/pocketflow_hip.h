@@ -267,6 +267,10 @@ int pf_conv1x1_wrw(const void* dY, const void* X, void* dW, int dw_dtype, float*
  *   Backward-data of a stride-1 convolution is the same call on dY with the kernel flipped and transposed:
  *   W'[c][r][s][n] = W[n][th-1-r][tw-1-s][c], pad' = th-1-pad.                                                      */
 int pf_conv2d_stats_groups(int M, int N);
+/* the same for a given geometry: 3x3 / stride 1 / pad 1 convolutions run on the halo kernel (pf_conv3x3.hip), whose
+ * workgroups walk the padded-flat pixel space -- ask with the SAME arguments as the pf_conv2d_fwd call that follows           */
+int pf_conv2d_stats_groups_geom(int imgs, int H, int Wd, int C, int N, int th, int tw, int stride, int pad_h, int pad_w,
+                                int Ho, int Wo);
 int pf_conv2d_fwd(const void* X, const void* W, void* Y, const void* zero, const void* R, float* partial,
                   const void* bn_x, const float* bn_scale_shift, const float* bn_mean_invstd, int bn_act,
                   int imgs, int H, int Wd, int C, int N, int th, int tw, int stride, int pad_h, int pad_w,

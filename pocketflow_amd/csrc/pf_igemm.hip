@@ -552,8 +552,11 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
 struct IgCfg { int bm, bn, slots; bool pro3, prow; };    // slots: resident workgroups on the chip (256 CUs x workgroups per CU)
 
 static bool ig_prow_enabled() {
-  const char* e = getenv("PF_IGEMM_PROW");                 // =0: the single-role three-stage kernel (A/B runs)
-  return e == nullptr || atoi(e) != 0;
+  // =1: the wave-specialised variant (IG_PROW).  Measured in round 3 (profiles/r03_pro_bench.txt, step A/B 9 092 vs 9 199
+  // images/s): no faster than the single-role three-stage kernel -- the prologue's VALU work was not what bounds these
+  // layers (the LDS fill is) -- so it is opt-in; the tests keep it alive.
+  const char* e = getenv("PF_IGEMM_PROW");
+  return e != nullptr && atoi(e) != 0;
 }
 
 static bool ig_pro3_enabled() {
@@ -653,6 +656,20 @@ static int ig_launch(IgArgs& a, hipStream_t st) {
 #undef PF_IG
 }
 
+// pf_conv3x3.hip: 3x3 / stride 1 / pad 1 with the input window (halo included) staged once per 64-channel chunk
+int pf_conv3x3_halo_ok(int imgs, int H, int Wd, int C, int N, int th, int tw, int stride, int pad_h, int pad_w, int Ho, int Wo);
+int pf_conv3x3_halo_groups(int imgs, int H, int Wd, int N);
+int pf_conv3x3_halo_launch(const void* X, const void* W, void* Y, const void* R, float* partial, const void* bn_x,
+                           const float* bss, const float* bmi, float b_lo, float b_hi, int imgs, int H, int Wd, int C, int N,
+                           hipStream_t st);
+
+// rows of the [G][.][N] statistics array pf_conv2d_fwd writes for THIS convolution (depends on the kernel it is dispatched to)
+extern "C" int pf_conv2d_stats_groups_geom(int imgs, int H, int Wd, int C, int N, int th, int tw, int stride, int pad_h,
+                                           int pad_w, int Ho, int Wo) {
+  if (pf_conv3x3_halo_ok(imgs, H, Wd, C, N, th, tw, stride, pad_h, pad_w, Ho, Wo)) return pf_conv3x3_halo_groups(imgs, H, Wd, N);
+  return pf_igemm_stats_groups(imgs * Ho * Wo, N, 0);
+}
+
 // forward convolution (or any implicit GEMM of that form).  X [img][H][Wd][C], W [N][th][tw][C], Y [img][Ho][Wo][N].
 // zero: >= 128 zero bytes in device memory.  R / partial / bn_*: epilogue options as for pf_conv1x1_fwd /
 // pf_conv1x1_bwd_data_bnstats (partial: [G][4][N] or, with bn_x, [G][2][N]; G = pf_conv2d_stats_groups(M, N)).
@@ -670,6 +687,10 @@ extern "C" int pf_conv2d_fwd(const void* X, const void* W, void* Y, const void* 
     return (int)hipErrorInvalidValue;
   if ((int64_t)imgs * H * Wd * C >= ((int64_t)1 << 30) || (int64_t)N * th * tw * C >= ((int64_t)1 << 30) || th * tw > 32)
     return (int)hipErrorInvalidValue;                     // 31-bit byte offsets and a 32-bit tap mask inside the kernel
+  if (pf_conv3x3_halo_ok(imgs, H, Wd, C, N, th, tw, stride, pad_h, pad_w, Ho, Wo))
+    return pf_conv3x3_halo_launch(X, W, Y, R, partial, bn_x, bn_scale_shift, bn_mean_invstd,
+                                  (bn_act == PF_ACT_NONE) ? -INFINITY : 0.0f, (bn_act == PF_ACT_RELU6) ? 6.0f : INFINITY, imgs, H, Wd,
+                                  C, N, (hipStream_t)stream);
   IgArgs a;
   a.X = (const bf16_t*)X; a.W = (const bf16_t*)W; a.Y = (bf16_t*)Y; a.zero = (const bf16_t*)zero;
   a.R = (const bf16_t*)R; a.partial = partial; a.bx = (const bf16_t*)bn_x; a.bss = bn_scale_shift; a.bmi = bn_mean_invstd;

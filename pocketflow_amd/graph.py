@@ -848,9 +848,7 @@ def _run_conv2d(x, w_krsc, stride, pad, want_stats):
   M = B * Ho * Wo
   partial, G = None, 0
   if want_stats:
-    G = hip.conv2d_stats_groups(M, N)
-    partial = torch.empty((G, 4, N), dtype=torch.float32, device=x.device)
-  with region('conv2d_fwd', float((B * H * W * C + M * N) * 2)):
+XX, float((B * H * W * C + M * N) * 2)):
     hip.conv2d_fwd(x, w_krsc, y, B, H, W, C, N, R, S, stride, pad[0], pad[1], Ho, Wo, partial=partial)
   if want_stats:
     y._pf_stats = (partial, G)
@@ -918,7 +916,7 @@ class _Conv2dIgemm(torch.autograd.Function):
                 and bn_box.get('act') in ('Relu', 'Relu6') and bn_box['x'].shape == x.shape)
         with region('conv2d_bwd_data', float((dy.numel() + x.numel() * (2 if fuse else 1)) * 2)):
           if fuse:
-            G = hip.conv2d_stats_groups(M, C)
+            G = hip.conv2d_stats_groups(M, C, geom=(B, H, W, N, C, R, S, 1, R - 1 - pad[0], S - 1 - pad[1], H, W))
             partial = torch.empty((G, 2, C), dtype=torch.float32, device=x.device)
             hip.conv2d_fwd(dy, wb, dx, B, H, W, N, C, R, S, 1, R - 1 - pad[0], S - 1 - pad[1], H, W, partial=partial,
                            bn_x=bn_box['x'], bn_scale_shift=bn_box['scale_shift'], bn_mean_invstd=bn_box['mean_invstd'],

@@ -44,7 +44,7 @@ SYMBOLS = [
     'pf_conv1x1_stats_groups', 'pf_conv1x1_stats_groups_k', 'pf_conv1x1_fwd', 'pf_conv1x1_bwd_data_bnstats', 'pf_conv1x1_wrw_splits',
     'pf_conv1x1_wrw', 'pf_conv2d_stats_groups', 'pf_conv2d_fwd', 'pf_conv2d_wrw_splits', 'pf_conv2d_wrw', 'pf_maxpool_fwd', 'pf_maxpool_bwd', 'pf_seg_transpose', 'pf_conv_stem_supported', 'pf_conv_stem_fwd', 'pf_conv_stem_wrw_slabs', 'pf_conv_stem_wrw',
     'pf_image_resize_bilinear', 'pf_depthwise_supported', 'pf_depthwise_groups', 'pf_depthwise_fwd', 'pf_depthwise_bwd_data',
-    'pf_depthwise_wrw',
+    'pf_depthwise_wrw', 'pf_conv2d_stats_groups_geom',
 ]
 
 
@@ -362,7 +362,11 @@ def zero_page(device):
   return z
 
 
-def conv2d_stats_groups(M: int, N: int) -> int:
+def conv2d_stats_groups(M: int, N: int, geom=None) -> int:
+  """Rows of the statistics array of a pf_conv2d_fwd call.  `geom` = (imgs, H, Wd, C, N, th, tw, stride, pad_h, pad_w, Ho, Wo)
+  of THAT call: the kernel (and with it the number of workgroup rows) depends on the geometry."""
+  if geom is not None:
+    return int(_lib.pf_conv2d_stats_groups_geom(*[c_int(int(v)) for v in geom]))
   return int(_lib.pf_conv2d_stats_groups(c_int(M), c_int(N)))
 
 

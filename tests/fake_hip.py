@@ -207,7 +207,7 @@ class FakeHip(object):
     dW.copy_(g.permute(0, 2, 3, 1))
 
   # -- RxS convolutions (pf_igemm.hip) ------------------------------------------------------------------------------------
-  def conv2d_stats_groups(self, M, N):
+  def conv2d_stats_groups(self, M, N, geom=None):
     return 3
 
   def conv2d_fwd(self, X, W, Y, imgs, H, Wd, C, N, th, tw, stride, pad_h, pad_w, Ho, Wo, R=None, partial=None, bn_x=None,

@@ -89,5 +89,12 @@ c12)
   timeout 400 python tools/gpu/wrw_ablate.py 2>&1 | tee gpurun_out/r03_wrw_ablation.txt
   run_bench c2_wrw3b --steps 15 --warmup 5 --no_cpu_baseline
   ;;
+c13)
+  # halo 3x3 kernel: numerics (forward, statistics + residual, backward-data + BN sums), per-layer table vs per-tap igemm / MIOpen, step
+  timeout 900 python -m pytest tests/test_igemm_gpu.py -m gpu -q --tb=short -x -k "conv2d_fwd or backward_data" 2>&1 | tail -12 | cut -c1-300
+  timeout 600 python tools/gpu/igemm_bench.py 2>&1 | tee gpurun_out/r03_igemm_layers.txt | cut -c1-220
+  PF_CONV3X3_HALO=1 run_bench c2_halo --steps 15 --warmup 5 --no_cpu_baseline
+  PF_CONV3X3_HALO=0 run_bench c2_nohalo --steps 15 --warmup 5 --no_cpu_baseline
+  ;;
 *) echo "unknown payload $1"; exit 2;;
 esac
