@@ -185,6 +185,27 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a)
 
     // ---- epilogue of one [128][BN_T] tile ---------------------------------------------------------
     // accumulators: D row = channel (lane >> 4) * 4 + r of block i, D col = pixel (lane & 15) of block j
+    const int m0 = (g + ti * a.G) * CV_BM;
+    if (!bwd_stats && a.R != nullptr) {
+      // residual added to the fp32 accumulators: the sum is rounded to bf16 ONCE (in the staging below).  This lane's
+      // four channels of pixel (j, frow) are 8 contiguous bytes of R.
+#pragma unroll
+      for (int j = 0; j < JM; ++j) {
+        const int m = m0 + wm * WM + j * 16 + frow;
+        if (m < a.M) {
+          const int64_t orow = (MAP && a.ymap) ? map_row(a, m) : (int64_t)m;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+            if (n < a.N) {
+              const uint2 r = *reinterpret_cast<const uint2*>(a.R + orow * a.N + n);
+              acc[i][j][0] += __uint_as_float(r.x << 16); acc[i][j][1] += __uint_as_float(r.x & 0xFFFF0000u);
+              acc[i][j][2] += __uint_as_float(r.y << 16); acc[i][j][3] += __uint_as_float(r.y & 0xFFFF0000u);
+            }
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -192,10 +213,10 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a)
         const uint2 v = make_uint2(pack_bf16x2(acc[i][j][0], acc[i][j][1]), pack_bf16x2(acc[i][j][2], acc[i][j][3]));
         *reinterpret_cast<uint2*>(Cs + (wm * WM + j * 16 + frow) * CS_LD + wn * 64 + i * 16 + (lane >> 4) * 4) = v;
       }
-    // residual vectors of this thread's 8 (or 4) output rows: all loads in flight before the LDS hand-off
-    const int m0 = (g + ti * a.G) * CV_BM;
+    // BN-input vectors (backward statistics) of this thread's 8 (or 4) output rows: all loads in flight before the LDS
+    // hand-off
     uint4 rres[CV_BM / RPP];
-    const bf16_t* __restrict__ side = bwd_stats ? a.bx : a.R;   // second [M][N] operand of the epilogue
+    const bf16_t* __restrict__ side = bwd_stats ? a.bx : nullptr;   // second [M][N] operand of the row pass
     if (side != nullptr) {
 #pragma unroll
       for (int p = 0; p < CV_BM / RPP; ++p) {
@@ -230,14 +251,6 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a)
         } else if (a.R != nullptr || a.partial != nullptr) {
           float f[8];
           unpack8(c, f);
-          if (a.R != nullptr) {
-            float r[8];
-            unpack8(rres[p], r);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] += r[j];
-            c = pack8(f);
-            unpack8(c, f);                           // statistics see the stored (bf16) values
-          }
           if (a.partial != nullptr) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {

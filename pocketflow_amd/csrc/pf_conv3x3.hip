@@ -108,7 +108,7 @@ __global__ __launch_bounds__(H3_T) void k_conv3x3_halo(const H3Args a) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; st_mn[j] = INFINITY; st_mx[j] = -INFINITY; }
   const int wvec = tid % VPR, wrw = tid / VPR;
-  const bf16_t* __restrict__ side = BWD ? a.bx : a.R;
+  const bf16_t* __restrict__ side = BWD ? a.bx : nullptr;                 // the residual is added on the accumulators
 
   const pf_hrsrc_t rsX = PF_H_MAKE_RSRC(a.X, a.x_bytes);
   const pf_hrsrc_t rsW = PF_H_MAKE_RSRC(a.W, a.w_bytes);
@@ -218,6 +218,30 @@ __global__ __launch_bounds__(H3_T) void k_conv3x3_halo(const H3Args a) {
     h3_wait_vm<0>();                                                        // the trailing dummy loads (the sink is never read)
 
     // ---- epilogue of one [BM][BN] tile; rows are flat positions: border positions are skipped ---------------------------
+    if (!BWD && a.R != nullptr) {
+      // residual on the fp32 accumulators (one rounding, in the staging below); this lane's rows are flat positions
+#pragma unroll
+      for (int j = 0; j < JM; ++j) {
+        const int f = f0 + wm * WR + j * 16 + l15;
+        int m = -1;
+        if (f < a.F) {
+          const int img = f / HWp, rem = f - img * HWp;
+          const int hp = rem / Wp, wp = rem - hp * Wp;
+          if (hp > 0 && wp > 0) m = (img * a.H + hp - 1) * a.Wd + wp - 1;
+        }
+        if (m >= 0) {
+#pragma unroll
+          for (int i = 0; i < NI; ++i) {
+            const int n = n0 + wn * WC + i * 16 + q * 4;
+            if (n < a.N) {
+              const uint2 r = *reinterpret_cast<const uint2*>(a.R + (int64_t)m * a.N + n);
+              acc[i][j][0] += __uint_as_float(r.x << 16); acc[i][j][1] += __uint_as_float(r.x & 0xFFFF0000u);
+              acc[i][j][2] += __uint_as_float(r.y << 16); acc[i][j][3] += __uint_as_float(r.y & 0xFFFF0000u);
+            }
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -276,14 +300,6 @@ __global__ __launch_bounds__(H3_T) void k_conv3x3_halo(const H3Args a) {
           } else if (a.R != nullptr || a.partial != nullptr) {
             float f[8];
             unpack8(c, f);
-            if (a.R != nullptr) {
-              float rr[8];
-              unpack8(rres[pp], rr);
-#pragma unroll
-              for (int j = 0; j < 8; ++j) f[j] += rr[j];
-              c = pack8(f);
-              unpack8(c, f);                                                // statistics see the stored (bf16) values
-            }
             if (a.partial != nullptr) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) {
@@ -326,8 +342,14 @@ __global__ __launch_bounds__(H3_T) void k_conv3x3_halo(const H3Args a) {
 
 // ---- host side ---------------------------------------------------------------------------------------------------
 static bool h3_enabled() {
-  const char* e = getenv("PF_CONV3X3_HALO");               // =0: the per-tap implicit GEMM of pf_igemm.hip (A/B runs)
-  return e == nullptr || atoi(e) != 0;
+  // =1: this kernel; default: the per-tap implicit GEMM of pf_igemm.hip.  Measured in round 3 (profiles/r03_igemm_layers.txt,
+  // B = 256, us, halo vs 128 x 128 igemm with two workgroups per CU): 56x56 C=64 135 vs 136, 28x28 C=128 92 vs 85, 14x14 C=256
+  // 82 vs 74, 7x7 C=512 72 vs 65.  A 3.2x smaller LDS fill did NOT make it faster: with one 8-wavefront workgroup per CU
+  // every wavefront runs issue -> fragment reads -> MFMAs -> wait -> barrier in lockstep and the matrix pipe idles through
+  // the first and the last two; two independent 4-wavefront workgroups per CU overlap those phases by drifting apart.
+  // Kept opt-in (tests run it): the structure it needs next is a ping-pong schedule of the two wavefronts of a SIMD.
+  const char* e = getenv("PF_CONV3X3_HALO");
+  return e != nullptr && atoi(e) != 0;
 }
 
 // does the halo kernel take this convolution?  (3x3, stride 1, pad 1, same size; 64-channel chunks; window fits the LDS)

@@ -92,12 +92,14 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
   __syncthreads();
 
   const int wswz = (KV >= 16) ? l15 : (l15 & 7);                          // this lane's weight-row swizzle
-  const bf16_t* __restrict__ side = BWD ? a.bx : a.R;                    // second [M][N] operand of the epilogue
+  const bf16_t* __restrict__ side = BWD ? a.bx : nullptr;                // second [M][N] operand of the row pass
+  const bool has_r = !BWD && a.R != nullptr;                             // residual: added on the fp32 accumulators
   const int wvec = lane % VPR, wrow = lane / VPR;
 
   f32x4 acc[NI][JM];
   uint4 ring[D][NR];
   uint4 rres[NP];
+  uint2 rr[NI][JM];                                                      // residual of the NEXT strip, accumulator layout
   float st_s[8], st_q[8], st_mn[8], st_mx[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; st_mn[j] = INFINITY; st_mx[j] = -INFINITY; }
@@ -126,9 +128,25 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
     rres[p] = v;
   };
 
+  // residual of strip s in the accumulator layout (this lane: pixel (j, l15), four channels of block i = 8 bytes)
+  auto issue_res = [&](int s) {
+#pragma unroll
+    for (int j = 0; j < JM; ++j) {
+      const int m = s * RS + j * 16 + l15;
+      const int64_t orow = (m < a.M) ? ((MAP && a.ymap) ? map_row(a, m) : (int64_t)m) : 0;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int n = n0 + i * 16 + q * 4;
+        uint2 v = make_uint2(0, 0);
+        if (m < a.M && n < a.N) v = *reinterpret_cast<const uint2*>(a.R + orow * a.N + n);
+        rr[i][j] = v;
+      }
+    }
+  };
 #pragma clang loop unroll(full)
   for (int d = 0; d < D; ++d)
     if (d < T) issue(ring[d]);
+  if (has_r && cnt > 0) issue_res(s_first);
   if (side != nullptr && cnt > 0) {
 #pragma unroll
     for (int p = 0; p < NP; ++p) issue_side(s_first, p);
@@ -195,6 +213,15 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
     if (!last) continue;
 
     // ---- epilogue of one [RS][NW] tile: wave-private transposition, no workgroup barrier ----------------------
+    if (has_r) {                                                         // ONE rounding to bf16 (in the staging below)
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < JM; ++j) {
+          acc[i][j][0] += __uint_as_float(rr[i][j].x << 16); acc[i][j][1] += __uint_as_float(rr[i][j].x & 0xFFFF0000u);
+          acc[i][j][2] += __uint_as_float(rr[i][j].y << 16); acc[i][j][3] += __uint_as_float(rr[i][j].y & 0xFFFF0000u);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -203,6 +230,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
         *reinterpret_cast<uint2*>(Cs + (j * 16 + l15) * CS_LD + i * 16 + q * 4) = w;
       }
     const bool more = (cs < NS);                                         // this wavefront has another strip
+    if (has_r && more) issue_res(cs);                                    // next strip's residual travels under its main loop
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int rl = p * RPP + wrow;
@@ -227,14 +255,6 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
         } else if (a.R != nullptr || a.partial != nullptr) {
           float f[8];
           unpack8(c, f);
-          if (a.R != nullptr) {
-            float r[8];
-            unpack8(sv, r);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] += r[j];
-            c = pack8(f);
-            unpack8(c, f);                                               // statistics see the stored (bf16) values
-          }
           if (a.partial != nullptr) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
 #pragma unroll
   for (int j = 0; j < 8; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; st_mn[j] = INFINITY; st_mx[j] = -INFINITY; }
   const int wvec = tid % VPR, wrw = tid / VPR;
-  const bf16_t* __restrict__ side = BWD ? a.bx : a.R;
+  const bf16_t* __restrict__ side = BWD ? a.bx : nullptr;                 // the residual is added on the accumulators
   Pro pro;
   pro_init(pro, a.act_lo, a.act_hi, a.kq, PRO ? a.slot : nullptr);
   if (PRO3) {
@@ -221,6 +221,24 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < JM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // residual add on the fp32 accumulators (ONE rounding to bf16, in the staging below): this lane's four columns of
+    // row (j, l15) are 8 contiguous bytes of R -- 32-byte segments per row, which only the pre-activation networks
+    // (shortcut added to a raw convolution) pay
+    auto add_residual = [&](auto& c) {
+#pragma unroll
+      for (int j = 0; j < JM; ++j) {
+        const int m = m0 + wm * WR + j * 16 + l15;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int n = n0 + wn * WC + i * 16 + q * 4;
+          if (m < a.M && n < a.N) {
+            const uint2 r = *reinterpret_cast<const uint2*>(a.R + (int64_t)m * a.N + n);
+            c[i][j][0] += __uint_as_float(r.x << 16); c[i][j][1] += __uint_as_float(r.x & 0xFFFF0000u);
+            c[i][j][2] += __uint_as_float(r.y << 16); c[i][j][3] += __uint_as_float(r.y & 0xFFFF0000u);
+          }
+        }
+      }
+    };
 
     // ring of NS stages, NS - 1 steps of loads in flight.  Step ks is multiplied from buffer ks % NS while the loads of
     // steps ks+1 .. ks+NS-1 travel; a stage is waited for with a COUNTED vmcnt (the younger stages stay in flight
@@ -334,6 +352,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
           __builtin_amdgcn_sched_barrier(0);
         }
         // C tile staging (aliases the ring: every fragment read of the tile is behind the last barrier)
+        if (a.R != nullptr) add_residual(cacc);
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -412,6 +431,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
 
     // ---- epilogue of one [BM][BN] tile (C staging aliases the stage buffers: all reads of them are complete) ----
     if (!WS) {
+    if (!BWD && a.R != nullptr) add_residual(acc);
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -463,14 +483,6 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
           } else if (a.R != nullptr || a.partial != nullptr) {
             float f[8];
             unpack8(c, f);
-            if (a.R != nullptr) {
-              float r[8];
-              unpack8(rres[pp], r);
-#pragma unroll
-              for (int j = 0; j < 8; ++j) f[j] += r[j];
-              c = pack8(f);
-              unpack8(c, f);                                                // statistics see the stored (bf16) values
-            }
             if (a.partial != nullptr) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) {

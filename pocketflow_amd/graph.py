@@ -848,7 +848,9 @@ def _run_conv2d(x, w_krsc, stride, pad, want_stats):
   M = B * Ho * Wo
   partial, G = None, 0
   if want_stats:
-XX, float((B * H * W * C + M * N) * 2)):
+    G = hip.conv2d_stats_groups(M, N, geom=(B, H, W, C, N, R, S, stride, pad[0], pad[1], Ho, Wo))
+    partial = torch.empty((G, 4, N), dtype=torch.float32, device=x.device)
+  with region('conv2d_fwd', float((B * H * W * C + M * N) * 2)):
     hip.conv2d_fwd(x, w_krsc, y, B, H, W, C, N, R, S, stride, pad[0], pad[1], Ho, Wo, partial=partial)
   if want_stats:
     y._pf_stats = (partial, G)

@@ -1,0 +1,66 @@
+"""The two reducers behind profiles/ (tools/prof_summary.py, tools/pmc_table.py) on synthetic rocprofv3 CSVs:
+the step window is exactly K Adam launches wide, and pmc_table accepts both a raw counter_collection.csv and
+one of its own tables (which is what profiles/ holds)."""
+import csv
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(tool, *args):
+  r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', tool)] + list(args), capture_output=True, text=True)
+  assert r.returncode == 0, r.stderr
+  return r.stdout
+
+
+def test_prof_summary_takes_exactly_k_steps(tmp_path):
+  p = tmp_path / 'x_kernel_trace.csv'
+  t = 1000
+  with open(p, 'w', newline='') as f:
+    w = csv.writer(f)
+    w.writerow(['Kind', 'Kernel_Name', 'Start_Timestamp', 'End_Timestamp'])
+    for step in range(6):
+      # warm-up junk in the first two steps must stay outside the window
+      if step < 2:
+        w.writerow(['KERNEL_DISPATCH', 'miopen_search_kernel(int)', t, t + 50000])
+        t += 60000
+      for _ in range(3):
+        w.writerow(['KERNEL_DISPATCH', 'void k_igemm<128, 128, 2, 2, 2, 1>(IgArgs)', t, t + 2000])
+        t += 2500
+      w.writerow(['KERNEL_DISPATCH', 'void k_adam_flat<unsigned short, true>(AdamArgs)', t, t + 1000])
+      t += 1500
+  out = _run('prof_summary.py', str(p), '--steps', '3')
+  parsed = list(csv.reader(out.strip().splitlines()))
+  assert parsed[0][0].startswith('# steady state over 3 steps')
+  body = [l for l in parsed if l and not l[0].startswith('#')]
+  rows = {r[0]: r for r in body[1:]}
+  assert 'miopen_search_kernel' not in rows
+  ig = rows['k_igemm<128, 128, 2, 2, 2, 1>']
+  assert ig[1] == 'pocketflow_hip' and float(ig[2]) == 3.0 and abs(float(ig[3]) - 2.0) < 1e-6
+  assert float(rows['k_adam_flat<unsigned short, true>'][2]) == 1.0
+
+
+def test_pmc_table_reads_raw_and_its_own_output(tmp_path):
+  raw = tmp_path / 'x_counter_collection.csv'
+  with open(raw, 'w', newline='') as f:
+    w = csv.writer(f)
+    w.writerow(['Dispatch_Id', 'Kernel_Name', 'Counter_Name', 'Counter_Value'])
+    for i, v in enumerate((100.0, 300.0)):
+      w.writerow([i, 'void k_wrw2<256, 128, 64, 64, true, 0>(Wrw2Args)', 'FETCH_SIZE', v])
+      w.writerow([i, 'void k_wrw2<256, 128, 64, 64, true, 0>(Wrw2Args)', 'WRITE_SIZE', v / 2])
+    w.writerow([9, 'at::native::vectorized_elementwise_kernel<4>(int)', 'FETCH_SIZE', 7.0])
+  out = _run('pmc_table.py', str(raw))
+  rows = list(csv.reader(out.strip().splitlines()))
+  assert rows[0] == ['kernel', 'dispatches', 'FETCH_SIZE', 'WRITE_SIZE']
+  assert rows[1] == ['k_wrw2<256, 128, 64, 64, true, 0>', '2', '200', '100'] and len(rows) == 2
+  table = tmp_path / 'table.csv'
+  table.write_text(out)
+  again = _run('pmc_table.py', str(table))
+  assert list(csv.reader(again.strip().splitlines())) == rows
+  bad = tmp_path / 'bad.csv'
+  bad.write_text('a,b\n1,2\n')
+  r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'pmc_table.py'), str(bad)], capture_output=True,
+                     text=True)
+  assert r.returncode != 0 and 'Kernel_Name' in r.stderr

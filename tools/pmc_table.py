@@ -16,7 +16,19 @@ def main():
   agg = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
   counters = []
   with open(args.csv, newline='') as f:
-    for r in csv.DictReader(f):
+    rd = csv.DictReader(f)
+    if 'Kernel_Name' not in (rd.fieldnames or []):
+      if 'kernel' in (rd.fieldnames or []):
+        # already one of this tool's tables (what profiles/ holds): echo it, filtered by the prefix
+        w = csv.writer(sys.stdout)
+        w.writerow(rd.fieldnames)
+        for r in rd:
+          if r['kernel'].startswith(args.prefix):
+            w.writerow([r[k] for k in rd.fieldnames])
+        return
+      sys.exit('%s: neither a rocprofv3 counter_collection.csv (no Kernel_Name column) nor a pmc_table output'
+               % args.csv)
+    for r in rd:
       name = re.sub(r'^void ', '', r['Kernel_Name'])
       if not name.startswith(args.prefix):
         continue
