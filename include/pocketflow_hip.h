@@ -193,24 +193,6 @@ int pf_bn_eval_scale_shift(const float* gamma, const float* beta, const float* m
                            const float* moving_var, float eps, int C, float* scale_shift,
                            void* stream);
 
-/* ---- K12: dense contraction on the matrix cores (MFMA) --------------------------------------
- * replaces tf.nn.conv2d / tf.matmul forward, Conv2DBackpropInput and Conv2DBackpropFilter for the
- * 1x1 convolutions and dense layers (utils/external/resnet_model.py:92-103; uq utils.py:92-103):
- * in NHWC a 1x1 stride-1 convolution IS a row-major GEMM.  bf16 in, fp32 accumulate.
- *   pf_gemm_bf16_nt : C[M][N]  = A[M][K] * B[N][K]^T   (forward:  X[rows][Cin]  x W[Cout][Cin])
- *   pf_gemm_bf16_nn : C[M][N]  = A[M][K] * B[K][N]     (bwd-data: dY[rows][Cout] x W[Cout][Cin])
- *   pf_gemm_bf16_tn : C[M][N] += A[K][M]^T * B[K][N]     (bwd-filter: dY[rows][Cout]^T x X[rows][Cin];
- *                     split-K over the huge rows dimension, fp32 atomic accumulation into C, which
- *                     is the flat fp32 gradient buffer; out_dtype must be PF_F32)
- * out_dtype selects bf16 or fp32 C for nt/nn.  Requirements: K % 32 == 0 for nt/nn; M % 8 == 0,
- * N % 8 == 0 for nn/tn (16-byte row segments); checked, hipErrorInvalidValue otherwise.          */
-int pf_gemm_bf16_nt(const void* A, const void* B, void* C, int M, int N, int K, int out_dtype,
-                    void* stream);
-int pf_gemm_bf16_nn(const void* A, const void* B, void* C, int M, int N, int K, int out_dtype,
-                    void* stream);
-int pf_gemm_bf16_tn(const void* A, const void* B, void* C, int M, int N, int K, int out_dtype,
-                    void* stream);
-
 /* ---- K12 fused with K13/K4: 1x1 convolutions with BN/ReLU/fake-quant prologue and residual-add /
  * BN-statistics epilogue (bf16 NHWC, fp32 accumulate) -------------------------------------------
  * replaces, per bottleneck block, the chain  tf.layers.batch_normalization -> tf.nn.relu ->

@@ -7,7 +7,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function"
 OBJS=()
-for f in pf_api pf_quant pf_normalize pf_sparse pf_optim pf_loss pf_bn pf_gemm pf_conv pf_conv_stream pf_igemm pf_conv3x3 pf_wrw pf_pool pf_transpose pf_stem pf_image pf_depthwise; do
+for f in pf_api pf_quant pf_normalize pf_sparse pf_optim pf_loss pf_bn pf_conv pf_conv_stream pf_igemm pf_conv3x3 pf_wrw pf_pool pf_transpose pf_stem pf_image pf_depthwise; do
   if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ] || [ pf_common.h -nt "$f.o" ] || [ pf_conv_common.h -nt "$f.o" ] || [ ../../include/pocketflow_hip.h -nt "$f.o" ]; then
     $HIPCC $FLAGS -c "$f.hip" -o "$f.o" &
   fi

@@ -40,7 +40,7 @@ SYMBOLS = [
     'pf_ws_mask_apply', 'pf_count_nonzero', 'pf_cp_build_mask', 'pf_cp_mask_grad', 'pf_adam_flat',
     'pf_momentum_flat', 'pf_ce_distill_fwd_bwd', 'pf_bn_stats', 'pf_bn_finalize',
     'pf_bn_act_quant_apply', 'pf_bn_bwd_stats', 'pf_bn_bwd_finalize', 'pf_bn_bwd_apply', 'pf_bn_bwd_apply_add',
-    'pf_bn_eval_scale_shift', 'pf_gemm_bf16_nt', 'pf_gemm_bf16_nn', 'pf_gemm_bf16_tn',
+    'pf_bn_eval_scale_shift',
     'pf_conv1x1_stats_groups', 'pf_conv1x1_stats_groups_k', 'pf_conv1x1_fwd', 'pf_conv1x1_bwd_data_bnstats', 'pf_conv1x1_wrw_splits',
     'pf_conv1x1_wrw', 'pf_conv2d_stats_groups', 'pf_conv2d_fwd', 'pf_conv2d_wrw_splits', 'pf_conv2d_wrw', 'pf_maxpool_fwd', 'pf_maxpool_bwd', 'pf_seg_transpose', 'pf_conv_stem_supported', 'pf_conv_stem_fwd', 'pf_conv_stem_wrw_slabs', 'pf_conv_stem_wrw',
     'pf_image_resize_bilinear', 'pf_depthwise_supported', 'pf_depthwise_groups', 'pf_depthwise_fwd', 'pf_depthwise_bwd_data',
@@ -288,21 +288,6 @@ def bn_eval_scale_shift(gamma, beta, moving_mean, moving_var, eps: float, scale_
 # ------------------------------------------------------------------------------------------------
 # MFMA GEMM
 # ------------------------------------------------------------------------------------------------
-
-def gemm_bf16_nt(A, B, C, M: int, N: int, K: int) -> None:
-  _check(_lib.pf_gemm_bf16_nt(_ptr(A), _ptr(B), _ptr(C), c_int(M), c_int(N), c_int(K), c_int(dtype_code(C)),
-                              _stream()), 'pf_gemm_bf16_nt')
-
-
-def gemm_bf16_nn(A, B, C, M: int, N: int, K: int) -> None:
-  _check(_lib.pf_gemm_bf16_nn(_ptr(A), _ptr(B), _ptr(C), c_int(M), c_int(N), c_int(K), c_int(dtype_code(C)),
-                              _stream()), 'pf_gemm_bf16_nn')
-
-
-def gemm_bf16_tn(A, B, C, M: int, N: int, K: int) -> None:
-  _check(_lib.pf_gemm_bf16_tn(_ptr(A), _ptr(B), _ptr(C), c_int(M), c_int(N), c_int(K), c_int(dtype_code(C)),
-                              _stream()), 'pf_gemm_bf16_tn')
-
 
 # ------------------------------------------------------------------------------------------------
 # fused 1x1 convolutions

@@ -439,43 +439,6 @@ def test_bn_eval_mode(hip):
 
 
 # ------------------------------------------------------------------------------------------------
-# MFMA GEMM
-# ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (256, 64, 256), (1000, 256, 64), (392, 512, 128), (130, 72, 96)])
-def test_gemm_bf16_nt_nn(hip, M, N, K):
-  rng = np.random.RandomState(M + N + K)
-  # asymmetric operands (transpose-detecting)
-  A = (rng.randn(M, K) + np.arange(K)[None, :] * 0.01).astype(np.float32)
-  B = (rng.randn(N, K) - np.arange(N)[:, None] * 0.02).astype(np.float32)
-  Ab, Bb = dev(A).to(torch.bfloat16), dev(B).to(torch.bfloat16)
-  ref = Ab.float() @ Bb.float().t()
-  C = torch.empty((M, N), dtype=torch.float32, device='cuda')
-  hip.gemm_bf16_nt(Ab, Bb, C, M, N, K)
-  # fp32 accumulation of exact bf16 products: only the summation order differs
-  torch.testing.assert_close(C, ref, rtol=1e-4, atol=1e-3)
-  Cb = torch.empty((M, N), dtype=torch.bfloat16, device='cuda')
-  hip.gemm_bf16_nt(Ab, Bb, Cb, M, N, K)
-  torch.testing.assert_close(Cb.float(), ref, rtol=1e-2, atol=1e-1)
-  if N % 8 == 0:
-    Bt = Bb.t().contiguous()                          # [K][N]
-    hip.gemm_bf16_nn(Ab, Bt, C, M, N, K)
-    torch.testing.assert_close(C, ref, rtol=1e-4, atol=1e-3)
-
-
-@pytest.mark.parametrize('M,N,K', [(64, 64, 1000), (256, 128, 4096), (72, 40, 333 * 8)])
-def test_gemm_bf16_tn_accumulates(hip, M, N, K):
-  rng = np.random.RandomState(K)
-  A = rng.randn(K, M).astype(np.float32)
-  B = (rng.randn(K, N) + 0.5).astype(np.float32)
-  Ab, Bb = dev(A).to(torch.bfloat16), dev(B).to(torch.bfloat16)
-  C0 = rng.randn(M, N).astype(np.float32)
-  C = dev(C0).clone()
-  hip.gemm_bf16_tn(Ab, Bb, C, M, N, K)
-  ref = dev(C0) + Ab.float().t() @ Bb.float()
-  torch.testing.assert_close(C, ref, rtol=1e-4, atol=2e-3)
-
-
-# ------------------------------------------------------------------------------------------------
 # full-size, size-independent properties (ResNet-50 @ batch 256 shapes; no oracle at this size)
 # ------------------------------------------------------------------------------------------------
 def test_fullsize_activation_quant_properties(hip):

@@ -96,5 +96,12 @@ c13)
   PF_CONV3X3_HALO=1 run_bench c2_halo --steps 15 --warmup 5 --no_cpu_baseline
   PF_CONV3X3_HALO=0 run_bench c2_nohalo --steps 15 --warmup 5 --no_cpu_baseline
   ;;
+c14)
+  # residual on the fp32 accumulators (all four forward kernels): numerics, per-layer cost, the roofline region layer by layer, step
+  timeout 1200 python -m pytest tests/test_conv_gpu.py tests/test_igemm_gpu.py -m gpu -q --tb=short -x 2>&1 | tail -12 | cut -c1-300
+  timeout 300 python tools/gpu/pro_bench.py 2>&1 | tee gpurun_out/r03_pro_bench_res32.txt | cut -c1-220
+  timeout 400 python tools/gpu/fwd1x1_layers.py 2>&1 | tee gpurun_out/r03_fwd1x1_layers.txt | cut -c1-220
+  run_bench c2_res32 --steps 15 --warmup 5 --no_cpu_baseline
+  ;;
 *) echo "unknown payload $1"; exit 2;;
 esac
