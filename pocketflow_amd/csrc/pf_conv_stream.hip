@@ -312,18 +312,24 @@ static int stream_enabled() {
   return (e == nullptr) ? 1 : atoi(e);
 }
 
+static int stream_max_split() {
+  const char* e = getenv("PF_CONV_STREAM_MAXSPLIT");      // column slices a row panel may be cut into, read per call
+  return (e == nullptr) ? 2 : atoi(e);
+}
+
 // column slices (0: the stream kernel does not apply) and the slice width
 int pf_conv_stream_plan(int M, int N, int K, int* nw_out) {
   if (!stream_enabled()) return 0;
-  if ((K % 64) || K > 512 || (N % 64) || N > 512) return 0;
+  if ((K % 64) || K > 512 || (N % 64) || N > 2048) return 0;
   if (M < 4096) return 0;                                 // too few strips for 2048 persistent wavefronts
   int nsplit = 1;
   while ((int64_t)(N / nsplit) * K > 32768 || N / nsplit > 256) nsplit *= 2;
   const int nw = N / nsplit;
-  if (nsplit > 2 || (nw != 64 && nw != 128 && nw != 256)) return 0;
-  // two column slices re-read the input panel (from L2) and repeat its prologue: only worth it when the input is the
-  // small operand (128 -> 512); 512 -> 128 stays on the tiled kernel (measured: 109 vs 83 us at 28x28, batch 256)
-  if (nsplit == 2 && K > 128) return 0;
+  if (nsplit > stream_max_split() || (ST_GRID % (8 * nsplit)) || (nw != 64 && nw != 128 && nw != 256)) return 0;
+  // column slices re-read the input panel (from L2) and repeat its prologue: only worth it when the input is the
+  // small operand (128 -> 512, 256 -> 1024); 512 -> 128 stays on the tiled kernel (measured: 109 vs 83 us at 28x28,
+  // batch 256)
+  if (nsplit >= 2 && N < 4 * K) return 0;
   *nw_out = nw;
   return nsplit;
 }

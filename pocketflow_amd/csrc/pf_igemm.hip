@@ -223,21 +223,31 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
       for (int j = 0; j < JM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // residual add on the fp32 accumulators (ONE rounding to bf16, in the staging below): this lane's four columns of
     // row (j, l15) are 8 contiguous bytes of R -- 32-byte segments per row, which only the pre-activation networks
-    // (shortcut added to a raw convolution) pay
-    auto add_residual = [&](auto& c) {
+    // (shortcut added to a raw convolution) pay.  The loads are issued at the top of the LAST k-step and travel under its
+    // MFMAs (issued in the epilogue they cost 10-13 us per launch on the 14x14 / 7x7 conv3 layers).
+    uint2 rr[NI][JM];
+    const bool has_r = !BWD && a.R != nullptr;
+    constexpr bool RPRE = !WS && BM * BN <= 128 * 256;                       // larger tiles have no 32 spare registers: load at use
+    auto load_residual = [&]() {
 #pragma unroll
       for (int j = 0; j < JM; ++j) {
         const int m = m0 + wm * WR + j * 16 + l15;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
           const int n = n0 + wn * WC + i * 16 + q * 4;
-          if (m < a.M && n < a.N) {
-            const uint2 r = *reinterpret_cast<const uint2*>(a.R + (int64_t)m * a.N + n);
-            c[i][j][0] += __uint_as_float(r.x << 16); c[i][j][1] += __uint_as_float(r.x & 0xFFFF0000u);
-            c[i][j][2] += __uint_as_float(r.y << 16); c[i][j][3] += __uint_as_float(r.y & 0xFFFF0000u);
-          }
+          rr[i][j] = make_uint2(0, 0);
+          if (m < a.M && n < a.N) rr[i][j] = *reinterpret_cast<const uint2*>(a.R + (int64_t)m * a.N + n);
         }
       }
+    };
+    auto add_residual = [&](auto& c) {
+#pragma unroll
+      for (int j = 0; j < JM; ++j)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          c[i][j][0] += __uint_as_float(rr[i][j].x << 16); c[i][j][1] += __uint_as_float(rr[i][j].x & 0xFFFF0000u);
+          c[i][j][2] += __uint_as_float(rr[i][j].y << 16); c[i][j][3] += __uint_as_float(rr[i][j].y & 0xFFFF0000u);
+        }
     };
 
     // ring of NS stages, NS - 1 steps of loads in flight.  Step ks is multiplied from buffer ks % NS while the loads of
@@ -352,7 +362,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
           __builtin_amdgcn_sched_barrier(0);
         }
         // C tile staging (aliases the ring: every fragment read of the tile is behind the last barrier)
-        if (a.R != nullptr) add_residual(cacc);
+        if (has_r) { load_residual(); add_residual(cacc); }
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -389,6 +399,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
       if (PRO3) {                                                           // own part of stage ks+1 (issued one step ago) has landed
         if (more) wait_vm<LPS>(); else wait_vm<0>();
       }
+      if (RPRE && has_r && ks == nk - 1) load_residual();                           // no LDS-DMA is issued after this point
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int coff = (((kk * 4 + q) ^ (l15 & 7)) << 4);
@@ -431,7 +442,25 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
 
     // ---- epilogue of one [BM][BN] tile (C staging aliases the stage buffers: all reads of them are complete) ----
     if (!WS) {
-    if (!BWD && a.R != nullptr) add_residual(acc);
+    if (has_r) {
+      if constexpr (RPRE) add_residual(acc);
+      else {
+#pragma unroll
+        for (int j = 0; j < JM; ++j) {                                      // row block by row block: NI vectors live at a time
+          const int m = m0 + wm * WR + j * 16 + l15;
+#pragma unroll
+          for (int i = 0; i < NI; ++i) {
+            const int n = n0 + wn * WC + i * 16 + q * 4;
+            if (m < a.M && n < a.N) {
+              const uint2 r = *reinterpret_cast<const uint2*>(a.R + (int64_t)m * a.N + n);
+              acc[i][j][0] += __uint_as_float(r.x << 16); acc[i][j][1] += __uint_as_float(r.x & 0xFFFF0000u);
+              acc[i][j][2] += __uint_as_float(r.y << 16); acc[i][j][3] += __uint_as_float(r.y & 0xFFFF0000u);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll

@@ -103,5 +103,18 @@ c14)
   timeout 400 python tools/gpu/fwd1x1_layers.py 2>&1 | tee gpurun_out/r03_fwd1x1_layers.txt | cut -c1-220
   run_bench c2_res32 --steps 15 --warmup 5 --no_cpu_baseline
   ;;
+c15)
+  # residual prefetch in the tiled kernel + resident-kernel variant with 4-32 column slices: numerics, the roofline region layer by
+  # layer under both plans, step A/B, and the idle-gap analysis of the step
+  timeout 1200 python -m pytest tests/test_conv_gpu.py tests/test_igemm_gpu.py -m gpu -q --tb=short -x 2>&1 | tail -12 | cut -c1-300
+  PF_CONV_STREAM_MAXSPLIT=2 timeout 400 python tools/gpu/fwd1x1_layers.py 2>&1 | tee gpurun_out/r03_fwd1x1_layers_split2.txt | cut -c1-220
+  PF_CONV_STREAM_MAXSPLIT=32 timeout 400 python tools/gpu/fwd1x1_layers.py 2>&1 | tee gpurun_out/r03_fwd1x1_layers_split32.txt | cut -c1-220
+  PF_CONV_STREAM_MAXSPLIT=2 run_bench c2_split2 --steps 15 --warmup 5 --no_cpu_baseline
+  PF_CONV_STREAM_MAXSPLIT=32 run_bench c2_split32 --steps 15 --warmup 5 --no_cpu_baseline
+  cd /tmp
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r3b -o r3b -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 4 --no_cpu_baseline > $GRAFT_REPO_ROOT/gpurun_out/r03_prof_b.log 2>&1
+  cd $GRAFT_REPO_ROOT
+  python tools/prof_summary.py $(find /tmp/prof_r3b -name '*kernel_trace.csv' | head -1) --steps 4 --out gpurun_out/r03_step_kernels_b256_c15.csv | head -16 | cut -c1-200
+  ;;
 *) echo "unknown payload $1"; exit 2;;
 esac

@@ -66,6 +66,16 @@ def main():
       a[1] += e - s
       busy += e - s
   wall = (t1 - t0) / K
+  # idle time of the device inside the window: gaps between the end of everything launched so far and the next start
+  gaps, horizon, prev = [], None, None
+  for s, e, n in rows:
+    if s < t0 or e > t1:
+      continue
+    if horizon is not None and s > horizon:
+      gaps.append((s - horizon, prev, n))
+    if horizon is None or e > horizon:
+      horizon, prev = e, n
+  idle = sum(g[0] for g in gaps)
   lines = []
   cats = defaultdict(int)
   for n, (c, ns) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
@@ -74,6 +84,11 @@ def main():
   out = open(args.out, 'w', newline='') if args.out else sys.stdout
   w = csv.writer(out)
   w.writerow(['# steady state over %d steps: wall %.3f ms/step, GPU busy %.3f ms/step' % (K, wall / 1e6, busy / K / 1e6)])
+  w.writerow(['# idle between kernels: %.3f ms/step in %.0f gaps/step (median %.1f us); gaps > 20 us: %d/step, %.3f ms/step'
+              % (idle / K / 1e6, len(gaps) / K, (sorted(g[0] for g in gaps)[len(gaps) // 2] / 1e3) if gaps else 0.0,
+                 sum(1 for g in gaps if g[0] > 20000) / K, sum(g[0] for g in gaps if g[0] > 20000) / K / 1e6)])
+  for d, a, b in sorted(gaps, key=lambda g: -g[0])[:6]:
+    w.writerow(['# gap', '%.1f us' % (d / 1e3), short(a)[:60], '->', short(b)[:60]])
   for c, ns in sorted(cats.items(), key=lambda kv: -kv[1]):
     w.writerow(['# category', c, '%.3f ms/step' % (ns / K / 1e6), '%.1f %%' % (100.0 * ns / busy)])
   w.writerow(['kernel', 'category', 'calls_per_step', 'avg_us', 'ms_per_step', 'pct_of_busy'])
