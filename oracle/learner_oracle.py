@@ -127,7 +127,23 @@ class Scope(object):
     self.quant = QuantSpec()
     self.matmul_names: List[str] = []
     self.act_names: List[str] = []
+    self.rec = None                  # graph trace of one forward (start_trace), the channel pruner's view of the network
+    self.freeze_stats = False        # training-mode BN WITHOUT the moving-average update ops (sess.run of a feature tensor)
     self._begin()
+
+  # -- graph trace: ops in creation order with TF's op types, tensors by '<op>:0' (oracle/cp_features_oracle.py) -------------
+  def start_trace(self):
+    self.rec = {'ops': [], 'ids': {}, 'tensors': {}, 'keep': [], 'convs': {}}
+
+  def _r(self, type_, name, inputs, out):
+    if self.rec is None:
+      return out
+    r, full = self.rec, self.scope + '/' + name
+    r['ops'].append((full, type_, [r['ids'][id(t)] for t in inputs]))
+    r['ids'][id(out)] = full
+    r['tensors'][full + ':0'] = out
+    r['keep'].append(out)            # keeps id() unique for the lifetime of the trace
+    return out
 
   # -- bookkeeping: TF auto names, creation-order indices -----------------------------------------
   def _begin(self):
@@ -173,24 +189,33 @@ class Scope(object):
     """tf.layers.conv2d / slim.conv2d on NCHW-logical x with an HWIO kernel variable."""
     w = self._quant_weight(self.var(name + '/' + kernel_name), name + '/' + kernel_name)
     k = w.shape[0]
+    x_in = x
     if padding == 'SAME':
       ph, pw = self._same_pads(x.shape[2], k, stride), self._same_pads(x.shape[3], k, stride)
       if any(ph) or any(pw):
         x = F.pad(x, (pw[0], pw[1], ph[0], ph[1]))
     b = self.var(name + '/' + bias_name) if bias_name else None
-    return F.conv2d(x, w.permute(3, 2, 0, 1), b, stride=stride)
+    if self.rec is None:
+      return F.conv2d(x, w.permute(3, 2, 0, 1), b, stride=stride)
+    y = self._r('Conv2D', name + '/Conv2D', [x_in], F.conv2d(x, w.permute(3, 2, 0, 1), None, stride=stride))
+    self.rec['convs'][self.scope + '/' + name + '/Conv2D'] = dict(
+        name=self.scope + '/' + name + '/Conv2D', input=self.rec['ids'][id(x_in)] + ':0', h=int(w.shape[0]), w=int(w.shape[1]),
+        c=int(w.shape[2]), strides=(stride, stride), padding=padding, kernel=self.scope + '/' + name + '/' + kernel_name)
+    return y if b is None else self._r('BiasAdd', name + '/BiasAdd', [y], y + b.view(1, -1, 1, 1))
 
   def depthwise(self, x, name, stride=1, kernel_name='depthwise_weights'):
     w = self._quant_weight(self.var(name + '/' + kernel_name), name + '/' + kernel_name)   # [kh,kw,C,1]
     k, C = w.shape[0], w.shape[2]
+    x_in = x
     ph, pw = self._same_pads(x.shape[2], k, stride), self._same_pads(x.shape[3], k, stride)
     if any(ph) or any(pw):
       x = F.pad(x, (pw[0], pw[1], ph[0], ph[1]))
-    return F.conv2d(x, w.permute(2, 3, 0, 1), None, stride=stride, groups=C)
+    return self._r('DepthwiseConv2dNative', name + '/depthwise', [x_in],
+                   F.conv2d(x, w.permute(2, 3, 0, 1), None, stride=stride, groups=C))
 
   def dense(self, x, name):
     w = self._quant_weight(self.var(name + '/kernel'), name + '/kernel')        # [in, out]
-    return x @ w + self.var(name + '/bias')
+    return self._r('MatMul', name + '/MatMul', [x], x @ w + self.var(name + '/bias'))
 
   # -- normalisation / activation -------------------------------------------------------------------
   def batch_norm(self, x, name, momentum, eps, names=('gamma', 'beta', 'moving_mean', 'moving_variance')):
@@ -201,15 +226,16 @@ class Scope(object):
       n = x.numel() // x.shape[1]
       mean = x.mean(dim=(0, 2, 3))
       var = x.var(dim=(0, 2, 3), unbiased=False)
-      with torch.no_grad():                  # moving average fed the UNBIASED variance (fused BN)
-        mm.mul_(momentum).add_(mean * (1 - momentum))
-        mv.mul_(momentum).add_(var * (n / max(n - 1, 1)) * (1 - momentum))
+      if not self.freeze_stats:
+        with torch.no_grad():                  # moving average fed the UNBIASED variance (fused BN)
+          mm.mul_(momentum).add_(mean * (1 - momentum))
+          mv.mul_(momentum).add_(var * (n / max(n - 1, 1)) * (1 - momentum))
     else:
       mean, var = mm, mv
     inv = torch.rsqrt(var + eps)
     scale = (gamma * inv).view(1, -1, 1, 1)
     shift = (beta - mean * gamma * inv).view(1, -1, 1, 1)
-    return x * scale + shift
+    return self._r('FusedBatchNorm', name + '/FusedBatchNorm', [x], x * scale + shift)
 
   def activation(self, u, kind, name):
     j = self.i_act
@@ -218,7 +244,7 @@ class Scope(object):
     q = self.quant
     bits = q.a_bits[j] if (q.a_bits is not None and q.kind != 'none') else None
     if bits is None:
-      return F.relu(u) if kind == 'Relu' else F.relu6(u)
+      return self._r(kind, name, [u], F.relu(u) if kind == 'Relu' else F.relu6(u))
     return _ActUQ.apply(u, int(bits), kind)
 
 
@@ -229,10 +255,12 @@ class Scope(object):
 def lenet_forward(s: Scope, x, nb_classes):
   """nets/lenet_at_cifar10.py:34-68 (incl. the trailing softmax)."""
   x = s.conv2d(x, 'conv1', 1, 'VALID', bias_name='bias')
-  x = F.max_pool2d(s.activation(x, 'Relu', 'relu1'), 2, 2)
+  a = s.activation(x, 'Relu', 'relu1')
+  x = s._r('MaxPool', 'pool1/MaxPool', [a], F.max_pool2d(a, 2, 2))
   x = s.conv2d(x, 'conv2', 1, 'VALID', bias_name='bias')
-  x = F.max_pool2d(s.activation(x, 'Relu', 'relu2'), 2, 2)
-  x = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)
+  a = s.activation(x, 'Relu', 'relu2')
+  x = s._r('MaxPool', 'pool2/MaxPool', [a], F.max_pool2d(a, 2, 2))
+  x = s._r('Reshape', 'flatten/Reshape', [x], x.permute(0, 2, 3, 1).reshape(x.shape[0], -1))
   x = s.activation(s.dense(x, 'fc3'), 'Relu', 'relu3')
   x = s.dense(x, 'fc4')
   return torch.softmax(x, dim=1)
@@ -248,7 +276,9 @@ def _conv_fixed_padding(s: Scope, x, k, strides):
     pt = k - 1
     pb = pt // 2
     if pt:
-      x = F.pad(x, (pb, pt - pb, pb, pt - pb))
+      x = s._r('Pad', name + '/Pad', [x], F.pad(x, (pb, pt - pb, pb, pt - pb)))
+    elif s.rec is not None:          # fixed_padding() always emits its tf.pad, also with zero widths (kernel_size 1)
+      x = s._r('Pad', name + '/Pad', [x], x.clone())
   return s.conv2d(x, name, strides, 'SAME' if strides == 1 else 'VALID')
 
 
@@ -265,9 +295,10 @@ def resnet_v2_forward(s: Scope, x, cfg):
   if cfg['first_pool_size']:
     k, st = cfg['first_pool_size'], cfg['first_pool_stride']
     ph, pw = s._same_pads(x.shape[2], k, st), s._same_pads(x.shape[3], k, st)
+    x_in = x
     if any(ph) or any(pw):
       x = F.pad(x, (pw[0], pw[1], ph[0], ph[1]), value=float('-inf'))
-    x = F.max_pool2d(x, k, st)
+    x = s._r('MaxPool', 'resnet_model/max_pooling2d/MaxPool', [x_in], F.max_pool2d(x, k, st))
   for i, nblocks in enumerate(cfg['block_sizes']):
     filters = cfg['num_filters'] * (2 ** i)
     for b in range(nblocks):
@@ -286,9 +317,9 @@ def resnet_v2_forward(s: Scope, x, cfg):
         y = _conv_fixed_padding(s, y, 3, strides)
         y = _bn_relu(s, y)
         y = _conv_fixed_padding(s, y, 3, 1)
-      x = y + shortcut
+      x = s._r('Add', s.uname('resnet_model/add'), [y, shortcut], y + shortcut)
   x = _bn_relu(s, x)
-  x = x.mean(dim=(2, 3))
+  x = s._r('Mean', 'resnet_model/Mean', [x], x.mean(dim=(2, 3)))
   return s.dense(x, 'resnet_model/dense')
 
 
@@ -318,10 +349,10 @@ def mobilenet_v1_forward(s: Scope, x, cfg):
       x = s.batch_norm(x, name + '/BatchNorm', *_MBV1_BN, names=_SLIM_BN)
       x = s.activation(x, 'Relu6', name + '/Relu6')
   kk = (min(x.shape[2], 7), min(x.shape[3], 7))
-  x = F.avg_pool2d(x, kk)
+  x = s._r('AvgPool', sc + '/Logits/AvgPool_1a/AvgPool', [x], F.avg_pool2d(x, kk))
   mask = cfg.get('dropout_mask')
   if s.training and mask is not None:
-    x = x * torch.from_numpy(mask).view(x.shape[0], -1, 1, 1)
+    x = s._r('Mul', sc + '/Logits/Dropout_1b/dropout/mul', [x], x * torch.from_numpy(mask).view(x.shape[0], -1, 1, 1))
   x = s.conv2d(x, sc + '/Logits/Conv2d_1c_1x1', 1, 'SAME', bias_name='biases', kernel_name='weights')
   return x.reshape(x.shape[0], -1)
 
@@ -392,6 +423,8 @@ class OracleLearner(object):
     s.training = training
     s._begin()
     x = x_nhwc.permute(0, 3, 1, 2)
+    if s.rec is not None:
+      s._r('Placeholder', 'mem_images', [], x)
     m = self.cfg['model']
     if m == 'lenet':
       return lenet_forward(s, x, self.cfg['nb_classes'])
@@ -400,6 +433,31 @@ class OracleLearner(object):
     if m == 'mobilenet_v1':
       return mobilenet_v1_forward(s, x, extra or {})
     raise ValueError(m)
+
+  def pruner_view(self, training: bool = True, extra=None):
+    """The channel pruner's view of the STUDENT network (cp learner.py:250-255 builds it with forward_train, i.e. batch
+    statistics; its sess.run of a feature tensor runs no moving-average update): (ops, convs, shapes, run) for
+    oracle/cp_features_oracle.py -- `run(images NHWC, names) -> [NHWC float32 arrays]` re-executes the network."""
+    s = self.student
+
+    def trace(images):
+      s.start_trace()
+      s.freeze_stats = True
+      try:
+        with torch.no_grad():
+          self._forward(s, torch.from_numpy(np.ascontiguousarray(images, dtype=np.float32)), training, extra)
+        return s.rec
+      finally:
+        s.rec, s.freeze_stats = None, False
+
+    def run(images, names):
+      rec = trace(images)
+      return [rec['tensors'][n].permute(0, 2, 3, 1).contiguous().numpy() if rec['tensors'][n].dim() == 4
+              else rec['tensors'][n].numpy() for n in names]
+    shape = self.cfg.get('image_shape', (32, 32, 3))
+    rec = trace(np.zeros((2,) + tuple(shape), np.float32))
+    shapes = {n: (int(t.shape[2]), int(t.shape[3]), int(t.shape[1])) for n, t in rec['tensors'].items() if t.dim() == 4}
+    return rec['ops'], rec['convs'], shapes, run
 
   def _dry_run(self):
     shape = self.cfg.get('image_shape', (32, 32, 3))

@@ -1145,7 +1145,7 @@ def _tapped(layer, x, residual=None):
   g = layer.graph
   y = layer.plain(x)
   y_add = None if residual is None else y + residual   # a residual sum has no single producer: tag dropped
-  g.taps[layer] = (x, y, getattr(x, '_pf_src', None), y_add)
+  g.taps[layer] = (x, y, getattr(x, '_pf_src', None), y_add, residual)
   if g.tap_stop is layer:
     raise TapStop()
   y._pf_src = layer

@@ -19,10 +19,17 @@ RL mode (`cp_prune_option auto`, :118-213): one 8-number state per convolution
 [layer, n, c, H, W, stride, maxreduce, layercomp] / column maximum, the action (preserve ratio) constrained so
 that the FLOP target `cp_preserve_ratio` stays reachable when every later layer is pruned to the lower bound.
 
-Deviations (documented, host-side): feature maps are sampled with inference-mode BN (the reference builds the
-pruner's graph with forward_train, i.e. batch statistics, learner.py:255); the residual-sum samples are taken at
-the SAME points as the convolution's (the reference draws independent points for the two tensors, :327-331,
-which mis-aligns the correction); the sampling generator is seeded (`cp_seed`).
+Sampling modes (`--cp_sampling`).  'reference' reproduces channel_pruner.py:215-227, 263-341 to the letter: one pair of
+point vectors per TENSOR NAME in the order [conv output, the Add it closes, ...] over the convolutions in creation
+order, i.e. the residual sums get their OWN points (the correction `Y + residual_branch_diff` of :611-614 then adds
+values taken at other pixels than Y's), and the projection shortcut of a block counts as "last in the block" like its
+conv3 (its only consumer is the Add, model_wrapper.py:304-341).  'aligned' (default) samples a residual sum at the
+points of the convolution it corrects and applies the correction to the block's last convolution only.
+Feature BN mode (`--cp_feature_bn`): 'train' = batch statistics without moving-average updates, what the reference's
+pruner graph computes (it is built with forward_train, learner.py:250-255, and sess.run of a feature tensor runs no
+update op); 'inference' (default) = moving statistics.  With both switches on the reference setting the sampled
+features, convolution inputs and residual diffs equal oracle/cp_features_oracle.py (tests/test_learners_cpu.py,
+tests/test_learner_gpu.py).  The sampling generator is seeded (`cp_seed`; the reference uses the global np.random).
 """
 from __future__ import annotations
 
@@ -42,6 +49,8 @@ flags.DEFINE_string('cp_reward_policy', 'accuracy', "'accuracy': best accuracy u
 flags.DEFINE_integer('cp_nb_points_per_layer', 10, 'Sample how many point for each layer')
 flags.DEFINE_integer('cp_nb_batches', 30, 'Input how many bathes data into a model')
 flags.DEFINE_integer('cp_seed', 2018, 'seed of the host-side sampling (the reference never seeds np.random)')
+flags.DEFINE_string('cp_sampling', 'aligned', "'aligned': residual sums sampled at their convolution's points | 'reference': channel_pruner.py:263-341 to the letter")
+flags.DEFINE_string('cp_feature_bn', 'inference', "BN statistics of the pruner's forward passes: 'inference' (moving) | 'train' (batch statistics, no update: the reference)")
 
 log = logging.getLogger('pocketflow_amd')
 
@@ -126,9 +135,14 @@ class ChannelPruner(object):  # pylint: disable=too-many-instance-attributes
   FEATURE_NAMES = ['layer', 'n', 'c', 'H', 'W', 'stride', 'maxreduce', 'layercomp']
 
   def __init__(self, graph: Graph, forward_eval, batches, sm_writer=None, lbound=0, calc_loss=None,
-               trainable_vars=None):
+               trainable_vars=None, forward_train=None):
     self.graph = graph
     self.forward_eval = forward_eval
+    self.forward_train = forward_train
+    if FLAGS.cp_sampling not in ('aligned', 'reference') or FLAGS.cp_feature_bn not in ('inference', 'train'):
+      raise ValueError('cp_sampling: aligned | reference, cp_feature_bn: inference | train')
+    if FLAGS.cp_feature_bn == 'train' and forward_train is None:
+      raise ValueError("cp_feature_bn 'train' needs the learner's forward_train")
     self.batches = batches                       # list of (images NHWC float32 device tensor, labels)
     self.sm_writer = sm_writer
     self.lbound = lbound
@@ -144,11 +158,21 @@ class ChannelPruner(object):  # pylint: disable=too-many-instance-attributes
     self.initialize_state()
 
   # -- topology ------------------------------------------------------------------------------------
-  def __run(self, images):
-    """One eval-mode forward in tap mode; returns {layer: (input, output, producer, residual sum)}."""
+  def __run(self, images, features=False):
+    """One forward in tap mode; returns {layer: (input, output, producer, residual sum, residual operand)}.  `features`
+    and cp_feature_bn 'train': batch statistics as in the reference's pruner graph (forward_train, learner.py:250-255) --
+    the training path of the BN layers runs (it needs grad mode), the moving statistics it updates are put back."""
     g = self.graph
     g.taps = OrderedDict()
     try:
+      if features and FLAGS.cp_feature_bn == 'train':
+        state = g.store.state.clone()
+        try:
+          with torch.enable_grad(), g.as_default():
+            self.logits = self.forward_train(to_device_images(images, g)).detach()
+        finally:
+          g.store.state.copy_(state)
+        return OrderedDict((l, tuple(t.detach() if torch.is_tensor(t) else t for t in v)) for l, v in g.taps.items())
       with torch.no_grad(), g.as_default():
         self.logits = self.forward_eval(to_device_images(images, g))
       return g.taps
@@ -157,11 +181,23 @@ class ChannelPruner(object):  # pylint: disable=too-many-instance-attributes
 
   def __trace(self):
     taps = self.__run(self.batches[0][0])
-    self.layers = list(taps.keys())
+    order = {id(op): i for i, op in enumerate(self.graph.matmul_ops)}
+    # creation order = the order of g.get_operations() in the reference (the projection shortcut of a block is created
+    # BEFORE its conv1, resnet_model.py:295-298, whatever order the executor calls them in)
+    self.layers = sorted(taps.keys(), key=lambda l: order[id(l.op)])
     self.thisconvs: List[Conv2D] = [l for l in self.layers if isinstance(l, Conv2D)]
     self.fathers: Dict[object, Optional[object]] = {l: taps[l][2] for l in self.layers}
     self.out_hw = {l: (taps[l][1].shape[2], taps[l][1].shape[3]) for l in self.layers}
     self.last_in_resblock = {l for l in self.thisconvs if taps[l][3] is not None}
+    # every convolution whose output enters a residual sum DIRECTLY -> the convolution the executor forms that sum in:
+    # the block's last convolution itself and the projection shortcut (model_wrapper.py:304-341 names both)
+    self.add_owner: Dict[object, object] = {}
+    for l in self.thisconvs:
+      if taps[l][3] is not None:
+        self.add_owner[l] = l
+        for p in self.thisconvs:
+          if taps[p][1] is taps[l][4]:
+            self.add_owner[p] = l
     self.names = [c.op.name for c in self.thisconvs]
 
   def is_W1_prunable(self, conv) -> bool:
@@ -261,22 +297,30 @@ class ChannelPruner(object):  # pylint: disable=too-many-instance-attributes
   def extract_features(self):
     """Outputs of every convolution (and of the residual sum it feeds, if any) of the ORIGINAL model at
     cp_nb_points_per_layer random points per batch (the same points for every image of a batch), over
-    cp_nb_batches batches (:263-341)."""
+    cp_nb_batches batches (:263-341).  cp_sampling 'reference': one draw per tensor NAME in the reference's order."""
     npts = FLAGS.cp_nb_points_per_layer
     nb_batches = min(FLAGS.cp_nb_batches, len(self.batches))
+    ref = FLAGS.cp_sampling == 'reference'
     feats = {c: [] for c in self.thisconvs}
     adds = {c: [] for c in self.last_in_resblock}
     self.points = {}
     for b in range(nb_batches):
-      taps = self.__run(self.batches[b][0])
+      taps = self.__run(self.batches[b][0], features=True)
       for conv in self.thisconvs:
         h, w = self.out_hw[conv]
         xs = self.rng.randint(0, h, npts)
         ys = self.rng.randint(0, w, npts)
         self.points[(b, conv)] = (xs.copy(), ys.copy())
         feats[conv].append(self.__sample(taps[conv][1], xs, ys))       # logical NCHW
-        if conv in adds:
-          adds[conv].append(self.__sample(taps[conv][3], xs, ys))
+        owner = self.add_owner.get(conv) if ref else (conv if conv in adds else None)
+        if owner is None or (b, 'add', owner) in self.points:          # names are de-duplicated, first position kept (:299)
+          continue
+        if ref:                                                        # the Add tensor is a name of its own: own points
+          xs = self.rng.randint(0, h, npts)
+          ys = self.rng.randint(0, w, npts)
+        self.points[(b, 'add', owner)] = (xs.copy(), ys.copy())
+        if owner in taps and taps[owner][3] is not None:
+          adds[owner].append(self.__sample(taps[owner][3], xs, ys))
     self.feats_dict = {c: np.vstack(v) for c, v in feats.items()}
     self.feats_add = {c: np.vstack(v) for c, v in adds.items()}
     self.nb_batches = nb_batches
@@ -284,11 +328,12 @@ class ChannelPruner(object):  # pylint: disable=too-many-instance-attributes
   def residual_branch_diff(self, conv):
     """Change of the residual sum behind `conv` caused by the pruning done so far (:579-586)."""
     log.info("approximating residual branch diff")
+    owner = self.add_owner[conv]
     cur = []
     for b in range(self.nb_batches):
-      xs, ys = self.points[(b, conv)]
-      cur.append(self.__sample(self.__run(self.batches[b][0])[conv][3], xs, ys))
-    return self.feats_add[conv] - np.vstack(cur)
+      xs, ys = self.points[(b, 'add', owner)]
+      cur.append(self.__sample(self.__run(self.batches[b][0], features=True)[owner][3], xs, ys))
+    return self.feats_add[owner] - np.vstack(cur)
 
   def accuracy(self):
     """Mean `accuracy` metric of the current (partially pruned) model over the cached batches (:414-434)."""
@@ -311,7 +356,7 @@ class ChannelPruner(object):  # pylint: disable=too-many-instance-attributes
     kh, kw, cin, _ = conv.kernel.ref_shape
     Xs = []
     for b in range(self.nb_batches):
-      x = self.__run(self.batches[b][0])[conv][0]          # logical NCHW, materialised
+      x = self.__run(self.batches[b][0], features=True)[conv][0]          # logical NCHW, materialised
       xs, ys = self.points[(b, conv)]
       if kh == 1 and kw == 1:
         ix = torch.as_tensor(xs * conv.stride, device=x.device)
@@ -341,7 +386,8 @@ class ChannelPruner(object):  # pylint: disable=too-many-instance-attributes
     nb_channel_new = max(int(np.around(c * ratio)), 1)
     newX = self.__extract_input(conv)
     Y = self.feats_dict[conv]
-    if conv in self.feats_add:                             # the output feeds a residual sum (:611-614)
+    # the output feeds a residual sum (:611-614); 'reference' sampling: also for the projection shortcut of the block
+    if conv in self.feats_add or (FLAGS.cp_sampling == 'reference' and conv in self.add_owner):
       Y = Y + self.residual_branch_diff(conv)
     W2 = conv.kernel.to_ref(conv.kernel.master.detach().float().cpu().numpy()).astype(np.float64)
     if FLAGS.cp_lasso:

@@ -99,7 +99,8 @@ class ChannelPrunedLearner(AbstractLearner):  # pylint: disable=too-many-instanc
     batches = [self.iter_train.get_next() for _ in range(nb)]
     self.iter_train.reset()
     self.pruner = ChannelPruner(self.graph, self.forward_eval, batches, self.sm_writer, lbound=self.lbound,
-                                calc_loss=self.calc_loss, trainable_vars=self.trainable_vars)
+                                calc_loss=self.calc_loss, trainable_vars=self.trainable_vars,
+                                forward_train=self.forward_train)
 
   def evaluate(self):
     """Restore the latest checkpoint and evaluate it (:181-206)."""

@@ -301,3 +301,116 @@ def run_bf16_fused_parity(FLAGS, tmp_path, steps=10, expect_bf16=True):
       f.write(line + '\n')
 
 
+
+
+def run_cp_feature_sampling_parity(FLAGS, tmp_path, model='resnet', tol=None):
+  """the channel pruner's feature sampling in the reference's setting (`cp_sampling reference`,
+  `cp_feature_bn train`) against oracle/cp_features_oracle.py driven by the oracle network -- which is itself pinned to arrays
+  produced by executing the reference's extract_features / __extract_input / residual_branch_diff (tests/
+  test_cp_features_oracle.py).  Same seed on both sides => the SAME sample points (asserted), so the sampled outputs of
+  every convolution and residual sum, the convolution inputs of the partially pruned network and the residual diffs are
+  compared value by value; the moving statistics must come out untouched."""
+  from oracle import cp_features_oracle as CF
+  from oracle.learner_oracle import OracleLearner
+  from pocketflow_amd.learners.channel_pruning.learner import ChannelPrunedLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  from pocketflow_amd.utils import checkpoint
+  # float32 on both sides, different summation orders; MobileNet's 27 training-mode BN layers over 6 images (1x1 pixels at the
+  # end: statistics over 6 values) amplify that to a few 1e-5 at the deepest layer (measured 2.3e-5 on the CPU emulation)
+  tol = tol or (2e-5 if model == 'resnet' else 2e-4)
+  if model == 'resnet':
+    from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
+    flags = dict(batch_size=6, batch_size_eval=6, nb_classes=10, resnet_size=8)
+    shape, dataset = (32, 32, 3), 'cifar_10'
+  else:
+    from pocketflow_amd.nets.mobilenet_at_ilsvrc12 import ModelHelper
+    flags = dict(batch_size=6, batch_size_eval=6, image_size=32, nb_classes=11, mobilenet_depth_mult=0.25)
+    shape, dataset = (32, 32, 3), 'ilsvrc_12'
+  flags.update(cp_sampling='reference', cp_feature_bn='train', cp_nb_batches=2, cp_nb_points_per_layer=5, cp_seed=31,
+               enbl_dst=False, synthetic_pool=2,
+               cp_channel_pruned_path=str(tmp_path / 'models' / 'pruned_model.ckpt'),
+               cp_best_path=str(tmp_path / 'models' / 'best_model.ckpt'),
+               cp_original_path=str(tmp_path / 'models' / 'original_model.ckpt'))
+  old = {k: getattr(FLAGS, k) for k in ('cp_sampling', 'cp_feature_bn', 'cp_nb_batches', 'cp_nb_points_per_layer', 'cp_seed')}
+  for k, v in flags.items():
+    setattr(FLAGS, k, v)
+  try:
+    mh = ModelHelper()
+    create_synthetic_checkpoint(mh)
+    learner = ChannelPrunedLearner(None, mh)
+    learner.restore_vars(checkpoint.latest_checkpoint(str(tmp_path / 'models')))
+    st = learner.graph.store
+    vals = st.export_numpy()
+    rng = np.random.RandomState(3)
+    for name in list(vals):                       # generic BN parameters and moving statistics instead of 1 / 0 / 0 / 1
+      if name.endswith('/gamma'):
+        vals[name] = (1.0 + 0.2 * rng.standard_normal(vals[name].shape)).astype(np.float32)
+      if name.endswith('/beta') or name.endswith('/moving_mean'):
+        vals[name] = (0.2 * rng.standard_normal(vals[name].shape)).astype(np.float32)
+      if name.endswith('/moving_variance'):
+        vals[name] = (0.5 + rng.rand(*vals[name].shape)).astype(np.float32)
+    st.load_numpy(vals)
+    learner.create_pruner()
+    pr = learner.pruner
+    state0 = st.state.clone()
+    pr.extract_features()
+    cfg = dict(model='resnet' if model == 'resnet' else 'mobilenet_v1', dataset=dataset, resnet_size=flags.get('resnet_size', 0),
+               nb_classes=flags['nb_classes'], image_shape=shape, learner='full-prec')
+    ora = OracleLearner(vals, cfg, lambda s: 0.0)
+    ops, convs, shapes, run = ora.pruner_view(training=True)
+    batches = [b[0].detach().cpu().numpy() for b in pr.batches[:2]]
+    names = CF.conv_add_names(ops)
+    feats, points = CF.extract_features(run, names, shapes, batches, 5, np.random.RandomState(31))
+    by_kernel = {c['kernel']: c for c in convs.values()}
+    conv_of = {l: by_kernel[l.kernel.name] for l in pr.thisconvs}
+    assert [conv_of[l]['name'] for l in pr.thisconvs] == list(convs.keys()), 'creation order of the convolutions'
+    worst = 0.0
+
+    def close(got, ref, what):
+      nonlocal worst
+      assert got.shape == ref.shape, (what, got.shape, ref.shape)
+      err = float(np.max(np.abs(got - ref)) / max(1.0, float(np.max(np.abs(ref)))))
+      worst = max(worst, err)
+      assert err <= tol, '%s: %.3e' % (what, err)
+    n_add = 0
+    # MobileNet's forward_train puts a dropout in front of the Logits convolution (random per run, in the reference too: its
+    # pruner graph is the training graph): that layer's values are compared in no direction, its sample points are
+    skip = {pr.thisconvs[-1]} if model != 'resnet' else set()
+    for l in pr.thisconvs:
+      c = conv_of[l]
+      tname = c['name'] + ':0'
+      for b in range(2):
+        np.testing.assert_array_equal(pr.points[(b, l)][0], points[(b, tname, 'x_samples')], err_msg=tname)
+        np.testing.assert_array_equal(pr.points[(b, l)][1], points[(b, tname, 'y_samples')], err_msg=tname)
+      if l not in skip:
+        close(pr.feats_dict[l], feats[tname], 'features ' + tname)
+      add = CF.add_if_is_last_in_resblock(ops, c['name'])
+      assert (add is not None) == (l in pr.add_owner), c['name']
+      if add is not None:
+        owner = pr.add_owner[l]
+        for b in range(2):
+          np.testing.assert_array_equal(pr.points[(b, 'add', owner)][0], points[(b, add, 'x_samples')], err_msg=add)
+        close(pr.feats_add[owner], feats[add], 'features ' + add)
+        n_add += 1
+    # "the pruning done so far": zero input channels of some convolutions on both sides, then inputs and residual diffs
+    new = dict(vals)
+    for i, l in enumerate(pr.thisconvs[1:-1]):
+      w = new[l.kernel.name].copy()
+      w[:, :, rng.rand(w.shape[2]) < 0.4, :] = 0.0
+      new[l.kernel.name] = w
+    st.load_numpy(new)
+    ora2 = OracleLearner(new, cfg, lambda s: 0.0)
+    __, __, __, run2 = ora2.pruner_view(training=True)
+    for l in pr.thisconvs:
+      if l in skip:
+        continue
+      c = conv_of[l]
+      close(pr._ChannelPruner__extract_input(l), CF.extract_input(run2, c, points, 2), 'input of ' + c['name'])
+      add = CF.add_if_is_last_in_resblock(ops, c['name'])
+      if add is not None:
+        close(pr.residual_branch_diff(l), CF.residual_branch_diff(run2, add, shapes, points, 2, feats), 'diff ' + add)
+    assert torch.equal(st.state, state0), 'the moving statistics changed while sampling'
+    return dict(convs=len(pr.thisconvs), adds=n_add, worst=worst)
+  finally:
+    for k, v in old.items():
+      setattr(FLAGS, k, v)

@@ -147,6 +147,23 @@ def test_channel_pruned_mobilenet_uniform(tmp_path):
   assert all(learner.fake_pruning_dict[first.op.name][0]) and all(learner.fake_pruning_dict[last.op.name][1])
 
 
+@pytest.mark.parametrize('model', ['resnet', 'mobilenet'])
+def test_cp_feature_sampling_matches_oracle(tmp_path, model):
+  """sampled features / convolution inputs / residual diffs of the channel pruner in the reference's
+  setting (own points per tensor name, batch-statistics BN) against oracle/cp_features_oracle.py on the oracle network
+  (float32 compute: the pruner is a float32 procedure in the reference).  Body: tests/parity_common.py."""
+  import sys
+  sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+  import pocketflow_amd.nets.mobilenet_at_ilsvrc12  # noqa: F401  (flag definitions)
+  import pocketflow_amd.nets.resnet_at_cifar10  # noqa: F401
+  import pocketflow_amd.learners.channel_pruning.learner  # noqa: F401
+  from parity_common import run_cp_feature_sampling_parity
+  FLAGS = _setup(tmp_path, compute_dtype='float32')
+  r = run_cp_feature_sampling_parity(FLAGS, tmp_path, model)
+  print('a17 %s: %d convolutions, %d residual sums, worst relative error %.2e' % (model, r['convs'], r['adds'], r['worst']))
+  assert r['convs'] == (10 if model == 'resnet' else 15) and r['adds'] == (6 if model == 'resnet' else 0), r
+
+
 def test_bench_two_ranks_share_one_gpu(tmp_path):
   """The N > 1 control flow of bench.py end to end on a single-GPU box: two ranks on cuda:0 over gloo
   (RCCL refuses duplicate devices): shared scratch directory, rank-0 checkpoint + teacher hand-off,

@@ -847,3 +847,15 @@ def test_cp_masked_finetune_matches_oracle_on_cpu(cpu_learners, monkeypatch, opt
   FLAGS, fake, tmp = cpu_learners
   monkeypatch.setattr(CP, 'hip', fake)
   run_cp_masked_finetune(FLAGS, tmp, optimizer)
+
+
+@pytest.mark.parametrize('model', ['resnet', 'mobilenet'])
+def test_cp_feature_sampling_matches_oracle_on_cpu(cpu_learners, monkeypatch, model):
+  """SURVEY 8a row a17 with the HIP entry points emulated: same body as the GPU test (tests/test_learner_gpu.py)."""
+  import pocketflow_amd.learners.channel_pruning.learner as CP
+  import pocketflow_amd.nets.mobilenet_at_ilsvrc12  # noqa: F401
+  from parity_common import run_cp_feature_sampling_parity
+  FLAGS, fake, tmp = cpu_learners
+  monkeypatch.setattr(CP, 'hip', fake)
+  r = run_cp_feature_sampling_parity(FLAGS, tmp, model)
+  assert r['convs'] == (10 if model == 'resnet' else 15) and r['adds'] == (6 if model == 'resnet' else 0), r
