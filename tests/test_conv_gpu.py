@@ -323,7 +323,11 @@ def test_fused_path_is_as_accurate_as_unfused(tmp_path, a_bits):
   assert report['teacher'][1] > 0.999 and report['bn_state'][1] > 0.999, report
   for k in ('student', 'kernel_grads', 'bn_grads'):
     u, f = report[k]
-    assert f >= u - 0.05, (k, report)
+    # with 8-bit activations on a randomly initialised network NEITHER bf16 run correlates with float32 (cosines 0.08-0.15:
+    # the quantiser's step functions amplify every rounding difference; measured spread between two correct runs +-0.07), so
+    # the margin only means something where the cosines do; the conditioned-state comparison with the oracle
+    # (tests/test_parity_gpu.py::test_uq_resnet50_bf16_fused_path_matches_oracle_within_bf16_noise) is the quantitative bar
+    assert f >= u - (0.05 if u >= 0.5 else 0.15), (k, report)
   assert 0.7 < report['grad_norm'][2] / report['grad_norm'][0] < 1.4, report
 
 

@@ -116,5 +116,19 @@ c15)
   cd $GRAFT_REPO_ROOT
   python tools/prof_summary.py $(find /tmp/prof_r3b -name '*kernel_trace.csv' | head -1) --steps 4 --out gpurun_out/r03_step_kernels_b256_c15.csv | head -16 | cut -c1-200
   ;;
+c16)
+  # full GPU suite on the current tree (a17 GPU tests, residual changes, many-slice stream test), host-side API view of the
+  # steady state (what the host does during the device's idle gaps), own 3x3 backward-filter at C = 64 vs MIOpen in the step
+  rm -f gpurun_out/r03_parity_report.txt
+  PF_PARITY_REPORT=$GRAFT_REPO_ROOT/gpurun_out/r03_parity_report.txt timeout 2400 python -m pytest tests -m gpu -q --timeout=900 --tb=short 2>&1 | tail -30 | cut -c1-400 > gpurun_out/r03_c16_pytest.log
+  tail -14 gpurun_out/r03_c16_pytest.log
+  cd /tmp
+  timeout 600 rocprofv3 --hip-trace --kernel-trace --output-format csv -d /tmp/prof_r3h -o r3h -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 4 --no_cpu_baseline > $GRAFT_REPO_ROOT/gpurun_out/r03_prof_h.log 2>&1
+  cd $GRAFT_REPO_ROOT
+  ls /tmp/prof_r3h/*/ 2>/dev/null | head; head -2 $(find /tmp/prof_r3h -name '*hip_api_trace.csv' | head -1) | cut -c1-300
+  python tools/hip_api_summary.py $(find /tmp/prof_r3h -name '*hip_api_trace.csv' | head -1) $(find /tmp/prof_r3h -name '*kernel_trace.csv' | head -1) --steps 4 2>&1 | tee gpurun_out/r03_hip_api_summary.txt | cut -c1-400
+  PF_OWN_CONV2D_WRW_MIN_C=64 run_bench c2_wrw64own --steps 15 --warmup 5 --no_cpu_baseline
+  run_bench c2_wrw64miopen --steps 15 --warmup 5 --no_cpu_baseline
+  ;;
 *) echo "unknown payload $1"; exit 2;;
 esac
