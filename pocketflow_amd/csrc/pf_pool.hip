@@ -7,6 +7,7 @@
 // Algorithmic bytes per output element (k = 3, stride 2, bf16): forward 4*2 (input, read once through L2) + 2 + 1,
 // backward 4*2 (dx) + 2 + 1.
 #include "pf_common.h"
+#include <stdlib.h>
 
 template <typename T>
 __global__ __launch_bounds__(PF_THREADS) void k_maxpool_fwd(const T* __restrict__ x, T* __restrict__ y,
@@ -88,6 +89,131 @@ __global__ __launch_bounds__(PF_THREADS) void k_maxpool_bwd(const T* __restrict_
   }
 }
 
+// ---- 3x3 / stride 2 (the ResNet stem), round 3 -----------------------------------------------------------------------------
+// Same results as the generic kernels above, element for element (same window order, same NaN rule, same summation order
+// of the gradient), without their per-element 64-bit divisions and data-dependent loops: every load of a thread is issued
+// before the first comparison.  forward: one lane = one output pixel x 8 channels, nine 16-byte loads (clipped taps read
+// nothing and count as -inf).  backward: one lane = a 2 x 2 block of INPUT pixels x 8 channels -- the block touches exactly the
+// four windows (a-1..a) x (b-1..b), so 4 (dy, index) vectors serve 4 pixels (the per-pixel gather loads 9 for them).
+template <typename T>
+__global__ __launch_bounds__(PF_THREADS) void k_maxpool3s2_fwd(const T* __restrict__ x, T* __restrict__ y,
+                                                               uint8_t* __restrict__ idx, int B, int H, int W, int C,
+                                                               int pad_h, int pad_w, int Ho, int Wo) {
+  const int CV = C >> 3;
+  const int total = B * Ho * Wo * CV;
+  for (int64_t e64 = (int64_t)blockIdx.x * PF_THREADS + threadIdx.x; e64 < total; e64 += (int64_t)gridDim.x * PF_THREADS) {
+    const int e = (int)e64;                                              // total < 2^31 (launcher): 32-bit index arithmetic
+    const int cv = e % CV;
+    int p = e / CV;
+    const int wo = p % Wo; p /= Wo;
+    const int ho = p % Ho;
+    const int b = p / Ho;
+    const int h0 = ho * 2 - pad_h, w0 = wo * 2 - pad_w;
+    float v[9][8];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int hi = h0 + r, wi = w0 + s;
+        if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
+          load8<T>(x + (((int64_t)b * H + hi) * W + wi) * C + (cv << 3), v[r * 3 + s]);
+        else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[r * 3 + s][j] = -INFINITY;       // never selected: -inf > best is false
+        }
+      }
+    float best[8];
+    int arg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; arg[j] = 0; }
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (v[t][j] > best[j] || v[t][j] != v[t][j]) { best[j] = v[t][j]; arg[j] = t; }
+    const int64_t o = (((int64_t)b * Ho + ho) * Wo + wo) * C + (cv << 3);
+    store8<T>(y + o, best);
+    if (idx != nullptr) {
+      uint2 pk;
+      pk.x = (uint32_t)arg[0] | ((uint32_t)arg[1] << 8) | ((uint32_t)arg[2] << 16) | ((uint32_t)arg[3] << 24);
+      pk.y = (uint32_t)arg[4] | ((uint32_t)arg[5] << 8) | ((uint32_t)arg[6] << 16) | ((uint32_t)arg[7] << 24);
+      *reinterpret_cast<uint2*>(idx + o) = pk;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(PF_THREADS) void k_maxpool3s2_bwd(const T* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                               T* __restrict__ dx, int B, int H, int W, int C, int pad_h,
+                                                               int pad_w, int Ho, int Wo, int Ha, int Wb) {
+  const int CV = C >> 3;
+  const int total = B * Ha * Wb * CV;
+  for (int64_t e64 = (int64_t)blockIdx.x * PF_THREADS + threadIdx.x; e64 < total; e64 += (int64_t)gridDim.x * PF_THREADS) {
+    const int e = (int)e64;                                              // total < 2^31 (launcher): 32-bit index arithmetic
+    const int cv = e % CV;
+    int p = e / CV;
+    const int bb = p % Wb; p /= Wb;
+    const int a = p % Ha;
+    const int b = p / Ha;
+    // windows (a - i, bb - k), i, k in {0, 1}: padded coordinates u = hi + pad_h in {2a, 2a+1}, window ho covers u in [2ho, 2ho+2]
+    float d[2][2][8];
+    uint2 pk[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int ho = a - i, wo = bb - k;
+        pk[i][k] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);                   // 255: no tap
+        if ((unsigned)ho < (unsigned)Ho && (unsigned)wo < (unsigned)Wo) {
+          const int64_t o = (((int64_t)b * Ho + ho) * Wo + wo) * C + (cv << 3);
+          pk[i][k] = *reinterpret_cast<const uint2*>(idx + o);
+          load8<T>(dy + o, d[i][k]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) d[i][k][j] = 0.f;
+        }
+      }
+#pragma unroll
+    for (int du = 0; du < 2; ++du) {
+      const int hi = 2 * a + du - pad_h;
+      if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+      for (int dv = 0; dv < 2; ++dv) {
+        const int wi = 2 * bb + dv - pad_w;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        float g[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = 0.f;
+        // the generic kernel's order: ho descending from the last window that contains the row, wo likewise
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int r = du + 2 * i;                                        // tap row inside window a - i
+          if (r > 2) continue;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int s = dv + 2 * k;
+            if (s > 2) continue;
+            const uint32_t want = (uint32_t)(r * 3 + s);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const uint32_t t = ((j < 4 ? pk[i][k].x : pk[i][k].y) >> ((j & 3) * 8)) & 0xFFu;
+              if (t == want) g[j] += d[i][k][j];
+            }
+          }
+        }
+        store8<T>(dx + (((int64_t)b * H + hi) * W + wi) * C + (cv << 3), g);
+      }
+    }
+  }
+}
+
+static bool pool3s2_ok(int B, int H, int W, int C, int k, int stride, int pad_h, int pad_w, int Ho, int Wo) {
+  const char* e = getenv("PF_POOL3S2");                                    // =0: the generic kernels (A-B / tests)
+  if (e != nullptr && atoi(e) == 0) return false;
+  return k == 3 && stride == 2 && pad_h >= 0 && pad_h <= 1 && pad_w >= 0 && pad_w <= 1 &&
+         (int64_t)B * H * W * (C / 8) < (1ll << 31);
+}
+
 extern "C" int pf_maxpool_fwd(const void* x, void* y, void* idx, int dtype, int B, int H, int W, int C, int k, int stride,
                               int pad_h, int pad_w, int Ho, int Wo, void* stream) {
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || k < 1 || k > 15 || stride < 1 || Ho <= 0 || Wo <= 0)
@@ -96,6 +222,14 @@ extern "C" int pf_maxpool_fwd(const void* x, void* y, void* idx, int dtype, int 
   const int64_t total = (int64_t)B * Ho * Wo * (C / 8);
   const int grid = pf_grid_for(total, PF_THREADS);
   hipStream_t st = (hipStream_t)stream;
+  if (pool3s2_ok(B, H, W, C, k, stride, pad_h, pad_w, Ho, Wo) && (dtype == PF_F32 || dtype == PF_BF16)) {
+    if (dtype == PF_F32)
+      k_maxpool3s2_fwd<float><<<grid, PF_THREADS, 0, st>>>((const float*)x, (float*)y, (uint8_t*)idx, B, H, W, C, pad_h, pad_w, Ho, Wo);
+    else
+      k_maxpool3s2_fwd<bf16_t><<<grid, PF_THREADS, 0, st>>>((const bf16_t*)x, (bf16_t*)y, (uint8_t*)idx, B, H, W, C, pad_h, pad_w, Ho, Wo);
+    PF_LAUNCH_CHECK();
+    return 0;
+  }
   if (dtype == PF_F32)
     k_maxpool_fwd<float><<<grid, PF_THREADS, 0, st>>>((const float*)x, (float*)y, (uint8_t*)idx, B, H, W, C, k, stride,
                                                        pad_h, pad_w, Ho, Wo);
@@ -114,8 +248,18 @@ extern "C" int pf_maxpool_bwd(const void* dy, const void* idx, void* dx, int dty
     return (int)hipErrorInvalidValue;
   if (!pf_aligned16(dy) || !pf_aligned16(dx) || (((uintptr_t)idx) & 7)) return (int)hipErrorInvalidValue;
   const int64_t total = (int64_t)B * H * W * (C / 8);
-  const int grid = pf_grid_for(total, PF_THREADS);
   hipStream_t st = (hipStream_t)stream;
+  if (pool3s2_ok(B, H, W, C, k, stride, pad_h, pad_w, Ho, Wo) && (dtype == PF_F32 || dtype == PF_BF16)) {
+    const int Ha = (H + pad_h + 1) / 2, Wb = (W + pad_w + 1) / 2;        // 2 x 2 blocks of padded input coordinates
+    const int g2 = pf_grid_for((int64_t)B * Ha * Wb * (C / 8), PF_THREADS);
+    if (dtype == PF_F32)
+      k_maxpool3s2_bwd<float><<<g2, PF_THREADS, 0, st>>>((const float*)dy, (const uint8_t*)idx, (float*)dx, B, H, W, C, pad_h, pad_w, Ho, Wo, Ha, Wb);
+    else
+      k_maxpool3s2_bwd<bf16_t><<<g2, PF_THREADS, 0, st>>>((const bf16_t*)dy, (const uint8_t*)idx, (bf16_t*)dx, B, H, W, C, pad_h, pad_w, Ho, Wo, Ha, Wb);
+    PF_LAUNCH_CHECK();
+    return 0;
+  }
+  const int grid = pf_grid_for(total, PF_THREADS);
   if (dtype == PF_F32)
     k_maxpool_bwd<float><<<grid, PF_THREADS, 0, st>>>((const float*)dy, (const uint8_t*)idx, (float*)dx, B, H, W, C, k,
                                                        stride, pad_h, pad_w, Ho, Wo);

@@ -331,7 +331,7 @@ def run_cp_feature_sampling_parity(FLAGS, tmp_path, model='resnet', tol=None):
                cp_channel_pruned_path=str(tmp_path / 'models' / 'pruned_model.ckpt'),
                cp_best_path=str(tmp_path / 'models' / 'best_model.ckpt'),
                cp_original_path=str(tmp_path / 'models' / 'original_model.ckpt'))
-  old = {k: getattr(FLAGS, k) for k in ('cp_sampling', 'cp_feature_bn', 'cp_nb_batches', 'cp_nb_points_per_layer', 'cp_seed')}
+  old = {k: getattr(FLAGS, k) for k in flags if k in FLAGS}       # FLAGS are process-global: leave none of them behind
   for k, v in flags.items():
     setattr(FLAGS, k, v)
   try:

@@ -130,5 +130,14 @@ c16)
   PF_OWN_CONV2D_WRW_MIN_C=64 run_bench c2_wrw64own --steps 15 --warmup 5 --no_cpu_baseline
   run_bench c2_wrw64miopen --steps 15 --warmup 5 --no_cpu_baseline
   ;;
+c17)
+  # the two parity tests that failed in the full run: alone, then behind the a17 tests (flag leakage?); new max-pool kernels
+  timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -q --tb=line -k "conditioned_state or cp_mobilenet" 2>&1 | tail -8 | cut -c1-300
+  timeout 900 python -m pytest tests/test_learner_gpu.py tests/test_parity_gpu.py -m gpu -q --tb=line -k "cp_feature_sampling or conditioned_state or cp_mobilenet" 2>&1 | tail -8 | cut -c1-300
+  PF_OWN_DEPTHWISE=0 timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -q --tb=line -k "cp_mobilenet" 2>&1 | tail -5 | cut -c1-300
+  timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q --tb=short -k "maxpool" 2>&1 | tail -6 | cut -c1-300
+  PF_POOL3S2=1 run_bench c2_pool1 --steps 15 --warmup 5 --no_cpu_baseline
+  PF_POOL3S2=0 run_bench c2_pool0 --steps 15 --warmup 5 --no_cpu_baseline
+  ;;
 *) echo "unknown payload $1"; exit 2;;
 esac
