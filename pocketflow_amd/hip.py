@@ -286,10 +286,6 @@ def bn_eval_scale_shift(gamma, beta, moving_mean, moving_var, eps: float, scale_
 
 
 # ------------------------------------------------------------------------------------------------
-# MFMA GEMM
-# ------------------------------------------------------------------------------------------------
-
-# ------------------------------------------------------------------------------------------------
 # fused 1x1 convolutions
 # ------------------------------------------------------------------------------------------------
 

@@ -139,5 +139,10 @@ c17)
   PF_POOL3S2=1 run_bench c2_pool1 --steps 15 --warmup 5 --no_cpu_baseline
   PF_POOL3S2=0 run_bench c2_pool0 --steps 15 --warmup 5 --no_cpu_baseline
   ;;
+c18)
+  # BN-backward apply: rows per trip x grid sizing
+  timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q --tb=short -k "bn" 2>&1 | tail -4 | cut -c1-300
+  timeout 400 python tools/gpu/bn_bwd_bench.py 2>&1 | tee gpurun_out/r03_bn_bwd_bench.txt | cut -c1-200
+  ;;
 *) echo "unknown payload $1"; exit 2;;
 esac
