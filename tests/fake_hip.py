@@ -359,7 +359,23 @@ class FakeHipFull(FakeHip):
     return True, 'split', int(sg['bucket_size'])
 
   def seg_minmax(self, w_flat, segs, blocks, n_blocks, slots):
-    pass                                             # ranges are recomputed by the apply emulations
+    # the apply emulations recompute their ranges; the slots are filled for what READS them (plan.alpha_beta(): logging,
+    # the integer export) in this emulation's own encoding: float32 (min, max) pairs, see minmax_decode above
+    w = w_flat.detach().float().numpy()
+    v = slots.view(torch.float32).view(-1, 2)
+    for sg in self._segs(segs):
+      off, n = int(sg['offset']), int(sg['len'])
+      ub, bt, bs = self._bucket_args(sg)
+      x = self._to_hwio(w[off:off + n], sg)
+      if ub and bt == 'split':
+        x = O.split_bucket(x, bs)[0]
+      elif ub:
+        x = O.channel_bucket(x)[0]
+      else:
+        x = x.reshape(-1, 1)
+      so = int(sg['slot_offset'])
+      v[so:so + x.shape[1], 0] = torch.from_numpy(np.ascontiguousarray(x.min(axis=0)))
+      v[so:so + x.shape[1], 1] = torch.from_numpy(np.ascontiguousarray(x.max(axis=0)))
 
   def seg_uq_apply(self, w_flat, qw_flat, segs, blocks, n_blocks, slots):
     w = w_flat.detach().numpy()

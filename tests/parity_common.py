@@ -414,3 +414,62 @@ def run_cp_feature_sampling_parity(FLAGS, tmp_path, model='resnet', tol=None):
   finally:
     for k, v in old.items():
       setattr(FLAGS, k, v)
+
+
+def run_int_export_roundtrip(FLAGS, tmp_path, model='lenet', use_buckets=True, bucket_type='split', bits=3):
+  """pocketflow_amd/tools/conversion/export_quant_int8_model.py on a live UniformQuantLearner: every quantised kernel of the
+  artefact decodes, bit for bit, to what oracle/pf_oracle.py uniform_quantize makes of the master weights (the reference's
+  quantiser executed), everything else is the float32 variable; a learner restored from the decoded artefact evaluates like
+  the one that wrote it (fake-quantisation is idempotent)."""
+  from oracle import pf_oracle as O
+  from pocketflow_amd.tools.conversion import export_quant_int8_model as E
+  from pocketflow_amd.learners.uniform_quantization.learner import UniformQuantLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  if model == 'lenet':
+    from pocketflow_amd.nets.lenet_at_cifar10 import ModelHelper
+    extra = {}
+  else:
+    from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
+    extra = dict(resnet_size=20)
+  flags = dict(batch_size=16, batch_size_eval=16, nb_classes=10, uql_weight_bits=bits, uql_activation_bits=8,
+               uql_use_buckets=use_buckets, uql_bucket_type=bucket_type, uql_bucket_size=64, enbl_dst=False,
+               uql_save_quant_model_path=str(tmp_path / 'uql' / 'm.ckpt'), nb_eval_batches_override=2, compute_dtype='float32',
+               **extra)
+  old = {k: getattr(FLAGS, k) for k in flags if k in FLAGS}
+  for k, v in flags.items():
+    setattr(FLAGS, k, v)
+  try:
+    mh = ModelHelper()
+    create_synthetic_checkpoint(mh)
+    lrn = UniformQuantLearner(None, mh)
+    for _ in range(2):
+      lrn.train_step()
+    path = str(tmp_path / 'int' / 'model_int.npz')
+    summ = E.export_from_learner(lrn, path)
+    vals = lrn.graph.store.export_numpy()
+    dec = E.load_exported(path)
+    assert set(dec) == set(vals)
+    quant = {op.var.name for op in lrn.uni_quant.matmul_ops}
+    assert summ['quantised_tensors'] == len(quant) > 0
+    for name, w in vals.items():
+      if name in quant:
+        ref, __ = O.uniform_quantize(w, bits, 'weight', use_buckets, bucket_type, 64)
+        assert np.array_equal(dec[name].view(np.uint32), ref.view(np.uint32)), name
+      else:
+        assert np.array_equal(dec[name], w), name
+    assert summ['int_bytes'] < summ['float32_bytes'] * (bits / 32.0 + 0.15)
+    lrn.graph.training = False
+    before = lrn.run_eval()
+    again = lrn.run_eval()
+    assert before == again, ('evaluation is not repeatable', before, again)
+    c0 = lrn.graph.store.w_compute.clone()
+    lrn.graph.store.load_numpy(dec)
+    after = lrn.run_eval()
+    # the network the evaluation multiplies with is the same, bit for bit; the reported loss carries loss_w_dcy * l2 of the
+    # MASTER weights, which now are the quantised ones
+    assert torch.equal(c0, lrn.graph.store.w_compute)
+    assert before['acc_top1'] == after['acc_top1'] and abs(before['loss'] - after['loss']) <= 5e-3 * abs(before['loss']), (before, after)
+    return summ
+  finally:
+    for k, v in old.items():
+      setattr(FLAGS, k, v)

@@ -164,6 +164,22 @@ def test_cp_feature_sampling_matches_oracle(tmp_path, model):
   assert r['convs'] == (10 if model == 'resnet' else 15) and r['adds'] == (6 if model == 'resnet' else 0), r
 
 
+@pytest.mark.parametrize('model,use_buckets,bucket_type,bits', [('lenet', True, 'split', 3), ('resnet', True, 'channel', 4), ('resnet', False, 'channel', 8)])
+def test_int_export_of_a_uq_learner(tmp_path, model, use_buckets, bucket_type, bits):
+  """integer codes read back from the device quantiser (pf_seg_minmax / pf_seg_uq_apply) decode bit for bit to
+  the oracle's fake-quantised weights; a learner restored from the artefact multiplies with the same numbers.  Body: tests/
+  parity_common.py."""
+  import sys
+  sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+  import pocketflow_amd.nets.lenet_at_cifar10  # noqa: F401  (flag definitions)
+  import pocketflow_amd.nets.resnet_at_cifar10  # noqa: F401
+  import pocketflow_amd.learners.uniform_quantization.learner  # noqa: F401
+  from parity_common import run_int_export_roundtrip
+  FLAGS = _setup(tmp_path)
+  summ = run_int_export_roundtrip(FLAGS, tmp_path, model, use_buckets, bucket_type, bits)
+  assert summ['quantised_tensors'] == (2 if model == 'lenet' else 21)
+
+
 def test_bench_two_ranks_share_one_gpu(tmp_path):
   """The N > 1 control flow of bench.py end to end on a single-GPU box: two ranks on cuda:0 over gloo
   (RCCL refuses duplicate devices): shared scratch directory, rank-0 checkpoint + teacher hand-off,

@@ -859,3 +859,12 @@ def test_cp_feature_sampling_matches_oracle_on_cpu(cpu_learners, monkeypatch, mo
   monkeypatch.setattr(CP, 'hip', fake)
   r = run_cp_feature_sampling_parity(FLAGS, tmp, model)
   assert r['convs'] == (10 if model == 'resnet' else 15) and r['adds'] == (6 if model == 'resnet' else 0), r
+
+
+@pytest.mark.parametrize('model,use_buckets,bucket_type,bits', [('lenet', True, 'split', 3), ('resnet', True, 'channel', 4), ('lenet', False, 'channel', 8)])
+def test_int_export_of_a_uq_learner_on_cpu(cpu_learners, model, use_buckets, bucket_type, bits):
+  """Integer export with the HIP entry points emulated: same body as the GPU test."""
+  from parity_common import run_int_export_roundtrip
+  FLAGS, fake, tmp = cpu_learners
+  summ = run_int_export_roundtrip(FLAGS, tmp, model, use_buckets, bucket_type, bits)
+  assert summ['quantised_tensors'] == (2 if model == 'lenet' else 21)       # ResNet-20: 23 matmul kernels, first and last stay float32
