@@ -246,6 +246,15 @@ def pmc_traffic_per_launch(region, tag=PROFILE_TAG):
   return tot
 
 
+def pmc_traffic_source(tag=PROFILE_TAG):
+  """Where `roofline.traffic` comes from: it is NOT measured by this run (PMC collection needs rocprofv3 around the process) but
+  read from the committed PMC passes of this command; profiles/<tag>_pmc_SOURCE.txt names the commit they were taken at."""
+  path = os.path.join(ROOT, 'profiles', '%s_pmc_SOURCE.txt' % tag)
+  if not os.path.exists(path):
+    return None
+  return open(path).read().strip()
+
+
 def memory_snapshot(torch):
   """Device-memory picture of this process: a caching allocator that has to go to the driver inside the step
   (retries after a failed hipMalloc, segments allocated / released per step) is what made some bench processes host-bound."""
@@ -396,6 +405,7 @@ def main():
                           if args.roofline_kernel == 'conv1x1_fwd' else args.roofline_kernel,
                 'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9,
                 'unit': 'GB/s', 'frac': ach / HBM_PEAK, 'traffic': pmc_traffic_per_launch(args.roofline_kernel),
+                'traffic_source': pmc_traffic_source(),
                 'algorithmic_bytes_per_launch': (work / n_launch) if n_launch else None, 'launches': n_launch,
                 'avg_launch_ms': (ms / n_launch) if n_launch else None,
                 'step_mfma_frac': per_gpu * cfg['flops'] / MFMA_BF16_PEAK}

@@ -222,7 +222,10 @@ def conditioned_uq_resnet50(FLAGS, tmp_path, a_bits=8, compute_dtype='bfloat16')
                    enbl_dst=True, dst_eval_teacher=False, save_path_dst=str(tmp_path / 'models_dst' / 'model.ckpt'),
                    uql_save_quant_model_path=str(tmp_path / 'uql' / 'm.ckpt'), nb_eval_batches_override=1,
                    resnet_size=50, nb_classes=1001, image_size=64, uql_use_buckets=False,
-                   compute_dtype=compute_dtype).items():
+                   # per-network flags are defined by whichever nets module was imported FIRST in the process (cifar-10's
+                   # loss_w_dcy is 2e-4, ilsvrc-12's 1e-4, ...): pin the ilsvrc-12 ResNet values, whatever ran before
+                   loss_w_dcy=1e-4, momentum=0.9, lrn_rate_init=0.1, batch_size_norm=256, nb_epochs_rat=1.0,
+                   loss_w_dst=4.0, tempr_dst=4.0, compute_dtype=compute_dtype).items():
     setattr(FLAGS, k, v)
   mh = ModelHelper()
   create_synthetic_checkpoint(mh)

@@ -37,7 +37,7 @@ TOL_WORK = 2e-5         # working tolerance for a handful of float32 steps (Mome
 GRAD_TOL = 1e-4
 
 
-def _check_gradients(learner, ora, batch, what, tol=GRAD_TOL, min_cos=None):
+def _check_gradients(learner, ora, batch, what, tol=GRAD_TOL, min_cos=None, min_whole_cos=None):
   """One backward pass on both sides from the SAME state and batch, no update: d(loss)/d(variable) of the HIP learner
   against the oracle's, variable by variable.  This is the gradient-level bar the Adam-bounded weight comparison below
   cannot give (Adam moves every element by ~lr whatever its gradient: a backward pass with wrong signs would pass it)."""
@@ -52,6 +52,8 @@ def _check_gradients(learner, ora, batch, what, tol=GRAD_TOL, min_cos=None):
   assert worst_l2[1][0] <= tol, '%s: gradient of %s differs by %.3e (relative L2)' % (what, worst_l2[0], worst_l2[1][0])
   if min_cos is not None:
     assert worst_cos[1][1] >= min_cos
+  if min_whole_cos is not None:
+    assert wc >= min_whole_cos, (what, wc)
   assert abs(wr - 1.0) <= max(10 * tol, 1e-3)
   return per
 
@@ -361,7 +363,10 @@ def test_uq_resnet50_float32_gradients_match_oracle_from_a_conditioned_state(tmp
   from parity_common import conditioned_uq_resnet50
   FLAGS = _setup(tmp_path)
   learner, ora, pool = conditioned_uq_resnet50(FLAGS, tmp_path, a_bits=32, compute_dtype='float32')[:3]
-  _check_gradients(learner, ora, pool[0], 'ResNet-50 UQ w8/a32 + dst @64 B=16, float32, conditioned state', tol=2e-3, min_cos=0.99999)
+  # worst variable of 153 (always a BN offset with a small gradient): 1.7e-3 ... 8.2e-3 relative L2 over boxes and test orders
+  # (MIOpen's float32 convolutions against torch-CPU's; its cosine never below 0.99997), whole gradient: cosine 1.000000
+  _check_gradients(learner, ora, pool[0], 'ResNet-50 UQ w8/a32 + dst @64 B=16, float32, conditioned state', tol=2e-2, min_cos=0.9999,
+                   min_whole_cos=0.999999)
 
 
 def test_nuq_resnet50_4bit_distillation_matches_oracle(tmp_path):

@@ -144,5 +144,15 @@ c18)
   timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q --tb=short -k "bn" 2>&1 | tail -4 | cut -c1-300
   timeout 400 python tools/gpu/bn_bwd_bench.py 2>&1 | tee gpurun_out/r03_bn_bwd_bench.txt | cut -c1-200
   ;;
+c19)
+  # final-state GPU suite (integer-export tests, hermetic conditioned-state test) + one default bench line with the committed PMC traffic
+  rm -f gpurun_out/r03_parity_report.txt
+  PF_PARITY_REPORT=$GRAFT_REPO_ROOT/gpurun_out/r03_parity_report.txt timeout 2400 python -m pytest tests -m gpu -q --timeout=900 --tb=short 2>&1 | tail -30 | cut -c1-400 > gpurun_out/r03_pytest_gpu.log
+  tail -8 gpurun_out/r03_pytest_gpu.log
+  run_bench final --steps 20 --warmup 5 --no_cpu_baseline
+  python -c "
+import json
+d = json.loads([l for l in open('gpurun_out/r03_bench_final.json') if l.startswith('{')][0]); print(d['roofline'])"
+  ;;
 *) echo "unknown payload $1"; exit 2;;
 esac
