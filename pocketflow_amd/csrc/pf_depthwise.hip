@@ -26,7 +26,7 @@
 
 struct DwArgs {
   const void* x;       // fwd: input; bwd-data: dy; wrw: x
-  const void* w;       // [C][3][3] in the activation dtype (bwd-data: the caller passes the kernel FLIPPED for stride 1)
+  const void* w;       // [C][3][3] in the activation dtype, always the forward kernel (`flip` reverses the tap order)
   void* y;             // fwd: output; bwd-data: dx
   const void* dy;      // wrw only
   float* partial;      // fwd: [G][4][C] statistics or null; wrw: [G][C][9] slabs
