@@ -133,6 +133,11 @@ __device__ __forceinline__ void lds_read_b128x2(uint32_t p0, uint32_t p1, uint4&
   asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(ra), "=&v"(rb) : "v"(p0), "v"(p1) : "memory");
   a = make_uint4(ra[0], ra[1], ra[2], ra[3]); b = make_uint4(rb[0], rb[1], rb[2], rb[3]);
 }
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lds_write_b64(uint32_t p, const uint2& v) {
+  const u32x2_t r = {v.x, v.y};
+  asm volatile("ds_write_b64 %0, %1" : : "v"(p), "v"(r) : "memory");
+}
 __device__ __forceinline__ void lds_write_b128(uint32_t p, const uint4& v) {
   const u32x4_t r = {v.x, v.y, v.z, v.w};
   asm volatile("ds_write_b128 %0, %1" : : "v"(p), "v"(r) : "memory");

@@ -57,6 +57,7 @@ struct IgArgs {
   int th, tw;           // taps
   int H, Wd, Ho, Wo, stride, pad_h, pad_w;
   int tiles_m, tiles_n, G;
+  int stagger;          // clocks between the start phases of the workgroups (0: all start together), see k_igemm
 };
 
 // Ablation builds for tools/gpu/igemm_ablate.py ONLY (never in libpocketflow_hip.so): -DPF_IG_ABLATE=1 drops the MFMAs and
@@ -138,6 +139,12 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
     }
   }
 
+  if (a.stagger > 0) {
+    // Phase stagger: identical tiles keep the persistent workgroups of all CUs in the SAME phase (everybody streams its epilogue
+    // through HBM at once, then everybody fills LDS, ...); workgroup phase p = (blockIdx / 8) % 4 starts p * stagger clocks late.
+    const int64_t t_end = (int64_t)__builtin_readcyclecounter() + (int64_t)((blockIdx.x >> 3) & 3) * a.stagger;
+    while ((int64_t)__builtin_readcyclecounter() < t_end) __builtin_amdgcn_s_sleep(32);
+  }
   float st_s[8], st_q[8], st_mn[8], st_mx[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; st_mn[j] = INFINITY; st_mx[j] = -INFINITY; }
@@ -173,16 +180,29 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
       if (n0 + col < a.N) a.partial[((int64_t)g * 4 + stat) * a.N + n0 + col] = (stat < 2) ? 0.f : (stat == 2 ? INFINITY : -INFINITY);
     }
   }
-  for (int tm = g; tm < a.tiles_m; tm += a.G) {
-    const int m0 = tm * BM;
-    // input rows of this lane: byte offset of the top-left input pixel of the receptive field (may lie outside the
-    // image: the sum with the tap offset is only used for taps whose bit is set) and the mask of taps inside the image
-    uint32_t pbase[AS], pmask[AS];
+  const bool pointwise = a.th == 1 && a.tw == 1 && a.stride == 1 && a.pad_h == 0 && a.pad_w == 0 && a.Ho == a.H && a.Wo == a.Wd;
+  // Cross-tile prefetch (three-stage kernels, forward / plain modes): the C staging of the epilogue aliases ring buffers 0 and 1
+  // only, so every tile starts its ring at buffer RB0 = 2 and the FIRST stage of the next tile is issued into that buffer right
+  // behind the last k-step's barrier -- its latency (~2 us, a seventh of a 4-step tile) travels under the epilogue.  The epilogue
+  // of such a kernel touches LDS through the asm helpers only (an ordinary LDS access beside a pending LDS-DMA makes hipcc wait
+  // vmcnt(0)) and uses raw barriers.
+  constexpr bool XPRE = !WS && !BWD && NS == 3 && 2 * STAGE >= BM * CS_LD_B * 2;
+  constexpr int RB0 = XPRE ? 2 : 0;
+  // input rows of this lane: byte offset of the top-left input pixel of the receptive field (may lie outside the
+  // image: the sum with the tap offset is only used for taps whose bit is set) and the mask of taps inside the image
+  uint32_t pbase[AS], pmask[AS];
+  // the steps are staged in order: running (tap, tap row, tap column, channel step) instead of divisions
+  int s_r = 0, s_s = 0, s_cc = 0, s_ks = 0, s_tap = 0;
+  auto setup_tile = [&](int m0) {
 #pragma unroll
     for (int i = 0; i < AS; ++i) {
       const int m = m0 + i * (TS / 8) + srow;
       pbase[i] = 0; pmask[i] = 0;
-      if (m < a.M && (!WS || prod)) {
+      if (pointwise) {
+        // 1x1, stride 1, no padding (every 1x1 layer of the step): input row == output row, one tap -- no divisions, no tap
+        // loop (the generic branch costs ~300 instructions per tile, 5 % of a 4-step tile)
+        if (m < a.M && (!WS || prod)) { pbase[i] = (uint32_t)(m * a.C + schunk * 8) * 2u; pmask[i] = 1u; }
+      } else if (m < a.M && (!WS || prod)) {
         const int img = m / hw_o, rem = m - img * hw_o;
         const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
         const int h0 = ho * a.stride - a.pad_h, w0 = wo * a.stride - a.pad_w;
@@ -194,27 +214,31 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
         pmask[i] = mk;
       }
     }
-    // the steps are staged in order: running (tap, tap row, tap column, channel step) instead of divisions
-    int s_r = 0, s_s = 0, s_cc = 0, s_ks = 0, s_tap = 0;
-    auto stage = [&](int buf) {
-      unsigned char* As = smem + buf * STAGE;
-      unsigned char* Bs = As + A_BYTES;
-      const uint32_t tapoff = (uint32_t)(((s_r * a.Wd + s_s) * a.C + s_cc * 64) * 2);   // wave-uniform
+    s_r = 0; s_s = 0; s_cc = 0; s_ks = 0; s_tap = 0;
+  };
+  auto stage = [&](int buf) {
+    unsigned char* As = smem + buf * STAGE;
+    unsigned char* Bs = As + A_BYTES;
+    const uint32_t tapoff = (uint32_t)(((s_r * a.Wd + s_s) * a.C + s_cc * 64) * 2);   // wave-uniform
 #if PF_IG_ABLATE < 2
 #pragma unroll
-      for (int i = 0; i < AS; ++i) {
-        const uint32_t voff = ((pmask[i] >> s_tap) & 1u) ? (pbase[i] + tapoff) : OOB;
-        PF_BUFFER_LOAD_LDS16(rsX, As + (i * (TS / 8) + swave * 8) * 128, voff, 0);
-      }
+    for (int i = 0; i < AS; ++i) {
+      const uint32_t voff = ((pmask[i] >> s_tap) & 1u) ? (pbase[i] + tapoff) : OOB;
+      PF_BUFFER_LOAD_LDS16(rsX, As + (i * (TS / 8) + swave * 8) * 128, voff, 0);
+    }
 #pragma unroll
-      for (int i = 0; i < BS; ++i)
-        PF_BUFFER_LOAD_LDS16(rsW, Bs + (i * (TS / 8) + swave * 8) * 128, boff[i], s_ks * 128);
+    for (int i = 0; i < BS; ++i)
+      PF_BUFFER_LOAD_LDS16(rsW, Bs + (i * (TS / 8) + swave * 8) * 128, boff[i], s_ks * 128);
 #else
-      (void)As; (void)Bs; (void)tapoff;
+    (void)As; (void)Bs; (void)tapoff;
 #endif
-      ++s_ks;
-      if (++s_cc == cch) { s_cc = 0; ++s_tap; if (++s_s == a.tw) { s_s = 0; ++s_r; } }
-    };
+    ++s_ks;
+    if (++s_cc == cch) { s_cc = 0; ++s_tap; if (++s_s == a.tw) { s_s = 0; ++s_r; } }
+  };
+  bool pre = false;                                                         // XPRE: stage 0 of this tile is already in flight
+  for (int tm = g; tm < a.tiles_m; tm += a.G) {
+    const int m0 = tm * BM;
+    if (!pre) setup_tile(m0);
 
     f32x4 acc[NI][JM];
 #pragma unroll
@@ -253,7 +277,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
     // ring of NS stages, NS - 1 steps of loads in flight.  Step ks is multiplied from buffer ks % NS while the loads of
     // steps ks+1 .. ks+NS-1 travel; a stage is waited for with a COUNTED vmcnt (the younger stages stay in flight
     // across the barrier: raw s_barrier, never __syncthreads(), which would drain them) and read one barrier later.
-    int ibuf = 0;                                                           // buffer of the next stage to issue
+    int ibuf = RB0;                                                         // buffer of the next stage to issue
     // PRO: every thread transforms, in place, exactly the 16-byte groups it staged itself (its LDS-DMA destinations): the
     // data is complete for it after its own vmcnt wait, no extra barrier is needed before the pass, and its channels are
     // cc*64 + schunk*8 + 0..7 for every one of its rows -- one scale / shift fetch per step.  The pass for step ks+1 runs
@@ -375,15 +399,17 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
 #pragma unroll
     for (int d = 0; d < NS - 1; ++d)
       if (d < nk) {
-        if (PRO && !PRO3) fetch_ss(s_cc);
-        stage(ibuf);
+        if (d > 0 || !pre) {                                                // XPRE: stage 0 was issued before the previous epilogue
+          if (PRO && !PRO3) fetch_ss(s_cc);
+          stage(ibuf);
+        }
         ibuf = (ibuf + 1 == NS) ? 0 : ibuf + 1;
       }
     if (nk >= NS - 1) wait_vm<(NS - 2) * LPS>(); else wait_vm<0>();
-    if (PRO3) { transform3(0, 0, 0, AS); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-    else if (PRO) { transform(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    if (PRO3) { transform3(RB0, 0, 0, AS); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    else if (PRO) { transform(RB0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
     __builtin_amdgcn_s_barrier();
-    int cbuf = 0;
+    int cbuf = RB0;
     for (int ks = 0; ks < nk; ++ks) {
       const bool more = ks + NS - 1 < nk;
       const int tbuf = ibuf;                                                // buffer the stage issued now lands in
@@ -461,12 +487,25 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
         }
       }
     }
+    pre = false;
+    if constexpr (XPRE) {
+      // behind the residual add on purpose: the compiler waits for the residual registers with vmcnt(0) when a CONDITIONAL
+      // batch of loads was issued after them (it cannot count across the branch)
+      __builtin_amdgcn_sched_barrier(0);
+      if (tm + a.G < a.tiles_m) {                                           // every ring buffer is free behind the last k-step's barrier
+        setup_tile((tm + a.G) * BM);
+        stage(RB0);
+        pre = true;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < JM; ++j) {
         const uint2 v = make_uint2(pack_bf16x2(acc[i][j][0], acc[i][j][1]), pack_bf16x2(acc[i][j][2], acc[i][j][3]));
-        *reinterpret_cast<uint2*>(Cs + (wm * WR + j * 16 + l15) * CS_LD + wn * WC + i * 16 + q * 4) = v;
+        if constexpr (XPRE) lds_write_b64(lds_addr(Cs + (wm * WR + j * 16 + l15) * CS_LD + wn * WC + i * 16 + q * 4), v);
+        else *reinterpret_cast<uint2*>(Cs + (wm * WR + j * 16 + l15) * CS_LD + wn * WC + i * 16 + q * 4) = v;
       }
     }
     if constexpr (WS) {                                                     // per-tile statistics: (re)defined HERE, dead in the role loops
@@ -487,7 +526,8 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
     };
     const bool etid = !WS || tid < TE;                                      // WS: the producers only keep the barriers company
     if (side != nullptr && etid) load_side(0);
-    __syncthreads();
+    if constexpr (XPRE) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+    else __syncthreads();
 #pragma unroll
     for (int p0 = 0; p0 < NP; p0 += PG) {
 #pragma unroll
@@ -496,7 +536,9 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
         const int rl = wrw + p * RPP;
         const int m = m0 + rl, n = n0 + wvec * 8;
         if (m < a.M && n < a.N && etid) {
-          uint4 c = *reinterpret_cast<const uint4*>(Cs + rl * CS_LD + wvec * 8);
+          uint4 c;
+          if constexpr (XPRE) c = lds_read_b128(lds_addr(Cs + rl * CS_LD + wvec * 8));
+          else c = *reinterpret_cast<const uint4*>(Cs + rl * CS_LD + wvec * 8);
           if (BWD) {
             float f[8], xv[8];
             unpack8(c, f);
@@ -527,7 +569,8 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
       }
       if (side != nullptr && p0 + PG < NP && etid) load_side(p0 + PG);
     }
-    __syncthreads();
+    if constexpr (XPRE) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+    else __syncthreads();
     if constexpr (WS) {
       // statistics of THIS tile -> partial[g][4][N] at once (first tile of the workgroup: store, later tiles: combine, in
       // tile order: deterministic): the 32 accumulator registers are dead while the next tile's main loop runs (the
@@ -659,6 +702,10 @@ static int ig_launch_t(IgArgs& a, int slots, hipStream_t st) {
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
   const int grid = ig_grid(slots, a.tiles_m, a.tiles_n, &a.G);
+  {
+    const char* e = getenv("PF_IGEMM_STAGGER");           // experiment: clocks between workgroup start phases (default 0)
+    a.stagger = (e != nullptr) ? atoi(e) : 0;
+  }
   // stage ring and (aliased on it) the C tile; the BWD vectors / the folded prologue constants sit behind whichever is larger
   constexpr size_t ring = NS * (size_t)(BM + BN) * 128, ctile = (size_t)BM * (BN + 8) * 2;
   constexpr size_t base = (ring > ctile ? ring : ctile);

@@ -637,7 +637,12 @@ int pf_wrw2_splits(int M, int N, int C, int taps) {
   if ((int64_t)M * N >= ((int64_t)1 << 30)) return 0;
   const Wrw2Cfg c = wrw2_pick(N, C);
   const int tiles = (N / c.tn) * (taps * C / c.tk);
-  int S = (512 + tiles - 1) / tiles;                      // ~ two workgroups per CU
+  // workgroups a launch aims at: every pixel split writes (and the reduction reads) one fp32 slab of the whole dW tile, so
+  // more splits buy parallelism with HBM traffic.  Measured per layer over 128 ... 1024 (profiles/r03_wrw_target_bench.txt):
+  // one workgroup per CU for the 1x1 layers, 1.5 for the 3x3 ones (round 2's two per CU cost 0.35 ms per ResNet-50 step).
+  const char* e = getenv("PF_WRW2_TARGET");               // tuning / A-B override
+  const int target = (e != nullptr && atoi(e) > 0) ? atoi(e) : (taps == 1 ? 256 : 384);
+  int S = (target + tiles - 1) / tiles;
   const int maxS = (M + 255) / 256;                       // >= 8 steps of 32 pixels per workgroup
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;

@@ -91,7 +91,7 @@ def test_conv1x1_fwd_prologue_matches_standalone_bn_act_quant(hip, act, bits, sh
 # persistent workgroups that walk several row tiles, residual + statistics in the epilogue, and PF_IGEMM_PRO3=0 (round 2's
 # two-stage kernel) on the same inputs -- the two must agree to the last bit (same prologue arithmetic, same k order)
 @pytest.mark.parametrize('M,N,K', [(3000, 256, 1024), (5003, 512, 192), (2600, 128, 2048), (4133, 1024, 256), (40000, 256, 576),
-                                   (1, 256, 64), (129, 128, 64), (36000, 128, 640)])
+                                   (1, 256, 64), (129, 128, 64), (36000, 128, 640), (100003, 256, 192), (70001, 512, 64)])
 @pytest.mark.parametrize('act,bits', [('Relu', 8), ('Relu', None)])
 def test_conv1x1_fwd_prologue_three_stage_kernel(hip, M, N, K, act, bits, monkeypatch):
   g = torch.Generator(device='cuda').manual_seed(M + N + K)
@@ -128,6 +128,15 @@ def test_conv1x1_fwd_prologue_three_stage_kernel(hip, M, N, K, act, bits, monkey
   assert torch.equal(partial[:, 2].min(0).values, y.min(0).values)
   assert torch.equal(partial[:, 3].max(0).values, y.max(0).values)
   assert torch.equal(Y, out['2'][0]) and torch.equal(Y, out['3'][0]), 'the three prologue kernels differ'
+  # race screen for the cross-tile prefetch of the three-stage kernel (the next tile's first stage lands in ring buffer 2 while
+  # the epilogue of this one runs; workgroups walk up to 4 tiles at the larger sizes): repeated launches must agree to the bit
+  monkeypatch.setenv('PF_IGEMM_PRO3', '1')
+  monkeypatch.setenv('PF_IGEMM_PROW', '0')
+  for _ in range(4):
+    Y2 = torch.full((M, N), float('nan'), device='cuda', dtype=torch.bfloat16)
+    p2 = torch.full_like(out['3'][1], float('nan'))
+    hip.conv1x1_fwd(X, W, Y2, M, N, K, R=R, scale_shift=ss, act=act, slot=sl, bits=bits or 8, partial=p2)
+    assert torch.equal(Y2, out['3'][0]) and torch.equal(p2, out['3'][1])
   for mode in ('3', '2'):                                      # and so do their statistics (different partial layouts, same sums)
     torch.testing.assert_close(out[mode][1][:, 0].sum(0), partial[:, 0].sum(0), rtol=1e-5, atol=1e-3)
     assert torch.equal(out[mode][1][:, 2].min(0).values, partial[:, 2].min(0).values)

@@ -154,5 +154,29 @@ c19)
 import json
 d = json.loads([l for l in open('gpurun_out/r03_bench_final.json') if l.startswith('{')][0]); print(d['roofline'])"
   ;;
+c20)
+  # backward-filter: workgroups per launch (pixel splits -> slab traffic vs parallelism), kernel + reduction per layer
+  timeout 600 python tools/gpu/wrw_target_bench.py 2>&1 | tee gpurun_out/r03_wrw_target_bench.txt | cut -c1-200
+  ;;
+c21)
+  # backward-filter split targets below one workgroup per CU, numerics with the new defaults, step A/B
+  TARGETS=128,192,256,320,384 timeout 600 python tools/gpu/wrw_target_bench.py 2>&1 | tee gpurun_out/r03_wrw_target_bench_low.txt | cut -c1-200
+  timeout 900 python -m pytest tests/test_conv_gpu.py tests/test_igemm_gpu.py -m gpu -q --tb=short -k "wrw" 2>&1 | tail -4 | cut -c1-300
+  run_bench c2_wrwtarget_new --steps 15 --warmup 5 --no_cpu_baseline
+  PF_WRW2_TARGET=512 run_bench c2_wrwtarget_512 --steps 15 --warmup 5 --no_cpu_baseline
+  ;;
+c22)
+  # igemm: 1x1 fast path of the tile setup + cross-tile prefetch of the three-stage kernels: numerics, race screen, per-layer, step
+  timeout 1500 python -m pytest tests/test_conv_gpu.py tests/test_igemm_gpu.py -m gpu -q --tb=short -x 2>&1 | tail -8 | cut -c1-300
+  timeout 400 python tools/gpu/fwd1x1_layers.py 2>&1 | tee gpurun_out/r03_fwd1x1_layers_xpre.txt | cut -c1-220
+  run_bench c2_xpre --steps 15 --warmup 5 --no_cpu_baseline
+  ;;
+c23)
+  # phase stagger of the persistent workgroups of k_igemm: the roofline region layer by layer
+  for st in 0 3000 6000 12000; do
+    echo "== PF_IGEMM_STAGGER=$st"
+    PF_IGEMM_STAGGER=$st timeout 300 python tools/gpu/fwd1x1_layers.py 2>&1 | grep -v amdgpu.ids | awk 'NR==1 || /s2 conv1 |s3 conv|s4 conv|proj|per step/' | cut -c1-150
+  done | tee gpurun_out/r03_stagger.txt
+  ;;
 *) echo "unknown payload $1"; exit 2;;
 esac
