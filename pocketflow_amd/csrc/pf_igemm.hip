@@ -67,6 +67,15 @@ struct IgArgs {
 #define PF_IG_ABLATE 0
 #endif
 
+// -DPF_IG_TIMING (tools/gpu/igemm_timeline.py only, never in libpocketflow_hip.so): wavefront 0 of the middle workgroup keeps
+// s_memtime stamps of its THIRD tile in scalar registers and writes them to `a.zero` when the tile is done (stores inside the tile
+// would ride on vmcnt and falsify the counted waits).
+#ifdef PF_IG_TIMING
+#define PF_IG_STAMP(k) do { if (tm_tile == 2) tmk[k] = (uint32_t)__builtin_readcyclecounter(); } while (0)
+#else
+#define PF_IG_STAMP(k) do { } while (0)
+#endif
+
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // MODE 0: plain (+ residual / statistics), 1: backward-data with BN-backward sums, 2: producer's BN + act + fake-quant
@@ -236,8 +245,18 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
     if (++s_cc == cch) { s_cc = 0; ++s_tap; if (++s_s == a.tw) { s_s = 0; ++s_r; } }
   };
   bool pre = false;                                                         // XPRE: stage 0 of this tile is already in flight
+#ifdef PF_IG_TIMING
+  uint32_t tmk[16];
+  int tm_tile = -1;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) tmk[k] = 0;
+#endif
   for (int tm = g; tm < a.tiles_m; tm += a.G) {
     const int m0 = tm * BM;
+#ifdef PF_IG_TIMING
+    ++tm_tile;
+#endif
+    PF_IG_STAMP(0);
     if (!pre) setup_tile(m0);
 
     f32x4 acc[NI][JM];
@@ -405,10 +424,13 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
         }
         ibuf = (ibuf + 1 == NS) ? 0 : ibuf + 1;
       }
+    PF_IG_STAMP(1);                                                         // prologue stages issued
     if (nk >= NS - 1) wait_vm<(NS - 2) * LPS>(); else wait_vm<0>();
+    PF_IG_STAMP(2);                                                         // first stage landed
     if (PRO3) { transform3(RB0, 0, 0, AS); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
     else if (PRO) { transform(RB0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
     __builtin_amdgcn_s_barrier();
+    PF_IG_STAMP(3);                                                         // first transform + barrier
     int cbuf = RB0;
     for (int ks = 0; ks < nk; ++ks) {
       const bool more = ks + NS - 1 < nk;
@@ -463,6 +485,10 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // own fragment reads / prologue writes are done
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+#ifdef PF_IG_TIMING
+      if (ks < 4) PF_IG_STAMP(4 + ks);                                      // k-steps 0..3
+      if (ks == nk - 1) PF_IG_STAMP(8);                                     // last k-step
+#endif
     }
     }
 
@@ -487,6 +513,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
         }
       }
     }
+    PF_IG_STAMP(9);                                                         // residual vectors arrived and added
     pre = false;
     if constexpr (XPRE) {
       // behind the residual add on purpose: the compiler waits for the residual registers with vmcnt(0) when a CONDITIONAL
@@ -526,8 +553,10 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
     };
     const bool etid = !WS || tid < TE;                                      // WS: the producers only keep the barriers company
     if (side != nullptr && etid) load_side(0);
+    PF_IG_STAMP(10);                                                        // next tile's first stage issued, C tile packed and written
     if constexpr (XPRE) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
     else __syncthreads();
+    PF_IG_STAMP(11);
 #pragma unroll
     for (int p0 = 0; p0 < NP; p0 += PG) {
 #pragma unroll
@@ -569,8 +598,18 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
       }
       if (side != nullptr && p0 + PG < NP && etid) load_side(p0 + PG);
     }
+    PF_IG_STAMP(12);                                                        // row passes: statistics, stores issued
     if constexpr (XPRE) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
     else __syncthreads();
+    PF_IG_STAMP(13);
+#ifdef PF_IG_TIMING
+    if (tm_tile == 2 && blockIdx.x == gridDim.x / 2 && tid == 0) {
+      uint32_t* out = reinterpret_cast<uint32_t*>(const_cast<bf16_t*>(a.zero));
+#pragma unroll
+      for (int k = 0; k < 14; ++k) out[k] = tmk[k];
+      out[14] = (uint32_t)__builtin_readcyclecounter();
+    }
+#endif
     if constexpr (WS) {
       // statistics of THIS tile -> partial[g][4][N] at once (first tile of the workgroup: store, later tiles: combine, in
       // tile order: deterministic): the 32 accumulator registers are dead while the next tile's main loop runs (the
@@ -804,6 +843,9 @@ int pf_igemm_conv1x1(const void* X, const void* W, void* Y, const void* R, float
   if ((K % 64) || rows_in * K >= ((int64_t)1 << 30) || (int64_t)N * K >= ((int64_t)1 << 30)) return -1;
   IgArgs a;
   a.X = (const bf16_t*)X; a.W = (const bf16_t*)W; a.Y = (bf16_t*)Y; a.zero = (const bf16_t*)X;
+#ifdef PF_IG_TIMING
+  a.zero = (const bf16_t*)(uintptr_t)strtoull(getenv("PF_IG_TIMING_PTR"), nullptr, 0);
+#endif
   a.R = (const bf16_t*)R; a.partial = partial; a.bx = (const bf16_t*)bn_x; a.bss = bss; a.bmi = bmi;
   a.b_lo = b_lo; a.b_hi = b_hi;
   a.ss = scale_shift; a.slot = slot; a.kq = kq; a.act_lo = act_lo; a.act_hi = act_hi;

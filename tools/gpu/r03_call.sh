@@ -178,5 +178,9 @@ c23)
     PF_IGEMM_STAGGER=$st timeout 300 python tools/gpu/fwd1x1_layers.py 2>&1 | grep -v amdgpu.ids | awk 'NR==1 || /s2 conv1 |s3 conv|s4 conv|proj|per step/' | cut -c1-150
   done | tee gpurun_out/r03_stagger.txt
   ;;
+c24)
+  # where a tile of the three-stage prologue kernel spends its time
+  timeout 300 python tools/gpu/igemm_timeline.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r03_igemm_timeline.txt | cut -c1-400
+  ;;
 *) echo "unknown payload $1"; exit 2;;
 esac
