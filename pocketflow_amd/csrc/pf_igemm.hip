@@ -445,6 +445,8 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
       cbuf = (cbuf + 1 == NS) ? 0 : cbuf + 1;
       const bool tnext = PRO3 && (ks + 1 < nk);                             // PRO3: step ks+1 is transformed beside the MFMAs of ks
       if (PRO3) {                                                           // own part of stage ks+1 (issued one step ago) has landed
+        // (waiting for its INPUT slots only here and for the kernel slots -- 2/3 of the bytes, issued behind them -- at the end of
+        // the step was measured: no difference, profiles/r03_igemm_timeline_split.txt: the steps are bound by the fill RATE)
         if (more) wait_vm<LPS>(); else wait_vm<0>();
       }
       if (RPRE && has_r && ks == nk - 1) load_residual();                           // no LDS-DMA is issued after this point

@@ -182,5 +182,13 @@ c24)
   # where a tile of the three-stage prologue kernel spends its time
   timeout 300 python tools/gpu/igemm_timeline.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r03_igemm_timeline.txt | cut -c1-400
   ;;
+c25)
+  # three-stage prologue kernel: the input part of a stage is waited for a step earlier than its kernel part -- numerics incl. the
+  # race screen, timeline, the region layer by layer, step
+  timeout 1500 python -m pytest tests/test_conv_gpu.py -m gpu -q --tb=short -x -k "three_stage or prologue or stream" 2>&1 | tail -5 | cut -c1-300
+  timeout 300 python tools/gpu/igemm_timeline.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r03_igemm_timeline_split.txt | cut -c1-400
+  timeout 400 python tools/gpu/fwd1x1_layers.py 2>&1 | tee gpurun_out/r03_fwd1x1_layers_split.txt | cut -c1-220
+  run_bench c2_splitwait --steps 15 --warmup 5 --no_cpu_baseline
+  ;;
 *) echo "unknown payload $1"; exit 2;;
 esac
