@@ -189,7 +189,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
 #pragma unroll
       for (int j = 0; j < JM; ++j) {
         uint4 u = v[j * 2 + kk];
-        if (PRO) u = pro_apply(pro, u);
+        if (PRO) u = (NW == 128) ? pro_apply_scalar(pro, u) : pro_apply(pro, u);
         xf[j] = *reinterpret_cast<const bf16x8*>(&u);
       }
       const int c = (ckc * 8 + kk * 4 + q) ^ wswz;

@@ -190,5 +190,11 @@ c25)
   timeout 400 python tools/gpu/fwd1x1_layers.py 2>&1 | tee gpurun_out/r03_fwd1x1_layers_split.txt | cut -c1-220
   run_bench c2_splitwait --steps 15 --warmup 5 --no_cpu_baseline
   ;;
+c26)
+  # prologue arithmetic on packed FMAs + uniform quant branch: numerics (incl. tie enumeration, wrw prologue), region per layer, step
+  timeout 1500 python -m pytest tests/test_conv_gpu.py tests/test_igemm_gpu.py -m gpu -q --tb=short -x 2>&1 | tail -5 | cut -c1-300
+  timeout 400 python tools/gpu/fwd1x1_layers.py 2>&1 | tee gpurun_out/r03_fwd1x1_layers_pk.txt | cut -c1-220
+  run_bench c2_pk --steps 15 --warmup 5 --no_cpu_baseline
+  ;;
 *) echo "unknown payload $1"; exit 2;;
 esac
