@@ -516,3 +516,25 @@ def test_seg_transpose_gives_the_backward_data_layout_of_every_kernel(dtype):
   st.sync_compute()
   assert not st.w_t_fresh
   assert torch.equal(st.transposed(vs[1]), vs[1].tensor.detach().permute(0, 2, 3, 1).flip(1, 2).permute(3, 1, 2, 0).contiguous())
+
+
+def test_launch_stream_is_torchs_current_stream(hip):
+  """hip._stream() (the raw getter) must follow torch's stream context exactly: the default stream, a side stream, and a stream
+  being captured into a graph (tools/gpu/_timing.py launches the kernels there)."""
+  assert hip._stream().value in (torch.cuda.current_stream().cuda_stream, None if torch.cuda.current_stream().cuda_stream == 0 else -1) \
+      or (hip._stream().value or 0) == torch.cuda.current_stream().cuda_stream
+  s = torch.cuda.Stream()
+  with torch.cuda.stream(s):
+    assert (hip._stream().value or 0) == s.cuda_stream
+  assert (hip._stream().value or 0) == torch.cuda.current_stream().cuda_stream
+  # a kernel launched on the side stream is ordered with that stream's work
+  x = torch.zeros(1 << 20, device='cuda')
+  slot = torch.empty(2, dtype=torch.int32, device='cuda')
+  s.wait_stream(torch.cuda.current_stream())
+  with torch.cuda.stream(s):
+    x.add_(3.0)
+    hip.minmax_slots_init(slot)
+    hip.minmax_tensor(x, slot)
+  s.synchronize()
+  ab = hip.minmax_decode(slot).cpu().numpy()
+  assert abs(float(ab[0, 1]) - 3.0) < 1e-6                       # beta = min = 3: the reduction saw the add

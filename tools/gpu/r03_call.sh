@@ -196,5 +196,16 @@ c26)
   timeout 400 python tools/gpu/fwd1x1_layers.py 2>&1 | tee gpurun_out/r03_fwd1x1_layers_pk.txt | cut -c1-220
   run_bench c2_pk --steps 15 --warmup 5 --no_cpu_baseline
   ;;
+c27)
+  # host side of the host-bound configurations
+  CFG=c1 timeout 400 python tools/gpu/host_overhead.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r03_host_overhead_c1.txt | cut -c1-170
+  ;;
+c28)
+  # raw stream getter: semantics, a kernel subset, the host-bound configurations and the default one
+  timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_depthwise_gpu.py -m gpu -q --tb=short 2>&1 | tail -4 | cut -c1-300
+  run_bench c1_rawstream --config c1 --steps 20 --warmup 5 --no_cpu_baseline
+  run_bench c3_rawstream --config c3 --steps 10 --warmup 4 --no_cpu_baseline
+  run_bench c2_rawstream --steps 15 --warmup 5 --no_cpu_baseline
+  ;;
 *) echo "unknown payload $1"; exit 2;;
 esac
