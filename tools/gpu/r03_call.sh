@@ -207,5 +207,19 @@ c28)
   run_bench c3_rawstream --config c3 --steps 10 --warmup 4 --no_cpu_baseline
   run_bench c2_rawstream --steps 15 --warmup 5 --no_cpu_baseline
   ;;
+c29)
+  CFG=c3 timeout 400 python tools/gpu/host_overhead.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r03_host_overhead_c3.txt | cut -c1-170
+  ;;
+c30)
+  # MobileNet dropout mask through pinned memory (no host/GPU synchronisation per step): parity of the MobileNet steps, C3 bench
+  timeout 900 python -m pytest tests/test_parity_gpu.py tests/test_learner_gpu.py -m gpu -q --tb=short -k "mobilenet" 2>&1 | tail -4 | cut -c1-300
+  run_bench c3_pinned --config c3 --steps 10 --warmup 4 --no_cpu_baseline
+  CFG=c3 timeout 300 python tools/gpu/host_overhead.py 2>&1 | grep -v amdgpu.ids | sed -n 7,14p | cut -c1-170
+  ;;
+c31)
+  timeout 900 python -m pytest tests/test_learner_gpu.py tests/test_parity_gpu.py -m gpu -q --tb=short -k "mobilenet" 2>&1 | tail -25 | cut -c1-300
+  run_bench c3_ring --config c3 --steps 10 --warmup 4 --no_cpu_baseline
+  CFG=c3 timeout 300 python tools/gpu/host_overhead.py 2>&1 | grep -v amdgpu.ids | sed -n 7,14p | cut -c1-170
+  ;;
 *) echo "unknown payload $1"; exit 2;;
 esac
