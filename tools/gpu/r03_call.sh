@@ -221,5 +221,9 @@ c31)
   run_bench c3_ring --config c3 --steps 10 --warmup 4 --no_cpu_baseline
   CFG=c3 timeout 300 python tools/gpu/host_overhead.py 2>&1 | grep -v amdgpu.ids | sed -n 7,14p | cut -c1-170
   ;;
+c32)
+  timeout 900 python -m pytest tests/test_learner_gpu.py tests/test_parity_gpu.py -m gpu -q --tb=short -k "mobilenet" 2>&1 | tail -6 | cut -c1-300
+  run_bench c3_chunk --config c3 --steps 40 --warmup 4 --no_cpu_baseline
+  ;;
 *) echo "unknown payload $1"; exit 2;;
 esac
