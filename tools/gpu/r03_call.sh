@@ -225,5 +225,10 @@ c32)
   timeout 900 python -m pytest tests/test_learner_gpu.py tests/test_parity_gpu.py -m gpu -q --tb=short -k "mobilenet" 2>&1 | tail -6 | cut -c1-300
   run_bench c3_chunk --config c3 --steps 40 --warmup 4 --no_cpu_baseline
   ;;
+c33)
+  # learner-level GPU tests on the last commit (raw stream getter, chunked dropout masks)
+  rm -f gpurun_out/r03_parity_report_last.txt
+  PF_PARITY_REPORT=$GRAFT_REPO_ROOT/gpurun_out/r03_parity_report_last.txt timeout 1200 python -m pytest tests/test_learner_gpu.py tests/test_parity_gpu.py -m gpu -q --tb=short 2>&1 | tail -6 | cut -c1-300 | tee gpurun_out/r03_pytest_gpu_learners_last.log
+  ;;
 *) echo "unknown payload $1"; exit 2;;
 esac
