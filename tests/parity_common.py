@@ -464,14 +464,17 @@ def run_int_export_roundtrip(FLAGS, tmp_path, model='lenet', use_buckets=True, b
     lrn.graph.training = False
     before = lrn.run_eval()
     again = lrn.run_eval()
-    assert before == again, ('evaluation is not repeatable', before, again)
+    # float32 mode: the convolutions are MIOpen's, which are reproducible to ~1e-7 only and whose solver choice depends on the
+    # process history (tools/gpu/miopen_determinism.py) -- the losses agree to that level, the accuracies to one sample
+    close = lambda a, b: abs(a['loss'] - b['loss']) <= 1e-5 * max(1.0, abs(a['loss'])) and abs(a['acc_top1'] - b['acc_top1']) <= 1.0 / 16 + 1e-9
+    assert close(before, again), ('evaluation is not repeatable', before, again)
     c0 = lrn.graph.store.w_compute.clone()
     lrn.graph.store.load_numpy(dec)
     after = lrn.run_eval()
     # the network the evaluation multiplies with is the same, bit for bit; the reported loss carries loss_w_dcy * l2 of the
     # MASTER weights, which now are the quantised ones
     assert torch.equal(c0, lrn.graph.store.w_compute)
-    assert before['acc_top1'] == after['acc_top1'] and abs(before['loss'] - after['loss']) <= 5e-3 * abs(before['loss']), (before, after)
+    assert abs(before['acc_top1'] - after['acc_top1']) <= 1.0 / 16 + 1e-9 and abs(before['loss'] - after['loss']) <= 5e-3 * abs(before['loss']), (before, after)
     return summ
   finally:
     for k, v in old.items():
