@@ -658,9 +658,12 @@ def test_channel_pruned_auto_mode_on_cpu(cpu_learners, monkeypatch, caplog):
     FLAGS.cp_prune_option, FLAGS.ddpg_seed, FLAGS.nb_iters_override = 'uniform', -1, 0
 
 
-def test_channel_pruned_resnet_uniform_on_cpu(cpu_learners, monkeypatch):
+@pytest.mark.parametrize('sampling,feature_bn', [('aligned', 'inference'), ('reference', 'train')])
+def test_channel_pruned_resnet_uniform_on_cpu(cpu_learners, monkeypatch, sampling, feature_bn):
   """Residual network: convolutions fed by a residual sum keep their producer untouched (not W1-prunable) and the last
-  convolution of a block is re-fitted against Y + residual_branch_diff (reference channel_pruner.py:579-586, 611-614)."""
+  convolution of a block is re-fitted against Y + residual_branch_diff (reference channel_pruner.py:579-586, 611-614).
+  Second variant: the reference's own sampling (points per tensor name, projection shortcuts corrected too, batch-statistics
+  BN) through the WHOLE prune + fine-tune run."""
   FLAGS, fake, tmp = cpu_learners
   import pocketflow_amd.learners.channel_pruning.learner as CP
   from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
@@ -673,6 +676,8 @@ def test_channel_pruned_resnet_uniform_on_cpu(cpu_learners, monkeypatch):
   FLAGS.cp_best_path = str(tmp / 'models' / 'best_model.ckpt')
   FLAGS.cp_original_path = str(tmp / 'models' / 'original_model.ckpt')
   FLAGS.nb_iters_override, FLAGS.summ_step, FLAGS.synthetic_pool = 2, 2, 4
+  old_modes = (FLAGS.cp_sampling, FLAGS.cp_feature_bn)
+  FLAGS.cp_sampling, FLAGS.cp_feature_bn = sampling, feature_bn
   try:
     mh = ModelHelper()
     create_synthetic_checkpoint(mh)
@@ -683,6 +688,7 @@ def test_channel_pruned_resnet_uniform_on_cpu(cpu_learners, monkeypatch):
     names = [c.op.name for c in pr.thisconvs]
     assert len(names) == 10                                      # stem + 3 x (projection, conv1, conv2)
     assert len(pr.last_in_resblock) == 3 and len(pr.feats_add) == 3
+    assert len(pr.add_owner) == 6                                # conv2 AND the projection of every block feed its sum
     prunable = [pr.is_W1_prunable(c) for c in pr.thisconvs]
     # stem; block 1: projection + conv1 read BN(stem) (producer = stem), conv2 reads conv1; blocks 2, 3: fed by a sum
     assert prunable == [False, True, True, True, False, False, True, False, False, True]
@@ -693,6 +699,7 @@ def test_channel_pruned_resnet_uniform_on_cpu(cpu_learners, monkeypatch):
     assert 0.2 < pr.preserve_ratio < 0.8
   finally:
     FLAGS.nb_iters_override = 0
+    FLAGS.cp_sampling, FLAGS.cp_feature_bn = old_modes
 
 
 def test_proximal_shrink_against_numpy():
