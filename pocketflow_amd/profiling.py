@@ -5,7 +5,6 @@ kernels are launched on) when that name is enabled; otherwise it costs one dict 
 """
 from __future__ import annotations
 
-from contextlib import contextmanager
 from typing import Dict, List, Tuple
 
 import torch
@@ -26,18 +25,43 @@ def reset() -> None:
     _enabled[k] = []
 
 
-@contextmanager
+class _Noop(object):
+  """What `region` returns for a name that is not enabled: entering and leaving costs two trivial calls (the generator-based
+  context manager this replaces cost ~1.2 us per launch site, a few hundred sites per step)."""
+  __slots__ = ()
+
+  def __enter__(self):
+    return None
+
+  def __exit__(self, exc_type, exc, tb):
+    return False
+
+
+class _Timed(object):
+  __slots__ = ('rec', 'work', 'a')
+
+  def __init__(self, rec, work):
+    self.rec, self.work, self.a = rec, work, None
+
+  def __enter__(self):
+    self.a = torch.cuda.Event(enable_timing=True)
+    self.a.record()
+    return None
+
+  def __exit__(self, exc_type, exc, tb):
+    if exc_type is None:
+      b = torch.cuda.Event(enable_timing=True)
+      b.record()
+      self.rec.append((self.a, b, self.work))
+    return False
+
+
+_NOOP = _Noop()
+
+
 def region(name: str, work: float = 0.0):
   rec = _enabled.get(name)
-  if rec is None:
-    yield
-    return
-  a = torch.cuda.Event(enable_timing=True)
-  b = torch.cuda.Event(enable_timing=True)
-  a.record()
-  yield
-  b.record()
-  rec.append((a, b, work))
+  return _NOOP if rec is None else _Timed(rec, work)
 
 
 def summary(name: str):

@@ -64,3 +64,49 @@ def test_pmc_table_reads_raw_and_its_own_output(tmp_path):
   r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'pmc_table.py'), str(bad)], capture_output=True,
                      text=True)
   assert r.returncode != 0 and 'Kernel_Name' in r.stderr
+
+
+def test_profiling_regions_record_event_pairs_and_cost_nothing_when_disabled(monkeypatch):
+  """pocketflow_amd/profiling.py with a stand-in for torch.cuda.Event: an enabled region records (start, stop, work) around its
+  body -- not when the body raises --, `summary` adds up, and a region that is not enabled is the shared no-op object."""
+  import torch
+  import pocketflow_amd.profiling as PR
+
+  clock = [0.0]
+
+  class FakeEvent(object):
+    def __init__(self, enable_timing=False):
+      assert enable_timing
+      self.t = None
+
+    def record(self):
+      clock[0] += 1.5
+      self.t = clock[0]
+
+    def elapsed_time(self, other):
+      return other.t - self.t
+
+  monkeypatch.setattr(torch.cuda, 'Event', FakeEvent)
+  PR.disable_all()
+  try:
+    assert PR.region('conv1x1_fwd', 10.0) is PR.region('anything')          # disabled: one shared object, no allocation
+    with PR.region('conv1x1_fwd', 10.0):
+      pass
+    assert PR.summary('conv1x1_fwd') == (0, 0, 0)
+    PR.enable('conv1x1_fwd')
+    for w in (10.0, 20.0):
+      with PR.region('conv1x1_fwd', w):
+        clock[0] += 100.0                                                    # the "kernel"
+    with PR.region('bn_stats'):                                              # another name stays disabled
+      pass
+    try:
+      with PR.region('conv1x1_fwd', 5.0):
+        raise ValueError('launch failed')
+    except ValueError:
+      pass
+    n, ms, work = PR.summary('conv1x1_fwd')
+    assert n == 2 and abs(ms - 2 * 101.5) < 1e-9 and work == 30.0
+    PR.reset()
+    assert PR.summary('conv1x1_fwd') == (0, 0, 0)
+  finally:
+    PR.disable_all()
