@@ -366,8 +366,9 @@ def test_uq_resnet50_float32_gradients_match_oracle_from_a_conditioned_state(tmp
   # worst variable of 153 (a BN offset with a small gradient): 1.67e-3 relative L2 when the whole GPU suite runs, 8.2e-3 (cosine
   # 0.99997) when only the learner-level files do, with identical losses on both sides -- the float32 convolutions of this mode are
   # MIOpen's and which solver it picks depends on what the process ran before (tools/gpu/miopen_determinism.py); the whole gradient
-  # agrees to cosine 1.000000 either way
-  _check_gradients(learner, ora, pool[0], 'ResNet-50 UQ w8/a32 + dst @64 B=16, float32, conditioned state', tol=2e-2, min_cos=0.9999,
+  # agrees to cosine 1.000000 either way.  The per-variable cosine bar is the one that corresponds to the relative bar
+  # (1 - tol^2 / 2 = 0.9998), not a tighter one in disguise
+  _check_gradients(learner, ora, pool[0], 'ResNet-50 UQ w8/a32 + dst @64 B=16, float32, conditioned state', tol=2e-2, min_cos=0.9998,
                    min_whole_cos=0.999999)
 
 
