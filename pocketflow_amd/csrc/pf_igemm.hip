@@ -58,14 +58,19 @@ struct IgArgs {
   int H, Wd, Ho, Wo, stride, pad_h, pad_w;
   int tiles_m, tiles_n, G;
   int stagger;          // clocks between the start phases of the workgroups (0: all start together), see k_igemm
+  int stagger_mode;     // 0: four phases over the CUs, (blockIdx / 8) % 4;  1: the second half of the grid starts late
 };
 
 // Ablation builds for tools/gpu/igemm_ablate.py ONLY (never in libpocketflow_hip.so): -DPF_IG_ABLATE=1 drops the MFMAs and
 // their fragment reads (what is left is the LDS-DMA fill + barriers), =2 drops the LDS-DMA (matrix work + fragment reads +
-// barriers), =3 drops both the LDS-DMA and the fragment reads (matrix work + barriers).  Results are garbage by design.
+// barriers), =3 drops both the LDS-DMA and the fragment reads (matrix work + barriers); =4 is 3 WITHOUT THE EPILOGUE (no C
+// staging, no statistics, no stores: the main loop's matrix work and barriers alone), =5 the complete main loop without the
+// epilogue (full - 5 = what the epilogue costs).  Results are garbage by design.
 #ifndef PF_IG_ABLATE
 #define PF_IG_ABLATE 0
 #endif
+#define PF_IG_NO_DMA (PF_IG_ABLATE == 2 || PF_IG_ABLATE == 3 || PF_IG_ABLATE == 4)
+#define PF_IG_FAKE_FRAGS (PF_IG_ABLATE == 3 || PF_IG_ABLATE == 4)
 
 // -DPF_IG_TIMING (tools/gpu/igemm_timeline.py only, never in libpocketflow_hip.so): wavefront 0 of the middle workgroup keeps
 // s_memtime stamps of its THIRD tile in scalar registers and writes them to `a.zero` when the tile is done (stores inside the tile
@@ -151,7 +156,11 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
   if (a.stagger > 0) {
     // Phase stagger: identical tiles keep the persistent workgroups of all CUs in the SAME phase (everybody streams its epilogue
     // through HBM at once, then everybody fills LDS, ...); workgroup phase p = (blockIdx / 8) % 4 starts p * stagger clocks late.
-    const int64_t t_end = (int64_t)__builtin_readcyclecounter() + (int64_t)((blockIdx.x >> 3) & 3) * a.stagger;
+    // Mode 1 (kernels with TWO workgroups per CU): the second half of the grid -- the workgroups that take the second slot of
+    // every CU when the dispatcher fills the chip breadth-first -- starts `stagger` clocks late, so that the epilogue of one
+    // workgroup of a CU (no matrix work) falls into the main loop of the other instead of both idling the matrix pipe together.
+    const int phase = (a.stagger_mode == 1) ? (int)(blockIdx.x >= gridDim.x / 2) : (int)((blockIdx.x >> 3) & 3);
+    const int64_t t_end = (int64_t)__builtin_readcyclecounter() + (int64_t)phase * a.stagger;
     while ((int64_t)__builtin_readcyclecounter() < t_end) __builtin_amdgcn_s_sleep(32);
   }
   float st_s[8], st_q[8], st_mn[8], st_mx[8];
@@ -229,7 +238,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
     unsigned char* As = smem + buf * STAGE;
     unsigned char* Bs = As + A_BYTES;
     const uint32_t tapoff = (uint32_t)(((s_r * a.Wd + s_s) * a.C + s_cc * 64) * 2);   // wave-uniform
-#if PF_IG_ABLATE < 2
+#if !PF_IG_NO_DMA
 #pragma unroll
     for (int i = 0; i < AS; ++i) {
       const uint32_t voff = ((pmask[i] >> s_tap) & 1u) ? (pbase[i] + tapoff) : OOB;
@@ -455,7 +464,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
         const int coff = (((kk * 4 + q) ^ (l15 & 7)) << 4);
         bf16x8 wf[NI], xf[JM];
 #if PF_IG_ABLATE != 1
-#if PF_IG_ABLATE == 3
+#if PF_IG_FAKE_FRAGS
 #pragma unroll
         for (int i = 0; i < NI; ++i) { uint4 u = make_uint4(lane, i, kk, 0x3f803f80u); asm volatile("" : "+v"(u.x)); wf[i] = *reinterpret_cast<const bf16x8*>(&u); }
 #pragma unroll
@@ -494,6 +503,17 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
     }
     }
 
+#if PF_IG_ABLATE >= 4
+    if (!WS) {                                                              // no epilogue: a store that never executes keeps the matrix work alive
+      if (a.M < 0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < JM; ++j) reinterpret_cast<uint32_t*>(a.Y)[(i * JM + j) * 64 + lane] = pack_bf16x2(acc[i][j][0] + acc[i][j][1], acc[i][j][2] + acc[i][j][3]);
+      }
+      continue;
+    }
+#endif
     // ---- epilogue of one [BM][BN] tile (C staging aliases the stage buffers: all reads of them are complete) ----
     if (!WS) {
     if (has_r) {
@@ -746,6 +766,9 @@ static int ig_launch_t(IgArgs& a, int slots, hipStream_t st) {
   {
     const char* e = getenv("PF_IGEMM_STAGGER");           // experiment: clocks between workgroup start phases (default 0)
     a.stagger = (e != nullptr) ? atoi(e) : 0;
+    e = getenv("PF_IGEMM_STAGGER_MODE");                  // 1: delay the second workgroup of every CU (two-per-CU kernels)
+    a.stagger_mode = (e != nullptr) ? atoi(e) : 0;
+    if (a.stagger_mode == 1 && slots != 512) a.stagger = 0;   // only meaningful with two resident workgroups per CU
   }
   // stage ring and (aliased on it) the C tile; the BWD vectors / the folded prologue constants sit behind whichever is larger
   constexpr size_t ring = NS * (size_t)(BM + BN) * 128, ctile = (size_t)BM * (BN + 8) * 2;

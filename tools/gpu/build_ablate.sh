@@ -6,9 +6,9 @@
 set -euo pipefail
 cd "$(dirname "$0")/../../pocketflow_amd/csrc"
 mkdir -p ../../tools/gpu/_build
-for n in 1 2 3; do
+for n in 1 2 3 4 5; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
-    -Wno-unused-function -DPF_IG_ABLATE=$n -shared pf_igemm.hip -o ../../tools/gpu/_build/libig_ablate$n.so -L. -l:libpocketflow_hip.so -Wl,-rpath,'$ORIGIN/../../../pocketflow_amd/csrc' &
+    -Wno-unused-function -Wno-unused-variable -DPF_IG_ABLATE=$n -shared pf_igemm.hip -o ../../tools/gpu/_build/libig_ablate$n.so -L. -l:libpocketflow_hip.so -Wl,-rpath,'$ORIGIN/../../../pocketflow_amd/csrc' &
 done
 wait
 for n in 1 2 4 6; do
