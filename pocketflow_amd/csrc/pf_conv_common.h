@@ -155,6 +155,28 @@ __device__ __forceinline__ void lds_read_b128x4(uint32_t p0, uint32_t p1, float4
   a = make_float4(ra[0], ra[1], ra[2], ra[3]); b = make_float4(rb[0], rb[1], rb[2], rb[3]);
   c = make_float4(rc[0], rc[1], rc[2], rc[3]); d = make_float4(rd[0], rd[1], rd[2], rd[3]);
 }
+// the four constant vectors of a prologue step AND one / two data vectors behind ONE wait (scheduling experiment PF_IG_SGB)
+__device__ __forceinline__ void lds_read_b128x4_1(uint32_t p0, uint32_t p1, uint32_t pv, float4& a, float4& b, float4& c, float4& d, uint4& v) {
+  f32x4v_t ra, rb, rc, rd;
+  u32x4_t rv;
+  asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %6 offset:16\n\t"
+               "ds_read_b128 %4, %7\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(ra), "=&v"(rb), "=&v"(rc), "=&v"(rd), "=&v"(rv) : "v"(p0), "v"(p1), "v"(pv) : "memory");
+  a = make_float4(ra[0], ra[1], ra[2], ra[3]); b = make_float4(rb[0], rb[1], rb[2], rb[3]);
+  c = make_float4(rc[0], rc[1], rc[2], rc[3]); d = make_float4(rd[0], rd[1], rd[2], rd[3]);
+  v = make_uint4(rv[0], rv[1], rv[2], rv[3]);
+}
+__device__ __forceinline__ void lds_read_b128x4_2(uint32_t p0, uint32_t p1, uint32_t pv0, uint32_t pv1, float4& a, float4& b, float4& c,
+                                                  float4& d, uint4& v0, uint4& v1) {
+  f32x4v_t ra, rb, rc, rd;
+  u32x4_t r0, r1;
+  asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %7\n\tds_read_b128 %3, %7 offset:16\n\t"
+               "ds_read_b128 %4, %8\n\tds_read_b128 %5, %9\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(ra), "=&v"(rb), "=&v"(rc), "=&v"(rd), "=&v"(r0), "=&v"(r1) : "v"(p0), "v"(p1), "v"(pv0), "v"(pv1) : "memory");
+  a = make_float4(ra[0], ra[1], ra[2], ra[3]); b = make_float4(rb[0], rb[1], rb[2], rb[3]);
+  c = make_float4(rc[0], rc[1], rc[2], rc[3]); d = make_float4(rd[0], rd[1], rd[2], rd[3]);
+  v0 = make_uint4(r0[0], r0[1], r0[2], r0[3]); v1 = make_uint4(r1[0], r1[1], r1[2], r1[3]);
+}
 __device__ __forceinline__ uint4 lds_read_b128(uint32_t p) {
   u32x4_t v;
   asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(p) : "memory");

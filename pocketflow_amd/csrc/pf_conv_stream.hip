@@ -206,6 +206,17 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
           for (int j = 0; j < JM; ++j)
             acc[ib + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[ib + i][j], 0, 0, 0);
       }
+#ifdef PF_ST_SGB
+      // Experiment (tools/gpu/build_ablate.sh -> libst_sgb.so): the batches as written -- WB fragment reads, then their MFMAs
+      // (with the prologue, the four reads of the folded constants come first).  Left alone, hipcc keeps two fragment registers
+      // and runs read -> lgkmcnt(1) -> ONE MFMA -> read -> ... : an exposed LDS round trip per MFMA (ISA, round 3).
+      if (PRO) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int ib = 0; ib < NI; ib += WB) {
+        __builtin_amdgcn_sched_group_barrier(0x100, WB, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, WB * JM, 0);
+      }
+#endif
     }
     const bool last = (ckc == KC - 1);
     const int s = cs;

@@ -321,6 +321,22 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
       // the compiler drain the LDS-DMA ring (vmcnt(0)) once per step
       const uint32_t pss = lds_addr(ssl + cc * 64 + schunk * 8);
       float4 s0, s1, h0, h1;
+#ifdef PF_IG_SGB
+      // scheduling experiment: the data vectors of the call travel with the constants -- one exposed LDS round trip instead of two
+      if (i1 - i0 == 1 || i1 - i0 == 2) {
+        const uint32_t pd = lds_addr(smem + buf * STAGE + srow * 128 + (lane & 7) * 16) + (uint32_t)(i0 * (TS / 8) * 128);
+        uint4 v0, v1 = make_uint4(0, 0, 0, 0);
+        if (i1 - i0 == 1) lds_read_b128x4_1(pss, pss + (uint32_t)a.C * 4u, pd, s0, s1, h0, h1, v0);
+        else lds_read_b128x4_2(pss, pss + (uint32_t)a.C * 4u, pd, pd + (TS / 8) * 128, s0, s1, h0, h1, v0, v1);
+        pro.sc[0] = s0.x; pro.sc[1] = s0.y; pro.sc[2] = s0.z; pro.sc[3] = s0.w;
+        pro.sc[4] = s1.x; pro.sc[5] = s1.y; pro.sc[6] = s1.z; pro.sc[7] = s1.w;
+        pro.sh[0] = h0.x; pro.sh[1] = h0.y; pro.sh[2] = h0.z; pro.sh[3] = h0.w;
+        pro.sh[4] = h1.x; pro.sh[5] = h1.y; pro.sh[6] = h1.z; pro.sh[7] = h1.w;
+        lds_write_b128(pd, pro_apply(pro, v0));
+        if (i1 - i0 == 2) lds_write_b128(pd + (TS / 8) * 128, pro_apply(pro, v1));
+        return;
+      }
+#endif
       lds_read_b128x4(pss, pss + (uint32_t)a.C * 4u, s0, s1, h0, h1);
       pro.sc[0] = s0.x; pro.sc[1] = s0.y; pro.sc[2] = s0.z; pro.sc[3] = s0.w;
       pro.sc[4] = s1.x; pro.sc[5] = s1.y; pro.sc[6] = s1.z; pro.sc[7] = s1.w;
@@ -483,6 +499,30 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
 #pragma unroll
           for (int j = 0; j < JM; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+#ifdef PF_IG_SGB
+        // Experiment (tools/gpu/build_ablate.sh -> libig_sgb.so): prescribe the interleave of the block.  Left alone, hipcc keeps ONE
+        // kernel-fragment register and runs read -> lgkmcnt(0) -> 4 MFMAs -> read -> ... (an exposed LDS round trip per four
+        // MFMAs).  With the in-LDS prologue pass between the two halves (asm statements: two scheduling regions) every half asks
+        // for its eight fragments first; without it the two halves are ONE region and the second half's fragments are requested
+        // a group of MFMAs ahead, into the registers the first half has finished with.
+        if constexpr (NI == 4 && JM == 4 && PRO3) {
+          __builtin_amdgcn_sched_group_barrier(0x100, NI + JM, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, NI * JM, 0);
+        }
+        if constexpr (NI == 4 && JM == 4 && !PRO3) {
+          if (kk == 1) {
+            __builtin_amdgcn_sched_group_barrier(0x100, NI + JM, 0);
+#pragma unroll
+            for (int i = 0; i < NI - 1; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, JM, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, JM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1 + JM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NI * JM, 0);
+          }
+        }
+#endif
 #else
         (void)coff; (void)wf; (void)xf;
 #endif

@@ -14,7 +14,8 @@ from ctypes import c_float, c_int, c_int64, c_void_p
 import numpy as np
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libpocketflow_hip.so')
+# PF_HIP_LIB: a complete variant build of the library (tools/gpu/build_variant.sh) for A/B runs in one GPU box; unset = the in-tree one
+_LIB_PATH = os.environ.get('PF_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libpocketflow_hip.so')
 
 PF_F32, PF_BF16 = 0, 1
 PF_ACT_NONE, PF_ACT_RELU, PF_ACT_RELU6 = 0, 1, 2

@@ -1,0 +1,19 @@
+#!/usr/bin/env bash
+# A COMPLETE variant of the kernel library with extra compiler flags, for A/B runs of the test suite and of bench.py in one box:
+#   bash tools/gpu/build_variant.sh sgb -DPF_IG_SGB -DPF_ST_SGB      ->  tools/gpu/_build/libpocketflow_hip_sgb.so
+#   PF_HIP_LIB=$PWD/tools/gpu/_build/libpocketflow_hip_sgb.so python bench.py --no_cpu_baseline
+# (pocketflow_amd/hip.py loads $PF_HIP_LIB instead of the in-tree library when it is set; tools only.)
+set -euo pipefail
+name=$1; shift
+cd "$(dirname "$0")/../../pocketflow_amd/csrc"
+out=../../tools/gpu/_build/variant_$name
+mkdir -p $out
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-function $*"
+OBJS=()
+for f in pf_api pf_quant pf_normalize pf_sparse pf_optim pf_loss pf_bn pf_conv pf_conv_stream pf_igemm pf_conv3x3 pf_wrw pf_pool pf_transpose pf_stem pf_image pf_depthwise; do
+  /opt/rocm/bin/hipcc $FLAGS -c "$f.hip" -o "$out/$f.o" &
+  OBJS+=("$out/$f.o")
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/gpu/_build/libpocketflow_hip_$name.so "${OBJS[@]}"
+echo "built tools/gpu/_build/libpocketflow_hip_$name.so"

@@ -1,23 +1,39 @@
-# First gpurun call of the next round (≈ 4 GPU-minutes): the baselines every kernel change of round 4 will be measured against,
-# taken in ONE box (the round-3 boxes differed by up to 7 % for the same code, so cross-box comparisons mean nothing):
-#   gpurun --timeout 900 -- 'bash tools/gpu/next_round_first_call.sh'
+# First gpurun call of the next round (≈ 10 GPU-minutes).  Everything is taken in ONE box (the round-3 boxes differed by up to 7 % for
+# the same code, so cross-box comparisons mean nothing):
+#   gpurun --timeout 1500 -- 'bash tools/gpu/next_round_first_call.sh'
+# Round 3 ended with three questions that only the GPU answers; the builds for them are ready:
+#   A. ISA: hipcc serialises the LDS fragment reads of the contraction loops -- read, lgkmcnt(0), 4 MFMAs, read, ...
+#      (k_igemm), read, lgkmcnt(1), ONE MFMA (k_conv1x1_stream) -- an exposed LDS round trip per group.  The variant library
+#      (-DPF_IG_SGB -DPF_ST_SGB: sched_group_barrier pipelines, same arithmetic in the same order) must be bit-identical; is it faster?
+#   B. What does the epilogue cost (ablation builds 4 / 5), and how far is the main loop's matrix work from the tile schedule's ideal?
+#   C. Two workgroups per CU run in lockstep (both in their epilogue at once): does starting the second one late help?
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-# 1. the step (default configuration) and the host-bound CIFAR-size configuration
-for c in c2 c1; do
-  timeout 400 python bench.py --config $c --steps 15 --warmup 5 --no_cpu_baseline > gpurun_out/r04_first_bench_$c.json 2> gpurun_out/r04_first_bench_$c.err || tail -3 gpurun_out/r04_first_bench_$c.err
-  python -c "
+bash tools/gpu/build_ablate.sh > /dev/null 2>&1
+bash tools/gpu/build_variant.sh sgb -DPF_IG_SGB -DPF_ST_SGB > /dev/null 2>&1
+V=$GRAFT_REPO_ROOT/tools/gpu/_build/libpocketflow_hip_sgb.so
+line() { python -c "
 import json, sys
 for ln in open(sys.argv[1]):
     if ln.startswith('{'):
-        d = json.loads(ln); print(sys.argv[2], round(d['value']), 'img/s', round(d['ms_per_step'], 2), 'ms/step | host submit', d.get('host_submit_ms_min_median_max'), '| roofline frac', d['roofline']['frac'])
-" gpurun_out/r04_first_bench_$c.json $c
+        d = json.loads(ln); print(sys.argv[2], round(d['value']), 'img/s', round(d['ms_per_step'], 2), 'ms/step | host submit', d.get('host_submit_ms_min_median_max'), '| roofline frac', d['roofline']['frac'], '| region ms per launch', d['roofline'].get('avg_launch_ms'))
+" $1 $2; }
+# 1. the step: product library, variant library, product again (drift check)
+for tag in product sgb product2; do
+  lib=""; [ $tag = sgb ] && lib=$V
+  PF_HIP_LIB=$lib timeout 400 python bench.py --steps 15 --warmup 5 --no_cpu_baseline > gpurun_out/r04_first_bench_$tag.json 2> gpurun_out/r04_first_bench_$tag.err || tail -3 gpurun_out/r04_first_bench_$tag.err
+  line gpurun_out/r04_first_bench_$tag.json $tag
 done
-# 2. the roofline region layer by layer and one tile of its slowest kernel phase by phase (the k-steps wait on the
-#    LDS-DMA fill rate) -- what the next kernel has to beat
+# 2. A: per layer, bit-identity asserted; then the convolution test files against the variant library
+timeout 400 python tools/gpu/igemm_sgb_bench.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04_first_igemm_sgb.txt | cut -c1-200
+PF_HIP_LIB=$V timeout 900 python -m pytest tests/test_conv_gpu.py tests/test_igemm_gpu.py -m gpu -q -x --tb=line 2>&1 | tail -4 | cut -c1-300 | tee gpurun_out/r04_first_pytest_sgb.log
+PF_HIP_LIB=$V timeout 400 python tools/gpu/fwd1x1_layers.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_first_fwd1x1_layers_sgb.txt
 timeout 400 python tools/gpu/fwd1x1_layers.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04_first_fwd1x1_layers.txt | cut -c1-200
-bash tools/gpu/build_ablate.sh > /dev/null 2>&1
-timeout 300 python tools/gpu/igemm_timeline.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04_first_igemm_timeline.txt | cut -c1-400
-# 3. backward-filter per layer (kernel + reduction)
+# 3. B: ablations incl. the no-epilogue builds and the tile schedule's ideal
+TILES=128x128 timeout 400 python tools/gpu/igemm_ablate.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04_first_igemm_ablation.txt | cut -c1-220
+# 4. C: second workgroup of every CU started late
+timeout 400 python tools/gpu/igemm_stagger.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04_first_igemm_stagger.txt | cut -c1-200
+# 5. the host-bound CIFAR-size configuration and backward-filter per layer (baselines)
+timeout 400 python bench.py --config c1 --steps 15 --warmup 5 --no_cpu_baseline > gpurun_out/r04_first_bench_c1.json 2> gpurun_out/r04_first_bench_c1.err; line gpurun_out/r04_first_bench_c1.json c1
 TARGETS=256,384 timeout 300 python tools/gpu/wrw_target_bench.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04_first_wrw.txt | cut -c1-200
