@@ -89,8 +89,8 @@ __global__ __launch_bounds__(BN_BIG) void k_bn_stats_fast(const T* __restrict__ 
       const float d = v[j] - piv[j];
       s[j] += d;
       ss[j] = fmaf(d, d, ss[j]);
-      mn[j] = fminf(mn[j], v[j]);
-      mx[j] = fmaxf(mx[j], v[j]);
+      mn[j] = pf_acc_min(mn[j], v[j]);
+      mx[j] = pf_acc_max(mx[j], v[j]);
     }
   }
   bn_wave_reduce8<0>(s, CG); bn_wave_reduce8<0>(ss, CG); bn_wave_reduce8<1>(mn, CG); bn_wave_reduce8<2>(mx, CG);

@@ -109,6 +109,19 @@ __device__ __forceinline__ void slot_alpha_beta(const uint32_t* slot, float& alp
 }
 
 // ---- activation ------------------------------------------------------------------------------
+// Running per-channel minimum / maximum of the statistics passes.  fminf / fmaxf compile to FIVE instructions per element here:
+// the kernels run in IEEE mode, where v_min / v_max quiet a signalling NaN instead of ignoring it, so hipcc canonicalises every
+// operand it cannot prove quiet (v_max x, x, x of the value -- unpacked with a shift -- and of BOTH running values, which are loop
+// phis).  -DPF_RAW_MINMAX (scheduling-experiment builds, tools/gpu/build_variant.sh) issues the bare instruction: identical for
+// every input except a SIGNALLING NaN (result NaN instead of the other operand); quiet NaNs are ignored either way.
+#ifdef PF_RAW_MINMAX
+__device__ __forceinline__ float pf_acc_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float pf_acc_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#else
+__device__ __forceinline__ float pf_acc_min(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ float pf_acc_max(float a, float b) { return fmaxf(a, b); }
+#endif
+
 template <int ACT> __device__ __forceinline__ float apply_act(float x) {
   if (ACT == PF_ACT_RELU) return fmaxf(x, 0.0f);
   if (ACT == PF_ACT_RELU6) return fminf(fmaxf(x, 0.0f), 6.0f);

@@ -256,8 +256,8 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a)
             for (int j = 0; j < 8; ++j) {
               st_s[j] += f[j];
               st_q[j] = fmaf(f[j], f[j], st_q[j]);
-              st_mn[j] = fminf(st_mn[j], f[j]);
-              st_mx[j] = fmaxf(st_mx[j], f[j]);
+              st_mn[j] = pf_acc_min(st_mn[j], f[j]);
+              st_mx[j] = pf_acc_max(st_mx[j], f[j]);
             }
           }
         }

@@ -187,6 +187,14 @@ __device__ __forceinline__ void lds_read_b128x2(uint32_t p0, uint32_t p1, uint4&
   asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(ra), "=&v"(rb) : "v"(p0), "v"(p1) : "memory");
   a = make_uint4(ra[0], ra[1], ra[2], ra[3]); b = make_uint4(rb[0], rb[1], rb[2], rb[3]);
 }
+// a read WITHOUT its wait, and the wait that makes a batch of them valid (the registers are tied to the wait statement, so no use
+// of them can be scheduled in front of it)
+__device__ __forceinline__ void lds_read_b128_nowait(uint32_t p, u32x4_t& v) {
+  asm volatile("ds_read_b128 %0, %1" : "=&v"(v) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void lds_wait_batch8(u32x4_t (&v)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
+}
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void lds_write_b64(uint32_t p, const uint2& v) {
   const u32x2_t r = {v.x, v.y};

@@ -242,11 +242,24 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
       }
     const bool more = (cs < NS);                                         // this wavefront has another strip
     if (has_r && more) issue_res(cs);                                    // next strip's residual travels under its main loop
+#ifdef PF_ST_SGB
+    constexpr int CB = (NW == 128) ? 1 : 4;                              // scheduling experiment: rows requested CB at a time
+    uint4 cv[CB];                                                        // (NW = 128 has no registers to spare: it spills as it is)
+#endif
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int rl = p * RPP + wrow;
       const int m = s * RS + rl, n = n0 + wvec * 8;
+#ifdef PF_ST_SGB
+      if (p % CB == 0) {
+#pragma unroll
+        for (int pb = 0; pb < CB; ++pb)
+          if (p + pb < NP) cv[pb] = *reinterpret_cast<const uint4*>(Cs + ((p + pb) * RPP + wrow) * CS_LD + wvec * 8);
+      }
+      uint4 c = cv[p % CB];
+#else
       uint4 c = *reinterpret_cast<const uint4*>(Cs + rl * CS_LD + wvec * 8);
+#endif
       const uint4 sv = rres[p];
       if (side != nullptr && more) issue_side(cs, p);                    // next strip's vector into the freed register
       if (m < a.M && n < a.N) {
@@ -271,8 +284,8 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
             for (int j = 0; j < 8; ++j) {
               st_s[j] += f[j];
               st_q[j] = fmaf(f[j], f[j], st_q[j]);
-              st_mn[j] = fminf(st_mn[j], f[j]);
-              st_mx[j] = fmaxf(st_mx[j], f[j]);
+              st_mn[j] = pf_acc_min(st_mn[j], f[j]);
+              st_mx[j] = pf_acc_max(st_mx[j], f[j]);
             }
           }
         }

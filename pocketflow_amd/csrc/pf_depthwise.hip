@@ -100,8 +100,8 @@ __global__ __launch_bounds__(DW_T) void k_dw_fwd(const DwArgs a) {
           const float f = dw_round<T>(acc[p][j]);                 // statistics see the stored values
           st_s[j] += f;
           st_q[j] = fmaf(f, f, st_q[j]);
-          st_mn[j] = fminf(st_mn[j], f);
-          st_mx[j] = fmaxf(st_mx[j], f);
+          st_mn[j] = pf_acc_min(st_mn[j], f);
+          st_mx[j] = pf_acc_max(st_mx[j], f);
         }
       }
     }

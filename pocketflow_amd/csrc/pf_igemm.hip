@@ -509,7 +509,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
           __builtin_amdgcn_sched_group_barrier(0x100, NI + JM, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, NI * JM, 0);
         }
-        if constexpr (NI == 4 && JM == 4 && !PRO3) {
+        if constexpr ((NI == 4 || NI == 2) && JM == 4 && !PRO3) {
           if (kk == 1) {
             __builtin_amdgcn_sched_group_barrier(0x100, NI + JM, 0);
 #pragma unroll
@@ -621,6 +621,19 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
     PF_IG_STAMP(11);
 #pragma unroll
     for (int p0 = 0; p0 < NP; p0 += PG) {
+#ifdef PF_IG_SGB
+      // scheduling experiment: all C-tile vectors of the group are requested before the first row is processed (as written below,
+      // every pass is its own basic block -- read, wait, statistics, store -- and exposes its LDS round trip)
+      u32x4_t cv[8];
+      if constexpr (XPRE && PG == 8) {
+#pragma unroll
+        for (int pp = 0; pp < PG; ++pp) lds_read_b128_nowait(lds_addr(Cs + (wrw + (p0 + pp) * RPP) * CS_LD + wvec * 8), cv[pp]);
+        lds_wait_batch8(cv);
+      } else {
+#pragma unroll
+        for (int pp = 0; pp < PG; ++pp) cv[pp] = *reinterpret_cast<const u32x4_t*>(Cs + (wrw + (p0 + pp) * RPP) * CS_LD + wvec * 8);
+      }
+#endif
 #pragma unroll
       for (int pp = 0; pp < PG; ++pp) {
         const int p = p0 + pp;
@@ -628,8 +641,12 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
         const int m = m0 + rl, n = n0 + wvec * 8;
         if (m < a.M && n < a.N && etid) {
           uint4 c;
+#ifdef PF_IG_SGB
+          c = make_uint4(cv[pp][0], cv[pp][1], cv[pp][2], cv[pp][3]);
+#else
           if constexpr (XPRE) c = lds_read_b128(lds_addr(Cs + rl * CS_LD + wvec * 8));
           else c = *reinterpret_cast<const uint4*>(Cs + rl * CS_LD + wvec * 8);
+#endif
           if (BWD) {
             float f[8], xv[8];
             unpack8(c, f);
@@ -650,8 +667,8 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
               for (int j = 0; j < 8; ++j) {
                 st_s[j] += f[j];
                 st_q[j] = fmaf(f[j], f[j], st_q[j]);
-                st_mn[j] = fminf(st_mn[j], f[j]);
-                st_mx[j] = fmaxf(st_mx[j], f[j]);
+                st_mn[j] = pf_acc_min(st_mn[j], f[j]);
+                st_mx[j] = pf_acc_max(st_mx[j], f[j]);
               }
             }
           }
