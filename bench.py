@@ -436,7 +436,10 @@ def main():
         'launch_probe': {'after_warmup': probe_warm, 'after_timed_region': probe_after, 'extra_untimed_steps': 2},
         'memory': {'after_warmup': mem_warm, 'after_timed_region': mem_after},
         'config': {'workload': cfg['workload'].format(**vars(args)), 'name': args.config,
-                   'global_batch': args.batch * world, 'parallelism': 'dp%d' % world},
+                   'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
+                   # opt-in experiment (learners/teacher_ahead.py): the teacher's forward over batch k+1 on a second stream
+                   # beside step k's backward; the roofline region then holds the student's launches only
+                   'teacher': 'next batch, side stream' if getattr(learner, '_teacher_ahead', None) is not None else 'in line'},
         'roofline': roofline, 'cpu_baseline': cpu_baseline, 'multi_gpu': multi_gpu}
     print(json.dumps(line))
   if world > 1:

@@ -1,0 +1,117 @@
+"""Teacher forward of the NEXT batch on a second HIP stream (opt-in: PF_TEACHER_AHEAD=1; round-4 experiment, off by default).
+
+The distillation teacher is frozen: its logits for a batch depend on nothing the fine-tune step changes
+(learners/distillation_helper.py:62-64 of the reference builds it under `tf.stop_gradient`).  The step therefore does not have to
+run teacher -> student -> backward in one queue: with this helper the learner issues, at the END of step k, the upload of batch k+1
+and the teacher's forward pass over it on a side stream, and step k+1 starts from those logits.  Same work per step, same values
+(the teacher is deterministic) -- but the teacher's launches execute while the main stream is still working through step k's
+backward pass.  Why that can pay on this design: every contraction kernel is a persistent launch whose workgroups own
+ceil(tiles / slots) tiles (1.53 -> 2, 3.06 -> 4 rounds on the 14x14 / 7x7 layers); in ONE queue the CUs that
+finished their last tile idle until the slowest workgroup is done, with a second queue the next kernel's workgroups take them.
+
+Stream discipline:
+* everything of batch k+1 (upload, layout / dtype conversion, teacher forward) is issued on the side stream and allocated from its
+  pool; the tensors the main stream will read (x, y, logits) are `record_stream`ed for it, so the caching allocator does not hand
+  their memory to a later side-stream allocation while main is still reading them;
+* main waits for ONE event recorded behind the teacher forward before it touches them;
+* the side stream never waits for main: the teacher's weights and scratch were written long before (first, in-line teacher
+  forward of step 0), the batch comes from the host.
+The roofline region of bench.py is suspended while the teacher is issued (its launches run beside backward kernels: their
+event-to-event durations are not a kernel's duration any more); the student's launches of the same kernels remain in it.
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+
+import torch
+
+from pocketflow_amd import profiling
+
+
+def enabled() -> bool:
+  return os.environ.get('PF_TEACHER_AHEAD', '0') not in ('', '0')
+
+
+class CudaStreams(object):
+  """The HIP side of the helper (torch.cuda is HIP on ROCm)."""
+
+  def __init__(self, device):
+    self.device = device
+    self.side = torch.cuda.Stream(device=device)
+
+  def on_side(self):
+    return torch.cuda.stream(self.side)
+
+  def record(self):
+    ev = torch.cuda.Event()
+    ev.record(self.side)
+    return ev
+
+  def main_waits(self, ev):
+    torch.cuda.current_stream(self.device).wait_event(ev)
+
+  def hand_to_main(self, t):
+    if t is not None and t.is_cuda:
+      t.record_stream(torch.cuda.current_stream(self.device))
+
+
+class InlineStreams(object):
+  """No second queue (CPU emulation of the kernels in tests/): the same control flow, executed in program order."""
+
+  def on_side(self):
+    return contextlib.nullcontext()
+
+  def record(self):
+    return None
+
+  def main_waits(self, ev):
+    pass
+
+  def hand_to_main(self, t):
+    pass
+
+
+class TeacherAhead(object):
+  def __init__(self, learner, streams):
+    self.learner, self.streams, self.pending = learner, streams, None
+    self.n_issued = self.n_taken = 0
+
+  def issue(self):
+    """Fetch batch k+1, upload it and run the teacher over it -- all on the side stream."""
+    lrn, st = self.learner, self.streams
+    images, labels = lrn.iter_train.get_next()
+    with st.on_side(), profiling.suspended():
+      x, y = lrn.to_device(images, labels)
+      logits = lrn.helper_dst.calc_logits(None, x)
+      ev = st.record()
+    for t in (x, y, logits):
+      st.hand_to_main(t)
+    self.pending = (x, y, logits, ev)
+    self.n_issued += 1
+
+  def take(self):
+    x, y, logits, ev = self.pending
+    self.pending = None
+    self.streams.main_waits(ev)
+    self.n_taken += 1
+    return x, y, logits
+
+  def drop(self):
+    """Forget the prefetched batch (the data iterator was reset: the next step starts from the iterator again)."""
+    if self.pending is not None:
+      self.streams.main_waits(self.pending[3])       # nothing of it may still be running when its memory is released
+      self.pending = None
+
+
+def make(learner):
+  """A TeacherAhead for `learner`, or None: opt-in, distillation only, and a HIP device (or PF_TEACHER_AHEAD=inline: the
+  in-order stand-in for the CPU tests)."""
+  if not enabled() or not getattr(learner, 'helper_dst', None):
+    return None
+  dev = learner.device
+  if os.environ.get('PF_TEACHER_AHEAD') == 'inline':
+    return TeacherAhead(learner, InlineStreams())
+  if torch.device(dev).type != 'cuda':
+    return None
+  return TeacherAhead(learner, CudaStreams(dev))

@@ -95,12 +95,18 @@ class UniformQuantLearner(AbstractLearner):
   def train_step(self):
     """ops['train'] of the reference, one iteration."""
     g = self.graph
-    images, labels = self.iter_train.get_next()
-    x, y = self.to_device(images, labels)
+    ahead = self.__teacher_ahead()
+    if ahead is not None and ahead.pending is not None:
+      x, y, logits_dst = ahead.take()               # batch + teacher logits issued at the end of the previous step
+    else:
+      images, labels = self.iter_train.get_next()
+      x, y = self.to_device(images, labels)
+      logits_dst = None
     g.begin_step()
     self.uni_quant.quantize_weights()
     with g.as_default():
-      logits_dst = self.helper_dst.calc_logits(None, x) if FLAGS.enbl_dst else None
+      if FLAGS.enbl_dst and logits_dst is None:
+        logits_dst = self.helper_dst.calc_logits(None, x)
       logits = self.forward_train(x)
       model_loss, metrics = self.calc_loss(y, logits, self.trainable_vars)
       loss = model_loss
@@ -114,7 +120,16 @@ class UniformQuantLearner(AbstractLearner):
     self.optimizer.compute_gradients()
     self.optimizer.apply_gradients(lr)
     self.ft_step += 1
+    if ahead is not None:
+      ahead.issue()                                 # next batch's teacher forward, beside what the main stream still has queued
     return {'lr': lr, 'dst_loss': dst_loss, 'model_loss': model_loss, 'loss': loss, 'metrics': metrics}
+
+  def __teacher_ahead(self):
+    """learners/teacher_ahead.py (opt-in, PF_TEACHER_AHEAD=1): None unless enabled, distilling and on a HIP device."""
+    if not hasattr(self, '_teacher_ahead'):
+      from pocketflow_amd.learners import teacher_ahead
+      self._teacher_ahead = teacher_ahead.make(self) if FLAGS.enbl_dst else None
+    return self._teacher_ahead
 
   # -- callables handed to the bit optimiser (the reference passes TF ops + sessions) --------------------
   def __feed(self, w_bits, a_bits):

@@ -57,11 +57,27 @@ class _Timed(object):
 
 
 _NOOP = _Noop()
+_suspended = 0
+
+
+class suspended(object):
+  """`with suspended():` -- regions entered inside record nothing (launches issued on a side stream beside other work: an
+  event-to-event interval there is not a kernel's duration, learners/teacher_ahead.py)."""
+
+  def __enter__(self):
+    global _suspended
+    _suspended += 1
+    return None
+
+  def __exit__(self, exc_type, exc, tb):
+    global _suspended
+    _suspended -= 1
+    return False
 
 
 def region(name: str, work: float = 0.0):
   rec = _enabled.get(name)
-  return _NOOP if rec is None else _Timed(rec, work)
+  return _NOOP if (rec is None or _suspended) else _Timed(rec, work)
 
 
 def summary(name: str):

@@ -99,6 +99,12 @@ def test_profiling_regions_record_event_pairs_and_cost_nothing_when_disabled(mon
         clock[0] += 100.0                                                    # the "kernel"
     with PR.region('bn_stats'):                                              # another name stays disabled
       pass
+    with PR.suspended():                                                     # launches issued beside other work: not recorded
+      assert PR.region('conv1x1_fwd', 7.0) is PR.region('anything')
+      with PR.suspended():
+        pass
+      assert PR.region('conv1x1_fwd', 7.0) is PR.region('anything')
+    assert PR.region('conv1x1_fwd', 7.0) is not PR.region('anything')
     try:
       with PR.region('conv1x1_fwd', 5.0):
         raise ValueError('launch failed')

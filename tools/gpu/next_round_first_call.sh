@@ -1,4 +1,4 @@
-# First gpurun call of the next round (≈ 10 GPU-minutes).  Everything is taken in ONE box (the round-3 boxes differed by up to 7 % for
+# First gpurun call of the next round (≈ 14 GPU-minutes).  Everything is taken in ONE box (the round-3 boxes differed by up to 7 % for
 # the same code, so cross-box comparisons mean nothing):
 #   gpurun --timeout 1500 -- 'bash tools/gpu/next_round_first_call.sh'
 # Round 3 ended with three questions that only the GPU answers; the builds for them are ready:
@@ -7,6 +7,8 @@
 #      (-DPF_IG_SGB -DPF_ST_SGB -DPF_RAW_MINMAX: sched_group_barrier pipelines, batched epilogue reads, bare v_min / v_max in the statistics; same arithmetic in the same order) must be bit-identical; is it faster?
 #   B. What does the epilogue cost (ablation builds 4 / 5), and how far is the main loop's matrix work from the tile schedule's ideal?
 #   C. Two workgroups per CU run in lockstep (both in their epilogue at once): does starting the second one late help?
+#   D. Every persistent launch ends with idle CUs (ceil(tiles / slots) rounds): does a second queue -- the frozen teacher's forward
+#      pass over the NEXT batch -- fill them?  (PF_TEACHER_AHEAD=1)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -25,6 +27,13 @@ for tag in product sgb product2; do
   PF_HIP_LIB=$lib timeout 400 python bench.py --steps 15 --warmup 5 --no_cpu_baseline > gpurun_out/r04_first_bench_$tag.json 2> gpurun_out/r04_first_bench_$tag.err || tail -3 gpurun_out/r04_first_bench_$tag.err
   line gpurun_out/r04_first_bench_$tag.json $tag
 done
+# 1b. D: the teacher's forward over batch k+1 on a second stream beside step k's backward (learners/teacher_ahead.py, opt-in): the
+#     step with it, with it AND the variant library, and the distillation parity tests with it (a stream race would show there)
+PF_TEACHER_AHEAD=1 timeout 400 python bench.py --steps 15 --warmup 5 --no_cpu_baseline > gpurun_out/r04_first_bench_ahead.json 2> gpurun_out/r04_first_bench_ahead.err || tail -3 gpurun_out/r04_first_bench_ahead.err
+line gpurun_out/r04_first_bench_ahead.json teacher-ahead
+PF_TEACHER_AHEAD=1 PF_HIP_LIB=$V timeout 400 python bench.py --steps 15 --warmup 5 --no_cpu_baseline > gpurun_out/r04_first_bench_ahead_sgb.json 2> gpurun_out/r04_first_bench_ahead_sgb.err || tail -3 gpurun_out/r04_first_bench_ahead_sgb.err
+line gpurun_out/r04_first_bench_ahead_sgb.json teacher-ahead+sgb
+PF_TEACHER_AHEAD=1 timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -q -x --tb=line -k "distillation or bf16_fused or conditioned" 2>&1 | tail -4 | cut -c1-300 | tee gpurun_out/r04_first_pytest_ahead.log
 # 2. A: per layer, bit-identity asserted; then the convolution test files against the variant library
 timeout 400 python tools/gpu/igemm_sgb_bench.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04_first_igemm_sgb.txt | cut -c1-200
 PF_HIP_LIB=$V timeout 900 python -m pytest tests/test_conv_gpu.py tests/test_igemm_gpu.py -m gpu -q -x --tb=line 2>&1 | tail -4 | cut -c1-300 | tee gpurun_out/r04_first_pytest_sgb.log
