@@ -106,3 +106,18 @@ def test_every_reference_flag_on_the_path_exists_with_the_same_default():
         assert got is not None and abs(float(got) - float(want)) <= 1e-12 * max(1.0, abs(float(want))), (name, got, want)
       else:
         assert got == want, (name, got, want)
+
+
+def test_gpu_tools_parse_and_name_files_that_exist():
+  """tools/gpu/ is what a GPU session runs first (tools/gpu/next_round_first_call.sh): a syntax error or a renamed script there costs
+  GPU minutes.  Every Python tool must parse, every shell script must pass `bash -n`, and every `tools/...` path a script names must
+  exist."""
+  import subprocess
+  tools = os.path.join(ROOT, 'tools')
+  for path in glob.glob(os.path.join(tools, '**', '*.py'), recursive=True):
+    ast.parse(open(path).read(), filename=path)
+  for path in glob.glob(os.path.join(tools, 'gpu', '*.sh')):
+    r = subprocess.run(['bash', '-n', path], capture_output=True, text=True)
+    assert r.returncode == 0, (path, r.stderr)
+    for ref in re.findall(r'\btools/[\w/]+\.(?:py|sh)\b', open(path).read()):
+      assert os.path.exists(os.path.join(ROOT, ref)), (path, ref)
