@@ -472,9 +472,20 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
       if (PRO3) {                                                           // own part of stage ks+1 (issued one step ago) has landed
         // (waiting for its INPUT slots only here and for the kernel slots -- 2/3 of the bytes, issued behind them -- at the end of
         // the step was measured: no difference, profiles/r03_igemm_timeline_split.txt: the steps are bound by the fill RATE)
+#ifdef PF_IG_RES_EARLY
+        if (more) wait_vm<LPS>(); else if (ks + 1 < nk) wait_vm<0>();        // last step: no stage to wait for -- and the residual vectors may still travel
+#else
         if (more) wait_vm<LPS>(); else wait_vm<0>();
+#endif
       }
+#ifdef PF_IG_RES_EARLY
+      // experiment: one k-step earlier (its 16 loads per lane sit in front of a step's MFMAs wherever they are issued; here they
+      // have two steps to arrive and the LAST step -- the longest of the timeline -- starts its MFMAs at once)
+      // (three-stage prologue kernels only: no stage is issued from step nk - 2 on, so no wait of the ring covers these loads)
+      if (RPRE && has_r && ks == ((PRO3 && nk >= 2) ? nk - 2 : nk - 1)) load_residual();
+#else
       if (RPRE && has_r && ks == nk - 1) load_residual();                           // no LDS-DMA is issued after this point
+#endif
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int coff = (((kk * 4 + q) ^ (l15 & 7)) << 4);

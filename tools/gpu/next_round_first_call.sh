@@ -1,4 +1,4 @@
-# First gpurun call of the next round (≈ 14 GPU-minutes).  Everything is taken in ONE box (the round-3 boxes differed by up to 7 % for
+# First gpurun call of the next round (≈ 18 GPU-minutes).  Everything is taken in ONE box (the round-3 boxes differed by up to 7 % for
 # the same code, so cross-box comparisons mean nothing):
 #   gpurun --timeout 1500 -- 'bash tools/gpu/next_round_first_call.sh'
 # Round 3 ended with three questions that only the GPU answers; the builds for them are ready:
@@ -15,6 +15,9 @@ mkdir -p gpurun_out
 bash tools/gpu/build_ablate.sh > /dev/null 2>&1
 bash tools/gpu/build_variant.sh sgb -DPF_IG_SGB -DPF_ST_SGB -DPF_RAW_MINMAX > /dev/null 2>&1
 V=$GRAFT_REPO_ROOT/tools/gpu/_build/libpocketflow_hip_sgb.so
+# the same + the residual vectors of a conv3 tile requested one k-step earlier (three-stage prologue kernels; -DPF_IG_RES_EARLY)
+bash tools/gpu/build_variant.sh sgb2 -DPF_IG_SGB -DPF_ST_SGB -DPF_RAW_MINMAX -DPF_IG_RES_EARLY > /dev/null 2>&1
+V2=$GRAFT_REPO_ROOT/tools/gpu/_build/libpocketflow_hip_sgb2.so
 line() { python -c "
 import json, sys
 for ln in open(sys.argv[1]):
@@ -22,8 +25,8 @@ for ln in open(sys.argv[1]):
         d = json.loads(ln); print(sys.argv[2], round(d['value']), 'img/s', round(d['ms_per_step'], 2), 'ms/step | host submit', d.get('host_submit_ms_min_median_max'), '| roofline frac', d['roofline']['frac'], '| region ms per launch', d['roofline'].get('avg_launch_ms'))
 " $1 $2; }
 # 1. the step: product library, variant library, product again (drift check)
-for tag in product sgb product2; do
-  lib=""; [ $tag = sgb ] && lib=$V
+for tag in product sgb sgb2 product2; do
+  lib=""; [ $tag = sgb ] && lib=$V; [ $tag = sgb2 ] && lib=$V2
   PF_HIP_LIB=$lib timeout 400 python bench.py --steps 15 --warmup 5 --no_cpu_baseline > gpurun_out/r04_first_bench_$tag.json 2> gpurun_out/r04_first_bench_$tag.err || tail -3 gpurun_out/r04_first_bench_$tag.err
   line gpurun_out/r04_first_bench_$tag.json $tag
 done
@@ -38,6 +41,8 @@ PF_TEACHER_AHEAD=1 timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu 
 timeout 400 python tools/gpu/igemm_sgb_bench.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04_first_igemm_sgb.txt | cut -c1-200
 PF_HIP_LIB=$V timeout 900 python -m pytest tests/test_conv_gpu.py tests/test_igemm_gpu.py -m gpu -q -x --tb=line 2>&1 | tail -4 | cut -c1-300 | tee gpurun_out/r04_first_pytest_sgb.log
 PF_HIP_LIB=$V timeout 400 python tools/gpu/fwd1x1_layers.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_first_fwd1x1_layers_sgb.txt
+PF_HIP_LIB=$V2 timeout 400 python tools/gpu/fwd1x1_layers.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_first_fwd1x1_layers_sgb2.txt
+PF_HIP_LIB=$V2 timeout 600 python -m pytest tests/test_conv_gpu.py tests/test_igemm_gpu.py -m gpu -q -x --tb=line 2>&1 | tail -3 | cut -c1-300 | tee gpurun_out/r04_first_pytest_sgb2.log
 timeout 400 python tools/gpu/fwd1x1_layers.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04_first_fwd1x1_layers.txt | cut -c1-200
 # 3. B: ablations incl. the no-epilogue builds and the tile schedule's ideal
 TILES=128x128 timeout 400 python tools/gpu/igemm_ablate.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04_first_igemm_ablation.txt | cut -c1-220
