@@ -243,6 +243,16 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
     const bool more = (cs < NS);                                         // this wavefront has another strip
     if (has_r && more) issue_res(cs);                                    // next strip's residual travels under its main loop
 #ifdef PF_ST_SGB
+    float bpr[32];                                                       // BWD: this lane's 8 channels of scale | shift | mean | invstd
+    if (BWD && NW != 128) {
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bpr[qq * 8 + j] = aux[qq * NW + wvec * 8 + j];
+    } else if (BWD) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) bpr[i] = 0.f;
+    }
     constexpr int CB = (NW == 128) ? 1 : 4;                              // scheduling experiment: rows requested CB at a time
     uint4 cv[CB];                                                        // (NW = 128 has no registers to spare: it spills as it is)
 #endif
@@ -268,13 +278,19 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
           float f[8], xv[8];
           unpack8(c, f);
           unpack8(sv, xv);
+#ifdef PF_ST_SGB
+          const float* bp = (NW == 128) ? (aux + wvec * 8) : bpr;        // hoisted: hipcc re-reads the 8 vectors from LDS in every pass
+          constexpr int BPS = (NW == 128) ? NW : 8;
+#else
           const float* bp = aux + wvec * 8;
+          constexpr int BPS = NW;
+#endif
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const float u = fmaf(bp[j], xv[j], bp[NW + j]);
+            const float u = fmaf(bp[j], xv[j], bp[BPS + j]);
             const float dy = (u > a.b_lo && u < a.b_hi) ? f[j] : 0.f;
             st_s[j] += dy;
-            st_q[j] = fmaf(dy, (xv[j] - bp[2 * NW + j]) * bp[3 * NW + j], st_q[j]);
+            st_q[j] = fmaf(dy, (xv[j] - bp[2 * BPS + j]) * bp[3 * BPS + j], st_q[j]);
           }
         } else if (a.R != nullptr || a.partial != nullptr) {
           float f[8];

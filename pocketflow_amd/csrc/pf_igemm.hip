@@ -625,6 +625,15 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
       }
     };
     const bool etid = !WS || tid < TE;                                      // WS: the producers only keep the barriers company
+#ifdef PF_IG_SGB
+    float bpr[32];                                                          // BWD: this thread's 8 channels of scale | shift | mean | invstd
+    if (BWD) {
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bpr[qq * 8 + j] = bpl[qq * BN + wvec * 8 + j];
+    }
+#endif
     if (side != nullptr && etid) load_side(0);
     PF_IG_STAMP(10);                                                        // next tile's first stage issued, C tile packed and written
     if constexpr (XPRE) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
@@ -662,13 +671,19 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
             float f[8], xv[8];
             unpack8(c, f);
             unpack8(rres[pp], xv);
+#ifdef PF_IG_SGB
+            const float* bp = bpr;                                          // hoisted (below): hipcc re-reads the 8 vectors from LDS in every pass
+            constexpr int BPS = 8;
+#else
             const float* bp = bpl + wvec * 8;
+            constexpr int BPS = BN;
+#endif
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              const float u = fmaf(bp[j], xv[j], bp[BN + j]);
+              const float u = fmaf(bp[j], xv[j], bp[BPS + j]);
               const float dy = (u > a.b_lo && u < a.b_hi) ? f[j] : 0.f;
               st_s[j] += dy;
-              st_q[j] = fmaf(dy, (xv[j] - bp[2 * BN + j]) * bp[3 * BN + j], st_q[j]);
+              st_q[j] = fmaf(dy, (xv[j] - bp[2 * BPS + j]) * bp[3 * BPS + j], st_q[j]);
             }
           } else if (a.R != nullptr || a.partial != nullptr) {
             float f[8];
