@@ -377,6 +377,29 @@ __device__ __forceinline__ void tr_read_frags(uint32_t p, bf16x8 (&f)[2]) {
   f[0] = tr_join(l0, h0); f[1] = tr_join(l1, h1);
 }
 
+// scheduling experiment (-DPF_W2_SGB, variant builds only): BOTH operands' fragments behind one wait -- the two calls above expose
+// two LDS round trips per k-step of ~16 MFMAs
+template <int HIX, int HID>
+__device__ __forceinline__ void tr_read_frags2(uint32_t px, uint32_t pd, bf16x8 (&xf)[4], bf16x8 (&df)[4]) {
+  v4s a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3, d0, d1, d2, d3;
+  asm volatile("ds_read_b64_tr_b16 %0, %16\n\tds_read_b64_tr_b16 %4, %16 offset:%18\n\t"
+               "ds_read_b64_tr_b16 %1, %16 offset:256\n\tds_read_b64_tr_b16 %5, %16 offset:%19\n\t"
+               "ds_read_b64_tr_b16 %2, %16 offset:512\n\tds_read_b64_tr_b16 %6, %16 offset:%20\n\t"
+               "ds_read_b64_tr_b16 %3, %16 offset:768\n\tds_read_b64_tr_b16 %7, %16 offset:%21\n\t"
+               "ds_read_b64_tr_b16 %8, %17\n\tds_read_b64_tr_b16 %12, %17 offset:%22\n\t"
+               "ds_read_b64_tr_b16 %9, %17 offset:256\n\tds_read_b64_tr_b16 %13, %17 offset:%23\n\t"
+               "ds_read_b64_tr_b16 %10, %17 offset:512\n\tds_read_b64_tr_b16 %14, %17 offset:%24\n\t"
+               "ds_read_b64_tr_b16 %11, %17 offset:768\n\tds_read_b64_tr_b16 %15, %17 offset:%25\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3),
+                 "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+               : "v"(px), "v"(pd), "n"(HIX), "n"(HIX + 256), "n"(HIX + 512), "n"(HIX + 768), "n"(HID), "n"(HID + 256), "n"(HID + 512),
+                 "n"(HID + 768)
+               : "memory");
+  xf[0] = tr_join(a0, b0); xf[1] = tr_join(a1, b1); xf[2] = tr_join(a2, b2); xf[3] = tr_join(a3, b3);
+  df[0] = tr_join(c0, d0); df[1] = tr_join(c1, d1); df[2] = tr_join(c2, d2); df[3] = tr_join(c3, d3);
+}
+
 struct Wrw2Args {
   const bf16_t* dY;
   const bf16_t* X;
@@ -576,8 +599,16 @@ __global__ __launch_bounds__(64 * (TN / WTN) * (TK / WTK)) void k_wrw2(const Wrw
       // fragments by transposing LDS reads issued from inline asm (tr_read_frags): the compiler must not see them, or it
       // drains the LDS-DMA of the younger stages (vmcnt(0)) in front of the first one
       bf16x8 xf[NJ], df[NI];
+#ifdef PF_W2_SGB
+      if constexpr (NI == 4 && NJ == 4) {
+        tr_read_frags2<2 * NBK * 256, 2 * NBN * 256>(lds_addr(sbase + DY_BYTES + (pg_lo * NBK + wk * NJ) * 256 + tr_off),
+                                                     lds_addr(sbase + (pg_lo * NBN + wn * NI) * 256 + tr_off), xf, df);
+      } else
+#endif
+      {
       tr_read_frags<2 * NBK * 256>(lds_addr(sbase + DY_BYTES + (pg_lo * NBK + wk * NJ) * 256 + tr_off), xf);
       tr_read_frags<2 * NBN * 256>(lds_addr(sbase + (pg_lo * NBN + wn * NI) * 256 + tr_off), df);
+      }
       PF_W2_STAMP(2);
 #pragma unroll
       for (int i = 0; i < NI; ++i)

@@ -4,7 +4,7 @@
 # Round 3 ended with three questions that only the GPU answers; the builds for them are ready:
 #   A. ISA: hipcc serialises the LDS fragment reads of the contraction loops -- read, lgkmcnt(0), 4 MFMAs, read, ...
 #      (k_igemm), read, lgkmcnt(1), ONE MFMA (k_conv1x1_stream) -- an exposed LDS round trip per group.  The variant library
-#      (-DPF_IG_SGB -DPF_ST_SGB -DPF_RAW_MINMAX: sched_group_barrier pipelines, batched epilogue reads, bare v_min / v_max in the statistics; same arithmetic in the same order) must be bit-identical; is it faster?
+#      (-DPF_IG_SGB -DPF_ST_SGB -DPF_W2_SGB -DPF_RAW_MINMAX: sched_group_barrier pipelines, batched epilogue reads, bare v_min / v_max in the statistics; same arithmetic in the same order) must be bit-identical; is it faster?
 #   B. What does the epilogue cost (ablation builds 4 / 5), and how far is the main loop's matrix work from the tile schedule's ideal?
 #   C. Two workgroups per CU run in lockstep (both in their epilogue at once): does starting the second one late help?
 #   D. Every persistent launch ends with idle CUs (ceil(tiles / slots) rounds): does a second queue -- the frozen teacher's forward
@@ -13,10 +13,10 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 bash tools/gpu/build_ablate.sh > /dev/null 2>&1
-bash tools/gpu/build_variant.sh sgb -DPF_IG_SGB -DPF_ST_SGB -DPF_RAW_MINMAX > /dev/null 2>&1
+bash tools/gpu/build_variant.sh sgb -DPF_IG_SGB -DPF_ST_SGB -DPF_W2_SGB -DPF_RAW_MINMAX > /dev/null 2>&1
 V=$GRAFT_REPO_ROOT/tools/gpu/_build/libpocketflow_hip_sgb.so
 # the same + the residual vectors of a conv3 tile requested one k-step earlier (three-stage prologue kernels; -DPF_IG_RES_EARLY)
-bash tools/gpu/build_variant.sh sgb2 -DPF_IG_SGB -DPF_ST_SGB -DPF_RAW_MINMAX -DPF_IG_RES_EARLY > /dev/null 2>&1
+bash tools/gpu/build_variant.sh sgb2 -DPF_IG_SGB -DPF_ST_SGB -DPF_W2_SGB -DPF_RAW_MINMAX -DPF_IG_RES_EARLY > /dev/null 2>&1
 V2=$GRAFT_REPO_ROOT/tools/gpu/_build/libpocketflow_hip_sgb2.so
 line() { python -c "
 import json, sys
