@@ -210,12 +210,18 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
       // Experiment (tools/gpu/build_ablate.sh -> libst_sgb.so): the batches as written -- WB fragment reads, then their MFMAs
       // (with the prologue, the four reads of the folded constants come first).  Left alone, hipcc keeps two fragment registers
       // and runs read -> lgkmcnt(1) -> ONE MFMA -> read -> ... : an exposed LDS round trip per MFMA (ISA, round 3).
+      // Requested: a ROLLING window -- DEPTH fragment reads ahead, then one read per group of MFMAs, so that the LDS latency of a
+      // fragment is covered by the MFMAs of the DEPTH fragments before it (what -amdgpu-sched-strategy=max-ilp produces for this
+      // loop; as a global flag it blows the plain igemm kernels up to 300 registers, so the pipeline is prescribed here instead).
       if (PRO) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      constexpr int DEPTH = (NW == 128) ? 2 : 4;
+      __builtin_amdgcn_sched_group_barrier(0x100, DEPTH, 0);
 #pragma unroll
-      for (int ib = 0; ib < NI; ib += WB) {
-        __builtin_amdgcn_sched_group_barrier(0x100, WB, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, WB * JM, 0);
+      for (int i = 0; i < NI - DEPTH; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, JM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
+      __builtin_amdgcn_sched_group_barrier(0x008, DEPTH * JM, 0);
 #endif
     }
     const bool last = (ckc == KC - 1);
