@@ -515,22 +515,22 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
         // kernel-fragment register and runs read -> lgkmcnt(0) -> 4 MFMAs -> read -> ... (an exposed LDS round trip per four
         // MFMAs).  With the in-LDS prologue pass between the two halves (asm statements: two scheduling regions) every half asks
         // for its eight fragments first; without it the two halves are ONE region and the second half's fragments are requested
-        // a group of MFMAs ahead, into the registers the first half has finished with.
+        // under the first half's MFMAs, into the registers it has finished with.
         if constexpr (NI == 4 && JM == 4 && PRO3) {
           __builtin_amdgcn_sched_group_barrier(0x100, NI + JM, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, NI * JM, 0);
         }
         if constexpr ((NI == 4 || NI == 2) && JM == 4 && !PRO3) {
           if (kk == 1) {
+            // every fragment of the second half is requested under the MFMAs of the first (one read per two MFMAs): ONE exposed
+            // LDS round trip per k-step, at its start behind the barrier; 228 registers (236 as hipcc schedules it)
             __builtin_amdgcn_sched_group_barrier(0x100, NI + JM, 0);
 #pragma unroll
-            for (int i = 0; i < NI - 1; ++i) {
-              __builtin_amdgcn_sched_group_barrier(0x008, JM, 0);
+            for (int i = 0; i < NI + JM; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, (NI * JM) / (NI + JM), 0);
               __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, JM, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1 + JM, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, NI * JM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NI * JM - (NI + JM) * ((NI * JM) / (NI + JM)) + NI * JM, 0);
           }
         }
 #endif
