@@ -51,3 +51,4 @@ timeout 400 python tools/gpu/igemm_stagger.py 2>&1 | grep -v amdgpu.ids | tee gp
 # 5. the host-bound CIFAR-size configuration and backward-filter per layer (baselines)
 timeout 400 python bench.py --config c1 --steps 15 --warmup 5 --no_cpu_baseline > gpurun_out/r04_first_bench_c1.json 2> gpurun_out/r04_first_bench_c1.err; line gpurun_out/r04_first_bench_c1.json c1
 TARGETS=256,384 timeout 300 python tools/gpu/wrw_target_bench.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04_first_wrw.txt | cut -c1-200
+# afterwards, here:  python tools/first_call_report.py gpurun_out r04_first
