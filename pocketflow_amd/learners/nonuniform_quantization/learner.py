@@ -16,6 +16,7 @@ import torch
 
 from pocketflow_amd.flags import FLAGS, flags
 from pocketflow_amd.learners.abstract_learner import AbstractLearner
+from pocketflow_amd.learners import teacher_ahead
 from pocketflow_amd.learners.distillation_helper import DistillationHelper
 from pocketflow_amd.learners.nonuniform_quantization.bit_optimizer import BitOptimizer
 from pocketflow_amd.learners.nonuniform_quantization.utils import NonUniformQuantization
@@ -89,12 +90,12 @@ class NonUniformQuantLearner(AbstractLearner):
     """ops['train'] (Adam) or, with `optimizer=self.optimizer_fintune`, ops['rl_fintune'] (SGD) of the reference."""
     optimizer = optimizer or self.optimizer
     g = self.graph
-    images, labels = self.iter_train.get_next()
-    x, y = self.to_device(images, labels)
+    ahead, x, y, logits_dst = teacher_ahead.next_batch(self)   # opt-in PF_TEACHER_AHEAD: batch + teacher logits issued by the previous step
     g.begin_step()
     self.nonuni_quant.quantize_weights()
     with g.as_default():
-      logits_dst = self.helper_dst.calc_logits(None, x) if FLAGS.enbl_dst else None
+      if FLAGS.enbl_dst and logits_dst is None:
+        logits_dst = self.helper_dst.calc_logits(None, x)
       logits = self.forward_train(x)
       model_loss, metrics = self.calc_loss(y, logits, self.trainable_vars)
       loss, dst_loss = model_loss, None
@@ -109,6 +110,8 @@ class NonUniformQuantLearner(AbstractLearner):
     optimizer.compute_gradients()
     optimizer.apply_gradients(lr)
     self.ft_step += 1
+    if ahead is not None:
+      ahead.issue()                                 # next batch's teacher forward, beside what the main stream still has queued
     return {'lr': lr, 'dst_loss': dst_loss, 'model_loss': model_loss, 'loss': loss, 'metrics': metrics}
 
   # -- callables handed to the bit optimiser (the reference passes TF ops + sessions) --------------------

@@ -115,3 +115,21 @@ def make(learner):
   if torch.device(dev).type != 'cuda':
     return None
   return TeacherAhead(learner, CudaStreams(dev))
+
+
+def of(learner):
+  """The learner's helper (made on first use), or None."""
+  if not hasattr(learner, '_teacher_ahead'):
+    learner._teacher_ahead = make(learner)
+  return learner._teacher_ahead
+
+
+def next_batch(learner):
+  """(helper, x, y, teacher logits or None) for the step that starts now: what the previous step issued ahead, or -- first step,
+  helper off -- the next batch of the iterator with the teacher still to run in line."""
+  ahead = of(learner)
+  if ahead is not None and ahead.pending is not None:
+    return (ahead,) + ahead.take()
+  images, labels = learner.iter_train.get_next()
+  x, y = learner.to_device(images, labels)
+  return ahead, x, y, None

@@ -16,6 +16,7 @@ import torch
 
 from pocketflow_amd.flags import FLAGS, flags
 from pocketflow_amd.learners.abstract_learner import AbstractLearner
+from pocketflow_amd.learners import teacher_ahead
 from pocketflow_amd.learners.distillation_helper import DistillationHelper
 from pocketflow_amd.learners.uniform_quantization.bit_optimizer import BitOptimizer
 from pocketflow_amd.learners.uniform_quantization.utils import UniformQuantization
@@ -95,13 +96,7 @@ class UniformQuantLearner(AbstractLearner):
   def train_step(self):
     """ops['train'] of the reference, one iteration."""
     g = self.graph
-    ahead = self.__teacher_ahead()
-    if ahead is not None and ahead.pending is not None:
-      x, y, logits_dst = ahead.take()               # batch + teacher logits issued at the end of the previous step
-    else:
-      images, labels = self.iter_train.get_next()
-      x, y = self.to_device(images, labels)
-      logits_dst = None
+    ahead, x, y, logits_dst = teacher_ahead.next_batch(self)   # opt-in PF_TEACHER_AHEAD: batch + teacher logits issued by the previous step
     g.begin_step()
     self.uni_quant.quantize_weights()
     with g.as_default():
@@ -123,13 +118,6 @@ class UniformQuantLearner(AbstractLearner):
     if ahead is not None:
       ahead.issue()                                 # next batch's teacher forward, beside what the main stream still has queued
     return {'lr': lr, 'dst_loss': dst_loss, 'model_loss': model_loss, 'loss': loss, 'metrics': metrics}
-
-  def __teacher_ahead(self):
-    """learners/teacher_ahead.py (opt-in, PF_TEACHER_AHEAD=1): None unless enabled, distilling and on a HIP device."""
-    if not hasattr(self, '_teacher_ahead'):
-      from pocketflow_amd.learners import teacher_ahead
-      self._teacher_ahead = teacher_ahead.make(self) if FLAGS.enbl_dst else None
-    return self._teacher_ahead
 
   # -- callables handed to the bit optimiser (the reference passes TF ops + sessions) --------------------
   def __feed(self, w_bits, a_bits):

@@ -37,6 +37,8 @@ line gpurun_out/r04_first_bench_ahead.json teacher-ahead
 PF_TEACHER_AHEAD=1 PF_HIP_LIB=$V timeout 400 python bench.py --steps 15 --warmup 5 --no_cpu_baseline > gpurun_out/r04_first_bench_ahead_sgb.json 2> gpurun_out/r04_first_bench_ahead_sgb.err || tail -3 gpurun_out/r04_first_bench_ahead_sgb.err
 line gpurun_out/r04_first_bench_ahead_sgb.json teacher-ahead+sgb
 PF_TEACHER_AHEAD=1 timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -q -x --tb=line -k "distillation or bf16_fused or conditioned" 2>&1 | tail -4 | cut -c1-300 | tee gpurun_out/r04_first_pytest_ahead.log
+PF_TEACHER_AHEAD=1 timeout 400 python bench.py --config c4 --steps 10 --warmup 4 --no_cpu_baseline > gpurun_out/r04_first_bench_c4_ahead.json 2> gpurun_out/r04_first_bench_c4_ahead.err; line gpurun_out/r04_first_bench_c4_ahead.json c4-teacher-ahead
+timeout 400 python bench.py --config c4 --steps 10 --warmup 4 --no_cpu_baseline > gpurun_out/r04_first_bench_c4.json 2> gpurun_out/r04_first_bench_c4.err; line gpurun_out/r04_first_bench_c4.json c4
 # 2. A: per layer, bit-identity asserted; then the convolution test files against the variant library
 timeout 400 python tools/gpu/igemm_sgb_bench.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04_first_igemm_sgb.txt | cut -c1-200
 PF_HIP_LIB=$V timeout 900 python -m pytest tests/test_conv_gpu.py tests/test_igemm_gpu.py -m gpu -q -x --tb=line 2>&1 | tail -4 | cut -c1-300 | tee gpurun_out/r04_first_pytest_sgb.log
