@@ -486,6 +486,39 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
 #else
       if (RPRE && has_r && ks == nk - 1) load_residual();                           // no LDS-DMA is issued after this point
 #endif
+#if defined(PF_IG_SGB_PRO2) && PF_IG_ABLATE == 0
+      // experiment on top of PF_IG_SGB (three-stage prologue kernels): the fragments of BOTH halves are read in front of the first
+      // half's MFMAs -- the second half's under them -- so that the in-LDS pass between the halves is the only thing that still
+      // waits for LDS inside a k-step.  Costs 32 more fragment registers: 256 in the 128 x 256 kernel, no spill.
+      if constexpr (PRO3 && NI == 4 && JM == 4 && BM == 128) {            // (the 256 x 128 tile spills 11 registers with it)
+        bf16x8 wf0[NI], xf0[JM], wf1[NI], xf1[JM];
+        const int c0f = (((0 * 4 + q) ^ (l15 & 7)) << 4), c1f = (((1 * 4 + q) ^ (l15 & 7)) << 4);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) wf0[i] = *reinterpret_cast<const bf16x8*>(Bs + (wn * WC + i * 16 + l15) * 128 + c0f);
+#pragma unroll
+        for (int j = 0; j < JM; ++j) xf0[j] = *reinterpret_cast<const bf16x8*>(As + (wm * WR + j * 16 + l15) * 128 + c0f);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) wf1[i] = *reinterpret_cast<const bf16x8*>(Bs + (wn * WC + i * 16 + l15) * 128 + c1f);
+#pragma unroll
+        for (int j = 0; j < JM; ++j) xf1[j] = *reinterpret_cast<const bf16x8*>(As + (wm * WR + j * 16 + l15) * 128 + c1f);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < JM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], xf0[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NI + JM, 0);
+#pragma unroll
+        for (int i = 0; i < NI + JM; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if (tnext) transform3(cbuf, ks + 1, 0, AS / 2);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < JM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], xf1[j], acc[i][j], 0, 0, 0);
+        if (tnext) transform3(cbuf, ks + 1, AS / 2, AS);
+      } else
+#endif
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int coff = (((kk * 4 + q) ^ (l15 & 7)) << 4);
