@@ -1,6 +1,6 @@
-# First gpurun call of the next round (≈ 18 GPU-minutes).  Everything is taken in ONE box (the round-3 boxes differed by up to 7 % for
+# First gpurun call of the next round (≈ 22 GPU-minutes: builds 2, seven bench runs 8, three test runs 6, layer / ablation tables 6).  Everything is taken in ONE box (the round-3 boxes differed by up to 7 % for
 # the same code, so cross-box comparisons mean nothing):
-#   gpurun --timeout 1500 -- 'bash tools/gpu/next_round_first_call.sh'
+#   gpurun --timeout 2400 -- 'bash tools/gpu/next_round_first_call.sh'
 # Round 3 ended with three questions that only the GPU answers; the builds for them are ready:
 #   A. ISA: hipcc serialises the LDS fragment reads of the contraction loops -- read, lgkmcnt(0), 4 MFMAs, read, ...
 #      (k_igemm), read, lgkmcnt(1), ONE MFMA (k_conv1x1_stream) -- an exposed LDS round trip per group.  The variant library
