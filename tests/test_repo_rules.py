@@ -121,3 +121,34 @@ def test_gpu_tools_parse_and_name_files_that_exist():
     assert r.returncode == 0, (path, r.stderr)
     for ref in re.findall(r'\btools/[\w/]+\.(?:py|sh)\b', open(path).read()):
       assert os.path.exists(os.path.join(ROOT, ref)), (path, ref)
+
+
+def test_variant_builds_compile_without_spills(tmp_path):
+  """The scheduling-experiment builds of the contraction kernels (tools/gpu/build_variant.sh: -DPF_IG_SGB -DPF_ST_SGB -DPF_W2_SGB
+  -DPF_RAW_MINMAX -DPF_IG_RES_EARLY -DPF_IG_SGB_PRO2) are the first thing the next GPU session measures: they must keep compiling, and
+  none of the kernels the step dispatches to may spill vector registers or need more than 256 of them (two wavefronts per SIMD)."""
+  import subprocess
+  hipcc = '/opt/rocm/bin/hipcc'
+  if not os.path.exists(hipcc):
+    import pytest
+    pytest.skip('no hipcc')
+  flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fhip-fp32-correctly-rounded-divide-sqrt', '-S',
+           '--cuda-device-only', '-DPF_IG_SGB', '-DPF_ST_SGB', '-DPF_W2_SGB', '-DPF_RAW_MINMAX', '-DPF_IG_RES_EARLY', '-DPF_IG_SGB_PRO2']
+  procs = {}
+  for f in ('pf_igemm', 'pf_conv_stream', 'pf_wrw'):
+    out = str(tmp_path / (f + '.s'))
+    procs[f] = (out, subprocess.Popen([hipcc] + flags + [os.path.join(ROOT, 'pocketflow_amd', 'csrc', f + '.hip'), '-o', out],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+  dispatched = re.compile(r'k_igemmILi128ELi256ELi2ELi4ELi3ELi2E|k_igemmILi256ELi128ELi4ELi2ELi3ELi2E|k_igemmILi128ELi128ELi2ELi2ELi2ELi[01]E|'
+                          r'k_igemmILi128ELi64ELi2ELi2ELi2ELi[01]E|k_conv1x1_streamILi(64|256)E|k_wrw2I')
+  for f, (out, p) in procs.items():
+    _, err = p.communicate(timeout=600)
+    assert p.returncode == 0, (f, err[-2000:])
+    text = open(out).read()
+    for m in re.finditer(r'\.name:\s+(\S+)(.*?)\.wavefront_size', text, re.S):
+      name, blk = m.group(1), m.group(2)
+      if not dispatched.search(name):
+        continue
+      vg = int(re.search(r'\.vgpr_count:\s+(\d+)', blk).group(1))
+      sp = int(re.search(r'\.vgpr_spill_count:\s+(\d+)', blk).group(1))
+      assert sp == 0 and vg <= 256, (name, vg, sp)
