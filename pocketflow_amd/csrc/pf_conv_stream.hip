@@ -36,7 +36,10 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
   constexpr int JM = (NW == 256) ? 1 : 2;           // 16-pixel blocks per strip
   constexpr int RS = 16 * JM;                       // pixel rows per strip
   constexpr int NI = NW / 16;                       // 16-channel blocks
-  constexpr int D = (NW == 128) ? 3 : 4;              // input chunks (RS rows x 64 channels) in flight per wavefront (8-16 KiB).
+#ifndef PF_ST_D128
+#define PF_ST_D128 3                               // (-DPF_ST_D128=2, variant builds: the NW = 128 kernels spill 3-21 registers at depth 3)
+#endif
+  constexpr int D = (NW == 128) ? PF_ST_D128 : 4;     // input chunks (RS rows x 64 channels) in flight per wavefront (8-16 KiB).
   // Deep on purpose: gfx950 counts loads and stores on ONE counter (vmcnt) and they may retire out of order with
   // respect to each other, so the compiler drains the counter whenever a load result is needed while a store is
   // pending -- once per strip here.  What keeps HBM busy across that drain is the amount each wavefront has in flight.
