@@ -7,7 +7,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function"
 # PF_EXTRA_FLAGS: extra -D switches for the WHOLE product build (empty by default; the scheduling experiments of tools/gpu/build_variant.sh
-# become the product by naming them here once a GPU session has measured them)
+# become the product by naming them here once a GPU session has measured them; delete the *.o files when this changes)
 FLAGS="$FLAGS ${PF_EXTRA_FLAGS:-}"
 OBJS=()
 for f in pf_api pf_quant pf_normalize pf_sparse pf_optim pf_loss pf_bn pf_conv pf_conv_stream pf_igemm pf_conv3x3 pf_wrw pf_pool pf_transpose pf_stem pf_image pf_depthwise; do
