@@ -80,8 +80,10 @@ class TeacherAhead(object):
   def issue(self):
     """Fetch batch k+1, upload it and run the teacher over it -- all on the side stream."""
     lrn, st = self.learner, self.streams
-    images, labels = lrn.iter_train.get_next()
     with st.on_side(), profiling.suspended():
+      # the iterator itself may enqueue device work (pinned upload + resize kernel of the TFRecord reader run on the CURRENT stream):
+      # it has to be the side stream, or the teacher would read a batch the main stream has not finished writing
+      images, labels = lrn.iter_train.get_next()
       x, y = lrn.to_device(images, labels)
       logits = lrn.helper_dst.calc_logits(None, x)
       ev = st.record()

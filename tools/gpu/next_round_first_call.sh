@@ -12,12 +12,12 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-bash tools/gpu/build_ablate.sh > /dev/null 2>&1
-bash tools/gpu/build_variant.sh sgb -DPF_IG_SGB -DPF_ST_SGB -DPF_W2_SGB -DPF_RAW_MINMAX > /dev/null 2>&1
+[ -f tools/gpu/_build/libig_ablate5.so ] || bash tools/gpu/build_ablate.sh > /dev/null 2>&1      # prebuilt libraries travel with the snapshot
+[ -f tools/gpu/_build/libpocketflow_hip_sgb.so ] || bash tools/gpu/build_variant.sh sgb -DPF_IG_SGB -DPF_ST_SGB -DPF_W2_SGB -DPF_RAW_MINMAX > /dev/null 2>&1
 V=$GRAFT_REPO_ROOT/tools/gpu/_build/libpocketflow_hip_sgb.so
 # the same + (three-stage prologue kernels) the residual vectors of a conv3 tile requested one k-step earlier (-DPF_IG_RES_EARLY) and
 # both halves' fragments read in front of the first half's MFMAs (-DPF_IG_SGB_PRO2: 256 registers, no spill); the 128-wide resident kernel with two input chunks in flight instead of three (-DPF_ST_D128=2: no spills; 3-21 at depth 3)
-bash tools/gpu/build_variant.sh sgb2 -DPF_IG_SGB -DPF_ST_SGB -DPF_W2_SGB -DPF_RAW_MINMAX -DPF_IG_RES_EARLY -DPF_IG_SGB_PRO2 -DPF_ST_D128=2 > /dev/null 2>&1
+[ -f tools/gpu/_build/libpocketflow_hip_sgb2.so ] || bash tools/gpu/build_variant.sh sgb2 -DPF_IG_SGB -DPF_ST_SGB -DPF_W2_SGB -DPF_RAW_MINMAX -DPF_IG_RES_EARLY -DPF_IG_SGB_PRO2 -DPF_ST_D128=2 > /dev/null 2>&1
 V2=$GRAFT_REPO_ROOT/tools/gpu/_build/libpocketflow_hip_sgb2.so
 line() { python -c "
 import json, sys
