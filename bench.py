@@ -52,6 +52,12 @@ def parse_args():
                   help='profiling region whose launches are timed with HIP events: conv1x1_fwd | conv1x1_wrw | '
                        'conv1x1_bwd_data | conv2d_fwd | bn_bwd_apply | bn_bwd_stats | bn_act_quant_apply | bn_stats')
   ap.add_argument('--no_cpu_baseline', action='store_true')
+  ap.add_argument('--step_graph', type=int, default=None,
+                  help='1: the steady-state step is recorded in a hipGraph during the warm-up and replayed (default on ONE GPU; '
+                       'pocketflow_amd/step_graph.py); 0: every step is issued launch by launch (default for N > 1)')
+  ap.add_argument('--event_steps', type=int, default=2,
+                  help='with --step_graph 1: this many of the K timed steps run launch by launch, their roofline-region launches '
+                       'bracketed by HIP events (a replayed graph cannot carry timing events)')
   ap.add_argument('--no_reexec', action='store_true', help=argparse.SUPPRESS)       # accepted, ignored (older scripts)
   ap.add_argument('--no_prewarm', action='store_true', help=argparse.SUPPRESS)      # accepted, ignored (older scripts)
   ap.add_argument('--cpu_batch', type=int, default=32, help='batch of the CPU baseline sample (SURVEY 8d: 32)')
@@ -131,6 +137,7 @@ def set_flags(args, tmp, world):
   FLAGS.enbl_dst = cfg['dst']
   FLAGS.dst_eval_teacher = False            # the teacher's one-off evaluation is not part of a step
   FLAGS.synthetic_pool = 2
+  FLAGS.enbl_step_graph = bool(args.step_graph if getattr(args, 'step_graph', None) is not None else world == 1)
   FLAGS.save_path = os.path.join(tmp, 'models', 'model.ckpt')
   FLAGS.save_path_dst = os.path.join(tmp, 'models_dst', 'model.ckpt')
   if cfg['model'] != 'mobilenet':
@@ -215,7 +222,7 @@ REGION_KERNELS = {'conv1x1_fwd': [r'^k_conv1x1_stream<\d+, true, ', r'^k_igemm<\
                   'conv2d_fwd': [r'^k_igemm<\d+, \d+, \d+, \d+, \d+, 0>'],
                   'bn_bwd_apply': [r'^k_bn_bwd_apply<'], 'bn_bwd_stats': [r'^k_bn_bwd_stats'],
                   'bn_act_quant_apply': [r'^k_bn_apply<'], 'bn_stats': [r'^k_bn_stats']}
-PROFILE_TAG = 'r03'
+PROFILE_TAG = 'r04'
 
 
 def pmc_traffic_per_launch(region, tag=PROFILE_TAG):
@@ -323,6 +330,19 @@ def main():
 
   for _ in range(args.warmup):
     train_step()
+  # --step_graph: the recording (three launch-by-launch steps, then one pass of the Python step under stream capture) belongs to
+  # the warm-up whatever W is; a learner whose step cannot be recorded says so once and stays launch-by-launch
+  sg = None
+  if FLAGS.enbl_step_graph and world == 1:
+    from pocketflow_amd import step_graph
+    sg = step_graph.of(learner)
+    extra = 0
+    while sg.state == 'warm' and extra < 8:
+      train_step()
+      extra += 1
+    if sg.state != 'ready':
+      sys.stderr.write('bench.py: step graph not recorded (%r): launch-by-launch steps\n' % (sg.error,))
+      sg = None
   # Self-diagnosis of a host-bound process.  Seven bench processes of round 2 ran at 150 ms instead of
   # 29 ms per step with the same kernels: the caching allocator was going to the driver for every tensor (torch.empty at
   # 185 us) because a reference cycle in the layer executor kept each step's activations alive until Python's cyclic
@@ -358,11 +378,17 @@ def main():
     if os.path.isdir(out_dir):
       with open(os.path.join(out_dir, 'bench_host_bound_profile.txt'), 'w') as f:
         f.write(text)
+  n_event = args.steps if sg is None else max(0, min(args.event_steps, args.steps))
+  if sg is not None:
+    sg.suspend()                       # the first n_event timed steps are issued launch by launch, with events around the region
   profiling.enable(args.roofline_kernel)
   sync()
   t0 = time.perf_counter()
   marks = []
-  for _ in range(args.steps):
+  for i in range(args.steps):
+    if sg is not None and i == n_event:
+      profiling.pause()
+      sg.resume()
     train_step()
     marks.append(time.perf_counter())
   sync()
@@ -439,7 +465,9 @@ def main():
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                    # opt-in experiment (learners/teacher_ahead.py): the teacher's forward over batch k+1 on a second stream
                    # beside step k's backward; the roofline region then holds the student's launches only
-                   'teacher': 'next batch, side stream' if getattr(learner, '_teacher_ahead', None) is not None else 'in line'},
+                   'teacher': 'next batch, side stream' if getattr(learner, '_teacher_ahead', None) is not None else 'in line',
+                   'step_graph': ({'replayed_steps': args.steps - n_event, 'launch_by_launch_steps_with_events': n_event,
+                                   'teacher_branch': sg.nxt is not None} if sg is not None else None)},
         'roofline': roofline, 'cpu_baseline': cpu_baseline, 'multi_gpu': multi_gpu}
     print(json.dumps(line))
   if world > 1:

@@ -59,6 +59,9 @@ typedef struct PfBlock { int32_t seg; int32_t chunk; int32_t row0; int32_t nrows
 
 const char* pf_error_string(int err);
 int pf_version(void);
+/* The launchers' PF_* tuning / A-B environment switches are read once, on first use (csrc/pf_api.hip, struct PfTuning); a tool or
+ * test that changes one in-process calls this to have them read again.  No reference counterpart (tuning service). */
+int pf_tuning_reload(void);
 
 /* ---- K1: min/max calibration -------------------------------------------------------------
  * replaces tf.reduce_max / tf.reduce_min (+stop_gradient) of __scale,
@@ -141,6 +144,18 @@ int pf_adam_flat(float* p, const void* g, int g_dtype, float* m, float* v, const
 int pf_momentum_flat(float* p, const void* g, int g_dtype, float* acc, const float* mask,
                      int64_t n, int64_t n_decay, float wd, float g_scale, float lr, float momentum,
                      void* stream);
+/* The same two updates for a step that was captured in a hipGraph (pocketflow_amd/step_graph.py; the reference's counterpart is
+ * the ONE `sess.run(train_op)` of uq learner.py:172 -- a TF session also replays a compiled graph whose learning rate is a tensor,
+ * every learner's `setup_lrn_rate`): the per-step scalars are read from device memory, hp[0] = Adam's
+ * alpha_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) (float32, computed by the host exactly as pf_adam_flat does), hp[1] = lr.
+ * pf_set_floats writes dst[0..3] from by-value kernel arguments (no staging buffer the host could overrun). */
+int pf_adam_flat_dev(float* p, const void* g, int g_dtype, float* m, float* v, const float* mask,
+                     int64_t n, int64_t n_decay, float wd, float g_scale, const float* hp, float beta1,
+                     float beta2, float eps, void* stream);
+int pf_momentum_flat_dev(float* p, const void* g, int g_dtype, float* acc, const float* mask,
+                         int64_t n, int64_t n_decay, float wd, float g_scale, const float* hp,
+                         float momentum, void* stream);
+int pf_set_floats(float* dst, float a, float b, float c, float d, void* stream);
 
 /* ---- K10+K11: distillation + hard-label losses, forward and backward in one kernel ---------
  * replaces tf.losses.softmax_cross_entropy(labels, logits) (nets/<model>.py calc_loss) and

@@ -19,6 +19,24 @@
 
 typedef uint16_t bf16_t;
 
+// ---- tuning / A-B switches (host) --------------------------------------------------------------
+// Every PF_* environment switch of the launchers is read ONCE, on first use, into this struct (pf_api.hip): a launcher and the
+// workspace-size query that precedes it always see the same decision, and no launch pays for getenv / atoi / sscanf.  Tools and
+// tests that flip a switch in-process call pf_tuning_reload() (hip.tuning_reload()) afterwards.
+struct PfTuning {
+  int conv_bn;                    // PF_CONV_BN            0 | 64 | 128
+  int conv_igemm, conv_igemm_pro; // PF_CONV_IGEMM[_PRO]   1 (default) | 0
+  int conv3x3_halo;               // PF_CONV3X3_HALO       0 (default) | 1
+  int conv_stream;                // PF_CONV_STREAM        1 (default) | 0
+  int conv_stream_maxsplit;       // PF_CONV_STREAM_MAXSPLIT  2
+  int igemm_prow, igemm_pro3;     // PF_IGEMM_PROW 0, PF_IGEMM_PRO3 1
+  int igemm_tile_bm, igemm_tile_bn;   // PF_IGEMM_TILE "BMxBN" (0, 0: none)
+  int pool3s2;                    // PF_POOL3S2            1 (default) | 0
+  int wrw_tr, wrw2, wrw2_target;  // PF_WRW_TR 0, PF_WRW2 1, PF_WRW2_TARGET 0 (= per-shape default)
+  int splitk;                     // PF_IGEMM_SPLITK       1 (default) | 0
+};
+const PfTuning& pf_tuning();
+
 // ---- bf16 <-> f32 (round-to-nearest-even, same as torch / XLA) ------------------------------
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) {
   return __uint_as_float(((uint32_t)h) << 16);
@@ -112,15 +130,10 @@ __device__ __forceinline__ void slot_alpha_beta(const uint32_t* slot, float& alp
 // Running per-channel minimum / maximum of the statistics passes.  fminf / fmaxf compile to FIVE instructions per element here:
 // the kernels run in IEEE mode, where v_min / v_max quiet a signalling NaN instead of ignoring it, so hipcc canonicalises every
 // operand it cannot prove quiet (v_max x, x, x of the value -- unpacked with a shift -- and of BOTH running values, which are loop
-// phis).  -DPF_RAW_MINMAX (scheduling-experiment builds, tools/gpu/build_variant.sh) issues the bare instruction: identical for
+// phis).  The accumulators therefore issue the bare instruction (round 4): identical for
 // every input except a SIGNALLING NaN (result NaN instead of the other operand); quiet NaNs are ignored either way.
-#ifdef PF_RAW_MINMAX
 __device__ __forceinline__ float pf_acc_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float pf_acc_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-#else
-__device__ __forceinline__ float pf_acc_min(float a, float b) { return fminf(a, b); }
-__device__ __forceinline__ float pf_acc_max(float a, float b) { return fmaxf(a, b); }
-#endif
 
 template <int ACT> __device__ __forceinline__ float apply_act(float x) {
   if (ACT == PF_ACT_RELU) return fmaxf(x, 0.0f);

@@ -298,9 +298,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void k_conv1x1_fwd(const ConvArgs a)
 
 #include <stdlib.h>
 static int conv_bn_of(int N) {
-  static int forced = -1;                           // PF_CONV_BN=64|128: tuning override (experiments only)
-  if (forced < 0) { const char* e = getenv("PF_CONV_BN"); forced = e ? atoi(e) : 0; }
-  if (forced == 64) return 64;
+  if (pf_tuning().conv_bn == 64) return 64;           // PF_CONV_BN=64: tuning override (experiments only)
   return (N % 128 == 0) ? 128 : 64;
 }
 
@@ -340,8 +338,7 @@ int pf_igemm_conv1x1(const void* X, const void* W, void* Y, const void* R, float
 // (tools/gpu/igemm_bench.py, conv_bench2.py): prologue-free GEMMs win from K = 512 up; with the prologue the in-LDS pass
 // behind asynchronous staging beats the register-staged tiles of this file on every shape it was tried on.
 static bool conv_use_igemm(bool pro, int K) {
-  const char* e = getenv(pro ? "PF_CONV_IGEMM_PRO" : "PF_CONV_IGEMM");    // =0: tuning / A-B override
-  if (e != nullptr && atoi(e) == 0) return false;
+  if ((pro ? pf_tuning().conv_igemm_pro : pf_tuning().conv_igemm) == 0) return false;    // PF_CONV_IGEMM[_PRO]=0: tuning / A-B override
   return (K % 64) == 0 && (pro || K >= 512);
 }
 

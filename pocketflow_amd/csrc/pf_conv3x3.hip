@@ -348,8 +348,7 @@ static bool h3_enabled() {
   // every wavefront runs issue -> fragment reads -> MFMAs -> wait -> barrier in lockstep and the matrix pipe idles through
   // the first and the last two; two independent 4-wavefront workgroups per CU overlap those phases by drifting apart.
   // Kept opt-in (tests run it): the structure it needs next is a ping-pong schedule of the two wavefronts of a SIMD.
-  const char* e = getenv("PF_CONV3X3_HALO");
-  return e != nullptr && atoi(e) != 0;
+  return pf_tuning().conv3x3_halo != 0;                   // PF_CONV3X3_HALO
 }
 
 // does the halo kernel take this convolution?  (3x3, stride 1, pad 1, same size; 64-channel chunks; window fits the LDS)

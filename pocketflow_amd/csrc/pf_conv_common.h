@@ -155,7 +155,7 @@ __device__ __forceinline__ void lds_read_b128x4(uint32_t p0, uint32_t p1, float4
   a = make_float4(ra[0], ra[1], ra[2], ra[3]); b = make_float4(rb[0], rb[1], rb[2], rb[3]);
   c = make_float4(rc[0], rc[1], rc[2], rc[3]); d = make_float4(rd[0], rd[1], rd[2], rd[3]);
 }
-// the four constant vectors of a prologue step AND one / two data vectors behind ONE wait (scheduling experiment PF_IG_SGB)
+// the four constant vectors of a prologue step AND one / two data vectors behind ONE wait
 __device__ __forceinline__ void lds_read_b128x4_1(uint32_t p0, uint32_t p1, uint32_t pv, float4& a, float4& b, float4& c, float4& d, uint4& v) {
   f32x4v_t ra, rb, rc, rd;
   u32x4_t rv;

@@ -36,10 +36,8 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
   constexpr int JM = (NW == 256) ? 1 : 2;           // 16-pixel blocks per strip
   constexpr int RS = 16 * JM;                       // pixel rows per strip
   constexpr int NI = NW / 16;                       // 16-channel blocks
-#ifndef PF_ST_D128
-#define PF_ST_D128 3                               // (-DPF_ST_D128=2, variant builds: the NW = 128 kernels spill 3-21 registers at depth 3)
-#endif
-  constexpr int D = (NW == 128) ? PF_ST_D128 : 4;     // input chunks (RS rows x 64 channels) in flight per wavefront (8-16 KiB).
+  // NW = 128: two chunks in flight (three spill 3-21 registers; measured round 4, 56x56 256->128: 147 -> 140 us)
+  constexpr int D = (NW == 128) ? 2 : 4;             // input chunks (RS rows x 64 channels) in flight per wavefront (8-16 KiB).
   // Deep on purpose: gfx950 counts loads and stores on ONE counter (vmcnt) and they may retire out of order with
   // respect to each other, so the compiler drains the counter whenever a load result is needed while a store is
   // pending -- once per strip here.  What keeps HBM busy across that drain is the amount each wavefront has in flight.
@@ -209,7 +207,6 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
           for (int j = 0; j < JM; ++j)
             acc[ib + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[ib + i][j], 0, 0, 0);
       }
-#ifdef PF_ST_SGB
       // Experiment (tools/gpu/build_ablate.sh -> libst_sgb.so): the batches as written -- WB fragment reads, then their MFMAs
       // (with the prologue, the four reads of the folded constants come first).  Left alone, hipcc keeps two fragment registers
       // and runs read -> lgkmcnt(1) -> ONE MFMA -> read -> ... : an exposed LDS round trip per MFMA (ISA, round 3).
@@ -225,7 +222,6 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
       __builtin_amdgcn_sched_group_barrier(0x008, DEPTH * JM, 0);
-#endif
     }
     const bool last = (ckc == KC - 1);
     const int s = cs;
@@ -251,7 +247,6 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
       }
     const bool more = (cs < NS);                                         // this wavefront has another strip
     if (has_r && more) issue_res(cs);                                    // next strip's residual travels under its main loop
-#ifdef PF_ST_SGB
     float bpr[32];                                                       // BWD: this lane's 8 channels of scale | shift | mean | invstd
     if (BWD && NW != 128) {
 #pragma unroll
@@ -264,21 +259,16 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
     }
     constexpr int CB = (NW == 128) ? 1 : 4;                              // scheduling experiment: rows requested CB at a time
     uint4 cv[CB];                                                        // (NW = 128 has no registers to spare: it spills as it is)
-#endif
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int rl = p * RPP + wrow;
       const int m = s * RS + rl, n = n0 + wvec * 8;
-#ifdef PF_ST_SGB
       if (p % CB == 0) {
 #pragma unroll
         for (int pb = 0; pb < CB; ++pb)
           if (p + pb < NP) cv[pb] = *reinterpret_cast<const uint4*>(Cs + ((p + pb) * RPP + wrow) * CS_LD + wvec * 8);
       }
       uint4 c = cv[p % CB];
-#else
-      uint4 c = *reinterpret_cast<const uint4*>(Cs + rl * CS_LD + wvec * 8);
-#endif
       const uint4 sv = rres[p];
       if (side != nullptr && more) issue_side(cs, p);                    // next strip's vector into the freed register
       if (m < a.M && n < a.N) {
@@ -287,13 +277,8 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
           float f[8], xv[8];
           unpack8(c, f);
           unpack8(sv, xv);
-#ifdef PF_ST_SGB
           const float* bp = (NW == 128) ? (aux + wvec * 8) : bpr;        // hoisted: hipcc re-reads the 8 vectors from LDS in every pass
           constexpr int BPS = (NW == 128) ? NW : 8;
-#else
-          const float* bp = aux + wvec * 8;
-          constexpr int BPS = NW;
-#endif
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float u = fmaf(bp[j], xv[j], bp[BPS + j]);
@@ -357,13 +342,11 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
 
 // ---- host side ---------------------------------------------------------------------------------------------------
 static int stream_enabled() {
-  const char* e = getenv("PF_CONV_STREAM");               // PF_CONV_STREAM=0: tuning / A-B override, read per call
-  return (e == nullptr) ? 1 : atoi(e);
+  return pf_tuning().conv_stream;                         // PF_CONV_STREAM=0: tuning / A-B override
 }
 
 static int stream_max_split() {
-  const char* e = getenv("PF_CONV_STREAM_MAXSPLIT");      // column slices a row panel may be cut into, read per call
-  return (e == nullptr) ? 2 : atoi(e);
+  return pf_tuning().conv_stream_maxsplit;                // PF_CONV_STREAM_MAXSPLIT: column slices a row panel may be cut into
 }
 
 // column slices (0: the stream kernel does not apply) and the slice width

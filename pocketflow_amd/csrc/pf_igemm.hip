@@ -57,8 +57,6 @@ struct IgArgs {
   int th, tw;           // taps
   int H, Wd, Ho, Wo, stride, pad_h, pad_w;
   int tiles_m, tiles_n, G;
-  int stagger;          // clocks between the start phases of the workgroups (0: all start together), see k_igemm
-  int stagger_mode;     // 0: four phases over the CUs, (blockIdx / 8) % 4;  1: the second half of the grid starts late
 };
 
 // Ablation builds for tools/gpu/igemm_ablate.py ONLY (never in libpocketflow_hip.so): -DPF_IG_ABLATE=1 drops the MFMAs and
@@ -153,16 +151,6 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
     }
   }
 
-  if (a.stagger > 0) {
-    // Phase stagger: identical tiles keep the persistent workgroups of all CUs in the SAME phase (everybody streams its epilogue
-    // through HBM at once, then everybody fills LDS, ...); workgroup phase p = (blockIdx / 8) % 4 starts p * stagger clocks late.
-    // Mode 1 (kernels with TWO workgroups per CU): the second half of the grid -- the workgroups that take the second slot of
-    // every CU when the dispatcher fills the chip breadth-first -- starts `stagger` clocks late, so that the epilogue of one
-    // workgroup of a CU (no matrix work) falls into the main loop of the other instead of both idling the matrix pipe together.
-    const int phase = (a.stagger_mode == 1) ? (int)(blockIdx.x >= gridDim.x / 2) : (int)((blockIdx.x >> 3) & 3);
-    const int64_t t_end = (int64_t)__builtin_readcyclecounter() + (int64_t)phase * a.stagger;
-    while ((int64_t)__builtin_readcyclecounter() < t_end) __builtin_amdgcn_s_sleep(32);
-  }
   float st_s[8], st_q[8], st_mn[8], st_mx[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; st_mn[j] = INFINITY; st_mx[j] = -INFINITY; }
@@ -321,7 +309,6 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
       // the compiler drain the LDS-DMA ring (vmcnt(0)) once per step
       const uint32_t pss = lds_addr(ssl + cc * 64 + schunk * 8);
       float4 s0, s1, h0, h1;
-#ifdef PF_IG_SGB
       // scheduling experiment: the data vectors of the call travel with the constants -- one exposed LDS round trip instead of two
       if (i1 - i0 == 1 || i1 - i0 == 2) {
         const uint32_t pd = lds_addr(smem + buf * STAGE + srow * 128 + (lane & 7) * 16) + (uint32_t)(i0 * (TS / 8) * 128);
@@ -336,7 +323,6 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
         if (i1 - i0 == 2) lds_write_b128(pd + (TS / 8) * 128, pro_apply(pro, v1));
         return;
       }
-#endif
       lds_read_b128x4(pss, pss + (uint32_t)a.C * 4u, s0, s1, h0, h1);
       pro.sc[0] = s0.x; pro.sc[1] = s0.y; pro.sc[2] = s0.z; pro.sc[3] = s0.w;
       pro.sc[4] = s1.x; pro.sc[5] = s1.y; pro.sc[6] = s1.z; pro.sc[7] = s1.w;
@@ -472,53 +458,12 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
       if (PRO3) {                                                           // own part of stage ks+1 (issued one step ago) has landed
         // (waiting for its INPUT slots only here and for the kernel slots -- 2/3 of the bytes, issued behind them -- at the end of
         // the step was measured: no difference, profiles/r03_igemm_timeline_split.txt: the steps are bound by the fill RATE)
-#ifdef PF_IG_RES_EARLY
         if (more) wait_vm<LPS>(); else if (ks + 1 < nk) wait_vm<0>();        // last step: no stage to wait for -- and the residual vectors may still travel
-#else
-        if (more) wait_vm<LPS>(); else wait_vm<0>();
-#endif
       }
-#ifdef PF_IG_RES_EARLY
       // experiment: one k-step earlier (its 16 loads per lane sit in front of a step's MFMAs wherever they are issued; here they
       // have two steps to arrive and the LAST step -- the longest of the timeline -- starts its MFMAs at once)
       // (three-stage prologue kernels only: no stage is issued from step nk - 2 on, so no wait of the ring covers these loads)
       if (RPRE && has_r && ks == ((PRO3 && nk >= 2) ? nk - 2 : nk - 1)) load_residual();
-#else
-      if (RPRE && has_r && ks == nk - 1) load_residual();                           // no LDS-DMA is issued after this point
-#endif
-#if defined(PF_IG_SGB_PRO2) && PF_IG_ABLATE == 0
-      // experiment on top of PF_IG_SGB (three-stage prologue kernels): the fragments of BOTH halves are read in front of the first
-      // half's MFMAs -- the second half's under them -- so that the in-LDS pass between the halves is the only thing that still
-      // waits for LDS inside a k-step.  Costs 32 more fragment registers: 256 in the 128 x 256 kernel, no spill.
-      if constexpr (PRO3 && NI == 4 && JM == 4 && BM == 128) {            // (the 256 x 128 tile spills 11 registers with it)
-        bf16x8 wf0[NI], xf0[JM], wf1[NI], xf1[JM];
-        const int c0f = (((0 * 4 + q) ^ (l15 & 7)) << 4), c1f = (((1 * 4 + q) ^ (l15 & 7)) << 4);
-#pragma unroll
-        for (int i = 0; i < NI; ++i) wf0[i] = *reinterpret_cast<const bf16x8*>(Bs + (wn * WC + i * 16 + l15) * 128 + c0f);
-#pragma unroll
-        for (int j = 0; j < JM; ++j) xf0[j] = *reinterpret_cast<const bf16x8*>(As + (wm * WR + j * 16 + l15) * 128 + c0f);
-#pragma unroll
-        for (int i = 0; i < NI; ++i) wf1[i] = *reinterpret_cast<const bf16x8*>(Bs + (wn * WC + i * 16 + l15) * 128 + c1f);
-#pragma unroll
-        for (int j = 0; j < JM; ++j) xf1[j] = *reinterpret_cast<const bf16x8*>(As + (wm * WR + j * 16 + l15) * 128 + c1f);
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-          for (int j = 0; j < JM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], xf0[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, NI + JM, 0);
-#pragma unroll
-        for (int i = 0; i < NI + JM; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        if (tnext) transform3(cbuf, ks + 1, 0, AS / 2);
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-          for (int j = 0; j < JM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], xf1[j], acc[i][j], 0, 0, 0);
-        if (tnext) transform3(cbuf, ks + 1, AS / 2, AS);
-      } else
-#endif
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int coff = (((kk * 4 + q) ^ (l15 & 7)) << 4);
@@ -543,7 +488,6 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
 #pragma unroll
           for (int j = 0; j < JM; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-#ifdef PF_IG_SGB
         // Experiment (tools/gpu/build_ablate.sh -> libig_sgb.so): prescribe the interleave of the block.  Left alone, hipcc keeps ONE
         // kernel-fragment register and runs read -> lgkmcnt(0) -> 4 MFMAs -> read -> ... (an exposed LDS round trip per four
         // MFMAs).  With the in-LDS prologue pass between the two halves (asm statements: two scheduling regions) every half asks
@@ -566,7 +510,6 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
             __builtin_amdgcn_sched_group_barrier(0x008, NI * JM - (NI + JM) * ((NI * JM) / (NI + JM)) + NI * JM, 0);
           }
         }
-#endif
 #else
         (void)coff; (void)wf; (void)xf;
 #endif
@@ -658,7 +601,6 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
       }
     };
     const bool etid = !WS || tid < TE;                                      // WS: the producers only keep the barriers company
-#ifdef PF_IG_SGB
     float bpr[32];                                                          // BWD: this thread's 8 channels of scale | shift | mean | invstd
     if (BWD) {
 #pragma unroll
@@ -666,7 +608,6 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
 #pragma unroll
         for (int j = 0; j < 8; ++j) bpr[qq * 8 + j] = bpl[qq * BN + wvec * 8 + j];
     }
-#endif
     if (side != nullptr && etid) load_side(0);
     PF_IG_STAMP(10);                                                        // next tile's first stage issued, C tile packed and written
     if constexpr (XPRE) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
@@ -674,7 +615,6 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
     PF_IG_STAMP(11);
 #pragma unroll
     for (int p0 = 0; p0 < NP; p0 += PG) {
-#ifdef PF_IG_SGB
       // scheduling experiment: all C-tile vectors of the group are requested before the first row is processed (as written below,
       // every pass is its own basic block -- read, wait, statistics, store -- and exposes its LDS round trip)
       u32x4_t cv[8];
@@ -686,7 +626,6 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
 #pragma unroll
         for (int pp = 0; pp < PG; ++pp) cv[pp] = *reinterpret_cast<const u32x4_t*>(Cs + (wrw + (p0 + pp) * RPP) * CS_LD + wvec * 8);
       }
-#endif
 #pragma unroll
       for (int pp = 0; pp < PG; ++pp) {
         const int p = p0 + pp;
@@ -694,23 +633,13 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
         const int m = m0 + rl, n = n0 + wvec * 8;
         if (m < a.M && n < a.N && etid) {
           uint4 c;
-#ifdef PF_IG_SGB
           c = make_uint4(cv[pp][0], cv[pp][1], cv[pp][2], cv[pp][3]);
-#else
-          if constexpr (XPRE) c = lds_read_b128(lds_addr(Cs + rl * CS_LD + wvec * 8));
-          else c = *reinterpret_cast<const uint4*>(Cs + rl * CS_LD + wvec * 8);
-#endif
           if (BWD) {
             float f[8], xv[8];
             unpack8(c, f);
             unpack8(rres[pp], xv);
-#ifdef PF_IG_SGB
             const float* bp = bpr;                                          // hoisted (below): hipcc re-reads the 8 vectors from LDS in every pass
             constexpr int BPS = 8;
-#else
-            const float* bp = bpl + wvec * 8;
-            constexpr int BPS = BN;
-#endif
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               const float u = fmaf(bp[j], xv[j], bp[BPS + j]);
@@ -816,13 +745,11 @@ static bool ig_prow_enabled() {
   // =1: the wave-specialised variant (IG_PROW).  Measured in round 3 (profiles/r03_pro_bench.txt, step A/B 9 092 vs 9 199
   // images/s): no faster than the single-role three-stage kernel -- the prologue's VALU work was not what bounds these
   // layers (the LDS fill is) -- so it is opt-in; the tests keep it alive.
-  const char* e = getenv("PF_IGEMM_PROW");
-  return e != nullptr && atoi(e) != 0;
+  return pf_tuning().igemm_prow != 0;                      // PF_IGEMM_PROW
 }
 
 static bool ig_pro3_enabled() {
-  const char* e = getenv("PF_IGEMM_PRO3");                 // =0: round 2's two-stage prologue kernel (A/B runs)
-  return e == nullptr || atoi(e) != 0;
+  return pf_tuning().igemm_pro3 != 0;                      // PF_IGEMM_PRO3=0: round 2's two-stage prologue kernel (A/B runs)
 }
 
 // ONE decision for the launcher and for the statistics-group query (the [G][.][N] partial array is sized from it)
@@ -838,10 +765,9 @@ static IgCfg ig_pick(int M, int N, bool pro) {
     }
     return IgCfg{128, (N % 128 == 0) ? 128 : 64, 512, false, false};
   }
-  const char* e = getenv("PF_IGEMM_TILE");                 // tuning override: "256x128" | "128x128" | "256x64" | "128x64"
-  if (e != nullptr) {
-    int bm = 0, bn = 0;
-    if (sscanf(e, "%dx%d", &bm, &bn) == 2 && (bm == 128 || bm == 256) && (bn == 64 || bn == 128 || (bn == 256 && bm == 256)) &&
+  {                                                        // PF_IGEMM_TILE, tuning override: "256x128" | "128x128" | "256x64" | "128x64"
+    const int bm = pf_tuning().igemm_tile_bm, bn = pf_tuning().igemm_tile_bn;
+    if ((bm == 128 || bm == 256) && (bn == 64 || bn == 128 || (bn == 256 && bm == 256)) &&
         (N % bn == 0 || bn == 64))
       return IgCfg{bm, bn, (bm == 256) ? 256 : 512, false, false};
   }
@@ -879,13 +805,6 @@ static int ig_launch_t(IgArgs& a, int slots, hipStream_t st) {
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
   const int grid = ig_grid(slots, a.tiles_m, a.tiles_n, &a.G);
-  {
-    const char* e = getenv("PF_IGEMM_STAGGER");           // experiment: clocks between workgroup start phases (default 0)
-    a.stagger = (e != nullptr) ? atoi(e) : 0;
-    e = getenv("PF_IGEMM_STAGGER_MODE");                  // 1: delay the second workgroup of every CU (two-per-CU kernels)
-    a.stagger_mode = (e != nullptr) ? atoi(e) : 0;
-    if (a.stagger_mode == 1 && slots != 512) a.stagger = 0;   // only meaningful with two resident workgroups per CU
-  }
   // stage ring and (aliased on it) the C tile; the BWD vectors / the folded prologue constants sit behind whichever is larger
   constexpr size_t ring = NS * (size_t)(BM + BN) * 128, ctile = (size_t)BM * (BN + 8) * 2;
   constexpr size_t base = (ring > ctile ? ring : ctile);

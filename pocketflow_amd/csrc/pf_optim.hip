@@ -33,7 +33,10 @@ __global__ __launch_bounds__(PF_THREADS) void k_adam_flat(float* __restrict__ p,
                                                           const float* __restrict__ mask, int64_t n,
                                                           int64_t n_decay, float wd, float g_scale,
                                                           float alpha_t, float omb1, float omb2,
-                                                          float eps) {
+                                                          float eps, const float* __restrict__ hp) {
+  // hp (captured steps): the step's alpha_t is read from device memory -- a launch recorded in a hipGraph keeps its BY-VALUE
+  // arguments for ever, and alpha_t (learning-rate schedule, bias correction) changes every step
+  if (hp != nullptr) alpha_t = hp[0];
   const int64_t nv = n >> 2;
   for (int64_t i = (int64_t)blockIdx.x * PF_THREADS + threadIdx.x; i < nv;
        i += (int64_t)gridDim.x * PF_THREADS) {
@@ -69,10 +72,10 @@ __global__ __launch_bounds__(PF_THREADS) void k_adam_flat(float* __restrict__ p,
   }
 }
 
-extern "C" int pf_adam_flat(float* p, const void* g, int g_dtype, float* m, float* v,
-                            const float* mask, int64_t n, int64_t n_decay, float wd, float g_scale,
-                            float lr, float beta1, float beta2, float eps, float beta1_power,
-                            float beta2_power, void* stream) {
+static int adam_launch(float* p, const void* g, int g_dtype, float* m, float* v,
+                       const float* mask, int64_t n, int64_t n_decay, float wd, float g_scale,
+                       float lr, float beta1, float beta2, float eps, float beta1_power,
+                       float beta2_power, const float* hp, void* stream) {
   if (n <= 0) return 0;
   if (!pf_aligned16(p) || !pf_aligned16(g) || !pf_aligned16(m) || !pf_aligned16(v) ||
       (mask && !pf_aligned16(mask)))
@@ -82,7 +85,7 @@ extern "C" int pf_adam_flat(float* p, const void* g, int g_dtype, float* m, floa
   const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
   hipStream_t st = (hipStream_t)stream;
   const int grid = pf_grid_for(n, PF_THREADS * 4);
-#define PF_AD(TG, MK) k_adam_flat<TG, MK><<<grid, PF_THREADS, 0, st>>>(p, (const TG*)g, m, v, mask, n, n_decay, wd, g_scale, alpha_t, omb1, omb2, eps)
+#define PF_AD(TG, MK) k_adam_flat<TG, MK><<<grid, PF_THREADS, 0, st>>>(p, (const TG*)g, m, v, mask, n, n_decay, wd, g_scale, alpha_t, omb1, omb2, eps, hp)
   if (g_dtype == PF_F32) { if (mask) PF_AD(float, true); else PF_AD(float, false); }
   else if (g_dtype == PF_BF16) { if (mask) PF_AD(bf16_t, true); else PF_AD(bf16_t, false); }
   else return (int)hipErrorInvalidValue;
@@ -91,12 +94,30 @@ extern "C" int pf_adam_flat(float* p, const void* g, int g_dtype, float* m, floa
   return 0;
 }
 
+extern "C" int pf_adam_flat(float* p, const void* g, int g_dtype, float* m, float* v,
+                            const float* mask, int64_t n, int64_t n_decay, float wd, float g_scale,
+                            float lr, float beta1, float beta2, float eps, float beta1_power,
+                            float beta2_power, void* stream) {
+  return adam_launch(p, g, g_dtype, m, v, mask, n, n_decay, wd, g_scale, lr, beta1, beta2, eps, beta1_power, beta2_power, nullptr,
+                     stream);
+}
+
+// The same update with alpha_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) read from hp[0] (device memory, written by pf_set_floats
+// before the step): the form a step captured in a hipGraph launches.
+extern "C" int pf_adam_flat_dev(float* p, const void* g, int g_dtype, float* m, float* v,
+                                const float* mask, int64_t n, int64_t n_decay, float wd, float g_scale,
+                                const float* hp, float beta1, float beta2, float eps, void* stream) {
+  if (hp == nullptr) return (int)hipErrorInvalidValue;
+  return adam_launch(p, g, g_dtype, m, v, mask, n, n_decay, wd, g_scale, 0.f, beta1, beta2, eps, 0.5f, 0.5f, hp, stream);
+}
+
 template <typename TG, bool MASK>
 __global__ __launch_bounds__(PF_THREADS) void k_momentum_flat(float* __restrict__ p, const TG* __restrict__ g,
                                                               float* __restrict__ acc,
                                                               const float* __restrict__ mask, int64_t n,
                                                               int64_t n_decay, float wd, float g_scale,
-                                                              float lr, float mu) {
+                                                              float lr, float mu, const float* __restrict__ hp) {
+  if (hp != nullptr) lr = hp[1];                        // captured steps: the learning rate lives in device memory
   const int64_t nv = n >> 2;
   for (int64_t i = (int64_t)blockIdx.x * PF_THREADS + threadIdx.x; i < nv;
        i += (int64_t)gridDim.x * PF_THREADS) {
@@ -127,19 +148,46 @@ __global__ __launch_bounds__(PF_THREADS) void k_momentum_flat(float* __restrict_
   }
 }
 
-extern "C" int pf_momentum_flat(float* p, const void* g, int g_dtype, float* acc, const float* mask,
-                                int64_t n, int64_t n_decay, float wd, float g_scale, float lr,
-                                float momentum, void* stream) {
+static int momentum_launch(float* p, const void* g, int g_dtype, float* acc, const float* mask,
+                           int64_t n, int64_t n_decay, float wd, float g_scale, float lr,
+                           float momentum, const float* hp, void* stream) {
   if (n <= 0) return 0;
   if (!pf_aligned16(p) || !pf_aligned16(g) || !pf_aligned16(acc) || (mask && !pf_aligned16(mask)))
     return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   const int grid = pf_grid_for(n, PF_THREADS * 4);
-#define PF_MO(TG, MK) k_momentum_flat<TG, MK><<<grid, PF_THREADS, 0, st>>>(p, (const TG*)g, acc, mask, n, n_decay, wd, g_scale, lr, momentum)
+#define PF_MO(TG, MK) k_momentum_flat<TG, MK><<<grid, PF_THREADS, 0, st>>>(p, (const TG*)g, acc, mask, n, n_decay, wd, g_scale, lr, momentum, hp)
   if (g_dtype == PF_F32) { if (mask) PF_MO(float, true); else PF_MO(float, false); }
   else if (g_dtype == PF_BF16) { if (mask) PF_MO(bf16_t, true); else PF_MO(bf16_t, false); }
   else return (int)hipErrorInvalidValue;
 #undef PF_MO
+  PF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pf_momentum_flat(float* p, const void* g, int g_dtype, float* acc, const float* mask,
+                                int64_t n, int64_t n_decay, float wd, float g_scale, float lr,
+                                float momentum, void* stream) {
+  return momentum_launch(p, g, g_dtype, acc, mask, n, n_decay, wd, g_scale, lr, momentum, nullptr, stream);
+}
+
+// ... with the learning rate read from hp[1] (captured steps, see pf_adam_flat_dev)
+extern "C" int pf_momentum_flat_dev(float* p, const void* g, int g_dtype, float* acc, const float* mask,
+                                    int64_t n, int64_t n_decay, float wd, float g_scale, const float* hp,
+                                    float momentum, void* stream) {
+  if (hp == nullptr) return (int)hipErrorInvalidValue;
+  return momentum_launch(p, g, g_dtype, acc, mask, n, n_decay, wd, g_scale, 0.f, momentum, hp, stream);
+}
+
+// dst[0..3] = (a, b, c, d): per-step scalars of a captured step.  The values travel as kernel arguments (copied at launch time), so
+// the host may run any number of steps ahead of the GPU -- a pinned staging buffer would be overwritten before its copy executes.
+__global__ void k_set_floats(float* __restrict__ dst, float a, float b, float c, float d) {
+  if (threadIdx.x == 0) { dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d; }
+}
+
+extern "C" int pf_set_floats(float* dst, float a, float b, float c, float d, void* stream) {
+  if (dst == nullptr) return (int)hipErrorInvalidValue;
+  k_set_floats<<<1, 64, 0, (hipStream_t)stream>>>(dst, a, b, c, d);
   PF_LAUNCH_CHECK();
   return 0;
 }

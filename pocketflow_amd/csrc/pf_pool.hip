@@ -208,8 +208,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_maxpool3s2_bwd(const T* __restri
 }
 
 static bool pool3s2_ok(int B, int H, int W, int C, int k, int stride, int pad_h, int pad_w, int Ho, int Wo) {
-  const char* e = getenv("PF_POOL3S2");                                    // =0: the generic kernels (A-B / tests)
-  if (e != nullptr && atoi(e) == 0) return false;
+  if (pf_tuning().pool3s2 == 0) return false;                              // PF_POOL3S2=0: the generic kernels (A-B / tests)
   return k == 3 && stride == 2 && pad_h >= 0 && pad_h <= 1 && pad_w >= 0 && pad_w <= 1 &&
          (int64_t)B * H * W * (C / 8) < (1ll << 31);
 }

@@ -224,8 +224,7 @@ __global__ __launch_bounds__(256) void k_wrw_tr(const WrwArgs a) {
 // dispatcher therefore uses it only on request (PF_WRW_TR=1); pf_conv2d_wrw (the RxS entry point, which has no
 // other implementation here) always runs it.  The fix is a shared 256 x 256 output tile.
 static bool wrw_tr_1x1_enabled() {
-  const char* e = getenv("PF_WRW_TR");
-  return e != nullptr && atoi(e) != 0;
+  return pf_tuning().wrw_tr != 0;                          // PF_WRW_TR
 }
 
 int pf_wrw_tr_splits(int M, int N, int C, int taps);
@@ -377,7 +376,7 @@ __device__ __forceinline__ void tr_read_frags(uint32_t p, bf16x8 (&f)[2]) {
   f[0] = tr_join(l0, h0); f[1] = tr_join(l1, h1);
 }
 
-// scheduling experiment (-DPF_W2_SGB, variant builds only): BOTH operands' fragments behind one wait -- the two calls above expose
+// BOTH operands' fragments behind one wait (round 4; measured with the other scheduling changes, +2.2 % per step) -- the two calls above expose
 // two LDS round trips per k-step of ~16 MFMAs
 template <int HIX, int HID>
 __device__ __forceinline__ void tr_read_frags2(uint32_t px, uint32_t pd, bf16x8 (&xf)[4], bf16x8 (&df)[4]) {
@@ -599,12 +598,10 @@ __global__ __launch_bounds__(64 * (TN / WTN) * (TK / WTK)) void k_wrw2(const Wrw
       // fragments by transposing LDS reads issued from inline asm (tr_read_frags): the compiler must not see them, or it
       // drains the LDS-DMA of the younger stages (vmcnt(0)) in front of the first one
       bf16x8 xf[NJ], df[NI];
-#ifdef PF_W2_SGB
       if constexpr (NI == 4 && NJ == 4) {
         tr_read_frags2<2 * NBK * 256, 2 * NBN * 256>(lds_addr(sbase + DY_BYTES + (pg_lo * NBK + wk * NJ) * 256 + tr_off),
                                                      lds_addr(sbase + (pg_lo * NBN + wn * NI) * 256 + tr_off), xf, df);
       } else
-#endif
       {
       tr_read_frags<2 * NBK * 256>(lds_addr(sbase + DY_BYTES + (pg_lo * NBK + wk * NJ) * 256 + tr_off), xf);
       tr_read_frags<2 * NBN * 256>(lds_addr(sbase + (pg_lo * NBN + wn * NI) * 256 + tr_off), df);
@@ -658,8 +655,7 @@ static Wrw2Cfg wrw2_pick(int N, int C) {
 }
 
 static bool wrw2_enabled() {
-  const char* e = getenv("PF_WRW2");                       // PF_WRW2=0: tuning / A-B override
-  return e == nullptr || atoi(e) != 0;
+  return pf_tuning().wrw2 != 0;                            // PF_WRW2=0: tuning / A-B override
 }
 
 // pixel splits of the shared-tile kernel (0: does not apply)
@@ -671,8 +667,8 @@ int pf_wrw2_splits(int M, int N, int C, int taps) {
   // workgroups a launch aims at: every pixel split writes (and the reduction reads) one fp32 slab of the whole dW tile, so
   // more splits buy parallelism with HBM traffic.  Measured per layer over 128 ... 1024 (profiles/r03_wrw_target_bench.txt):
   // one workgroup per CU for the 1x1 layers, 1.5 for the 3x3 ones (round 2's two per CU cost 0.35 ms per ResNet-50 step).
-  const char* e = getenv("PF_WRW2_TARGET");               // tuning / A-B override
-  const int target = (e != nullptr && atoi(e) > 0) ? atoi(e) : (taps == 1 ? 256 : 384);
+  const int forced = pf_tuning().wrw2_target;             // PF_WRW2_TARGET: tuning / A-B override
+  const int target = (forced > 0) ? forced : (taps == 1 ? 256 : 384);
   int S = (target + tiles - 1) / tiles;
   const int maxS = (M + 255) / 256;                       // >= 8 steps of 32 pixels per workgroup
   if (S > maxS) S = maxS;

@@ -354,6 +354,8 @@ class Graph:
     self.matmul_ops: List[MatmulOp] = []
     self.activation_ops: List[ActivationOp] = []
     self.nets: Dict[str, object] = {}          # cached net objects (tf.AUTO_REUSE)
+    self.capturing = False                     # a hipGraph is recording this graph's step (step_graph.py): nothing per-step on the host
+    self.step_feeders: List = []               # callables run before every replay of a recorded step (per-step host draws)
     self.training = True
     self.frozen = False                        # teacher: BN scale/shift cached
     self.act_slots: Optional[torch.Tensor] = None

@@ -45,7 +45,8 @@ SYMBOLS = [
     'pf_conv1x1_stats_groups', 'pf_conv1x1_stats_groups_k', 'pf_conv1x1_fwd', 'pf_conv1x1_bwd_data_bnstats', 'pf_conv1x1_wrw_splits',
     'pf_conv1x1_wrw', 'pf_conv2d_stats_groups', 'pf_conv2d_fwd', 'pf_conv2d_wrw_splits', 'pf_conv2d_wrw', 'pf_maxpool_fwd', 'pf_maxpool_bwd', 'pf_seg_transpose', 'pf_conv_stem_supported', 'pf_conv_stem_fwd', 'pf_conv_stem_wrw_slabs', 'pf_conv_stem_wrw',
     'pf_image_resize_bilinear', 'pf_depthwise_supported', 'pf_depthwise_groups', 'pf_depthwise_fwd', 'pf_depthwise_bwd_data',
-    'pf_depthwise_wrw', 'pf_conv2d_stats_groups_geom',
+    'pf_depthwise_wrw', 'pf_conv2d_stats_groups_geom', 'pf_tuning_reload',
+    'pf_adam_flat_dev', 'pf_momentum_flat_dev', 'pf_set_floats',
 ]
 
 
@@ -114,6 +115,11 @@ def _dev(t: torch.Tensor) -> None:
 
 def version() -> int:
   return int(_lib.pf_version())
+
+
+def tuning_reload() -> None:
+  """The launchers read their PF_* tuning switches once; tools / tests that change one in-process call this afterwards."""
+  _check(_lib.pf_tuning_reload(), 'pf_tuning_reload')
 
 
 # ------------------------------------------------------------------------------------------------
@@ -235,6 +241,26 @@ def momentum_flat(p, g, acc, mask, n_decay: int, wd: float, g_scale: float, lr: 
   _check(_lib.pf_momentum_flat(_ptr(p), _ptr(g), c_int(dtype_code(g)), _ptr(acc), _ptr(mask), c_int64(p.numel()),
                                c_int64(int(n_decay)), c_float(wd), c_float(g_scale), c_float(lr),
                                c_float(momentum), _stream()), 'pf_momentum_flat')
+
+
+def adam_flat_dev(p, g, m, v, mask, n_decay: int, wd: float, g_scale: float, hp, beta1: float, beta2: float,
+                  eps: float) -> None:
+  """pf_adam_flat with alpha_t read from hp[0] (device float32[4]): the launch a captured step records."""
+  _check(_lib.pf_adam_flat_dev(_ptr(p), _ptr(g), c_int(dtype_code(g)), _ptr(m), _ptr(v), _ptr(mask),
+                               c_int64(p.numel()), c_int64(int(n_decay)), c_float(wd), c_float(g_scale), _ptr(hp),
+                               c_float(beta1), c_float(beta2), c_float(eps), _stream()), 'pf_adam_flat_dev')
+
+
+def momentum_flat_dev(p, g, acc, mask, n_decay: int, wd: float, g_scale: float, hp, momentum: float) -> None:
+  _check(_lib.pf_momentum_flat_dev(_ptr(p), _ptr(g), c_int(dtype_code(g)), _ptr(acc), _ptr(mask), c_int64(p.numel()),
+                                   c_int64(int(n_decay)), c_float(wd), c_float(g_scale), _ptr(hp),
+                                   c_float(momentum), _stream()), 'pf_momentum_flat_dev')
+
+
+def set_floats(dst, a: float, b: float = 0.0, c: float = 0.0, d: float = 0.0) -> None:
+  """dst[0..3] = (a, b, c, d) by a one-thread kernel whose arguments carry the values."""
+  assert dst.dtype == torch.float32 and dst.numel() >= 4
+  _check(_lib.pf_set_floats(_ptr(dst), c_float(a), c_float(b), c_float(c), c_float(d), _stream()), 'pf_set_floats')
 
 
 # ------------------------------------------------------------------------------------------------

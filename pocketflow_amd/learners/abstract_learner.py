@@ -38,6 +38,8 @@ flags.DEFINE_string('ckpt_format', 'npz', "checkpoint files written by the learn
                     "bundle, readable by the reference's tools); both are read transparently")
 flags.DEFINE_boolean('fuse_conv1x1', True, 'bf16 mode: apply BN/ReLU/fake-quant inside the consuming 1x1 convolutions '
                      '(pf_conv.hip) instead of writing the activated tensor to HBM')
+flags.DEFINE_boolean('enbl_step_graph', False, 'record the steady-state fine-tune step in a hipGraph after three eager steps and replay '
+                     'it (single process; pocketflow_amd/step_graph.py).  Same results, one host call per step')
 flags.DEFINE_integer('nb_iters_override', 0, 'if > 0, train() stops after this many iterations')
 flags.DEFINE_integer('nb_eval_batches_override', 0, 'if > 0, evaluate() uses this many batches')
 
@@ -162,6 +164,14 @@ class AbstractLearner(ABC):  # pylint: disable=too-many-instance-attributes
       before_finalize(graph)
     graph.finalize(separate_compute=separate_compute, seed=FLAGS.init_seed, requires_grad=requires_grad)
     return graph
+
+  def train_step(self, *args, **kwargs):
+    """One fine-tune iteration (`sess.run(train_op)` of the reference learners): the learner's `_train_step_eager`, or -- with
+    --enbl_step_graph, single process -- the same step replayed from a hipGraph (step_graph.py)."""
+    if args or kwargs or not FLAGS.enbl_step_graph or FLAGS.enbl_multi_gpu:
+      return self._train_step_eager(*args, **kwargs)
+    from pocketflow_amd import step_graph
+    return step_graph.of(self).step()
 
   def to_device(self, images, labels):
     x = to_device_images(images, self.graph)

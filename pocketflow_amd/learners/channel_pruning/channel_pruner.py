@@ -167,11 +167,16 @@ class ChannelPruner(object):  # pylint: disable=too-many-instance-attributes
     try:
       if features and FLAGS.cp_feature_bn == 'train':
         state = g.store.state.clone()
+        # a training forward has two more side effects than the BN moving statistics: a network with dropout (MobileNet) advances its
+        # (seed, step)-keyed mask counter -- the later fine-tune must draw the masks it would draw without this pass
+        steps = {k: n.dropout_step for k, n in getattr(g, 'nets', {}).items() if hasattr(n, 'dropout_step')}
         try:
           with torch.enable_grad(), g.as_default():
             self.logits = self.forward_train(to_device_images(images, g)).detach()
         finally:
           g.store.state.copy_(state)
+          for k, v in steps.items():
+            g.nets[k].dropout_step = v
         return OrderedDict((l, tuple(t.detach() if torch.is_tensor(t) else t for t in v)) for l, v in g.taps.items())
       with torch.no_grad(), g.as_default():
         self.logits = self.forward_eval(to_device_images(images, g))

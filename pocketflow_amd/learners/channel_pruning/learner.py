@@ -30,6 +30,7 @@ from pocketflow_amd.flags import FLAGS, flags
 from pocketflow_amd.learners.abstract_learner import AbstractLearner
 from pocketflow_amd.learners.channel_pruning.channel_pruner import ChannelPruner
 from pocketflow_amd.learners.distillation_helper import DistillationHelper
+from pocketflow_amd.learners import teacher_ahead
 from pocketflow_amd.optim import FlatOptimizer
 from pocketflow_amd.rl_agents.ddpg.agent import Agent as DdpgAgent
 from pocketflow_amd.utils import checkpoint
@@ -96,6 +97,7 @@ class ChannelPrunedLearner(AbstractLearner):  # pylint: disable=too-many-instanc
 
   def create_pruner(self):
     nb = FLAGS.cp_nb_batches
+    teacher_ahead.drop(self)                       # a batch a fine-tune step prefetched belongs to the iterator's previous pass
     batches = [self.iter_train.get_next() for _ in range(nb)]
     self.iter_train.reset()
     self.pruner = ChannelPruner(self.graph, self.forward_eval, batches, self.sm_writer, lbound=self.lbound,
@@ -271,6 +273,8 @@ class ChannelPrunedLearner(AbstractLearner):  # pylint: disable=too-many-instanc
     masks, choose the optimiser (Adam(cp_lrn_rate_ft) for a fine-tune, the Momentum schedule for a re-train) with
     fresh slots and step 0.  `fake_pruning_dict`: use these keep-masks instead of the pruner's (parity tests)."""
     self.restore_vars(path)                               # every rank starts from the pruned checkpoint
+    from pocketflow_amd import step_graph
+    step_graph.invalidate(self)                           # new masks, new optimiser: a recorded step is void
     if fake_pruning_dict is not None:
       class _Dict(object):
         pass
@@ -296,14 +300,14 @@ class ChannelPrunedLearner(AbstractLearner):  # pylint: disable=too-many-instanc
     self.__train_pruned_model(finetune=finetune)
     log.info('fintuning time cost: {}s'.format(timer() - start))
 
-  def train_step(self):
+  def _train_step_eager(self):
     g = self.graph
     g.store.sync_compute()
-    images, labels = self.iter_train.get_next()
-    x, y = self.to_device(images, labels)
+    ahead, x, y, logits_dst = teacher_ahead.next_batch(self)   # batch (+ teacher logits issued by the previous step on the side stream)
     g.begin_step()
     with g.as_default():
-      logits_dst = self.learner_dst.calc_logits(None, x) if FLAGS.enbl_dst else None
+      if FLAGS.enbl_dst and logits_dst is None:
+        logits_dst = self.learner_dst.calc_logits(None, x)
       logits = self.forward_train(x)
       loss, metrics = self.calc_loss(y, logits, self.trainable_vars)
       if FLAGS.enbl_dst:
@@ -314,6 +318,8 @@ class ChannelPrunedLearner(AbstractLearner):  # pylint: disable=too-many-instanc
     self.optimizer.compute_gradients()
     self.optimizer.apply_gradients(lr)
     self.global_step += 1
+    if ahead is not None:
+      ahead.issue()                                 # next batch's teacher forward, beside what the main stream still has queued
     return lr, loss, metrics
 
   def __train_pruned_model(self, finetune=False):

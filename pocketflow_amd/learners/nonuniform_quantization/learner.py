@@ -82,15 +82,17 @@ class NonUniformQuantLearner(AbstractLearner):
     bit_optimizer = BitOptimizer(self.dataset_name, self.weights, self.statistics, self.bit_placeholders, self.ops,
                                  (None, None), self, self, None, None, self.auto_barrier, mpi_comm=self.mpi_comm)
     self.optimal_w_bit_list, self.optimal_a_bit_list = bit_optimizer.run()
+    from pocketflow_amd import step_graph
+    self.nonuni_quant.on_change = lambda: step_graph.invalidate(self)
     self.nonuni_quant.feed_bits(self.optimal_w_bit_list, self.optimal_a_bit_list)
     self.auto_barrier()
 
   # ---------------------------------------------------------------------------------------------
-  def train_step(self, optimizer=None):
+  def _train_step_eager(self, optimizer=None):
     """ops['train'] (Adam) or, with `optimizer=self.optimizer_fintune`, ops['rl_fintune'] (SGD) of the reference."""
     optimizer = optimizer or self.optimizer
     g = self.graph
-    ahead, x, y, logits_dst = teacher_ahead.next_batch(self)   # opt-in PF_TEACHER_AHEAD: batch + teacher logits issued by the previous step
+    ahead, x, y, logits_dst = teacher_ahead.next_batch(self)   # batch + teacher logits issued by the previous step on the side stream (PF_TEACHER_AHEAD=0: in line)
     g.begin_step()
     self.nonuni_quant.quantize_weights()
     with g.as_default():
@@ -149,7 +151,7 @@ class NonUniformQuantLearner(AbstractLearner):
     """layerwise_tune_ops[n] + layerwise_diff[n] under a bit-width feed (nuq learner.py:383-385)."""
     from pocketflow_amd.learners.layerwise import LayerwiseTuner, layers_of_vars
     self.nonuni_quant.feed_bits(w_bits, a_bits)
-    images, __ = self.iter_train.get_next()
+    images = teacher_ahead.next_images(self)             # the batch a previous step prefetched, if any: same data order either way
     if getattr(self, '_layer_tuner', None) is None:
       layers = layers_of_vars(self.graph, self.forward_eval, images, [op.var for op in self.nonuni_quant.matmul_ops])
       self._layer_tuner = LayerwiseTuner(self.graph, self.forward_train, layers)

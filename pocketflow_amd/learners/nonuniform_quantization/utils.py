@@ -106,6 +106,8 @@ class NonUniformQuantization:
     store = self.graph.store
     quant = {id(op.var): int(b) for op, b in zip(self.matmul_ops, w_bits)}
     bits = [quant.get(id(v), 0) for v in self._all_vars]
+    if (bits != self._bits or any(op.bits != int(b) for op, b in zip(self.activation_ops, a_bits))) and getattr(self, 'on_change', None):
+      self.on_change()                                 # (a step recorded in a hipGraph carries the widths by value: step_graph.py)
     if bits != self._bits:
       for v, b in zip(self._all_vars, bits):
         if b > 0 and (2 ** b) * self.n_bucket_of(v) > self.cluster_vars[id(v)].numel:

@@ -1,4 +1,6 @@
-"""Teacher forward of the NEXT batch on a second HIP stream (opt-in: PF_TEACHER_AHEAD=1; round-4 experiment, off by default).
+"""Teacher forward of the NEXT batch on a second HIP stream (default for the distillation learners since round 4; PF_TEACHER_AHEAD=0
+switches it off).  Measured in one box (profiles/r04_first_call_ab.txt): ResNet-50 UQ w8/a8 + distillation at B = 256, 9 735 -> 10 379
+images/s; NUQ 4-bit 9 716 -> 10 382; the distillation / bf16 parity tests pass with it.
 
 The distillation teacher is frozen: its logits for a batch depend on nothing the fine-tune step changes
 (learners/distillation_helper.py:62-64 of the reference builds it under `tf.stop_gradient`).  The step therefore does not have to
@@ -30,7 +32,7 @@ from pocketflow_amd import profiling
 
 
 def enabled() -> bool:
-  return os.environ.get('PF_TEACHER_AHEAD', '0') not in ('', '0')
+  return os.environ.get('PF_TEACHER_AHEAD', '1') not in ('', '0')
 
 
 class CudaStreams(object):
@@ -72,6 +74,15 @@ class InlineStreams(object):
     pass
 
 
+def fetch_raw(learner):
+  """The next (images, labels) of the training data in iterator order: batches that were drawn but not consumed (a suspended
+  step graph hands its look-ahead batch back) come first."""
+  back = getattr(learner, '_unget', None)
+  if back:
+    return back.pop(0)
+  return learner.iter_train.get_next()
+
+
 class TeacherAhead(object):
   def __init__(self, learner, streams):
     self.learner, self.streams, self.pending = learner, streams, None
@@ -80,36 +91,52 @@ class TeacherAhead(object):
   def issue(self):
     """Fetch batch k+1, upload it and run the teacher over it -- all on the side stream."""
     lrn, st = self.learner, self.streams
+    teacher = teacher_of(lrn)
     with st.on_side(), profiling.suspended():
       # the iterator itself may enqueue device work (pinned upload + resize kernel of the TFRecord reader run on the CURRENT stream):
       # it has to be the side stream, or the teacher would read a batch the main stream has not finished writing
-      images, labels = lrn.iter_train.get_next()
+      images, labels = fetch_raw(lrn)
       x, y = lrn.to_device(images, labels)
-      logits = lrn.helper_dst.calc_logits(None, x)
+      logits = teacher.calc_logits(None, x)
       ev = st.record()
-    for t in (x, y, logits):
+    for t in (images, x, y, logits):
       st.hand_to_main(t)
-    self.pending = (x, y, logits, ev)
+    self.pending = (x, y, logits, ev, images)
     self.n_issued += 1
 
   def take(self):
-    x, y, logits, ev = self.pending
+    x, y, logits, ev, __ = self.pending
     self.pending = None
-    self.streams.main_waits(ev)
+    if ev is not None:
+      self.streams.main_waits(ev)
     self.n_taken += 1
     return x, y, logits
+
+  def take_images(self):
+    """The prefetched batch as the iterator delivered it (for a consumer of the training iterator other than train_step: it must see
+    the batch train_step would have seen, or the data order differs from the run without this helper)."""
+    images, ev = self.pending[4], self.pending[3]
+    self.pending = None
+    self.streams.main_waits(ev)
+    return images
 
   def drop(self):
     """Forget the prefetched batch (the data iterator was reset: the next step starts from the iterator again)."""
     if self.pending is not None:
-      self.streams.main_waits(self.pending[3])       # nothing of it may still be running when its memory is released
+      if self.pending[3] is not None:
+        self.streams.main_waits(self.pending[3])     # nothing of it may still be running when its memory is released
       self.pending = None
 
 
+def teacher_of(learner):
+  """The learner's DistillationHelper (`helper_dst`; the channel-pruning learner calls it `learner_dst`, as the reference does), or None."""
+  return getattr(learner, 'helper_dst', None) or getattr(learner, 'learner_dst', None)
+
+
 def make(learner):
-  """A TeacherAhead for `learner`, or None: opt-in, distillation only, and a HIP device (or PF_TEACHER_AHEAD=inline: the
-  in-order stand-in for the CPU tests)."""
-  if not enabled() or not getattr(learner, 'helper_dst', None):
+  """A TeacherAhead for `learner`, or None: distillation only, and a HIP device (or PF_TEACHER_AHEAD=inline: the in-order stand-in
+  for the CPU tests)."""
+  if not enabled() or teacher_of(learner) is None:
     return None
   dev = learner.device
   if os.environ.get('PF_TEACHER_AHEAD') == 'inline':
@@ -128,10 +155,30 @@ def of(learner):
 
 def next_batch(learner):
   """(helper, x, y, teacher logits or None) for the step that starts now: what the previous step issued ahead, or -- first step,
-  helper off -- the next batch of the iterator with the teacher still to run in line."""
+  helper off -- the next batch of the iterator with the teacher still to run in line.  A step that is being recorded into / replayed
+  from a hipGraph (step_graph.py) gets the graph's static buffers instead."""
+  static = getattr(learner, '_static_batch', None)
+  if static is not None:
+    return (None,) + tuple(static)
   ahead = of(learner)
   if ahead is not None and ahead.pending is not None:
     return (ahead,) + ahead.take()
-  images, labels = learner.iter_train.get_next()
+  images, labels = fetch_raw(learner)
   x, y = learner.to_device(images, labels)
   return ahead, x, y, None
+
+
+def next_images(learner):
+  """iter_train.get_next()[0] for every consumer of the training iterator that is not train_step (layer-wise tuning): the batch a
+  previous step prefetched comes first."""
+  ahead = of(learner)
+  if ahead is not None and ahead.pending is not None and ahead.pending[4] is not None:
+    return ahead.take_images()
+  return fetch_raw(learner)[0]
+
+
+def drop(learner):
+  """Forget the prefetched batch, if any: call where the training iterator is reset or re-built."""
+  ahead = getattr(learner, '_teacher_ahead', None)
+  if ahead is not None:
+    ahead.drop()

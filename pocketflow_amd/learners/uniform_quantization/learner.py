@@ -17,6 +17,7 @@ import torch
 from pocketflow_amd.flags import FLAGS, flags
 from pocketflow_amd.learners.abstract_learner import AbstractLearner
 from pocketflow_amd.learners import teacher_ahead
+from pocketflow_amd import step_graph
 from pocketflow_amd.learners.distillation_helper import DistillationHelper
 from pocketflow_amd.learners.uniform_quantization.bit_optimizer import BitOptimizer
 from pocketflow_amd.learners.uniform_quantization.utils import UniformQuantization
@@ -93,10 +94,10 @@ class UniformQuantLearner(AbstractLearner):
     self.auto_barrier()
 
   # ---------------------------------------------------------------------------------------------
-  def train_step(self):
+  def _train_step_eager(self):
     """ops['train'] of the reference, one iteration."""
     g = self.graph
-    ahead, x, y, logits_dst = teacher_ahead.next_batch(self)   # opt-in PF_TEACHER_AHEAD: batch + teacher logits issued by the previous step
+    ahead, x, y, logits_dst = teacher_ahead.next_batch(self)   # batch + teacher logits issued by the previous step on the side stream (PF_TEACHER_AHEAD=0: in line)
     g.begin_step()
     self.uni_quant.quantize_weights()
     with g.as_default():
@@ -125,6 +126,7 @@ class UniformQuantLearner(AbstractLearner):
     if key != getattr(self, '_fed_bits', None):
       self.uni_quant.feed_bits(*key)
       self._fed_bits = key
+      step_graph.invalidate(self)                    # a recorded step carries the bit widths by value
 
   def __op_init(self):
     """ops['init'] = tf.global_variables_initializer(): fresh variables, empty Adam slots, step 0."""
@@ -154,7 +156,7 @@ class UniformQuantLearner(AbstractLearner):
     """layerwise_tune_ops[n] + layerwise_diff[n] under a bit-width feed (uq utils.py:136-161)."""
     from pocketflow_amd.learners.layerwise import LayerwiseTuner, layers_of_vars
     self.__feed(w_bits, a_bits)
-    images, __ = self.iter_train.get_next()
+    images = teacher_ahead.next_images(self)             # the batch a previous step prefetched, if any: same data order either way
     if getattr(self, '_layer_tuner', None) is None:
       layers = layers_of_vars(self.graph, self.forward_eval, images, [op.var for op in self.uni_quant.matmul_ops])
       self._layer_tuner = LayerwiseTuner(self.graph, self.forward_train, layers)

@@ -21,6 +21,7 @@ from pocketflow_amd import hip
 from pocketflow_amd.flags import FLAGS, flags
 from pocketflow_amd.learners.abstract_learner import AbstractLearner
 from pocketflow_amd.learners.distillation_helper import DistillationHelper
+from pocketflow_amd.learners import teacher_ahead
 from pocketflow_amd.learners.weight_sparsification.pr_optimizer import PROptimizer
 from pocketflow_amd.learners.weight_sparsification.utils import get_maskable_vars
 from pocketflow_amd.optim import FlatOptimizer
@@ -74,15 +75,15 @@ class WeightSparseLearner(AbstractLearner):  # pylint: disable=too-many-instance
     self.__build_eval()
 
   # ---------------------------------------------------------------------------------------------
-  def train_step(self):
+  def _train_step_eager(self):
     """`sess.run(train_op)`: fwd, loss, bwd, [all-reduce], grad*mask + Momentum (one fused launch)."""
     g = self.graph
     g.store.sync_compute()
-    images, labels = self.iter_train.get_next()
-    x, y = self.to_device(images, labels)
+    ahead, x, y, logits_dst = teacher_ahead.next_batch(self)   # batch (+ teacher logits issued by the previous step on the side stream)
     g.begin_step()
     with g.as_default():
-      logits_dst = self.helper_dst.calc_logits(None, x) if FLAGS.enbl_dst else None
+      if FLAGS.enbl_dst and logits_dst is None:
+        logits_dst = self.helper_dst.calc_logits(None, x)
       logits = self.forward_train(x)
       loss, metrics = self.calc_loss(y, logits, self.trainable_vars)
       if FLAGS.enbl_dst:
@@ -93,6 +94,8 @@ class WeightSparseLearner(AbstractLearner):  # pylint: disable=too-many-instance
     self.optimizer.compute_gradients()
     self.optimizer.apply_gradients(lr)
     self.global_step += 1
+    if ahead is not None:
+      ahead.issue()                                 # next batch's teacher forward, beside what the main stream still has queued
     return lr, loss, metrics
 
   def prune_step(self):

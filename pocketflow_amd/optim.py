@@ -38,6 +38,27 @@ class FlatOptimizer(object):
     self.g_scale = 1.0
     self.w_grad_src: Optional[torch.Tensor] = None  # set by the distributed wrapper: reduced gradients (staging)
     self.o_grad_src: Optional[torch.Tensor] = None
+    # captured steps (step_graph.py): per-step scalars in device memory, hp = [alpha_t (Adam), lr, 0, 0]
+    self.hp: Optional[torch.Tensor] = None
+    self.hyper_external = False
+
+  def enable_device_hyper(self) -> None:
+    """From now on the update kernels read the learning rate (Adam: alpha_t) from device memory, written by `feed_hyper` before
+    every step: what a step recorded in a hipGraph needs (kernel arguments passed by value are frozen at capture).  The values are
+    the float32 numbers the by-value path computes -- bit-identical updates."""
+    if self.hp is None:
+      self.hp = torch.zeros(4, dtype=torch.float32, device=self.store.device)
+
+  def feed_hyper(self, lrn_rate: float) -> None:
+    """Write this step's scalars (one tiny launch; values travel as kernel arguments) and advance the beta powers."""
+    one = np.float32(1.0)
+    alpha_t = 0.0
+    if self.kind == 'adam':
+      # TF ApplyAdam, float32, in the evaluation order of pf_adam_flat: (lr * sqrt(1 - b2^t)) / (1 - b1^t)
+      alpha_t = float(np.float32(np.float32(lrn_rate) * np.sqrt(one - np.float32(self.beta2_power))) / (one - np.float32(self.beta1_power)))
+      self.beta1_power = np.float32(self.beta1_power * np.float32(self.beta1))
+      self.beta2_power = np.float32(self.beta2_power * np.float32(self.beta2))
+    hip.set_floats(self.hp, alpha_t, float(lrn_rate))
 
   def state_tensors(self) -> List[torch.Tensor]:
     return self.slots_w + self.slots_o
@@ -66,6 +87,28 @@ class FlatOptimizer(object):
     wd = float(self.weight_decay)
     w_grad = self.w_grad_src if self.w_grad_src is not None else st.w_grad
     o_grad = self.o_grad_src if self.o_grad_src is not None else st.o_grad
+    if self.hp is not None:
+      # device-scalar mode.  `hyper_external`: a StepGraph drives this optimiser -- it feeds before every replay, and while the
+      # step is being recorded nothing must be fed (a capture executes nothing)
+      if not self.hyper_external:
+        self.feed_hyper(lrn_rate)
+      if self.kind == 'adam':
+        if st.w_size:
+          hip.adam_flat_dev(st.w_master, w_grad, self.slots_w[0], self.slots_w[1], self.w_mask, st.w_decay, wd, self.g_scale,
+                            self.hp, self.beta1, self.beta2, self.epsilon)
+        if st.o_size:
+          hip.adam_flat_dev(st.o_master, o_grad, self.slots_o[0], self.slots_o[1], self.o_mask, st.o_decay, wd, self.g_scale,
+                            self.hp, self.beta1, self.beta2, self.epsilon)
+      else:
+        if st.w_size:
+          hip.momentum_flat_dev(st.w_master, w_grad, self.slots_w[0], self.w_mask, st.w_decay, wd, self.g_scale, self.hp,
+                                self.momentum)
+        if st.o_size:
+          hip.momentum_flat_dev(st.o_master, o_grad, self.slots_o[0], self.o_mask, st.o_decay, wd, self.g_scale, self.hp,
+                                self.momentum)
+      st.w_t_fresh = False
+      st.zero_grad()
+      return
     if self.kind == 'adam':
       b1p, b2p = float(self.beta1_power), float(self.beta2_power)
       if st.w_size:

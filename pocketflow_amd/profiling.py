@@ -13,7 +13,15 @@ _enabled: Dict[str, List[Tuple[torch.cuda.Event, torch.cuda.Event, float]]] = {}
 
 
 def enable(name: str) -> None:
+  global _paused
+  _paused = False
   _enabled[name] = []
+
+
+def pause() -> None:
+  """Stop recording (what was recorded stays for `summary`)."""
+  global _paused
+  _paused = True
 
 
 def disable_all() -> None:
@@ -58,6 +66,7 @@ class _Timed(object):
 
 _NOOP = _Noop()
 _suspended = 0
+_paused = False
 
 
 class suspended(object):
@@ -77,7 +86,7 @@ class suspended(object):
 
 def region(name: str, work: float = 0.0):
   rec = _enabled.get(name)
-  return _NOOP if (rec is None or _suspended) else _Timed(rec, work)
+  return _NOOP if (rec is None or _suspended or _paused) else _Timed(rec, work)
 
 
 def summary(name: str):

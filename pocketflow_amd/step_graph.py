@@ -1,0 +1,330 @@
+"""The steady-state fine-tune step recorded ONCE in a hipGraph and replayed (`--enbl_step_graph`; single process).
+
+Why.  A step of this engine is 300-700 kernel launches issued from Python: 10 ms of host time for ResNet-50 (the GPU needs 24 ms:
+fine), 4.4 ms for ResNet-20 @ CIFAR-10 (the GPU needs less: the step is HOST-bound, profiles/r03_host_overhead_c1.txt) and 15 ms for
+MobileNet-v1.  The reference has the same structure one level up: `sess.run(train_op)` replays a graph TensorFlow compiled once
+(learners/uniform_quantization/learner.py:172-189), its learning rate and bit widths are tensors of that graph.  Here the shapes are
+static, every parameter / gradient / statistic lives in flat buffers that never move, and the kernels take a stream argument -- so
+the whole step (weight fake-quant, forward, losses, backward with straight-through estimators, fused optimiser update) can be
+captured from the eager code as it is and replayed with ONE host call.
+
+What changes per step and therefore cannot be a by-value kernel argument:
+  * the batch                       -> static input buffers, filled before the replay (device-to-device copies in stream order);
+  * the learning rate, Adam's bias correction
+                                    -> `FlatOptimizer.enable_device_hyper()`: the update kernels read them from device memory
+                                       (pf_adam_flat_dev / pf_momentum_flat_dev), `feed_hyper` writes them before the replay;
+  * anything a network draws per step on the host (MobileNet's dropout mask)
+                                    -> `graph.step_feeders`: callables run before every replay (stream-ordered copies into the
+                                       buffer the captured launch reads).
+The frozen teacher's forward pass over the NEXT batch (learners/teacher_ahead.py) is part of the graph as a forked branch: it
+runs on a second stream beside the student's step and joins before the tail, where `next` becomes `current` (three device copies).
+
+Eager steps and graph steps can alternate (`suspend()` / `resume()`): both draw from the same iterator in the same order and hand
+the prefetched batch over through `TeacherAhead.pending`.  Whatever goes wrong while recording (an op that synchronises, a library
+call that cannot be captured) is reported ONCE and the learner stays on the eager path -- the result of a step never depends on
+the mode (tests/test_learner_gpu.py compares them bit for bit).
+"""
+from __future__ import annotations
+
+import contextlib
+import logging
+import os
+
+import torch
+
+from pocketflow_amd import profiling
+from pocketflow_amd.flags import FLAGS
+from pocketflow_amd.learners import teacher_ahead
+
+log = logging.getLogger('pocketflow_amd')
+
+
+class CudaBackend(object):
+  """torch.cuda.CUDAGraph is a hipGraph on ROCm."""
+
+  def __init__(self, device):
+    self.device = device
+    self.graph = torch.cuda.CUDAGraph()
+    self.side = torch.cuda.Stream(device=device)
+    self._joined = True
+
+  def capture(self, body):
+    torch.cuda.synchronize(self.device)
+    with torch.cuda.graph(self.graph):
+      out = body(self)
+    torch.cuda.synchronize(self.device)
+    return out
+
+  @contextlib.contextmanager
+  def fork(self):
+    """A branch of the graph: the side stream joins the capture by waiting for the capturing stream."""
+    self.side.wait_stream(torch.cuda.current_stream(self.device))
+    self._joined = False
+    with torch.cuda.stream(self.side):
+      yield
+
+  def join(self):
+    if not self._joined:
+      torch.cuda.current_stream(self.device).wait_stream(self.side)
+      self._joined = True
+
+  def replay(self):
+    self.graph.replay()
+    return None
+
+  def recover(self):
+    torch.cuda.synchronize(self.device)
+
+
+class InlineBackend(object):
+  """No graph (CPU emulation of the kernels in tests/): "recording" keeps the body, a "replay" executes it -- the control flow,
+  the static buffers, the feeders and the hand-over between the modes are the ones of the real backend."""
+
+  def __init__(self):
+    self.body = None
+
+  def capture(self, body):
+    self.body = body
+    return None
+
+  def fork(self):
+    return contextlib.nullcontext()
+
+  def join(self):
+    pass
+
+  def replay(self):
+    return self.body(self)
+
+  def recover(self):
+    pass
+
+
+def _step_attr(learner) -> str:
+  return 'ft_step' if hasattr(learner, 'ft_step') else 'global_step'
+
+
+def _with_lr(out, lr):
+  """The step's return value with this step's learning rate in it (UQ / NUQ: a dict with 'lr'; WS / CP: (lr, loss, metrics))."""
+  if isinstance(out, dict):
+    r = dict(out)
+    r['lr'] = lr
+    return r
+  return (lr,) + tuple(out[1:])
+
+
+class StepGraph(object):
+  WARM = 3          # eager steps before recording: allocator pools, MIOpen / rocBLAS handles and solver choices, launch attributes
+
+  def __init__(self, learner, backend):
+    self.learner, self.backend = learner, backend
+    self.state = 'warm'                     # warm -> ready | failed
+    self.n_eager = self.n_replays = 0
+    self.suspended = False
+    self.out = None
+    self.cur = self.nxt = None              # static (x, y, teacher logits) of the step / of the next step (distillation only)
+    self.nxt_raw = None                     # the iterator's (images, labels) behind `nxt` (handed back when the graph is suspended)
+    self.nxt_stale = False                  # `nxt` was consumed by a replay: draw the following batch before the next one
+    self.cur_raw = None                     # without a teacher: the batch already loaded into `cur` (not yet consumed by a replay)
+    self.error = None
+
+  # -- mode switches --------------------------------------------------------------------------------
+  def suspend(self):
+    """Following steps run eagerly (bench.py times a few steps kernel by kernel with HIP events; a search changes bit widths)."""
+    if self.state == 'ready' and not self.suspended:
+      self._hand_to_eager()
+    if self.state == 'ready':
+      self.learner.optimizer.hyper_external = False
+    self.suspended = True
+
+  def resume(self):
+    if self.suspended and self.state == 'ready':
+      self.learner.optimizer.hyper_external = True
+      self._load_current()
+    self.suspended = False
+
+  def invalidate(self):
+    """Something the recorded launches carry by value changed (bit widths, masks re-built, optimiser replaced): record again."""
+    if self.state == 'ready':
+      self.suspend()
+      self.learner.optimizer.hyper_external = False
+    if self.state != 'failed':
+      self.state, self.n_eager, self.suspended = 'warm', 0, False
+      self.out = self.cur = self.nxt = None
+      self.backend = type(self.backend)(self.learner.device) if isinstance(self.backend, CudaBackend) else InlineBackend()
+
+  # -- one step ---------------------------------------------------------------------------------------
+  def step(self):
+    lrn = self.learner
+    if self.state == 'failed' or self.suspended:
+      return lrn._train_step_eager()
+    if self.state == 'warm':
+      if self.n_eager < self.WARM:
+        self.n_eager += 1
+        return lrn._train_step_eager()
+      try:
+        self._record()
+      except Exception as e:        # pylint: disable=broad-except
+        self.error = e
+        self.state = 'failed'
+        lrn._static_batch = None
+        lrn.optimizer.hyper_external = False
+        lrn.graph.capturing = False
+        try:
+          self.backend.recover()
+          if self.cur is not None:
+            self._hand_to_eager()                          # the batches drawn for the static buffers stay first in line
+        except Exception as e2:     # pylint: disable=broad-except
+          log.warning('step graph: clean-up after the failed recording: %s', e2)
+        log.warning('step graph: recording failed (%s: %s) -- the learner stays on the eager path', type(e).__name__, e)
+        if os.environ.get('PF_STEP_GRAPH_STRICT'):
+          raise
+        return lrn._train_step_eager()
+    return self._replay()
+
+  # -- internals ---------------------------------------------------------------------------------------
+  def _fetch(self, keep_raw=False):
+    lrn = self.learner
+    raw = teacher_ahead.fetch_raw(lrn)
+    if keep_raw:
+      self.nxt_raw = raw
+    return lrn.to_device(*raw)
+
+  def _load_current(self):
+    """Fill the static buffers of the NEXT replay: distillation -> (current from what an eager step prefetched or from the iterator
+    with the teacher in line, next from the iterator); otherwise nothing (the batch is fetched right before each replay)."""
+    lrn = self.learner
+    if self.nxt is None:
+      return
+    ahead = teacher_ahead.of(lrn)
+    if ahead is not None and ahead.pending is not None:
+      x, y, logits = ahead.take()
+    else:
+      x, y = self._fetch()
+      logits = teacher_ahead.teacher_of(lrn).calc_logits(None, x)
+    for dst, src in zip(self.cur, (x, y, logits)):
+      dst.copy_(src)
+    x, y = self._fetch(keep_raw=True)
+    self.nxt[0].copy_(x)
+    self.nxt[1].copy_(y)
+    self.nxt_stale = False
+
+  def _hand_to_eager(self):
+    """The batch in `current` (its teacher logits are computed) is the next one in data order: the eager path takes it first."""
+    lrn = self.learner
+    if self.nxt is None:
+      if self.cur_raw is not None:                         # drawn, never consumed: back in front of the iterator
+        lrn.__dict__.setdefault('_unget', []).insert(0, self.cur_raw)
+        self.cur_raw = None
+      return
+    x, y, logits = (t.clone() for t in self.cur)
+    ahead = teacher_ahead.of(lrn)
+    if ahead is None:                                      # (PF_TEACHER_AHEAD=0 with distillation: a helper just for the hand-over)
+      ahead = lrn._teacher_ahead = teacher_ahead.TeacherAhead(lrn, teacher_ahead.InlineStreams())
+    if ahead.pending is not None:
+      ahead.drop()
+    ahead.pending = (x, y, logits, None, None)
+    # a `next` that no replay has consumed yet holds one more batch drawn from the iterator: back it goes, in front of the iterator
+    if not self.nxt_stale and self.nxt_raw is not None:
+      lrn.__dict__.setdefault('_unget', []).insert(0, self.nxt_raw)
+    self.nxt_raw = None
+
+  def _record(self):
+    lrn = self.learner
+    opt = lrn.optimizer
+    g = lrn.graph
+    teacher = teacher_ahead.teacher_of(lrn) if FLAGS.enbl_dst else None
+    # static inputs
+    ahead = teacher_ahead.of(lrn) if teacher is not None else None
+    if ahead is not None and ahead.pending is not None:
+      x, y, logits = ahead.take()
+    elif teacher is not None:
+      x, y = self._fetch()
+      logits = teacher.calc_logits(None, x)
+    else:
+      self.cur_raw = teacher_ahead.fetch_raw(lrn)            # no look-ahead without a teacher: this batch is the first replay's
+      x, y = lrn.to_device(*self.cur_raw)
+      logits = None
+    self.cur = (x.clone(), y.clone(), logits.clone() if logits is not None else None)
+    if teacher is not None:
+      nx, ny = self._fetch(keep_raw=True)
+      self.nxt = (nx.clone(), ny.clone(), torch.empty_like(self.cur[2]))
+    opt.enable_device_hyper()
+    opt.hyper_external = True
+    g.capturing = True
+    cur, nxt = self.cur, self.nxt
+
+    def body(be):
+      if nxt is not None:
+        with be.fork(), profiling.suspended():
+          nxt[2].copy_(teacher.calc_logits(None, nxt[0]))
+      lrn._static_batch = cur
+      try:
+        out = lrn._train_step_eager()
+      finally:
+        lrn._static_batch = None
+      if nxt is not None:
+        be.join()
+        for dst, src in zip(cur, nxt):
+          dst.copy_(src)
+      return out
+    step0 = getattr(lrn, _step_attr(lrn))
+    pow0 = (opt.beta1_power, opt.beta2_power)
+    try:
+      self.out = self.backend.capture(body)
+    finally:
+      g.capturing = False
+    # recording executed nothing on the device; undo the host-side bookkeeping of the recorded step
+    setattr(lrn, _step_attr(lrn), step0)
+    opt.beta1_power, opt.beta2_power = pow0
+    self.state = 'ready'
+    log.info('step graph: recorded the %s step (%s)', type(lrn).__name__, 'teacher forked on a side stream' if nxt is not None else 'single stream')
+
+  def _replay(self):
+    lrn = self.learner
+    attr = _step_attr(lrn)
+    step = getattr(lrn, attr)
+    lr = lrn.lrn_rate(step)
+    if self.nxt is None:
+      if self.cur_raw is not None:
+        self.cur_raw = None                                  # loaded when the step was recorded / resumed
+      else:
+        x, y = self._fetch()
+        self.cur[0].copy_(x)
+        self.cur[1].copy_(y)
+    elif self.nxt_stale:
+      x, y = self._fetch(keep_raw=True)
+      self.nxt[0].copy_(x)
+      self.nxt[1].copy_(y)
+    lrn.optimizer.feed_hyper(lr)
+    for feed in getattr(lrn.graph, 'step_feeders', []):
+      feed()
+    out = self.backend.replay()
+    if out is not None:                                    # in-line stand-in: the body ran and advanced the counter itself
+      self.out = out
+    else:
+      setattr(lrn, attr, step + 1)
+    self.n_replays += 1
+    self.nxt_stale = True                                  # the tail of the replay moved `next` into `current`
+    return _with_lr(self.out, lr)
+
+
+def of(learner) -> StepGraph:
+  sg = getattr(learner, '_step_graph', None)
+  if sg is None:
+    if os.environ.get('PF_STEP_GRAPH') == 'inline':
+      backend = InlineBackend()
+    elif torch.device(learner.device).type == 'cuda':
+      backend = CudaBackend(learner.device)
+    else:
+      backend = None
+    sg = learner._step_graph = StepGraph(learner, backend)
+    if backend is None:
+      sg.state = 'failed'                                  # no HIP device: eager
+  return sg
+
+
+def invalidate(learner) -> None:
+  sg = getattr(learner, '_step_graph', None)
+  if sg is not None:
+    sg.invalidate()

@@ -37,3 +37,32 @@ def _dirty_allocator(request):
       torch.cuda.synchronize()
       del small, mid, big
   yield
+
+
+def _tuning_reload():
+  """The kernel library reads its PF_* switches once (pf_tuning(), csrc/pf_api.hip): re-read them after an in-process change."""
+  mod = sys.modules.get('pocketflow_amd.hip')
+  if mod is not None:
+    mod.tuning_reload()
+
+
+@pytest.fixture
+def monkeypatch(monkeypatch):
+  """pytest's monkeypatch, plus: setenv / delenv of a PF_* switch make the kernel library re-read its switches, and so does the
+  teardown (after the environment is restored), so that no test leaves a stale decision behind."""
+  class _Patch(object):
+    def __getattr__(self, name):
+      return getattr(monkeypatch, name)
+
+    def setenv(self, name, value, *a, **kw):
+      monkeypatch.setenv(name, value, *a, **kw)
+      if name.startswith('PF_'):
+        _tuning_reload()
+
+    def delenv(self, name, *a, **kw):
+      monkeypatch.delenv(name, *a, **kw)
+      if name.startswith('PF_'):
+        _tuning_reload()
+  yield _Patch()
+  monkeypatch.undo()
+  _tuning_reload()

@@ -474,6 +474,21 @@ class FakeHipFull(FakeHip):
     vn += (ge * ge - vn) * (one - np.float32(beta2))
     pn -= (mn * alpha_t) / (np.sqrt(vn) + np.float32(eps))
 
+  def set_floats(self, dst, a, b=0.0, c=0.0, d=0.0):
+    dst[:4] = torch.tensor([a, b, c, d], dtype=torch.float32)
+
+  def adam_flat_dev(self, p, g, m, v, mask, n_decay, wd, g_scale, hp, beta1, beta2, eps):
+    ge, pn = self._eff_grad(p, g, mask, n_decay, wd, g_scale)
+    one = np.float32(1)
+    alpha_t = np.float32(hp[0].item())
+    mn, vn = m.numpy(), v.numpy()
+    mn += (ge - mn) * (one - np.float32(beta1))
+    vn += (ge * ge - vn) * (one - np.float32(beta2))
+    pn -= (mn * alpha_t) / (np.sqrt(vn) + np.float32(eps))
+
+  def momentum_flat_dev(self, p, g, acc, mask, n_decay, wd, g_scale, hp, momentum):
+    self.momentum_flat(p, g, acc, mask, n_decay, wd, g_scale, float(hp[1].item()), momentum)
+
   def momentum_flat(self, p, g, acc, mask, n_decay, wd, g_scale, lr, momentum):
     ge, pn = self._eff_grad(p, g, mask, n_decay, wd, g_scale)
     an = acc.numpy()

@@ -226,3 +226,154 @@ def test_bench_two_gpus_over_rccl(tmp_path):
   assert rec['n_gpus'] == 2 and mg['backend'] == 'nccl'
   assert mg['params_identical_across_ranks'] is True
   assert mg['buckets'] >= 2 and mg['buckets_launched_inside_backward'] > 0
+
+
+# =================================================================================================
+# the recorded step (pocketflow_amd/step_graph.py): a hipGraph replay must BE the launch-by-launch step
+# =================================================================================================
+
+def _collect_losses_each_step(lrn, n_steps, suspend_at, graph_mode):
+  from pocketflow_amd import step_graph
+  losses = []
+  for i in range(n_steps):
+    if graph_mode and i in suspend_at:
+      sg = step_graph.of(lrn)
+      sg.resume() if sg.suspended else sg.suspend()
+    o = lrn.train_step()
+    losses.append((o['loss'] if isinstance(o, dict) else o[1]).detach().clone())
+  return [float(l) for l in losses]
+
+
+def _assert_same_run(a, b, la, lb, what, exact=True):
+  sa, sb = a.graph.store, b.graph.store
+  worst = max(float((x - y).abs().max()) for x, y in ((sa.w_master, sb.w_master), (sa.o_master, sb.o_master), (sa.state, sb.state)))
+  print('   %s: losses eager %s | graph %s | max parameter difference %.3e' % (what, la[-3:], lb[-3:], worst))
+  if exact:
+    assert la == lb, (what, la, lb)
+    assert torch.equal(sa.w_master, sb.w_master) and torch.equal(sa.o_master, sb.o_master) and torch.equal(sa.state, sb.state), what
+  else:
+    assert all(abs(x - y) <= 1e-5 * max(1.0, abs(x)) for x, y in zip(la, lb)), (what, la, lb)
+    assert worst <= 1e-5, (what, worst)
+
+
+def test_step_graph_uq_resnet50_bf16_distillation_is_the_eager_step(tmp_path, monkeypatch):
+  """BASELINE configs[2] shrunk (ResNet-v2-50 @64, batch 8, UQ w8/a8 + distillation, bf16 fused path): 9 steps launch by launch
+  vs 3 eager + recording + replays with the graph suspended for steps 6-7.  The teacher's forward over the next batch is a forked
+  branch of the graph; Adam's alpha_t comes from device memory.  Same batches in the same order, deterministic kernels: the losses
+  and every parameter, Adam slot and BN moving statistic must be bit-identical."""
+  from pocketflow_amd.flags import FLAGS
+  from pocketflow_amd.nets.resnet_at_ilsvrc12 import ModelHelper
+  from pocketflow_amd.learners.uniform_quantization.learner import UniformQuantLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  from pocketflow_amd import step_graph
+  import pocketflow_amd.learners.distillation_helper  # noqa: F401
+  _setup(tmp_path, batch_size=8, batch_size_eval=8, uql_weight_bits=8, uql_activation_bits=8, enbl_dst=True, dst_eval_teacher=False,
+         save_path_dst=str(tmp_path / 'models_dst' / 'model.ckpt'), uql_save_quant_model_path=str(tmp_path / 'uql' / 'm.ckpt'),
+         resnet_size=50, nb_classes=1001, image_size=64, compute_dtype='bfloat16', synthetic_pool=5)
+  monkeypatch.setenv('PF_STEP_GRAPH_STRICT', '1')
+  made = []
+
+  def make():
+    mh = ModelHelper()
+    if not made:
+      create_synthetic_checkpoint(mh)
+    made.append(1)
+    return UniformQuantLearner(None, mh)
+  FLAGS.enbl_step_graph = False
+  a = make()
+  la = _collect_losses_each_step(a, 9, (), False)
+  FLAGS.enbl_step_graph = True
+  b = make()
+  lb = _collect_losses_each_step(b, 9, (6, 8), True)
+  sg = step_graph.of(b)
+  assert sg.state == 'ready' and sg.error is None and sg.n_replays == 9 - 3 - 2 and sg.nxt is not None
+  _assert_same_run(a, b, la, lb, 'ResNet-50 UQ bf16 + dst')
+  assert a.optimizer.slots_w[1].abs().sum() > 0 and torch.equal(a.optimizer.slots_w[1], b.optimizer.slots_w[1])
+
+
+def test_step_graph_ws_resnet20_is_the_eager_step(tmp_path, monkeypatch):
+  """BASELINE configs[1] (ResNet-20 @ CIFAR-10, WeightSparseLearner, bf16): no teacher -> single-stream graph; Momentum's learning
+  rate from device memory; a mask refresh between replays (masks are updated in place: the recording stays valid)."""
+  from pocketflow_amd.flags import FLAGS
+  from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
+  from pocketflow_amd.learners.weight_sparsification.learner import WeightSparseLearner
+  from pocketflow_amd import step_graph
+  _setup(tmp_path, batch_size=32, batch_size_eval=32, ws_prune_ratio=0.5, ws_prune_ratio_prtl='uniform',
+         ws_save_path=str(tmp_path / 'ws' / 'm.ckpt'), resnet_size=20, nb_classes=10, ws_mask_update_step=2,
+         nb_smpls_train=32 * 12, nb_epochs_rat=1.0 / 250, compute_dtype='bfloat16', synthetic_pool=5)
+  monkeypatch.setenv('PF_STEP_GRAPH_STRICT', '1')
+
+  def run(graph_mode):
+    FLAGS.enbl_step_graph = graph_mode
+    lrn = WeightSparseLearner(None, ModelHelper())
+    losses = []
+    for it in range(9):
+      losses.append(lrn.train_step()[1].detach().clone())
+      if it in (4, 6):
+        lrn.prune_step()
+    return lrn, [float(l) for l in losses]
+  a, la = run(False)
+  b, lb = run(True)
+  sg = step_graph.of(b)
+  assert sg.state == 'ready' and sg.error is None and sg.n_replays == 6 and sg.nxt is None
+  _assert_same_run(a, b, la, lb, 'ResNet-20 WS bf16')
+  assert torch.equal(a.masks, b.masks)
+
+
+def test_step_graph_cp_mobilenet_is_the_eager_step(tmp_path, monkeypatch):
+  """BASELINE configs[3] shrunk (MobileNet-v1 x0.5 @64, channel-pruned masked fine-tune + distillation, bf16): the dropout mask of
+  every step reaches the recorded launches through graph.step_feeders."""
+  from pocketflow_amd.flags import FLAGS
+  from pocketflow_amd import step_graph
+  import pocketflow_amd.learners.distillation_helper  # noqa: F401
+  from pocketflow_amd.nets.mobilenet_at_ilsvrc12 import ModelHelper
+  from pocketflow_amd.learners.channel_pruning.learner import ChannelPrunedLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  from pocketflow_amd.utils import checkpoint
+  _setup(tmp_path, batch_size=16, batch_size_eval=16, image_size=64, nb_classes=101, mobilenet_depth_mult=0.5, enbl_dst=True,
+         dst_eval_teacher=False, save_path_dst=str(tmp_path / 'models_dst' / 'model.ckpt'), compute_dtype='bfloat16', synthetic_pool=5,
+         cp_channel_pruned_path=str(tmp_path / 'models' / 'pruned_model.ckpt'), cp_best_path=str(tmp_path / 'models' / 'best_model.ckpt'),
+         cp_original_path=str(tmp_path / 'models' / 'original_model.ckpt'), cp_lrn_rate_ft=1e-4)
+  monkeypatch.setenv('PF_STEP_GRAPH_STRICT', '1')
+  made = []
+
+  def make():
+    mh = ModelHelper()
+    if not made:
+      create_synthetic_checkpoint(mh)
+    made.append(1)
+    lrn = ChannelPrunedLearner(None, mh)
+    rng = np.random.RandomState(11)
+    convs = [op for op in lrn.graph.matmul_ops if op.var.kind == 'conv']
+    vals = lrn.graph.store.export_numpy()
+    fake = {}
+    for i, op in enumerate(convs):
+      kh, kw, cin, cout = op.var.ref_shape
+      keep_in = np.ones(cin, bool) if i == 0 else rng.rand(cin) < 0.5
+      keep_out = np.ones(cout, bool) if i == len(convs) - 1 else rng.rand(cout) < 0.5
+      keep_in[0] = keep_out[0] = True
+      fake[op.name] = [keep_in.tolist(), keep_out.tolist()]
+      m = np.zeros(op.var.ref_shape, np.float32)
+      m[:, :, keep_in, :] = 1.0
+      m[:, :, :, ~keep_out] = 0.0
+      vals[op.var.name] = vals[op.var.name] * m
+    pruned = checkpoint.save(vals, FLAGS.cp_channel_pruned_path, None)
+    lrn.setup_finetune(pruned, finetune=True, fake_pruning_dict=fake)
+    net = lrn.graph.nets['mobilenet']
+    net.keep = 0.8                                          # (the default 0.999 leaves almost every mask all-ones)
+    return lrn
+  FLAGS.enbl_step_graph = False
+  a = make()
+  la = _collect_losses_each_step(a, 8, (), False)
+  FLAGS.enbl_step_graph = True
+  b = make()
+  lb = _collect_losses_each_step(b, 8, (), True)
+  sg = step_graph.of(b)
+  assert sg.state == 'ready' and sg.error is None and sg.n_replays == 5
+  assert a.graph.nets['mobilenet'].dropout_step == b.graph.nets['mobilenet'].dropout_step == 8
+  _assert_same_run(a, b, la, lb, 'MobileNet-v1 CP bf16 + dst')
+  for op in b.graph.matmul_ops:
+    if op.name in b.fake_pruning_dict and op.var.kind == 'conv':
+      keep_in, keep_out = [np.asarray(k, bool) for k in b.fake_pruning_dict[op.name]]
+      w = op.var.to_ref(op.var.master.detach().cpu().numpy())
+      assert np.all(w[:, :, ~keep_in, :] == 0) and np.all(w[:, :, :, ~keep_out] == 0), op.name

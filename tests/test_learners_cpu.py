@@ -878,7 +878,7 @@ def test_int_export_of_a_uq_learner_on_cpu(cpu_learners, model, use_buckets, buc
 
 
 def test_teacher_ahead_gives_the_same_steps_on_cpu(cpu_learners, monkeypatch):
-  """learners/teacher_ahead.py (opt-in PF_TEACHER_AHEAD): the teacher's forward pass over batch k+1 issued at the end of step k.
+  """learners/teacher_ahead.py (PF_TEACHER_AHEAD, default on for HIP devices): the teacher's forward pass over batch k+1 issued at the end of step k.
   With the in-order stream stand-in the control flow runs on the CPU emulation: same batches in the same order, the same teacher
   logits, bit-identical losses and weights as the in-line teacher; one batch is always in flight after a step."""
   FLAGS, fake, tmp = cpu_learners
@@ -914,5 +914,151 @@ def test_teacher_ahead_gives_the_same_steps_on_cpu(cpu_learners, monkeypatch):
   a, b = base.graph.store.export_numpy(), ahead.graph.store.export_numpy()
   assert all(np.array_equal(a[k], b[k]) for k in a)
   assert ahead.iter_train.idx == base.iter_train.idx + 1                      # exactly one batch prefetched
+  # another consumer of the training iterator (layer-wise tuning) gets the prefetched batch first: same data order as without the helper
+  nxt = teacher_ahead.next_images(ahead)
+  assert h.pending is None and torch.equal(torch.as_tensor(nxt), torch.as_tensor(base.iter_train.batches[base.iter_train.idx % 3][0]))
+  assert torch.equal(torch.as_tensor(teacher_ahead.next_images(ahead)), torch.as_tensor(base.iter_train.batches[(base.iter_train.idx + 1) % 3][0]))
+  ahead.train_step()
   h.drop()
   assert h.pending is None
+
+
+def _run_steps(make, n, graph_mode, monkeypatch, suspend_at=(), FLAGS=None):
+  """n train steps of a fresh learner, eager or through step_graph's in-line stand-in; returns (learner, per-step losses)."""
+  from pocketflow_amd import step_graph
+  if graph_mode:
+    monkeypatch.setenv('PF_STEP_GRAPH', 'inline')
+    monkeypatch.setenv('PF_STEP_GRAPH_STRICT', '1')
+  else:
+    monkeypatch.delenv('PF_STEP_GRAPH', raising=False)
+  FLAGS.enbl_step_graph = bool(graph_mode)
+  lrn = make()
+  losses = []
+  for i in range(n):
+    if graph_mode and i in suspend_at:
+      sg = step_graph.of(lrn)
+      sg.suspend() if not sg.suspended else sg.resume()
+    o = lrn.train_step()
+    loss = o['loss'] if isinstance(o, dict) else o[1]
+    losses.append(float(loss.detach()))
+  return lrn, losses
+
+
+@pytest.mark.parametrize('ahead', ['inline', '0'])
+def test_step_graph_control_flow_uq_distillation_on_cpu(cpu_learners, monkeypatch, ahead):
+  """pocketflow_amd/step_graph.py with the in-line stand-in for the hipGraph (the body is executed at every "replay"): static
+  batch buffers, the teacher branch over the NEXT batch, the learning rate and Adam's bias correction fed through device memory
+  (pf_adam_flat_dev), the hand-over of the prefetched batch between eager and recorded steps in both directions.  The steps must
+  be the eager steps: same batches in the same order, bit-identical losses and weights, with and without the eager teacher-ahead
+  helper and with the graph suspended for two steps in the middle."""
+  FLAGS, fake, tmp = cpu_learners
+  from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
+  from pocketflow_amd.learners.uniform_quantization.learner import UniformQuantLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  from pocketflow_amd import step_graph
+  FLAGS.batch_size, FLAGS.batch_size_eval, FLAGS.nb_classes, FLAGS.resnet_size = 8, 8, 10, 20
+  FLAGS.uql_weight_bits, FLAGS.uql_activation_bits, FLAGS.uql_use_buckets, FLAGS.uql_bucket_type = 8, 8, False, 'channel'
+  FLAGS.enbl_dst, FLAGS.dst_eval_teacher = True, False
+  FLAGS.uql_save_quant_model_path = str(tmp / 'uql' / 'm.ckpt')
+  FLAGS.synthetic_pool = 5
+  monkeypatch.setenv('PF_TEACHER_AHEAD', ahead)
+
+  def make():
+    mh = ModelHelper()
+    create_synthetic_checkpoint(mh)
+    return UniformQuantLearner(None, mh)
+  base, l0 = _run_steps(make, 11, False, monkeypatch, FLAGS=FLAGS)
+  lrn, l1 = _run_steps(make, 11, True, monkeypatch, suspend_at=(6, 8), FLAGS=FLAGS)
+  sg = step_graph.of(lrn)
+  assert sg.state == 'ready' and sg.n_replays == 11 - 3 - 2 and sg.error is None
+  assert lrn.optimizer.hp is not None and lrn.ft_step == base.ft_step == 11
+  assert l0 == l1, (l0, l1)
+  a, b = base.graph.store.export_numpy(), lrn.graph.store.export_numpy()
+  assert all(np.array_equal(a[k], b[k]) for k in a)
+  assert lrn.optimizer.beta1_power == base.optimizer.beta1_power and lrn.optimizer.beta2_power == base.optimizer.beta2_power
+  # a change of bit widths voids the recording; the learner warms up and records again
+  lrn._UniformQuantLearner__feed([4] * len(lrn.optimal_w_bit_list), lrn.optimal_a_bit_list)
+  assert step_graph.of(lrn).state == 'warm'
+  for _ in range(5):
+    lrn.train_step()
+  assert step_graph.of(lrn).state == 'ready' and step_graph.of(lrn).n_replays == 6 + 2
+
+
+def test_step_graph_control_flow_ws_on_cpu(cpu_learners, monkeypatch):
+  """... a learner without a teacher (no look-ahead batch), Momentum with the learning rate in device memory
+  (pf_momentum_flat_dev), a mask refresh between recorded steps (the masks are updated in place: the recording stays valid)."""
+  FLAGS, fake, tmp = cpu_learners
+  from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
+  from pocketflow_amd.learners.weight_sparsification.learner import WeightSparseLearner
+  from pocketflow_amd import step_graph
+  FLAGS.batch_size, FLAGS.batch_size_eval, FLAGS.nb_classes, FLAGS.resnet_size = 8, 8, 10, 20
+  FLAGS.ws_prune_ratio, FLAGS.ws_prune_ratio_prtl, FLAGS.ws_mask_update_step = 0.5, 'uniform', 2
+  FLAGS.ws_save_path = str(tmp / 'ws' / 'm.ckpt')
+  FLAGS.nb_smpls_train, FLAGS.nb_epochs_rat, FLAGS.synthetic_pool = 8 * 12, 1.0 / 250, 5
+
+  def run(graph_mode):
+    if graph_mode:
+      monkeypatch.setenv('PF_STEP_GRAPH', 'inline')
+      monkeypatch.setenv('PF_STEP_GRAPH_STRICT', '1')
+    FLAGS.enbl_step_graph = graph_mode
+    lrn = WeightSparseLearner(None, ModelHelper())
+    losses = []
+    for it in range(9):
+      if graph_mode and it == 7:
+        step_graph.of(lrn).suspend()
+      losses.append(float(lrn.train_step()[1].detach()))
+      if it in (4, 6):
+        lrn.prune_step()
+    return lrn, losses
+  base, l0 = run(False)
+  lrn, l1 = run(True)
+  assert step_graph.of(lrn).state == 'ready' and step_graph.of(lrn).n_replays == 4
+  assert l0 == l1, (l0, l1)
+  a, b = base.graph.store.export_numpy(), lrn.graph.store.export_numpy()
+  assert all(np.array_equal(a[k], b[k]) for k in a)
+  assert torch.equal(base.masks, lrn.masks)
+
+
+def test_step_graph_control_flow_mobilenet_dropout_on_cpu(cpu_learners, monkeypatch):
+  """... a network that draws something on the host every step: MobileNet's (seed, step)-keyed dropout mask goes through
+  graph.step_feeders; the recorded step and the eager step see the same mask sequence."""
+  FLAGS, fake, tmp = cpu_learners
+  from pocketflow_amd.nets.mobilenet_at_ilsvrc12 import ModelHelper
+  from pocketflow_amd.learners.full_precision.learner import FullPrecLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  import pocketflow_amd.utils.external.mobilenet_v1 as MV
+  FLAGS.batch_size, FLAGS.batch_size_eval, FLAGS.image_size, FLAGS.nb_classes = 4, 4, 32, 11
+  FLAGS.mobilenet_depth_mult, FLAGS.synthetic_pool = 0.25, 3
+  net = None
+
+  def masks(n_steps, capturing_at):
+    mh = ModelHelper()
+    create_synthetic_checkpoint(mh)
+    lrn = FullPrecLearner(None, mh)
+    g = lrn.graph
+    with g.as_default():
+      lrn.forward_train(lrn.to_device(*lrn.iter_train.get_next())[0])
+    m = g.nets['mobilenet']
+    m.keep = 0.5                                           # (0.999 would make every mask all-ones)
+    # the CPU branch of dropout_mask draws per call; emulate the device branch's static buffer by hand
+    m._mask_buf = torch.empty((4, m.features))
+    g.step_feeders.append(m.feed_mask)
+    out = []
+    m.dropout_step = 0
+    for i in range(n_steps):
+      if i in capturing_at:                                # a recording: the buffer is read, nothing is fed, the counter stands
+        g.capturing = True
+        before = m.dropout_step
+        assert m._mask_buf is not None and m.dropout_step == before
+        g.capturing = False
+        continue
+      for f in g.step_feeders:
+        f()
+      out.append(m._mask_buf.clone())
+    return out
+  a = masks(5, ())
+  b = masks(6, (2,))
+  assert len(a) == len(b) == 5 and all(torch.equal(x, y) for x, y in zip(a, b))
+  assert not torch.equal(a[0], a[1])
+  ref = torch.from_numpy(MV.MobilenetV1._host_mask(type('S', (), {'dropout_seed': 2024, 'features': a[0].shape[1], 'keep': 0.5})(), 4, 3))
+  assert torch.equal(a[3], ref)

@@ -20,6 +20,3 @@ wait
   -Wno-unused-function -DPF_W2_TIMING -shared pf_wrw.hip -o ../../tools/gpu/_build/libwrw_timing.so -L. -l:libpocketflow_hip.so -Wl,-rpath,'$ORIGIN/../../../pocketflow_amd/csrc'
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
   -Wno-unused-function -DPF_IG_TIMING -shared pf_igemm.hip -o ../../tools/gpu/_build/libig_timing.so -L. -l:libpocketflow_hip.so -Wl,-rpath,'$ORIGIN/../../../pocketflow_amd/csrc'
-# scheduling experiment: fragment reads / MFMA interleave prescribed with sched_group_barrier (tools/gpu/igemm_sgb_bench.py)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
-  -Wno-unused-function -DPF_IG_SGB -DPF_RAW_MINMAX -shared pf_igemm.hip -o ../../tools/gpu/_build/libig_sgb.so -L. -l:libpocketflow_hip.so -Wl,-rpath,'$ORIGIN/../../../pocketflow_amd/csrc'

@@ -1,7 +1,8 @@
 #!/usr/bin/env bash
 # A COMPLETE variant of the kernel library with extra compiler flags, for A/B runs of the test suite and of bench.py in one box:
-#   bash tools/gpu/build_variant.sh sgb -DPF_IG_SGB -DPF_ST_SGB -DPF_W2_SGB -DPF_RAW_MINMAX   ->  tools/gpu/_build/libpocketflow_hip_sgb.so
-#   PF_HIP_LIB=$PWD/tools/gpu/_build/libpocketflow_hip_sgb.so python bench.py --no_cpu_baseline
+#   bash tools/gpu/build_variant.sh x -DPF_SOME_EXPERIMENT   ->  tools/gpu/_build/libpocketflow_hip_x.so
+#   PF_HIP_LIB=$PWD/tools/gpu/_build/libpocketflow_hip_x.so python bench.py --no_cpu_baseline
+# (round 4 measured the sched_group_barrier pipelines this way before they became the product: profiles/r04_first_call_ab.txt)
 # (pocketflow_amd/hip.py loads $PF_HIP_LIB instead of the in-tree library when it is set; tools only.)
 set -euo pipefail
 name=$1; shift

@@ -36,6 +36,7 @@ for hw, K, N, res in shapes:
   out = {}
   for mode in ('1', '0'):
     os.environ['PF_CONV_STREAM'] = mode
+    hip.tuning_reload()          # the library reads its switches once
     G = hip.conv1x1_stats_groups(M, N, K, prologue=True)
     partial = torch.empty(G, 4, N, device='cuda')
     f = lambda: hip.conv1x1_fwd(X, W, Y, M, N, K, R=R, scale_shift=ss, act='Relu', slot=slot, bits=8, partial=partial)

@@ -52,6 +52,7 @@ for H, C, N, k, s in shapes:
     if N % bn:
       continue
     os.environ['PF_IGEMM_TILE'] = t
+    hip.tuning_reload()          # the library reads its switches once
     args = make_args(x, w, y, z, B, H, C, N, k, s, pad, Ho)
     ts = {}
     for name, lib in libs.items():
@@ -67,3 +68,4 @@ for H, C, N, k, s in shapes:
         '%d,%d,%d,%d,%d' % (H, C, N, k, s), t, ts['full'], ts['fill'], ts['comp'], ts['mfma'], ts['mf-e'], ts['noepi'], ideal, mb, mb / ts['fill'],
         2.0 * M * N * C * k * k / ts['full'] * 1e-6))
 os.environ.pop('PF_IGEMM_TILE', None)
+hip.tuning_reload()          # the library reads its switches once

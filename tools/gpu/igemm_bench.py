@@ -33,18 +33,22 @@ for H, C, N, k, s in shapes:
   ts = []
   for t in tiles:
     os.environ['PF_CONV3X3_HALO'] = '1' if t == 'halo' else '0'
+    hip.tuning_reload()          # the library reads its switches once
     if t == 'halo':
       os.environ.pop('PF_IGEMM_TILE', None)
+      hip.tuning_reload()          # the library reads its switches once
       if not (k == 3 and s == 1):
         ts.append(float('nan')); continue
     else:
       if N % int(t.split('x')[1]):
         ts.append(float('nan')); continue
       os.environ['PF_IGEMM_TILE'] = t
+      hip.tuning_reload()          # the library reads its switches once
     G = hip.conv2d_stats_groups(M, N, geom=(B, H, H, C, N, k, k, s, pad, pad, Ho, Ho))
     partial = torch.empty(G, 4, N, device='cuda')
     ts.append(timeit(lambda: hip.conv2d_fwd(x, w, y, B, H, H, C, N, k, k, s, pad, pad, Ho, Ho, partial=partial)))
   os.environ.pop('PF_IGEMM_TILE', None); os.environ.pop('PF_CONV3X3_HALO', None)
+  hip.tuning_reload()          # the library reads its switches once
   x4 = x.permute(0, 3, 1, 2)
   w4 = w.permute(0, 3, 1, 2)
   ref = F.conv2d(x4, w4, stride=s, padding=pad)

@@ -28,14 +28,18 @@ for hw, K, N, res in shapes:
   t = {}
   for mode, (pro3, prow) in (('ws', ('1', '1')), ('1', ('1', '0')), ('0', ('0', '0'))):
     os.environ['PF_IGEMM_PRO3'] = pro3
+    hip.tuning_reload()          # the library reads its switches once
     os.environ['PF_IGEMM_PROW'] = prow
+    hip.tuning_reload()          # the library reads its switches once
     G = hip.conv1x1_stats_groups(M, N, K, prologue=True)
     partial = torch.empty(G, 4, N, device='cuda')
     t[mode] = timeit(lambda: hip.conv1x1_fwd(X, W, Y, M, N, K, R=R, scale_shift=ss, act='Relu', slot=slot, bits=8, partial=partial))
   os.environ.pop('PF_IGEMM_PRO3'); os.environ.pop('PF_IGEMM_PROW')
+  hip.tuning_reload()          # the library reads its switches once
   tp = timeit(lambda: hip.conv1x1_fwd(X, W, Y, M, N, K))
   # what the extras cost on the single-role three-stage kernel: + statistics, + residual, + prologue without / with fake-quant
   os.environ['PF_IGEMM_PROW'] = '0'
+  hip.tuning_reload()          # the library reads its switches once
   G = hip.conv1x1_stats_groups(M, N, K, prologue=False)
   part0 = torch.empty(G, 4, N, device='cuda')
   v_stats = timeit(lambda: hip.conv1x1_fwd(X, W, Y, M, N, K, partial=part0))
@@ -43,6 +47,7 @@ for hw, K, N, res in shapes:
   v_pro = timeit(lambda: hip.conv1x1_fwd(X, W, Y, M, N, K, scale_shift=ss, act='Relu'))
   v_proq = timeit(lambda: hip.conv1x1_fwd(X, W, Y, M, N, K, scale_shift=ss, act='Relu', slot=slot, bits=8))
   os.environ.pop('PF_IGEMM_PROW')
+  hip.tuning_reload()          # the library reads its switches once
   extra = ' | plain+stats %4.0f  plain+res %4.0f  pro(no quant) %4.0f  pro(quant) %4.0f' % (v_stats, v_res, v_pro, v_proq)
   floor = (M * K + (2 if res else 1) * M * N) * 2 / 6.3e12 * 1e6
   print('%-16s | %9.0f %9.0f %9.0f %9.0f | %6.0f | %5.0f' % ('%d,%d,%d,%d' % (hw, K, N, res), t['ws'], t['1'], t['0'], tp, floor, 2.0 * M * N * K / t['ws'] * 1e-6) + extra)

@@ -33,11 +33,13 @@ for hw, K, N in [(56, 64, 64), (56, 64, 256), (56, 256, 64), (56, 256, 128), (28
   res = {}
   for mode in ('1', '0'):
     os.environ['PF_WRW2'] = mode
+    hip.tuning_reload()          # the library reads its switches once
     ws = torch.empty((hip.conv1x1_wrw_splits(M, N, K) + 32) * N * K, device='cuda')
     dW = torch.empty(N, K, device='cuda', dtype=torch.bfloat16)
     t = timeit(lambda: hip.conv1x1_wrw(dY, X, dW, ws, M, N, K, scale_shift=ss, act='Relu', slot=slot, bits=8))
     res[mode] = (t, dW.float().clone())
   os.environ.pop('PF_WRW2')
+  hip.tuning_reload()          # the library reads its switches once
   err = float((res['1'][1] - res['0'][1]).abs().max() / (res['0'][1].abs().max() + 1e-9))
   print('%-14s | %7.0f | %7.0f | %6.0f | %.1e' % ('%d,%d,%d' % (hw, K, N), res['1'][0], res['0'][0], M * (K + N) * 2 / 6.3e12 * 1e6, err))
 print('3x3:  H,C,N,stride | tr us | miopen us | TF tr')

@@ -24,6 +24,7 @@ for H, C, N, k, n in LAYERS:
   line = '%-16s %d |' % ('%d,%d,%d,%d' % (H, C, N, k), n)
   for t in TARGETS:
     os.environ['PF_WRW2_TARGET'] = str(t)
+    hip.tuning_reload()          # the library reads its switches once
     if k == 1:
       S = hip.conv1x1_wrw_splits(M, N, C)
       ws = torch.empty((S + 32) * N * C, device='cuda')

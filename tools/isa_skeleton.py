@@ -1,7 +1,7 @@
 """What hipcc emits for a kernel's contraction loop, as a skeleton: LDS reads, waits, barriers and runs of MFMAs between the first and
 the last MFMA of the kernel, plus register / spill counts and how many v_max_f32 / v_min_f32 the whole kernel holds.  No GPU needed.
 
-    python tools/isa_skeleton.py pf_igemm.hip '_Z7k_igemmILi128ELi256ELi2ELi4ELi3ELi2EEv6IgArgs' [-DPF_IG_SGB ...]
+    python tools/isa_skeleton.py pf_igemm.hip '_Z7k_igemmILi128ELi256ELi2ELi4ELi3ELi2EEv6IgArgs' [-DPF_SOME_EXPERIMENT ...]
 """
 import os
 import re
