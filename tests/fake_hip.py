@@ -410,6 +410,8 @@ class FakeHipFull(FakeHip):
         q, info = O.nuq_quantize(self._to_hwio(src, sg), bits, self._codebook(codebooks, sg, ub), ub, bt, bs)
         self._nuq_info[s] = (info, ub, bt, bs)
         res = self._to_storage(q, sg)
+        if not ub and idx_flat is not None:              # per-tensor codebooks: the codeword index of every element, storage order
+          idx_flat[off:off + n] = torch.from_numpy(np.ascontiguousarray(self._to_storage(info['idx'].astype(np.float32), sg))).to(idx_flat.dtype)
       else:
         res = src
       qw_flat[off:off + n] = torch.from_numpy(np.ascontiguousarray(res)).to(qw_flat.dtype)

@@ -105,7 +105,7 @@ def _force_state(learner, ora):
     flat[v.offset:v.offset + v.numel] = torch.from_numpy(np.ascontiguousarray(acc)).to(flat.device)
 
 
-def run_cp_masked_finetune(FLAGS, tmp_path, optimizer, steps=3, report=None):
+def run_cp_masked_finetune(FLAGS, tmp_path, optimizer, steps=3, report=None, bf16=False):
   """BASELINE configs[3] shrunk: the masked fine-tune of the ChannelPrunedLearner (cp learner.py:381-471) on
   MobileNet-v1 x0.5 @64 with distillation.  The keep-masks are a seeded stand-in for the LASSO selector's output
   (which is pinned separately against the reference's own compute_pruned_kernel, tests/test_channel_pruner_host.py):
@@ -169,6 +169,24 @@ def run_cp_masked_finetune(FLAGS, tmp_path, optimizer, steps=3, report=None):
   ora = OracleLearner(init, cfg, learner.lrn_rate)
   net = learner.graph.nets[next(iter(learner.graph.nets))]
   pool = _pool(learner.iter_train)
+
+  def next_dropout_mask():
+    mask_rng = np.random.RandomState((net.dropout_seed + 7919 * net.dropout_step) % (2 ** 31))
+    return {'dropout_mask': (mask_rng.uniform(size=(16, net.features)) < net.keep).astype(np.float32) / np.float32(net.keep)}
+  if bf16:
+    # the mode bench.py --config c3 measures: bf16 storage, fused pointwise convolutions, the in-tree bf16 depthwise kernels.
+    # Gradients against the float32 oracle with the bf16-storage floor measured here; losses of `steps` steps; after them the
+    # pruned rows / columns are still exactly zero and the variables sit within the Adam bound.
+    assert (learner.graph.compute_dtype == torch.bfloat16) == (bf16 != 'emulated-float32')
+    what = 'MobileNet-v1 x0.5 CP masked fine-tune + dst @64 B=16, bf16 vs float32 oracle'
+    bf16_gradient_check(learner, ora, lambda: OracleLearner(init, cfg, learner.lrn_rate), pool[0], what, margin=0.05,
+                        extra=next_dropout_mask(), kinds=('weights', 'kernel'))
+    bf16_trajectory(learner, ora, pool, steps, what, loss_tol=1e-2, extra_fn=next_dropout_mask)
+    got = st.export_numpy()
+    for name, (keep_in, keep_out) in by_var.items():
+      assert np.all(got[name][:, :, ~keep_in, :] == 0) and np.all(got[name][:, :, :, ~keep_out] == 0), name
+    compare_after_steps(learner, ora, steps, what, stat_tol=2e-2)
+    return
   for step in range(steps):
     seed_step = net.dropout_step
     mask_rng = np.random.RandomState((net.dropout_seed + 7919 * seed_step) % (2 ** 31))
@@ -206,7 +224,227 @@ def run_cp_masked_finetune(FLAGS, tmp_path, optimizer, steps=3, report=None):
   assert worst <= 1e-3, (where, worst)
 
 
-def conditioned_uq_resnet50(FLAGS, tmp_path, a_bits=8, compute_dtype='bfloat16'):
+# =================================================================================================
+# bf16 (the benchmarked mode) against the float32 oracle, with the noise floor of bf16 STORAGE measured in the same test
+# =================================================================================================
+
+import contextlib
+
+
+@contextlib.contextmanager
+def bf16_storage_emulated():
+  """Inside: oracle learners round every tensor the product's bf16 mode keeps in HBM to bf16 on the way, forward and backward
+  (convolution / depthwise outputs, activated or fake-quantised tensors, the kernels' compute copies) -- float32 arithmetic
+  otherwise.  What such an oracle differs from the float32 oracle by is what ANY bf16-storage implementation differs by."""
+  import oracle.learner_oracle as LO
+  from bf16_noise_probe import _R16
+  names = ('conv2d', 'depthwise', 'activation', '_quant_weight')
+  orig = {n: getattr(LO.Scope, n) for n in names}
+
+  def wrap(f):
+    return lambda self, *a, **k: _R16.apply(f(self, *a, **k))
+  for n in names:
+    setattr(LO.Scope, n, wrap(orig[n]))
+  try:
+    yield
+  finally:
+    for n in names:
+      setattr(LO.Scope, n, orig[n])
+
+
+def _report(line):
+  import os
+  print(line)
+  if os.environ.get('PF_PARITY_REPORT'):
+    with open(os.environ['PF_PARITY_REPORT'], 'a') as f:
+      f.write(line + '\n')
+
+
+def bf16_gradient_check(learner, ora, make_oracle, batch, what, margin=0.05, extra=None, hard_floor=0.80, whole_cos=0.99,
+                        loss_tol=5e-3, kinds=('kernel', 'weights')):
+  """One backward pass of (1) the float32 oracle, (2) the oracle with bf16 storage emulated (`make_oracle()` builds a second
+  oracle in the same state), (3) the product in bf16 -- same state, same batch, no update.  The product's gradient of every
+  variable must be as close (cosine) to the float32 oracle's as the emulation's is, within `margin`; the concatenated gradient
+  within `whole_cos` and 5 % in norm; the loss within `loss_tol`.  Returns the measured numbers."""
+  from bf16_noise_probe import cosines
+  ref, g32 = ora.compute_grads(*batch, extra=extra)
+  with bf16_storage_emulated():
+    ref16, g16 = make_oracle().compute_grads(*batch, extra=extra)
+  floor = cosines(g16, g32)                                # {name: (cosine, relative L2)}
+  out, hg = product_gradients(learner)
+  loss0 = float((out['loss'] if isinstance(out, dict) else out[1]).detach())
+  per, wc, wr = compare_gradients(hg, ora, g32)
+  gradient_report(per, wc, wr, what)
+  sel = [k for k in per if k in floor and any(k.endswith(e) for e in kinds)] or [k for k in per if k in floor]
+  fl = sorted(floor[k][0] for k in sel)
+  pr = sorted(per[k][1] for k in sel)
+  _report('   %s | bf16 noise floor (oracle with bf16 storage vs float32 oracle), %d kernels: min cos %.4f median %.4f | product: min cos '
+          '%.4f median %.4f | loss: oracle %.6f, bf16-emulated oracle %.6f, product %.6f' % (
+              what, len(sel), fl[0], fl[len(fl) // 2], pr[0], pr[len(pr) // 2], ref['loss'], ref16['loss'], loss0))
+  assert abs(loss0 - ref['loss']) <= loss_tol * max(1.0, abs(ref['loss'])), (what, loss0, ref['loss'], ref16['loss'])
+  behind = {k: (per[k][1], floor[k][0]) for k in per if k in floor and per[k][1] < floor[k][0] - margin}
+  assert not behind, '%s: gradients further from the float32 oracle than bf16 storage explains: %s' % (what, sorted(behind.items())[:5])
+  assert min(v[1] for v in per.values()) >= hard_floor, (what, min(per.items(), key=lambda kv: kv[1][1]))
+  assert wc >= whole_cos and abs(wr - 1.0) <= 0.05, (what, wc, wr)
+  return dict(floor=floor, per=per, whole_cos=wc, whole_ratio=wr, loss=(ref['loss'], ref16['loss'], loss0))
+
+
+def bf16_trajectory(learner, ora, pool, steps, what, loss_tol=1e-2, first=1, extra_fn=None):
+  """`steps` fine-tune steps on both sides from the common state (batches pool[first], pool[first + 1], ...): the loss of every
+  step within `loss_tol` of the oracle's.  Returns the worst relative difference."""
+  worst = 0.0
+  for step in range(first, first + steps):
+    extra = extra_fn() if extra_fn is not None else None
+    o = learner.train_step()
+    r = ora.train_step(*pool[step % len(pool)], extra=extra)
+    loss = float((o['loss'] if isinstance(o, dict) else o[1]).detach())
+    rel = abs(loss - r['loss']) / max(1.0, abs(r['loss']))
+    worst = max(worst, rel)
+    assert rel <= loss_tol, (what, step, loss, r['loss'])
+  _report('   %s | %d-step loss trajectory, product (bf16) vs float32 oracle: max relative difference %.2e' % (what, steps, worst))
+  return worst
+
+
+def compare_after_steps(learner, ora, steps, what, w_tol=None, stat_tol=5e-3):
+  """After `steps` Adam steps on both sides: every variable within the Adam bound (an element whose gradient is noise follows the
+  sign of the noise: up to 2 * lr per step) and, in bulk (99 % of the elements), much closer; BN moving statistics within
+  `stat_tol` relative to their scale."""
+  got, ref = learner.graph.store.export_numpy(), ora.export()
+  lr = float(learner.lrn_rate(0))
+  tol = w_tol if w_tol is not None else adam_tol(steps, lr)
+  worst, where = _max_rel({k: v for k, v in got.items() if 'moving_' not in k}, {k: v for k, v in ref.items() if 'moving_' not in k and k in got})
+  errs = np.concatenate([(np.abs(got[k] - v) / np.maximum(1.0, np.abs(v))).reshape(-1) for k, v in ref.items() if 'moving_' not in k and k in got])
+  q99 = float(np.quantile(errs, 0.99))
+  sworst, swhere = 0.0, None
+  for k, v in ref.items():
+    if 'moving_' not in k or k not in got:
+      continue
+    e = float(np.max(np.abs(got[k] - v)) / max(1e-6, float(np.max(np.abs(v)))))
+    if e > sworst:
+      sworst, swhere = e, k
+  _report('   %s | after %d steps: variables worst %.3e (%s; Adam bound %.1e), 99 %% quantile %.3e | BN moving statistics worst %.3e (%s)' % (
+      what, steps, worst, where, tol, q99, sworst, swhere))
+  assert worst <= min(tol, 1e-3) + 1e-9, (what, where, worst, tol)
+  assert sworst <= stat_tol, (what, swhere, sworst)
+  return worst, q99, sworst
+
+
+def run_ws_bf16_parity(FLAGS, tmp_path, expect_bf16=True, batch=64):
+  """Body of tests/test_parity_gpu.py::test_ws_resnet20_bf16_matches_oracle_within_bf16_noise (see its docstring);
+  `expect_bf16=False`: the same body on the float32 CPU emulation (tests/test_learners_cpu.py)."""
+  from oracle.learner_oracle import OracleLearner
+  from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
+  from pocketflow_amd.learners.weight_sparsification.learner import WeightSparseLearner
+  for _k, _v in dict(batch_size=batch, batch_size_eval=batch, ws_prune_ratio=0.5, ws_prune_ratio_prtl='uniform',
+                     ws_save_path=str(tmp_path / 'ws' / 'm.ckpt'), nb_eval_batches_override=1, resnet_size=20,
+                     nb_classes=10, ws_mask_update_step=2, nb_smpls_train=batch * 12, nb_epochs_rat=1.0 / 250).items():
+    setattr(FLAGS, _k, _v)
+  learner = WeightSparseLearner(None, ModelHelper())
+  assert (learner.graph.compute_dtype == torch.bfloat16) == bool(expect_bf16)
+  N = learner.nb_iters_train
+  init = learner.graph.store.export_numpy()
+  cfg = dict(model='resnet', dataset='cifar_10', resnet_size=20, nb_classes=FLAGS.nb_classes, loss_w_dcy=FLAGS.loss_w_dcy, enbl_dst=False,
+             loss_w_dst=FLAGS.loss_w_dst, tempr_dst=FLAGS.tempr_dst, momentum=FLAGS.momentum, image_shape=(32, 32, 3))
+  cfg.update(learner='weight-sparse', ws_prune_ratio=0.5, ws_prune_ratio_prtl='uniform')
+  ora = OracleLearner(init, cfg, learner.lrn_rate)
+  pool = _pool(learner.iter_train)
+  what = 'ResNet-20 WS @32 B=%d, bf16 vs float32 oracle' % batch
+  bf16_gradient_check(learner, ora, lambda: OracleLearner(init, cfg, learner.lrn_rate), pool[0], what, margin=0.05, hard_floor=0.90,
+                      whole_cos=0.995)
+  bf16_trajectory(learner, ora, pool, 3, what, loss_tol=1e-2)
+  # mask refresh from a common state
+  learner.global_step = ora.step = max(int(0.3 * N), 3)            # inside [0.1 N, 0.5 N]: a non-trivial dynamic prune ratio
+  st = learner.graph.store
+  st.load_numpy(ora.export())
+  for v in learner.maskable_vars:
+    sl = slice(v.offset, v.offset + v.numel)
+    learner.masks[sl] = torch.from_numpy(v.to_storage(ora.masks[v.name]).reshape(-1)).to(learner.masks.device)
+    learner.var_bkup[sl] = torch.from_numpy(v.to_storage(ora.bkups[v.name]).reshape(-1)).to(learner.masks.device)
+  learner.prune_step()
+  ora.prune_step(N)
+  n_tot = 0
+  for v in learner.maskable_vars:
+    m = v.to_ref(learner.masks[v.offset:v.offset + v.numel].cpu().numpy())
+    assert np.array_equal(m, ora.masks[v.name]), 'mask of %s differs in %d elements' % (v.name, int(np.sum(m != ora.masks[v.name])))
+    n_tot += m.size
+  assert n_tot > 200000 and 0.05 < 1.0 - float(learner.masks.mean()) < 0.5
+  worst, where = _max_rel(learner.graph.store.export_numpy(), ora.export(), skip=('moving_',))
+  assert worst <= 1e-7, (where, worst)                    # masked weights: the same float32 values
+  bf16_trajectory(learner, ora, pool, 2, what + ' (masked)', loss_tol=1e-2, first=4)
+  st = learner.graph.store
+  for v in learner.maskable_vars:
+    m = learner.masks[v.offset:v.offset + v.numel]
+    assert float((st.w_master[v.offset:v.offset + v.numel] * (1 - m)).abs().max()) == 0.0
+
+
+def run_nuq_bf16_parity(FLAGS, tmp_path, expect_bf16=True, batch=32, steps=5):
+  """Body of tests/test_parity_gpu.py::test_nuq_resnet50_4bit_bf16_matches_oracle_within_bf16_noise."""
+  import os
+  from oracle.learner_oracle import OracleLearner
+  from oracle import pf_oracle as O
+  from bf16_noise_probe import conditioned_resnet50_state, moved_student
+  from pocketflow_amd.nets.resnet_at_ilsvrc12 import ModelHelper
+  from pocketflow_amd.learners.nonuniform_quantization.learner import NonUniformQuantLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  from pocketflow_amd.utils import checkpoint
+  for _k, _v in dict(batch_size=batch, batch_size_eval=batch, nuql_weight_bits=4, nuql_use_buckets=False,
+                     nuql_opt_mode='weights', nuql_activation_bits=32, enbl_dst=True, dst_eval_teacher=False,
+                     save_path_dst=str(tmp_path / 'models_dst' / 'model.ckpt'),
+                     nuql_save_quant_model_path=str(tmp_path / 'nuql' / 'm.ckpt'), nb_eval_batches_override=1,
+                     resnet_size=50, nb_classes=1001, image_size=64,
+                     loss_w_dcy=1e-4, momentum=0.9, lrn_rate_init=0.1, batch_size_norm=256, nb_epochs_rat=1.0, loss_w_dst=4.0,
+                     tempr_dst=4.0).items():
+    setattr(FLAGS, _k, _v)
+  mh = ModelHelper()
+  create_synthetic_checkpoint(mh)
+  prefix = checkpoint.latest_checkpoint(os.path.dirname(FLAGS.save_path))
+  rng = np.random.RandomState(5)
+  calib = rng.randn(16, 64, 64, 3).astype(np.float32)
+  cond = conditioned_resnet50_state(checkpoint.load(prefix), calib, branch_scale=0.1, dense_scale=0.2)
+  checkpoint.save(cond, FLAGS.save_path, 0)
+  learner = NonUniformQuantLearner(None, mh)               # student AND teacher restore the conditioned checkpoint
+  assert (learner.graph.compute_dtype == torch.bfloat16) == bool(expect_bf16)
+  learner.graph.store.load_numpy(moved_student(cond, 0.05), strict=False)
+  learner.init_clusters()
+  init = learner.graph.store.export_numpy()
+  tvals = learner.helper_dst.learner.graph.store.export_numpy()
+  cfg = dict(model='resnet', dataset='ilsvrc_12', resnet_size=50, nb_classes=1001, loss_w_dcy=FLAGS.loss_w_dcy, enbl_dst=True,
+             loss_w_dst=FLAGS.loss_w_dst, tempr_dst=FLAGS.tempr_dst, momentum=FLAGS.momentum, image_shape=(64, 64, 3))
+  cfg.update(learner='non-uniform', nuql_weight_bits=4, nuql_use_buckets=False, nuql_opt_mode='weights', nuql_activation_bits=32)
+  wvals = {k: v for k, v in init.items() if 'clusters' not in k}
+  ora = OracleLearner(wvals, cfg, learner.lrn_rate, teacher_values=tvals)
+  nq = learner.nonuni_quant
+  by_var = {op.var.name: nq.cluster_vars[id(op.var)].name for op in nq.matmul_ops}
+  n_cb = 0
+  for i, name in enumerate(ora.matmul_var_names):
+    if i in ora.student.quant.codebooks:
+      ref = ora.student.quant.codebooks[i].detach().numpy()
+      assert np.array_equal(init[by_var[name]].reshape(ref.shape), ref), 'codebook init of %s' % name
+      n_cb += 1
+  assert n_cb == 52
+  pool = _pool(learner.iter_train)
+  what = 'ResNet-50 NUQ 4-bit + dst @64 B=%d, bf16 vs float32 oracle' % batch
+  bf16_gradient_check(learner, ora, lambda: OracleLearner(wvals, cfg, learner.lrn_rate, teacher_values=tvals), pool[0], what,
+                      margin=0.05, kinds=('kernel',))
+  # codeword assignment of every quantised weight (the step function of this learner): the device's index buffer against the
+  # oracle's nearest-codeword search over the same float32 weights and codebooks
+  st = learner.graph.store
+  n_idx = n_diff = 0
+  for i, name in enumerate(ora.matmul_var_names):
+    if i not in ora.student.quant.codebooks:
+      continue
+    v = st.by_name[name]
+    w = init[name]
+    cb = ora.student.quant.codebooks[i].detach().numpy()
+    idx_ref = O.nuq_quantize(w, 4, codebook=cb)[1]['idx']
+    idx = v.to_ref(nq.idx_flat[v.offset:v.offset + v.numel].cpu().numpy())
+    n_idx += idx.size
+    n_diff += int(np.sum(idx.reshape(-1) != np.asarray(idx_ref).reshape(-1)))
+  assert n_idx > 2e7 and n_diff == 0, (n_idx, n_diff)
+  bf16_trajectory(learner, ora, pool, steps, what, loss_tol=1e-2)
+
+
+def conditioned_uq_resnet50(FLAGS, tmp_path, a_bits=8, compute_dtype='bfloat16', batch=16, image_size=64):
   """UniformQuantLearner on ResNet-v2-50 (64x64, batch 16, w8 / a`a_bits` + distillation) from the conditioned state of
   tests/bf16_noise_probe.py -- damped residual branches and classifier, calibrated BN moving statistics, the student moved
   5 % off its teacher -- plus the oracle learner on the same state.  Returns (learner, oracle, batch pool)."""
@@ -218,10 +456,10 @@ def conditioned_uq_resnet50(FLAGS, tmp_path, a_bits=8, compute_dtype='bfloat16')
   from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
   from pocketflow_amd.utils import checkpoint
   import os
-  for k, v in dict(batch_size=16, batch_size_eval=16, uql_weight_bits=8, uql_activation_bits=a_bits,
+  for k, v in dict(batch_size=batch, batch_size_eval=batch, uql_weight_bits=8, uql_activation_bits=a_bits,
                    enbl_dst=True, dst_eval_teacher=False, save_path_dst=str(tmp_path / 'models_dst' / 'model.ckpt'),
                    uql_save_quant_model_path=str(tmp_path / 'uql' / 'm.ckpt'), nb_eval_batches_override=1,
-                   resnet_size=50, nb_classes=1001, image_size=64, uql_use_buckets=False,
+                   resnet_size=50, nb_classes=1001, image_size=image_size, uql_use_buckets=False,
                    # per-network flags are defined by whichever nets module was imported FIRST in the process (cifar-10's
                    # loss_w_dcy is 2e-4, ilsvrc-12's 1e-4, ...): pin the ilsvrc-12 ResNet values, whatever ran before
                    loss_w_dcy=1e-4, momentum=0.9, lrn_rate_init=0.1, batch_size_norm=256, nb_epochs_rat=1.0,
@@ -231,7 +469,7 @@ def conditioned_uq_resnet50(FLAGS, tmp_path, a_bits=8, compute_dtype='bfloat16')
   create_synthetic_checkpoint(mh)
   prefix = checkpoint.latest_checkpoint(os.path.dirname(FLAGS.save_path))
   rng = np.random.RandomState(5)
-  calib = rng.randn(16, 64, 64, 3).astype(np.float32)
+  calib = rng.randn(min(batch, 16), image_size, image_size, 3).astype(np.float32)
   cond = conditioned_resnet50_state(checkpoint.load(prefix), calib, branch_scale=0.1, dense_scale=0.2)
   checkpoint.save(cond, FLAGS.save_path, 0)
   learner = UniformQuantLearner(None, mh)                 # student AND teacher restore the conditioned checkpoint
@@ -240,68 +478,43 @@ def conditioned_uq_resnet50(FLAGS, tmp_path, a_bits=8, compute_dtype='bfloat16')
   tvals = learner.helper_dst.learner.graph.store.export_numpy()
   assert all(k.startswith('distilled_model/') for k in tvals)
   cfg = dict(model='resnet', dataset='ilsvrc_12', resnet_size=50, nb_classes=1001, loss_w_dcy=FLAGS.loss_w_dcy, enbl_dst=True,
-             loss_w_dst=FLAGS.loss_w_dst, tempr_dst=FLAGS.tempr_dst, momentum=FLAGS.momentum, image_shape=(64, 64, 3),
+             loss_w_dst=FLAGS.loss_w_dst, tempr_dst=FLAGS.tempr_dst, momentum=FLAGS.momentum, image_shape=(image_size, image_size, 3),
              learner='uniform', uql_weight_bits=8, uql_activation_bits=a_bits, uql_use_buckets=False)
   ora = OracleLearner(init, cfg, learner.lrn_rate, teacher_values=tvals)
   pool = _pool(learner.iter_train)
   return learner, ora, pool, init, tvals, cfg
 
 
-def run_bf16_fused_parity(FLAGS, tmp_path, steps=10, expect_bf16=True):
+def run_bf16_fused_parity(FLAGS, tmp_path, steps=10, expect_bf16=True, batch=16, margin=0.05, image_size=64, after_steps=True):
   """Body of tests/test_parity_gpu.py::test_uq_resnet50_bf16_fused_path_matches_oracle_within_bf16_noise (see its
   docstring); `expect_bf16=False` runs the same body in float32 (CPU emulation: tests/test_learners_cpu.py)."""
-
   from oracle.learner_oracle import OracleLearner
-  import oracle.learner_oracle as LO
-  from bf16_noise_probe import _R16, cosines
-  import os
-  learner, ora, pool, init, tvals, cfg = conditioned_uq_resnet50(FLAGS, tmp_path, 8, 'bfloat16' if expect_bf16 else 'float32')
+  learner, ora, pool, init, tvals, cfg = conditioned_uq_resnet50(FLAGS, tmp_path, 8, 'bfloat16' if expect_bf16 else 'float32',
+                                                                 batch=batch, image_size=image_size)
   if expect_bf16:
     assert learner.graph.compute_dtype == torch.bfloat16 and learner.graph.fuse_conv1x1
+  what = 'ResNet-50 UQ w8/a8 + dst @%d B=%d, bf16 FUSED path vs float32 oracle' % (image_size, batch)
   # (1) float32 oracle, (2) the oracle with bf16 storage emulated, (3) the product: one backward each, same state and batch
-  ref, g32 = ora.compute_grads(*pool[0])
-  o_conv, o_act, o_qw = LO.Scope.conv2d, LO.Scope.activation, LO.Scope._quant_weight
-  LO.Scope.conv2d = lambda self, *a, **k: _R16.apply(o_conv(self, *a, **k))
-  LO.Scope.activation = lambda self, *a, **k: _R16.apply(o_act(self, *a, **k))
-  LO.Scope._quant_weight = lambda self, w, name: _R16.apply(o_qw(self, w, name))
-  try:
-    ora16 = OracleLearner(init, cfg, learner.lrn_rate, teacher_values=tvals)
-    ref16, g16 = ora16.compute_grads(*pool[0])
-  finally:
-    LO.Scope.conv2d, LO.Scope.activation, LO.Scope._quant_weight = o_conv, o_act, o_qw
-  floor = cosines(g16, g32)                                # {name: (cosine, relative L2)} of the emulation vs float32
-  out, hg = product_gradients(learner)
-  loss0 = float(out['loss'].detach())
-  assert abs(loss0 - ref['loss']) <= 5e-3 * abs(ref['loss']), (loss0, ref['loss'], ref16['loss'])
-  per, wc, wr = compare_gradients(hg, ora, g32)
-  gradient_report(per, wc, wr, 'ResNet-50 UQ w8/a8 + dst @64 B=16, bf16 FUSED path vs float32 oracle')
-  fl_k = sorted(v[0] for k, v in floor.items() if k.endswith('kernel'))
-  pr_k = sorted(v[1] for k, v in per.items() if k.endswith('kernel'))
-  line = ('   bf16 noise floor (oracle with bf16 storage vs float32 oracle), kernels: min cos %.4f median %.4f | product: min cos '
-          '%.4f median %.4f | loss: oracle %.6f, bf16-emulated oracle %.6f, product %.6f' % (
-              fl_k[0], fl_k[len(fl_k) // 2], pr_k[0], pr_k[len(pr_k) // 2], ref['loss'], ref16['loss'], loss0))
-  print(line)
-  if os.environ.get('PF_PARITY_REPORT'):
-    with open(os.environ['PF_PARITY_REPORT'], 'a') as f:
-      f.write(line + '\n')
-  assert len(per) == len(g32)
-  behind = {k: (per[k][1], floor[k][0]) for k in per if per[k][1] < floor[k][0] - 0.05}
-  assert not behind, 'gradients further from the float32 oracle than bf16 storage explains: %s' % sorted(behind.items())[:5]
-  assert min(v[1] for v in per.values()) >= 0.80
-  assert wc >= 0.99 and abs(wr - 1.0) <= 0.05, (wc, wr)
-  # (4) loss trajectory: 10 fine-tune steps on both sides
-  traj = []
-  for step in range(1, steps + 1):
-    o = learner.train_step()
-    r = ora.train_step(*pool[step % len(pool)])
-    traj.append((float(o['loss']), r['loss']))
-    assert abs(traj[-1][0] - traj[-1][1]) <= 1e-2 * abs(traj[-1][1]), (step, traj[-1])
-    assert abs(float(o['dst_loss']) - r['dst_loss']) <= 1e-2 * abs(r['dst_loss']) + 1e-3
-  line = '   %d-step loss trajectory, product vs oracle: max relative difference %.2e' % (steps, max(abs(a - b) / abs(b) for a, b in traj))
-  print(line)
-  if os.environ.get('PF_PARITY_REPORT'):
-    with open(os.environ['PF_PARITY_REPORT'], 'a') as f:
-      f.write(line + '\n')
+  res = bf16_gradient_check(learner, ora, lambda: OracleLearner(init, cfg, learner.lrn_rate, teacher_values=tvals), pool[0], what,
+                            margin=margin, kinds=('kernel',))
+  assert len(res['per']) == len(res['floor'])
+  if steps <= 0:
+    return res
+  # (4) loss trajectory: fine-tune steps on both sides
+  bf16_trajectory(learner, ora, pool, steps, what, loss_tol=1e-2)
+  if not after_steps:
+    return res
+  # (5) the north-star outputs after the steps: quantised-network weights (Adam bound), BN moving statistics, evaluation
+  compare_after_steps(learner, ora, steps, what)
+  learner.graph.training = False
+  rs = learner.run_eval()
+  ev = [ora.eval_batch(*b) for b in _pool(learner.iter_eval)[:1]]
+  top1 = float(np.mean([e['metrics']['acc_top1'] if 'acc_top1' in e['metrics'] else e['metrics']['accuracy'] for e in ev]))
+  _report('   %s | evaluation after the steps: loss product %.5f oracle %.5f | top-1 product %.4f oracle %.4f' % (
+      what, rs['loss'], float(np.mean([e['loss'] for e in ev])), rs['acc_top1'], top1))
+  assert abs(rs['loss'] - np.mean([e['loss'] for e in ev])) <= 1e-2 * max(1.0, abs(ev[0]['loss']))
+  assert abs(rs['acc_top1'] - top1) <= 2.0 / batch + 1e-6           # (1001 random classes: a borderline sample or two may flip)
+  return res
 
 
 

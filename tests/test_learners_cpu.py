@@ -1062,3 +1062,22 @@ def test_step_graph_control_flow_mobilenet_dropout_on_cpu(cpu_learners, monkeypa
   assert not torch.equal(a[0], a[1])
   ref = torch.from_numpy(MV.MobilenetV1._host_mask(type('S', (), {'dropout_seed': 2024, 'features': a[0].shape[1], 'keep': 0.5})(), 4, 3))
   assert torch.equal(a[3], ref)
+
+
+def test_bf16_parity_bodies_of_the_other_configurations_on_cpu(cpu_learners, monkeypatch):
+  """The bodies of the GPU tests `test_ws_resnet20_bf16_...`, `test_cp_mobilenet_bf16_...` and `test_nuq_resnet50_4bit_bf16_...`
+  (tests/parity_common.py) with the HIP entry points emulated in float32: the plumbing of the checks themselves (bf16-storage
+  oracle, per-variable floors, trajectories, bit-identical masks / codeword assignments) runs here before it costs GPU minutes."""
+  FLAGS, fake, tmp = cpu_learners
+  import pocketflow_amd.learners.channel_pruning.learner as CP
+  from parity_common import run_ws_bf16_parity, run_nuq_bf16_parity, run_cp_masked_finetune
+  monkeypatch.setattr(CP, 'hip', fake)
+  run_ws_bf16_parity(FLAGS, tmp / 'ws', expect_bf16=False, batch=16)
+  FLAGS.reset()
+  FLAGS.save_path = str(tmp / 'cp' / 'models' / 'model.ckpt')
+  FLAGS.synthetic_pool, FLAGS.compute_dtype = 2, 'float32'
+  run_cp_masked_finetune(FLAGS, tmp / 'cp', 'adam', steps=2, bf16='emulated-float32')
+  FLAGS.reset()
+  FLAGS.save_path = str(tmp / 'nuq' / 'models' / 'model.ckpt')
+  FLAGS.synthetic_pool, FLAGS.compute_dtype = 2, 'float32'
+  run_nuq_bf16_parity(FLAGS, tmp / 'nuq', expect_bf16=False, batch=4, steps=1)

@@ -353,7 +353,19 @@ def test_uq_resnet50_bf16_fused_path_matches_oracle_within_bf16_noise(tmp_path):
   step-0 loss within 5e-3 and a 10-step loss trajectory within 1 %.  The numbers are appended to $PF_PARITY_REPORT."""
   from parity_common import run_bf16_fused_parity
   FLAGS = _setup(tmp_path)
-  run_bf16_fused_parity(FLAGS, tmp_path, steps=10, expect_bf16=True)
+  # batch 64 (round 4): the per-variable noise floor of bf16 storage rises with the batch (more samples per gradient), so the
+  # same margin is a sharper bar; after the 10 steps the weights (Adam bound), the BN moving statistics (5e-3) and the
+  # evaluation loss / top-1 of the quantised network are compared with the oracle's as well
+  run_bf16_fused_parity(FLAGS, tmp_path, steps=10, expect_bf16=True, batch=64, margin=0.03)
+
+
+def test_uq_resnet50_bf16_one_step_at_224_with_8bit_activations(tmp_path):
+  """BASELINE configs[2] at its own resolution: 224x224, w8 / a8 + distillation, bf16 fused path, batch 8 -- the spatial sizes
+  (112 ... 7), strided projections and tile tails the benchmark runs, against the float32 oracle: gradient check against the
+  measured bf16-storage floor, then two steps."""
+  from parity_common import run_bf16_fused_parity
+  FLAGS = _setup(tmp_path)
+  run_bf16_fused_parity(FLAGS, tmp_path, steps=2, expect_bf16=True, batch=8, margin=0.05, image_size=224, after_steps=False)
 
 
 def test_uq_resnet50_float32_gradients_match_oracle_from_a_conditioned_state(tmp_path):
@@ -422,3 +434,36 @@ def test_cp_mobilenet_masked_finetune_matches_oracle(tmp_path, optimizer):
   from parity_common import run_cp_masked_finetune
   FLAGS = _setup(tmp_path)
   run_cp_masked_finetune(FLAGS, tmp_path, optimizer)
+
+
+# =================================================================================================
+# the other benchmarked configurations in the mode the bench measures them in: bf16 (VERDICT r3 "next" 4)
+# =================================================================================================
+
+def test_ws_resnet20_bf16_matches_oracle_within_bf16_noise(tmp_path):
+  """BASELINE configs[1] in bf16 (bench.py --config c1): ResNet-20 @ CIFAR-10, WeightSparseLearner, Momentum.  Gradients against
+  the float32 oracle with the bf16-storage noise floor measured in the same test; three steps of losses; then -- from a common
+  state (teacher forcing: a mask is a step function of |w|) -- a mask refresh on both sides: the masks are computed from the
+  float32 master weights by the same kernels as in float32 mode and must be BIT-IDENTICAL; two more masked steps; pruned
+  weights stay exactly zero.  Body: tests/parity_common.py run_ws_bf16_parity (also run on the CPU emulation)."""
+  from parity_common import run_ws_bf16_parity
+  FLAGS = _setup(tmp_path, compute_dtype='bfloat16')
+  run_ws_bf16_parity(FLAGS, tmp_path, expect_bf16=True)
+
+
+def test_cp_mobilenet_bf16_matches_oracle_within_bf16_noise(tmp_path):
+  """BASELINE configs[3] in bf16 (bench.py --config c3): MobileNet-v1 x0.5, channel-pruned masked fine-tune + distillation with
+  the in-tree bf16 depthwise kernels inside the step (tests/parity_common.py run_cp_masked_finetune, bf16 branch)."""
+  from parity_common import run_cp_masked_finetune
+  FLAGS = _setup(tmp_path, compute_dtype='bfloat16')
+  run_cp_masked_finetune(FLAGS, tmp_path, 'adam', steps=3, bf16=True)
+
+
+def test_nuq_resnet50_4bit_bf16_matches_oracle_within_bf16_noise(tmp_path):
+  """BASELINE configs[4] in bf16 (bench.py --config c4), shrunk: ResNet-v2-50 NonUniformQuantLearner, 4-bit codebooks + distillation,
+  64x64, batch 32, from the conditioned state of the UQ test.  The codebooks are initialised from the float32 master weights (bit-exact
+  vs the oracle, as in float32 mode); the nearest-codeword ASSIGNMENT of every weight is compared index by index; gradients against the
+  float32 oracle within the measured bf16-storage floor; a 5-step loss trajectory.  Body: tests/parity_common.py run_nuq_bf16_parity."""
+  from parity_common import run_nuq_bf16_parity
+  FLAGS = _setup(tmp_path, compute_dtype='bfloat16')
+  run_nuq_bf16_parity(FLAGS, tmp_path, expect_bf16=True)
