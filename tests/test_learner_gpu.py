@@ -13,6 +13,7 @@ def _setup(tmp_path, **kw):
   from pocketflow_amd.flags import FLAGS
   import pocketflow_amd.learners.learner_utils  # noqa: F401  (defines flags)
   import pocketflow_amd.learners.abstract_learner  # noqa: F401
+  import pocketflow_amd.datasets.abstract_dataset  # noqa: F401  (synthetic_pool)
   FLAGS.save_path = str(tmp_path / 'models' / 'model.ckpt')
   FLAGS.save_path_eval = str(tmp_path / 'models_eval' / 'model.ckpt')
   FLAGS.synthetic_pool = 2

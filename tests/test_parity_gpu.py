@@ -70,6 +70,7 @@ def _setup(tmp_path, **kw):
   from pocketflow_amd.flags import FLAGS
   import pocketflow_amd.learners.learner_utils  # noqa: F401
   import pocketflow_amd.learners.abstract_learner  # noqa: F401
+  import pocketflow_amd.datasets.abstract_dataset  # noqa: F401  (synthetic_pool)
   FLAGS.save_path = str(tmp_path / 'models' / 'model.ckpt')
   FLAGS.save_path_eval = str(tmp_path / 'models_eval' / 'model.ckpt')
   FLAGS.synthetic_pool = 2
@@ -352,6 +353,7 @@ def test_uq_resnet50_bf16_fused_path_matches_oracle_within_bf16_noise(tmp_path):
   has to stay within 0.05 of it variable by variable, the concatenated gradient within cosine 0.99 and 5 % in norm, the
   step-0 loss within 5e-3 and a 10-step loss trajectory within 1 %.  The numbers are appended to $PF_PARITY_REPORT."""
   from parity_common import run_bf16_fused_parity
+  import pocketflow_amd.nets.resnet_at_ilsvrc12  # noqa: F401
   FLAGS = _setup(tmp_path)
   # batch 64 (round 4): the per-variable noise floor of bf16 storage rises with the batch (more samples per gradient), so the
   # same margin is a sharper bar; after the 10 steps the weights (Adam bound), the BN moving statistics (5e-3) and the
@@ -364,6 +366,7 @@ def test_uq_resnet50_bf16_one_step_at_224_with_8bit_activations(tmp_path):
   (112 ... 7), strided projections and tile tails the benchmark runs, against the float32 oracle: gradient check against the
   measured bf16-storage floor, then two steps."""
   from parity_common import run_bf16_fused_parity
+  import pocketflow_amd.nets.resnet_at_ilsvrc12  # noqa: F401
   FLAGS = _setup(tmp_path)
   run_bf16_fused_parity(FLAGS, tmp_path, steps=2, expect_bf16=True, batch=8, margin=0.05, image_size=224, after_steps=False)
 
@@ -447,6 +450,8 @@ def test_ws_resnet20_bf16_matches_oracle_within_bf16_noise(tmp_path):
   float32 master weights by the same kernels as in float32 mode and must be BIT-IDENTICAL; two more masked steps; pruned
   weights stay exactly zero.  Body: tests/parity_common.py run_ws_bf16_parity (also run on the CPU emulation)."""
   from parity_common import run_ws_bf16_parity
+  import pocketflow_amd.nets.resnet_at_cifar10  # noqa: F401  (importing DEFINES the flags _setup assigns)
+  import pocketflow_amd.learners.weight_sparsification.learner  # noqa: F401
   FLAGS = _setup(tmp_path, compute_dtype='bfloat16')
   run_ws_bf16_parity(FLAGS, tmp_path, expect_bf16=True)
 
@@ -455,6 +460,8 @@ def test_cp_mobilenet_bf16_matches_oracle_within_bf16_noise(tmp_path):
   """BASELINE configs[3] in bf16 (bench.py --config c3): MobileNet-v1 x0.5, channel-pruned masked fine-tune + distillation with
   the in-tree bf16 depthwise kernels inside the step (tests/parity_common.py run_cp_masked_finetune, bf16 branch)."""
   from parity_common import run_cp_masked_finetune
+  import pocketflow_amd.nets.mobilenet_at_ilsvrc12  # noqa: F401
+  import pocketflow_amd.learners.channel_pruning.learner  # noqa: F401
   FLAGS = _setup(tmp_path, compute_dtype='bfloat16')
   run_cp_masked_finetune(FLAGS, tmp_path, 'adam', steps=3, bf16=True)
 
@@ -465,5 +472,7 @@ def test_nuq_resnet50_4bit_bf16_matches_oracle_within_bf16_noise(tmp_path):
   vs the oracle, as in float32 mode); the nearest-codeword ASSIGNMENT of every weight is compared index by index; gradients against the
   float32 oracle within the measured bf16-storage floor; a 5-step loss trajectory.  Body: tests/parity_common.py run_nuq_bf16_parity."""
   from parity_common import run_nuq_bf16_parity
+  import pocketflow_amd.nets.resnet_at_ilsvrc12  # noqa: F401
+  import pocketflow_amd.learners.nonuniform_quantization.learner  # noqa: F401
   FLAGS = _setup(tmp_path, compute_dtype='bfloat16')
   run_nuq_bf16_parity(FLAGS, tmp_path, expect_bf16=True)
