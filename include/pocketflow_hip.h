@@ -348,6 +348,30 @@ typedef struct PfImageDesc {
 int pf_image_resize_bilinear(const void* src, const PfImageDesc* desc, void* out, int out_dtype, int B, int OH,
                              int OW, float mean_r, float mean_g, float mean_b, void* stream);
 
+/* Backward-data of a STRIDED R x S convolution (resnet_model.py:92-103 conv2d_fixed_padding with strides 2; TF's
+ * Conv2DBackpropInput) by output-parity classes: stride * stride stride-1 launches of the implicit-GEMM kernel over dY, each walking
+ * a sub-grid of the flipped / transposed kernel buffer Wt[C][R][S][N] (Wt[c][r'][s'][n] = W[n][R-1-r'][S-1-s'][c]) in place and
+ * scattering its rows to the class's input pixels.  bf16; N % 64 == 0, C % 8 == 0, H % stride == W % stride == 0, R, S >= stride. */
+int pf_conv2d_bwd_data_strided(const void* dY, const void* Wt, void* dX, const void* zero, int imgs, int H, int Wd, int C, int N,
+                               int R, int S, int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream);
+
+/* ---- K12, general form: convolutions of any shape and stride, the dense layer; float32 or bf16 storage, float32 accumulation --
+ * replaces tf.nn.conv2d / tf.layers.conv2d / slim.conv2d, their Conv2DBackpropInput / Conv2DBackpropFilter and tf.layers.dense for
+ * every shape the MFMA kernels above do not take, and ALL of them in the float32 parity mode:
+ *   utils/external/resnet_model.py:92-103 (conv2d_fixed_padding), :552 (dense); utils/external/mobilenet_v1.py:233-292 (slim.conv2d);
+ *   nets/lenet_at_cifar10.py:34-68.
+ * NHWC activations [imgs][H][W][C], KRSC kernels [N][R][S][C]; pad_h / pad_w are the BEGIN pads (positions outside the image read 0,
+ * whatever Ho / Wo say about the end).  A dense layer is the 1x1 convolution of a [imgs][1][1][C] tensor.  Deterministic: one fused
+ * multiply-add per term in a fixed order; the backward-filter pixel splits are summed in ascending order.
+ * pf_convg_wrw: `slab` = float32 workspace of pf_convg_wrw_splits(...) * N * R * S * C elements; dw [N][R][S][C] in dw_dtype. */
+int pf_convg_fwd(const void* x, const void* w, const float* bias, void* y, int dtype, int imgs, int H, int W, int C, int N, int R,
+                 int S, int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream);
+int pf_convg_bwd_data(const void* dy, const void* w, void* dx, int dtype, int imgs, int H, int W, int C, int N, int R, int S,
+                      int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream);
+int pf_convg_wrw_splits(int imgs, int C, int N, int R, int S, int Ho, int Wo);
+int pf_convg_wrw(const void* dy, const void* x, void* dw, int dtype, int dw_dtype, float* slab, int imgs, int H, int W, int C, int N,
+                 int R, int S, int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,13 @@ struct IgArgs {
   int th, tw;           // taps
   int H, Wd, Ho, Wo, stride, pad_h, pad_w;
   int tiles_m, tiles_n, G;
+  // sub-filter walk (strided backward-data by output-parity classes, pf_conv2d_bwd_data_strided): the th x tw taps of THIS launch are
+  // taps (w_r0 + r * w_rs, w_s0 + s * w_ss) of a kernel buffer whose rows hold w_taps_full taps, w_S of them per kernel row.
+  // A plain convolution walks its own kernel: w_r0 = w_s0 = 0, w_rs = w_ss = 1, w_S = tw, w_taps_full = th * tw.
+  int w_r0, w_rs, w_s0, w_ss, w_S, w_taps_full;
+  // output scatter: row (img, i, j) of the launch's [Ho x Wo] grid is stored at pixel (i * o_sub + o_y, j * o_sub + o_x) of an
+  // [o_H x o_W] image (o_sub = 0: off, rows are stored where they are)
+  int o_sub, o_y, o_x, o_H, o_W;
 };
 
 // Ablation builds for tools/gpu/igemm_ablate.py ONLY (never in libpocketflow_hip.so): -DPF_IG_ABLATE=1 drops the MFMAs and
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
   const int cch = a.C >> 6;                                               // 64-channel steps per tap
   const int taps = a.th * a.tw;
   const int nk = taps * cch;
-  const int64_t wrow = (int64_t)taps * a.C;                               // kernel row length (elements)
+  const int64_t wrow = (int64_t)a.w_taps_full * a.C;                      // kernel row length (elements) of the buffer that is walked
   const int hw_o = a.Ho * a.Wo;
 
   if (BWD) {
@@ -232,9 +239,11 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
       const uint32_t voff = ((pmask[i] >> s_tap) & 1u) ? (pbase[i] + tapoff) : OOB;
       PF_BUFFER_LOAD_LDS16(rsX, As + (i * (TS / 8) + swave * 8) * 128, voff, 0);
     }
+    // byte offset of this step's (tap, 64-channel group) inside a kernel row -- s_ks * 128 when the launch walks its own kernel
+    const uint32_t woff = (uint32_t)((((a.w_r0 + s_r * a.w_rs) * a.w_S + a.w_s0 + s_s * a.w_ss) * a.C + s_cc * 64) * 2);   // wave-uniform
 #pragma unroll
     for (int i = 0; i < BS; ++i)
-      PF_BUFFER_LOAD_LDS16(rsW, Bs + (i * (TS / 8) + swave * 8) * 128, boff[i], s_ks * 128);
+      PF_BUFFER_LOAD_LDS16(rsW, Bs + (i * (TS / 8) + swave * 8) * 128, boff[i], woff);
 #else
     (void)As; (void)Bs; (void)tapoff;
 #endif
@@ -660,7 +669,13 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
               }
             }
           }
-          *reinterpret_cast<uint4*>(a.Y + (int64_t)m * a.N + n) = c;
+          int64_t orow = m;
+          if (a.o_sub != 0) {                                               // scatter of a parity class (wave-uniform condition)
+            const int oimg = m / hw_o, orem = m - oimg * hw_o;
+            const int oi = orem / a.Wo, oj = orem - oi * a.Wo;
+            orow = ((int64_t)oimg * a.o_H + oi * a.o_sub + a.o_y) * a.o_W + oj * a.o_sub + a.o_x;
+          }
+          *reinterpret_cast<uint4*>(a.Y + orow * a.N + n) = c;
         }
       }
       if (side != nullptr && p0 + PG < NP && etid) load_side(p0 + PG);
@@ -888,7 +903,51 @@ extern "C" int pf_conv2d_fwd(const void* X, const void* W, void* Y, const void* 
   a.H = H; a.Wd = Wd; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
   a.x_bytes = (uint32_t)((int64_t)imgs * H * Wd * C * 2);
   a.w_bytes = (uint32_t)((int64_t)N * th * tw * C * 2);
+  a.w_r0 = 0; a.w_rs = 1; a.w_s0 = 0; a.w_ss = 1; a.w_S = tw; a.w_taps_full = th * tw;
+  a.o_sub = 0; a.o_y = 0; a.o_x = 0; a.o_H = 0; a.o_W = 0;
   return ig_launch(a, (hipStream_t)stream);
+}
+
+// Backward-data of a STRIDED convolution by output-parity classes (round 4; until then MIOpen).  Forward: y[ho][wo] = sum_{r,s,c}
+// x[ho*st + r - pad_h][wo*st + s - pad_w][c] W[n][r][s][c].  The input pixels h = st*i + a of one class a (per axis) receive
+// contributions from the taps r = r1 + t*st only (r1 = (a + pad_h) mod st), from output row ho = i + (a + pad_h - r) / st: per
+// class a small STRIDE-1 convolution over dY whose taps are a sub-grid of the flipped / transposed kernel buffer
+// Wt[c][R-1-r][S-1-s][n] (VarStore.transposed) -- walked in place (IgArgs.w_*), its rows scattered to the class's pixels
+// (IgArgs.o_*).  st*st launches, exactly the flops of the convolution, no zero-filled intermediate, no atomics.
+// dY [imgs][Ho][Wo][N], Wt [C][R][S][N], dX [imgs][H][W][C]; H % st == 0 and W % st == 0, N % 64 == 0, C % 8 == 0, R, S >= st.
+extern "C" int pf_conv2d_bwd_data_strided(const void* dY, const void* Wt, void* dX, const void* zero, int imgs, int H, int Wd,
+                                          int C, int N, int R, int S, int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream) {
+  if (imgs <= 0 || H <= 0 || Wd <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || N <= 0 || (N % 64) || (C % 8) || stride < 2 || R < stride ||
+      S < stride || (H % stride) || (Wd % stride) || pad_h < 0 || pad_w < 0 || R * S > 32)
+    return (int)hipErrorInvalidValue;
+  if (!pf_aligned16(dY) || !pf_aligned16(Wt) || !pf_aligned16(dX) || zero == nullptr) return (int)hipErrorInvalidValue;
+  if ((int64_t)imgs * Ho * Wo * N >= ((int64_t)1 << 30) || (int64_t)C * R * S * N >= ((int64_t)1 << 30)) return (int)hipErrorInvalidValue;
+  const int Hc = H / stride, Wc = Wd / stride;                  // pixels per class and axis
+  for (int ay = 0; ay < stride; ++ay) {
+    for (int ax = 0; ax < stride; ++ax) {
+      // per axis: first tap of the class, number of taps, offset of the LAST tap's output row relative to i (= the smallest)
+      const int r1 = (ay + pad_h) % stride, s1 = (ax + pad_w) % stride;
+      const int th = (R - r1 + stride - 1) / stride, tw = (S - s1 + stride - 1) / stride;
+      const int dmin_h = (ay + pad_h - r1) / stride - (th - 1), dmin_w = (ax + pad_w - s1) / stride - (tw - 1);
+      IgArgs a;
+      a.X = (const bf16_t*)dY; a.W = (const bf16_t*)Wt; a.Y = (bf16_t*)dX; a.zero = (const bf16_t*)zero;
+      a.R = nullptr; a.partial = nullptr; a.bx = nullptr; a.bss = nullptr; a.bmi = nullptr; a.b_lo = -INFINITY; a.b_hi = INFINITY;
+      a.ss = nullptr; a.slot = nullptr; a.kq = 255.f; a.act_lo = -INFINITY; a.act_hi = INFINITY;
+      a.M = imgs * Hc * Wc; a.N = C; a.C = N; a.th = th; a.tw = tw;
+      // the launch's "input image" is dY, its "output grid" the class's pixels; tap u reads dY row i + dmin + u = i*1 + u - pad'
+      a.H = Ho; a.Wd = Wo; a.Ho = Hc; a.Wo = Wc; a.stride = 1; a.pad_h = -dmin_h; a.pad_w = -dmin_w;
+      a.x_bytes = (uint32_t)((int64_t)imgs * Ho * Wo * N * 2);
+      a.w_bytes = (uint32_t)((int64_t)C * R * S * N * 2);
+      // ascending offset u <-> descending r <-> ascending flipped row R-1-r: first flipped row (R-1-r1) - (th-1)*stride, step stride
+      a.w_r0 = (R - 1 - r1) - (th - 1) * stride; a.w_rs = stride;
+      a.w_s0 = (S - 1 - s1) - (tw - 1) * stride; a.w_ss = stride;
+      a.w_S = S; a.w_taps_full = R * S;
+      a.o_sub = stride; a.o_y = ay; a.o_x = ax; a.o_H = H; a.o_W = Wd;
+      const int rc = ig_launch(a, (hipStream_t)stream);
+      if (rc != 0) return rc;
+    }
+  }
+  return 0;
 }
 
 // 1x1 convolutions through the same kernel (called by pf_conv.hip for the shapes it routes here): plain, backward-data with
@@ -915,5 +974,7 @@ int pf_igemm_conv1x1(const void* X, const void* W, void* Y, const void* R, float
   a.pad_h = 0; a.pad_w = 0;
   a.x_bytes = (uint32_t)(rows_in * K * 2);
   a.w_bytes = (uint32_t)((int64_t)N * K * 2);
+  a.w_r0 = 0; a.w_rs = 1; a.w_s0 = 0; a.w_ss = 1; a.w_S = 1; a.w_taps_full = 1;
+  a.o_sub = 0; a.o_y = 0; a.o_x = 0; a.o_H = 0; a.o_W = 0;
   return ig_launch(a, st);
 }

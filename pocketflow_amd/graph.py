@@ -834,9 +834,11 @@ OWN_POOL = os.environ.get('PF_OWN_POOL', '1') != '0'         # stem max-pooling 
 # backward-filter of the RxS convolutions on pf_wrw.hip (shared-tile kernel); PF_OWN_CONV2D_WRW=0: MIOpen, for A/B runs
 OWN_CONV2D_WRW = os.environ.get('PF_OWN_CONV2D_WRW', '1') != '0'
 OWN_CONV2D_WRW_MIN_C = int(os.environ.get('PF_OWN_CONV2D_WRW_MIN_C', '128'))   # narrower inputs: MIOpen is faster (measured)
+OWN_CONV2D_BWD_STRIDED = os.environ.get('PF_OWN_CONV2D_BWD_STRIDED', '1') != '0'   # strided backward-data by parity classes (0: MIOpen)
 OWN_CONV2D = os.environ.get('PF_OWN_CONV2D', '1') != '0'     # RxS convolutions on pf_igemm.hip (0: MIOpen, for A/B runs)
 OWN_STEM = os.environ.get('PF_OWN_STEM', '1') != '0'         # the 7x7/2 stem on pf_stem.hip (0: MIOpen, for A/B runs)
 OWN_DEPTHWISE = os.environ.get('PF_OWN_DEPTHWISE', '1') != '0'   # depthwise 3x3 on pf_depthwise.hip (0: MIOpen, for A/B runs)
+OWN_CONV_GENERIC = os.environ.get('PF_OWN_CONV_GENERIC', '1') != '0'   # every other convolution / dense layer on pf_convg.hip (0: MIOpen / rocBLAS)
 DEPTHWISE_ANY_DEVICE = False     # tests: run the depthwise plumbing on CPU tensors (the HIP entry points are emulated there)
 
 
@@ -928,11 +930,82 @@ class _Conv2dIgemm(torch.autograd.Function):
             bn_box['bwd_stats'] = (partial, G, dx.data_ptr())
           else:
             hip.conv2d_fwd(dy, wb, dx, B, H, W, N, C, R, S, 1, R - 1 - pad[0], S - 1 - pad[1], H, W)
+      elif (OWN_CONV2D_BWD_STRIDED and stride > 1 and N % 64 == 0 and C % 8 == 0 and x.shape[2] % stride == 0 and x.shape[3] % stride == 0
+            and R >= stride and S >= stride and dy.dtype == torch.bfloat16 and igemm_limits_ok(dy.numel(), w.numel(), R * S)):
+        # strided backward-data by output-parity classes on the implicit-GEMM kernel (pf_conv2d_bwd_data_strided; MIOpen until round 4)
+        B, _, H, W = x.shape
+        wv = ctx.w_var
+        if USE_SEG_TRANSPOSE and wv is not None and wv.store is graph.store and wv.tensor is w:
+          wb = graph.store.transposed(wv)                                                 # [C][R][S][N], flipped
+        else:
+          wb = w.detach().permute(0, 2, 3, 1).flip(1, 2).permute(3, 1, 2, 0).contiguous()
+        dx = torch.empty_like(x)
+        with region('conv2d_bwd_data', float((dy.numel() + x.numel()) * 2)):
+          hip.conv2d_bwd_data_strided(dy, wb, dx, B, H, W, C, N, R, S, stride, pad[0], pad[1], dy.shape[2], dy.shape[3])
       else:
         with region('conv2d_bwd_data', float((dy.numel() + x.numel()) * 2)):
           dx = torch.ops.aten.convolution_backward(dy, x, w.detach(), None, [stride, stride], list(pad), [1, 1], False,
                                                    [0, 0], 1, [True, False, False])[0]
     return dx, dw, None, None, None, None, None, None, None
+
+
+class _ConvGeneric(torch.autograd.Function):
+  """y = conv2d(x, W) [+ bias] on the general kernels of pf_convg.hip (any shape / stride, float32 or bf16 storage, float32
+  accumulation): the float32 parity mode's convolutions and every bf16 layer the MFMA kernels do not take.  x: logical NCHW /
+  physical NHWC, W: logical [N][C][R][S] / physical KRSC; pad = BEGIN pads (the end pads follow from Ho / Wo)."""
+
+  @staticmethod
+  def forward(ctx, x, w, bias, stride, pad, out_hw, graph):
+    B, C, H, Wd = x.shape
+    N, _, R, S = w.shape
+    Ho, Wo = out_hw
+    wk = w.detach().permute(0, 2, 3, 1)
+    if not wk.is_contiguous() or wk.dtype != x.dtype:
+      wk = wk.contiguous().to(x.dtype)
+    y = torch.empty((B, N, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    bf = None if bias is None else bias.detach().float().contiguous()
+    with region('convg_fwd', float((x.numel() + y.numel()) * x.element_size())):
+      hip.convg_fwd(x, wk, bf, y, B, H, Wd, C, N, R, S, stride, pad[0], pad[1], Ho, Wo)
+    ctx.save_for_backward(x, w)
+    ctx.meta = (stride, pad, out_hw, graph, bias is not None)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    x, w = ctx.saved_tensors
+    stride, pad, (Ho, Wo), graph, has_bias = ctx.meta
+    B, C, H, Wd = x.shape
+    N, _, R, S = w.shape
+    dy = _nhwc(dy)
+    if dy.dtype != x.dtype:
+      dy = dy.to(x.dtype)
+    dx = dw = db = None
+    if ctx.needs_input_grad[0]:
+      wk = w.detach().permute(0, 2, 3, 1)
+      if not wk.is_contiguous() or wk.dtype != x.dtype:
+        wk = wk.contiguous().to(x.dtype)
+      dx = torch.empty_like(x, memory_format=torch.channels_last)
+      with region('convg_bwd_data', float((dy.numel() + dx.numel()) * x.element_size())):
+        hip.convg_bwd_data(dy, wk, dx, B, H, Wd, C, N, R, S, stride, pad[0], pad[1], Ho, Wo)
+    if ctx.needs_input_grad[1]:
+      splits = hip.convg_wrw_splits(B, C, N, R, S, Ho, Wo)
+      dwk = torch.empty((N, R, S, C), dtype=w.dtype, device=x.device)
+      with region('convg_wrw', float((dy.numel() + x.numel()) * x.element_size())):
+        hip.convg_wrw(dy, x, dwk, graph.scratch(splits * N * R * S * C), B, H, Wd, C, N, R, S, stride, pad[0], pad[1], Ho, Wo)
+      dw = dwk.permute(0, 3, 1, 2)
+    if has_bias and ctx.needs_input_grad[2]:
+      db = dy.float().sum(dim=(0, 2, 3))
+    return dx, dw, db, None, None, None, None
+
+
+def convg_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
+  return (OWN_CONV_GENERIC and isinstance(x, torch.Tensor) and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)
+          and w.dtype in (torch.float32, torch.bfloat16) and x.numel() > 0)
+
+
+def conv_generic(x, w, bias, stride, pad_begin, out_hw, graph):
+  """Dispatch helper: 4-D x (logical NCHW) through _ConvGeneric; works with or without autograd."""
+  return _ConvGeneric.apply(_nhwc(x), w, bias, stride, pad_begin, out_hw, graph)
 
 
 class _StemConv(torch.autograd.Function):
@@ -1126,7 +1199,13 @@ class Conv2D:
     bn_box = getattr(x, '_pf_bn', None)
     if bn_box is not None:
       bn_box['n_consumers'] += 2                 # a consumer that cannot fuse the BN-backward sums
-    y = F.conv2d(x, w, b, stride=self.stride, padding=pad)
+    if convg_ok(x, w):
+      ph, pw = (pad, pad) if isinstance(pad, int) else pad
+      Ho = (x.shape[2] + 2 * ph - self.k) // self.stride + 1
+      Wo = (x.shape[3] + 2 * pw - self.k) // self.stride + 1
+      y = conv_generic(x, w, self.bias.tensor if self.bias is not None else None, self.stride, (ph, pw), (Ho, Wo), self.graph)
+    else:
+      y = F.conv2d(x, w, b, stride=self.stride, padding=pad)
     return y if residual is None else y + residual
 
   def plain(self, x: torch.Tensor) -> torch.Tensor:
@@ -1287,10 +1366,19 @@ class Dense:
       if g.tap_stop is self:
         raise TapStop()
       return y + self.bias.tensor.to(x.dtype)
-    return F.linear(materialize(x), self.kernel.tensor, self.bias.tensor.to(x.dtype))
+    x = materialize(x)
+    if x.dim() == 2 and convg_ok(x, self.kernel.tensor):
+      # tf.layers.dense = the 1x1 convolution of a [B][1][1][in] tensor (+ BiasAdd in the epilogue): pf_convg.hip
+      w4 = self.kernel.tensor.view(self.kernel.tensor.shape[0], self.kernel.tensor.shape[1], 1, 1)
+      y = _ConvGeneric.apply(x.contiguous().view(x.shape[0], x.shape[1], 1, 1), w4, self.bias.tensor, 1, (0, 0), (1, 1), self.graph)
+      return y.view(x.shape[0], -1)
+    return F.linear(x, self.kernel.tensor, self.bias.tensor.to(x.dtype))
 
   def plain(self, x: torch.Tensor) -> torch.Tensor:
     """The MatMul op alone (no BiasAdd)."""
+    if x.dim() == 2 and convg_ok(x, self.kernel.tensor):
+      w4 = self.kernel.tensor.view(self.kernel.tensor.shape[0], self.kernel.tensor.shape[1], 1, 1)
+      return _ConvGeneric.apply(x.contiguous().view(x.shape[0], x.shape[1], 1, 1), w4, None, 1, (0, 0), (1, 1), self.graph).view(x.shape[0], -1)
     return F.linear(x, self.kernel.tensor)
 
 

@@ -47,6 +47,7 @@ SYMBOLS = [
     'pf_image_resize_bilinear', 'pf_depthwise_supported', 'pf_depthwise_groups', 'pf_depthwise_fwd', 'pf_depthwise_bwd_data',
     'pf_depthwise_wrw', 'pf_conv2d_stats_groups_geom', 'pf_tuning_reload',
     'pf_adam_flat_dev', 'pf_momentum_flat_dev', 'pf_set_floats',
+    'pf_convg_fwd', 'pf_convg_bwd_data', 'pf_convg_wrw_splits', 'pf_convg_wrw', 'pf_conv2d_bwd_data_strided',
 ]
 
 
@@ -442,6 +443,58 @@ def depthwise_wrw(dY, X, dW, slabs, B: int, H: int, Wd: int, C: int, k: int, str
   _check(_lib.pf_depthwise_wrw(_ptr(dY), _ptr(X), _ptr(dW), c_int(dtype_code(X)), c_int(dtype_code(dW)), _ptr(slabs), c_int(B),
                                c_int(H), c_int(Wd), c_int(C), c_int(k), c_int(stride), c_int(pad_h), c_int(pad_w), c_int(Ho),
                                c_int(Wo), _stream()), 'pf_depthwise_wrw')
+
+
+def conv2d_bwd_data_strided(dY, Wt, dX, B: int, H: int, Wd: int, C: int, N: int, R: int, S: int, stride: int, pad_h: int,
+                            pad_w: int, Ho: int, Wo: int) -> None:
+  """dX[B][H][Wd][C] of a strided convolution from dY[B][Ho][Wo][N] and the flipped / transposed kernel Wt[C][R][S][N] (bf16):
+  stride * stride launches of the implicit-GEMM kernel, one per output-parity class (pf_igemm.hip)."""
+  _dev(dY)
+  if dY.dtype != torch.bfloat16 or Wt.dtype != torch.bfloat16 or dX.dtype != torch.bfloat16:
+    raise TypeError('conv2d_bwd_data_strided: bf16 tensors')
+  _check(_lib.pf_conv2d_bwd_data_strided(_ptr(dY), _ptr(Wt), _ptr(dX), _ptr(zero_page(dY.device)), c_int(B), c_int(H), c_int(Wd),
+                                         c_int(C), c_int(N), c_int(R), c_int(S), c_int(stride), c_int(pad_h), c_int(pad_w), c_int(Ho),
+                                         c_int(Wo), _stream()), 'pf_conv2d_bwd_data_strided')
+
+
+# ------------------------------------------------------------------------------------------------
+# general convolutions / dense (pf_convg.hip): any shape and stride, float32 or bf16, float32 accumulation
+# ------------------------------------------------------------------------------------------------
+
+def convg_fwd(X, Wk, bias, Y, B: int, H: int, Wd: int, C: int, N: int, R: int, S: int, stride: int, pad_h: int, pad_w: int,
+              Ho: int, Wo: int) -> None:
+  """Y[B][Ho][Wo][N] = conv(X[B][H][Wd][C], Wk[N][R][S][C]) (+ bias[N], float32); pad_*: begin pads."""
+  _dev(X)
+  if Wk.dtype != X.dtype or Y.dtype != X.dtype or (bias is not None and bias.dtype != torch.float32):
+    raise TypeError('convg_fwd: X / Wk / Y share one dtype, the bias is float32')
+  _check(_lib.pf_convg_fwd(_ptr(X), _ptr(Wk), _ptr(bias), _ptr(Y), c_int(dtype_code(X)), c_int(B), c_int(H), c_int(Wd), c_int(C),
+                           c_int(N), c_int(R), c_int(S), c_int(stride), c_int(pad_h), c_int(pad_w), c_int(Ho), c_int(Wo), _stream()),
+         'pf_convg_fwd')
+
+
+def convg_bwd_data(dY, Wk, dX, B: int, H: int, Wd: int, C: int, N: int, R: int, S: int, stride: int, pad_h: int, pad_w: int,
+                   Ho: int, Wo: int) -> None:
+  _dev(dY)
+  if Wk.dtype != dY.dtype or dX.dtype != dY.dtype:
+    raise TypeError('convg_bwd_data: dY / Wk / dX share one dtype')
+  _check(_lib.pf_convg_bwd_data(_ptr(dY), _ptr(Wk), _ptr(dX), c_int(dtype_code(dY)), c_int(B), c_int(H), c_int(Wd), c_int(C),
+                                c_int(N), c_int(R), c_int(S), c_int(stride), c_int(pad_h), c_int(pad_w), c_int(Ho), c_int(Wo),
+                                _stream()), 'pf_convg_bwd_data')
+
+
+def convg_wrw_splits(B: int, C: int, N: int, R: int, S: int, Ho: int, Wo: int) -> int:
+  return int(_lib.pf_convg_wrw_splits(c_int(B), c_int(C), c_int(N), c_int(R), c_int(S), c_int(Ho), c_int(Wo)))
+
+
+def convg_wrw(dY, X, dW, slab, B: int, H: int, Wd: int, C: int, N: int, R: int, S: int, stride: int, pad_h: int, pad_w: int,
+              Ho: int, Wo: int) -> None:
+  """dW[N][R][S][C] (float32 or bf16); slab: float32 workspace of convg_wrw_splits(...) * N * R * S * C elements."""
+  _dev(X)
+  if dY.dtype != X.dtype or slab.dtype != torch.float32 or slab.numel() < convg_wrw_splits(B, C, N, R, S, Ho, Wo) * N * R * S * C:
+    raise TypeError('convg_wrw: dY / X share one dtype; float32 workspace of splits * N * R * S * C elements')
+  _check(_lib.pf_convg_wrw(_ptr(dY), _ptr(X), _ptr(dW), c_int(dtype_code(X)), c_int(dtype_code(dW)), _ptr(slab), c_int(B), c_int(H),
+                           c_int(Wd), c_int(C), c_int(N), c_int(R), c_int(S), c_int(stride), c_int(pad_h), c_int(pad_w), c_int(Ho),
+                           c_int(Wo), _stream()), 'pf_convg_wrw')
 
 
 TILE_DTYPE = np.dtype([('src_off', '<i8'), ('dst_off', '<i8'), ('O', '<i4'), ('I', '<i4'), ('src_ld', '<i4'),

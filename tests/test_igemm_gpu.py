@@ -209,3 +209,29 @@ def test_conv_stem_wrw_matches_autograd(hip, imgs, H, Wd, dw_dtype):
   assert torch.equal(outs[0], outs[1])
   err = float((outs[0].float() - ref).abs().max() / ref.abs().max())
   assert err <= (1e-4 if dw_dtype == torch.float32 else 6e-3), err
+
+
+@pytest.mark.parametrize('imgs,H,Wd,C,N,k,pad', [(4, 16, 16, 64, 128, 3, 1), (2, 28, 28, 128, 256, 3, 1), (3, 14, 10, 72, 64, 5, 2),
+                                                 (2, 8, 8, 64, 64, 2, 0)])
+def test_conv2d_backward_data_of_strided_convolutions_by_parity_classes(hip, imgs, H, Wd, C, N, k, pad):
+  """pf_conv2d_bwd_data_strided (stride 2): four stride-1 launches of the implicit-GEMM kernel over dY, each walking a sub-grid of
+  the flipped / transposed kernel in place and scattering its rows to one output-parity class, against autograd.  Every pixel of
+  dX is written (the NaN fill must be gone); a second call gives the same bits."""
+  g = torch.Generator(device='cuda').manual_seed(21 + k)
+  stride = 2
+  Ho, Wo = (H + 2 * pad - k) // stride + 1, (Wd + 2 * pad - k) // stride + 1
+  x = _bf(torch.randn(imgs, H, Wd, C, device='cuda', generator=g))
+  w = _bf(torch.randn(N, k, k, C, device='cuda', generator=g) * 0.05)
+  dy = _bf(torch.randn(imgs, Ho, Wo, N, device='cuda', generator=g) * 0.1)
+  xt = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+  F.conv2d(xt, w.float().permute(0, 3, 1, 2), stride=stride, padding=pad).backward(dy.float().permute(0, 3, 1, 2))
+  ref = xt.grad.permute(0, 2, 3, 1)
+  wb = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()            # [C][k][k][N]
+  dx = torch.full((imgs, H, Wd, C), float('nan'), device='cuda').bfloat16()
+  hip.conv2d_bwd_data_strided(dy, wb, dx, imgs, H, Wd, C, N, k, k, stride, pad, pad, Ho, Wo)
+  torch.cuda.synchronize()
+  assert torch.isfinite(dx.float()).all()
+  _close(dx, _bf(ref), 'strided bwd-data')
+  dx2 = torch.empty_like(dx)
+  hip.conv2d_bwd_data_strided(dy, wb, dx2, imgs, H, Wd, C, N, k, k, stride, pad, pad, Ho, Wo)
+  assert torch.equal(dx, dx2)

@@ -355,10 +355,12 @@ def test_uq_resnet50_bf16_fused_path_matches_oracle_within_bf16_noise(tmp_path):
   from parity_common import run_bf16_fused_parity
   import pocketflow_amd.nets.resnet_at_ilsvrc12  # noqa: F401
   FLAGS = _setup(tmp_path)
-  # batch 64 (round 4): the per-variable noise floor of bf16 storage rises with the batch (more samples per gradient), so the
-  # same margin is a sharper bar; after the 10 steps the weights (Adam bound), the BN moving statistics (5e-3) and the
-  # evaluation loss / top-1 of the quantised network are compared with the oracle's as well
-  run_bf16_fused_parity(FLAGS, tmp_path, steps=10, expect_bf16=True, batch=64, margin=0.03)
+  # batch 64 (round 4).  Measured: the bf16-storage floor of this configuration does NOT rise with the batch (kernels: min 0.921 /
+  # median 0.941 at batch 64, 0.921 / 0.944 at 16 -- the 8-bit activation quantiser's rounding flips dominate it, not sampling noise),
+  # the product sits 0.003 under it (0.919 / 0.938).  The bars: per variable floor - 0.05 (as in round 3), and -- new -- the kernels
+  # as a population within 0.02 (median) / 0.05 (minimum) of the floor, the whole gradient within 0.03 of the emulation's; after
+  # the 10 steps the weights (Adam bound), the BN moving statistics (5e-3) and the evaluation loss / top-1 against the oracle's
+  run_bf16_fused_parity(FLAGS, tmp_path, steps=10, expect_bf16=True, batch=64, margin=0.05)
 
 
 def test_uq_resnet50_bf16_one_step_at_224_with_8bit_activations(tmp_path):
