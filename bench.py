@@ -214,12 +214,12 @@ def build_learner(args, FLAGS, tmp, rank, world, barrier):
 # The fused 1x1 forward (region conv1x1_fwd: producer BN + ReLU + fake-quant prologue, residual / statistics epilogue) is
 # dispatched per shape to three kernels: the resident-kernel variant (pf_conv_stream.hip), the direct-to-LDS staged
 # variant with the in-LDS prologue pass (pf_igemm.hip, MODE 2) and the register-staged tiles (pf_conv.hip).
-REGION_KERNELS = {'conv1x1_fwd': [r'^k_conv1x1_stream<\d+, true, ', r'^k_igemm<\d+, \d+, \d+, \d+, \d+, 2>',
+REGION_KERNELS = {'conv1x1_fwd': [r'^k_conv1x1_stream<\d+, true, ', r'^k_igemm<\d+, \d+, \d+, \d+, \d+, 2[,>]',
                                   r'^k_conv1x1_fwd<\d+, true, '],
                   'conv1x1_wrw': [r'^k_wrw2<', r'^k_conv1x1_wrw<', r'^k_wrw_tr<'],
-                  'conv1x1_bwd_data': [r'^k_conv1x1_stream<\d+, false, ', r'^k_igemm<\d+, \d+, \d+, \d+, \d+, [01]>',
+                  'conv1x1_bwd_data': [r'^k_conv1x1_stream<\d+, false, ', r'^k_igemm<\d+, \d+, \d+, \d+, \d+, [01][,>]',
                                        r'^k_conv1x1_fwd<\d+, false, '],
-                  'conv2d_fwd': [r'^k_igemm<\d+, \d+, \d+, \d+, \d+, 0>'],
+                  'conv2d_fwd': [r'^k_igemm<\d+, \d+, \d+, \d+, \d+, 0[,>]'],
                   'bn_bwd_apply': [r'^k_bn_bwd_apply<'], 'bn_bwd_stats': [r'^k_bn_bwd_stats'],
                   'bn_act_quant_apply': [r'^k_bn_apply<'], 'bn_stats': [r'^k_bn_stats']}
 PROFILE_TAG = 'r04'

@@ -372,6 +372,17 @@ int pf_convg_wrw_splits(int imgs, int C, int N, int R, int S, int Ho, int Wo);
 int pf_convg_wrw(const void* dy, const void* x, void* dw, int dtype, int dw_dtype, float* slab, int imgs, int H, int W, int C, int N,
                  int R, int S, int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream);
 
+/* ---- proximal-gradient channel selection of the 'chn-pruned-gpu' learner ----------------------------------------------------------
+ * replaces learners/channel_pruning_gpu/learner.py:376-383 (var_prnd_new = var - lr * grad; var_norm = sqrt(reduce_sum(square, axes
+ * [0, 1, 3])); threshold = percentile(var_norm, p); shrk_vec = maximum(1 - threshold / var_norm, 0); assign(var_prnd_new * shrk_vec)).
+ * w: float32 master kernel in KRSC storage = [rows = O*R*S][I] with the input channel innermost; g: its gradient (float32 / bf16).
+ * pf_prox_norms: norms[I] of W - lr * G (partial: float32 workspace of pf_prox_groups(rows, I) * I elements; deterministic).
+ * The threshold is pf_kth_largest_nonneg over `norms` at the nearest-rank index of the percentile (host arithmetic as for K7).
+ * pf_prox_apply: W <- (W - lr * G) * max(1 - thr[0] / norms[c], 0). */
+int pf_prox_groups(int64_t rows, int I);
+int pf_prox_norms(const float* w, const void* g, int g_dtype, float lr, int64_t rows, int I, float* partial, float* norms, void* stream);
+int pf_prox_apply(float* w, const void* g, int g_dtype, float lr, int64_t rows, int I, const float* norms, const float* thr, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

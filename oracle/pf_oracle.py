@@ -759,3 +759,27 @@ def krsc_to_hwio(w: np.ndarray) -> np.ndarray:
   if w.ndim == 2:
     return np.ascontiguousarray(w.T)
   return np.ascontiguousarray(np.transpose(w, (1, 2, 3, 0)))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# 'chn-pruned-gpu': the stochastic proximal-gradient step (learners/channel_pruning_gpu/learner.py:376-383)
+# ---------------------------------------------------------------------------------------------------------------------------------
+
+def cpg_proximal_step(w_hwio: np.ndarray, g_hwio: np.ndarray, lrn_rate, prune_perctl) -> Tuple[np.ndarray, np.ndarray, np.float32]:
+  """var_prnd_new = var_prnd - lrn_rate_pgd * grad                                          (:376)
+  var_norm = tf.sqrt(tf.reduce_sum(tf.square(var_prnd_new), axis=[0, 1, 3], keepdims=True))  (:377)
+  threshold = tf.contrib.distributions.percentile(var_norm, prune_perctl)                     (:378, 'nearest')
+  shrk_vec = tf.maximum(1.0 - threshold / var_norm, 0.0)                                     (:379)
+  prune_op = var_prnd.assign(var_prnd_new * shrk_vec)                                        (:380)
+  One float32 rounding per TF op.  Returns (new kernel HWIO, var_norm [I], threshold).  A channel whose norm is exactly 0 under a
+  zero threshold gives 0 / 0 in TF (nan * 0-weights = nan); the learner never reaches that state from finite weights with p > 0
+  (the threshold is then a positive norm); this restatement maps it to 0 like the product (stated, not pinned)."""
+  w = f32(w_hwio)
+  g = f32(g_hwio)
+  new = f32(w - f32(np.float32(lrn_rate) * g))
+  norm = f32(np.sqrt(np.sum(np.square(new), axis=(0, 1, 3), keepdims=True, dtype=np.float32)))
+  thr = np.float32(percentile_nearest(norm, np.float32(prune_perctl)))
+  with np.errstate(divide='ignore', invalid='ignore'):
+    shrk = f32(np.maximum(f32(np.float32(1.0) - f32(thr / norm)), np.float32(0.0)))
+  shrk = np.where(np.isnan(shrk), np.float32(0.0), shrk).astype(np.float32)
+  return f32(new * shrk), norm.reshape(-1), thr

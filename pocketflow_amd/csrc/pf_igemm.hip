@@ -101,7 +101,10 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // consumer, 12 wavefronts = 3 per SIMD = 168 registers each.
 #define IG_PROW 3
 #define IG_NWP 4                                    // producer wavefronts of the wave-specialised variant (one per SIMD)
-template <int BM, int BN, int WM, int WN, int NS, int MODE>
+// SUB: the launch walks a sub-grid of a larger kernel buffer and scatters its rows (IgArgs.w_* / o_*: strided backward-data by parity
+// classes).  A template parameter, not a run-time branch: the extra scalar state cost the ordinary kernels 16-24 more spilled SGPRs
+// (v_writelane / v_readlane traffic in the staging code) when it was one.
+template <int BM, int BN, int WM, int WN, int NS, int MODE, bool SUB = false>
 __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) void k_igemm(const IgArgs a) {
   constexpr bool WS = (MODE == IG_PROW);
   constexpr bool BWD = (MODE == IG_BWD), PRO = (MODE == IG_PRO || WS);
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
   const int cch = a.C >> 6;                                               // 64-channel steps per tap
   const int taps = a.th * a.tw;
   const int nk = taps * cch;
-  const int64_t wrow = (int64_t)a.w_taps_full * a.C;                      // kernel row length (elements) of the buffer that is walked
+  const int64_t wrow = (int64_t)(SUB ? a.w_taps_full : taps) * a.C;       // kernel row length (elements) of the buffer that is walked
   const int hw_o = a.Ho * a.Wo;
 
   if (BWD) {
@@ -239,8 +242,9 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
       const uint32_t voff = ((pmask[i] >> s_tap) & 1u) ? (pbase[i] + tapoff) : OOB;
       PF_BUFFER_LOAD_LDS16(rsX, As + (i * (TS / 8) + swave * 8) * 128, voff, 0);
     }
-    // byte offset of this step's (tap, 64-channel group) inside a kernel row -- s_ks * 128 when the launch walks its own kernel
-    const uint32_t woff = (uint32_t)((((a.w_r0 + s_r * a.w_rs) * a.w_S + a.w_s0 + s_s * a.w_ss) * a.C + s_cc * 64) * 2);   // wave-uniform
+    // byte offset of this step's (tap, 64-channel group) inside a kernel row: s_ks * 128 when the launch walks its own kernel
+    uint32_t woff = (uint32_t)(s_ks * 128);                                             // wave-uniform
+    if constexpr (SUB) woff = (uint32_t)((((a.w_r0 + s_r * a.w_rs) * a.w_S + a.w_s0 + s_s * a.w_ss) * a.C + s_cc * 64) * 2);
 #pragma unroll
     for (int i = 0; i < BS; ++i)
       PF_BUFFER_LOAD_LDS16(rsW, Bs + (i * (TS / 8) + swave * 8) * 128, boff[i], woff);
@@ -670,7 +674,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
             }
           }
           int64_t orow = m;
-          if (a.o_sub != 0) {                                               // scatter of a parity class (wave-uniform condition)
+          if constexpr (SUB) {                                              // scatter of a parity class
             const int oimg = m / hw_o, orem = m - oimg * hw_o;
             const int oi = orem / a.Wo, oj = orem - oi * a.Wo;
             orow = ((int64_t)oimg * a.o_H + oi * a.o_sub + a.o_y) * a.o_W + oj * a.o_sub + a.o_x;
@@ -813,7 +817,7 @@ int pf_igemm_stats_groups(int M, int N, int pro) {
 
 extern "C" int pf_conv2d_stats_groups(int M, int N) { return pf_igemm_stats_groups(M, N, 0); }
 
-template <int BM, int BN, int WM, int WN, int NS, int MODE>
+template <int BM, int BN, int WM, int WN, int NS, int MODE, bool SUB = false>
 static int ig_launch_t(IgArgs& a, int slots, hipStream_t st) {
   constexpr bool BWD = (MODE == IG_BWD), PRO3 = ((MODE == IG_PRO || MODE == IG_PROW) && NS == 3);
   constexpr int THREADS = 64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0));
@@ -828,12 +832,12 @@ static int ig_launch_t(IgArgs& a, int slots, hipStream_t st) {
   static bool configured = false;
   if (!configured) {
     const size_t lds_max = base + (BWD ? 4 * BN * 4 : 0) + (PRO3 ? 2 * (size_t)CV_MAXK * 4 : 0);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<BM, BN, WM, WN, NS, MODE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<BM, BN, WM, WN, NS, MODE, SUB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
-  k_igemm<BM, BN, WM, WN, NS, MODE><<<grid, THREADS, lds, st>>>(a);
+  k_igemm<BM, BN, WM, WN, NS, MODE, SUB><<<grid, THREADS, lds, st>>>(a);
   PF_LAUNCH_CHECK();
   return 0;
 }
@@ -943,7 +947,9 @@ extern "C" int pf_conv2d_bwd_data_strided(const void* dY, const void* Wt, void* 
       a.w_s0 = (S - 1 - s1) - (tw - 1) * stride; a.w_ss = stride;
       a.w_S = S; a.w_taps_full = R * S;
       a.o_sub = stride; a.o_y = ay; a.o_x = ax; a.o_H = H; a.o_W = Wd;
-      const int rc = ig_launch(a, (hipStream_t)stream);
+      // (the two plain tile configurations the dispatcher picks for these shapes, with the sub-grid walk compiled in)
+      const int rc = (C % 128 == 0) ? ig_launch_t<128, 128, 2, 2, 2, IG_PLAIN, true>(a, 512, (hipStream_t)stream)
+                                    : ig_launch_t<128, 64, 2, 2, 2, IG_PLAIN, true>(a, 512, (hipStream_t)stream);
       if (rc != 0) return rc;
     }
   }

@@ -48,6 +48,7 @@ SYMBOLS = [
     'pf_depthwise_wrw', 'pf_conv2d_stats_groups_geom', 'pf_tuning_reload',
     'pf_adam_flat_dev', 'pf_momentum_flat_dev', 'pf_set_floats',
     'pf_convg_fwd', 'pf_convg_bwd_data', 'pf_convg_wrw_splits', 'pf_convg_wrw', 'pf_conv2d_bwd_data_strided',
+    'pf_prox_groups', 'pf_prox_norms', 'pf_prox_apply',
 ]
 
 
@@ -262,6 +263,26 @@ def set_floats(dst, a: float, b: float = 0.0, c: float = 0.0, d: float = 0.0) ->
   """dst[0..3] = (a, b, c, d) by a one-thread kernel whose arguments carry the values."""
   assert dst.dtype == torch.float32 and dst.numel() >= 4
   _check(_lib.pf_set_floats(_ptr(dst), c_float(a), c_float(b), c_float(c), c_float(d), _stream()), 'pf_set_floats')
+
+
+def prox_groups(rows: int, I: int) -> int:
+  return int(_lib.pf_prox_groups(c_int64(rows), c_int(I)))
+
+
+def prox_norms(w, g, lr: float, rows: int, I: int, partial, norms) -> None:
+  """norms[I] = per-input-channel L2 norm of W - lr * G, W a float32 [rows][I] matrix (KRSC kernel), G float32 / bf16."""
+  _dev(w)
+  if w.dtype != torch.float32 or partial.numel() < prox_groups(rows, I) * I or norms.numel() < I:
+    raise TypeError('prox_norms: float32 master kernel, workspace of prox_groups(rows, I) * I floats')
+  _check(_lib.pf_prox_norms(_ptr(w), _ptr(g), c_int(dtype_code(g)), c_float(lr), c_int64(rows), c_int(I), _ptr(partial), _ptr(norms),
+                            _stream()), 'pf_prox_norms')
+
+
+def prox_apply(w, g, lr: float, rows: int, I: int, norms, thr) -> None:
+  """W <- (W - lr * G) * max(1 - thr[0] / norms[c], 0), in place."""
+  _dev(w)
+  _check(_lib.pf_prox_apply(_ptr(w), _ptr(g), c_int(dtype_code(g)), c_float(lr), c_int64(rows), c_int(I), _ptr(norms), _ptr(thr),
+                            _stream()), 'pf_prox_apply')
 
 
 # ------------------------------------------------------------------------------------------------

@@ -78,6 +78,19 @@ def proximal_shrink(w_krsc: torch.Tensor, prune_perctl: float):
   return w_krsc * shrk.to(w_krsc.dtype), norm
 
 
+def proximal_step(w_flat, g_flat, lrn_rate_pgd: float, prune_perctl: float, rows: int, cin: int, ws) -> None:
+  """layer_ops[idx]['prune'] of the reference (:376-380) on the device, in place on the float32 master kernel `w_flat` (KRSC storage =
+  [rows][cin]): pf_prox_norms (one read of W and G) -> nearest-rank percentile of the cin norms (pf_kth_largest_nonneg, the index in
+  float64 on the float32 percentile as for the weight-sparsification masks) -> pf_prox_apply (one read of W and G, one write of W).
+  Until round 4: `proximal_shrink` above, five torch ops."""
+  partial, norms, thr, kth_ws = ws
+  hip.prox_norms(w_flat, g_flat, float(lrn_rate_pgd), rows, cin, partial, norms)
+  q = np.float64(np.float32(prune_perctl))
+  idx = int(np.clip(np.rint(np.float64(cin - 1) * (np.float64(1.0) - q / np.float64(100.0))), 0, cin - 1))
+  hip.kth_largest_nonneg(norms[:cin], idx, thr, kth_ws)
+  hip.prox_apply(w_flat, g_flat, float(lrn_rate_pgd), rows, cin, norms, thr)
+
+
 class ChannelPrunedGpuLearner(AbstractLearner):  # pylint: disable=too-many-instance-attributes
   """Channel pruning learner with GPU-based optimization."""
 
@@ -259,13 +272,21 @@ class ChannelPrunedGpuLearner(AbstractLearner):  # pylint: disable=too-many-inst
     var = self.vars_prnd['maskable'][idx]
     kh, kw, cin, cout = var.ref_shape
     sl = slice(var.offset, var.offset + var.numel)
-    w = st.w_master[sl].view(cout, kh * kw, cin)
-    g = st.w_grad[sl].view(cout, kh * kw, cin).float()
-    w_new, __ = proximal_shrink(w - lrn_rate_pgd * g, prune_perctl)
-    w.copy_(w_new)
+    proximal_step(st.w_master[sl], st.w_grad[sl], lrn_rate_pgd, prune_perctl, cout * kh * kw, cin, self.__prox_ws(cout * kh * kw, cin))
     st.zero_grad()
     st.sync_compute()
     return reg_loss
+
+  def __prox_ws(self, rows, cin):
+    """(partial sums, norms, threshold, radix-select workspace) of the fused proximal step, grown on demand."""
+    need = hip.prox_groups(rows, cin) * cin
+    ws = getattr(self, '_prox_ws', None)
+    if ws is None or ws[0].numel() < need or ws[1].numel() < cin:
+      dev = self.graph.store.device
+      ws = self._prox_ws = (torch.empty(max(need, 1 << 16), dtype=torch.float32, device=dev),
+                            torch.empty(max(cin, 4096), dtype=torch.float32, device=dev),
+                            torch.empty(1, dtype=torch.float32, device=dev), torch.empty(4096, dtype=torch.int32, device=dev))
+    return ws
 
   def __update_mask(self, idx):
     """mask_updt_ops[idx]: mask = (||W[:, :, c, :]|| > 0) broadcast over the kernel (:243-250)."""

@@ -476,6 +476,20 @@ class FakeHipFull(FakeHip):
     vn += (ge * ge - vn) * (one - np.float32(beta2))
     pn -= (mn * alpha_t) / (np.sqrt(vn) + np.float32(eps))
 
+  # -- chn-pruned-gpu: the proximal step ------------------------------------------------------------------------------------
+  def prox_groups(self, rows, I):
+    return 1
+
+  def prox_norms(self, w, g, lr, rows, I, partial, norms):
+    new = w.detach().float().view(rows, I) - np.float32(lr) * g.detach().float().view(rows, I)
+    norms[:I] = torch.sqrt((new * new).sum(dim=0))
+
+  def prox_apply(self, w, g, lr, rows, I, norms, thr):
+    new = w.detach().view(rows, I) - np.float32(lr) * g.detach().float().view(rows, I)
+    shrk = torch.clamp(1.0 - thr[0] / norms[:I], min=0.0)
+    shrk = torch.where(torch.isnan(shrk), torch.zeros_like(shrk), shrk)
+    w.view(rows, I).copy_(new * shrk)
+
   def set_floats(self, dst, a, b=0.0, c=0.0, d=0.0):
     dst[:4] = torch.tensor([a, b, c, d], dtype=torch.float32)
 

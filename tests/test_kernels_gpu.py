@@ -538,3 +538,40 @@ def test_launch_stream_is_torchs_current_stream(hip):
   s.synchronize()
   ab = hip.minmax_decode(slot).cpu().numpy()
   assert abs(float(ab[0, 1]) - 3.0) < 1e-6                       # beta = min = 3: the reduction saw the add
+
+
+@pytest.mark.parametrize('O_,k,I,gdt', [(64, 3, 64, torch.float32), (256, 1, 512, torch.bfloat16), (10, 5, 24, torch.float32), (512, 3, 256, torch.bfloat16)])
+def test_cpg_proximal_step_matches_oracle(O_, k, I, gdt):
+  """pf_prox_norms -> pf_kth_largest_nonneg -> pf_prox_apply (the 'chn-pruned-gpu' learner's proximal-gradient step, pf_prox.hip)
+  against oracle/pf_oracle.py cpg_proximal_step on the same float32 kernel and gradient: channel norms to float32 summation order,
+  the threshold IS one of the device's norms (nearest rank), the shrunk kernel to 2e-6, pruned channels exactly zero; a second
+  run gives the same bits."""
+  from oracle import pf_oracle as O
+  from pocketflow_amd import hip
+  from pocketflow_amd.learners.channel_pruning_gpu.learner import proximal_step
+  rng = np.random.RandomState(O_ + I)
+  w_hwio = (rng.randn(k, k, I, O_) * (0.2 + rng.rand(1, 1, I, 1))).astype(np.float32)
+  g_hwio = rng.randn(k, k, I, O_).astype(np.float32)
+  if gdt == torch.bfloat16:
+    g_hwio = torch.from_numpy(g_hwio).bfloat16().float().numpy()
+  w_hwio[:, :, 3, :] = 0
+  g_hwio[:, :, 3, :] = 0
+  rows = O_ * k * k
+  to_krsc = lambda a: np.ascontiguousarray(a.transpose(3, 0, 1, 2)).reshape(-1)
+  for lr, perctl in ((1e-3, 0.0), (2e-2, 30.0), (1e-2, 50.0)):
+    want, norm, thr = O.cpg_proximal_step(w_hwio, g_hwio, lr, perctl)
+    outs = []
+    for rep in range(2):
+      w = torch.from_numpy(to_krsc(w_hwio)).cuda()
+      g = torch.from_numpy(to_krsc(g_hwio)).cuda().to(gdt)
+      ws = (torch.full((hip.prox_groups(rows, I) * I,), float('nan'), device='cuda'), torch.full((max(I, 4096),), float('nan'), device='cuda'),
+            torch.empty(1, device='cuda'), torch.empty(4096, dtype=torch.int32, device='cuda'))
+      proximal_step(w, g, lr, perctl, rows, I, ws)
+      outs.append((w.cpu().numpy(), ws[1][:I].cpu().numpy(), float(ws[2][0])))
+    got, n, t = outs[0]
+    assert np.array_equal(got, outs[1][0]) and t == outs[1][2]
+    np.testing.assert_allclose(n, norm, rtol=3e-6)
+    assert t in set(n.tolist()) and abs(t - float(thr)) <= 3e-6 * max(1.0, float(thr))
+    got_hwio = got.reshape(O_, k, k, I).transpose(1, 2, 3, 0)
+    np.testing.assert_allclose(got_hwio, want, rtol=5e-5, atol=3e-6 * float(np.abs(want).max()))
+    assert np.array_equal(np.all(got_hwio == 0, axis=(0, 1, 3)), np.all(want == 0, axis=(0, 1, 3)))

@@ -726,6 +726,40 @@ def test_proximal_shrink_against_numpy():
     assert dead >= int(np.floor(12 * perctl / 100.0)) or perctl == 0.0
 
 
+def test_cpg_proximal_step_oracle_and_plumbing():
+  """oracle/pf_oracle.py cpg_proximal_step (restating channel_pruning_gpu/learner.py:376-380) against the torch expression the
+  learner used until round 4 (`proximal_shrink`), and the learner's `proximal_step` plumbing (norms -> nearest-rank threshold ->
+  shrink) over the emulated entry points."""
+  from oracle import pf_oracle as O
+  from fake_hip import FakeHipFull
+  import pocketflow_amd.learners.channel_pruning_gpu.learner as CPG
+  rng = np.random.RandomState(3)
+  w_hwio = (rng.randn(3, 3, 24, 10) * rng.rand(1, 1, 24, 1)).astype(np.float32)
+  g_hwio = rng.randn(3, 3, 24, 10).astype(np.float32)
+  w_hwio[:, :, 7, :] = 0
+  g_hwio[:, :, 7, :] = 0                                               # a dead channel stays dead
+  fake = FakeHipFull()
+  old = CPG.hip
+  CPG.hip = fake
+  try:
+    for lr, perctl in ((1e-3, 0.0), (1e-2, 25.0), (5e-2, 50.0), (1e-3, 90.0)):
+      want, norm, thr = O.cpg_proximal_step(w_hwio, g_hwio, lr, perctl)
+      w_krsc = torch.from_numpy(np.ascontiguousarray(w_hwio.transpose(3, 0, 1, 2)).reshape(10, 9, 24))
+      g_krsc = torch.from_numpy(np.ascontiguousarray(g_hwio.transpose(3, 0, 1, 2)).reshape(10, 9, 24))
+      got, n = CPG.proximal_shrink(w_krsc - np.float32(lr) * g_krsc, perctl)
+      np.testing.assert_allclose(got.numpy().reshape(10, 3, 3, 24).transpose(1, 2, 3, 0), want, rtol=5e-5, atol=1e-6)
+      np.testing.assert_allclose(n.numpy(), norm, rtol=2e-6)
+      w_flat, g_flat = w_krsc.clone().reshape(-1), g_krsc.reshape(-1)
+      ws = (torch.empty(24), torch.empty(24), torch.empty(1), torch.empty(16, dtype=torch.int32))
+      CPG.proximal_step(w_flat, g_flat, lr, perctl, 90, 24, ws)
+      np.testing.assert_allclose(w_flat.numpy().reshape(10, 3, 3, 24).transpose(1, 2, 3, 0), want, rtol=5e-5, atol=1e-6)
+      assert abs(float(ws[2][0]) - float(thr)) <= 2e-6 * max(1.0, float(thr))
+      dead = int(np.sum(np.all(want == 0, axis=(0, 1, 3))))
+      assert dead >= int(np.floor(24 * perctl / 100.0))
+  finally:
+    CPG.hip = old
+
+
 def test_channel_pruned_gpu_learner_on_cpu(cpu_learners, monkeypatch, caplog):
   """'chn-pruned-gpu' (reference learners/channel_pruning_gpu/learner.py): proximal-gradient channel selection layer by
   layer against the full network, masked per-layer re-fit, masked whole-network fine-tune."""

@@ -29,12 +29,12 @@ for r_ in rows[:12]:
     print(' '.join(r_))
 body = [r_ for r_ in rows if r_ and not r_[0].startswith('#') and r_[0] != 'kernel']
 tot = lambda pat: sum(float(r_[4]) for r_ in body if re.match(pat, r_[0]))
-for name, pat in (('igemm prologue (mode 2)', r'k_igemm<\d+, \d+, \d+, \d+, \d+, 2>'), ('resident kernel, prologue', r'k_conv1x1_stream<\d+, true'),
-                  ('igemm plain (mode 0)', r'k_igemm<.*, 0>'), ('igemm backward-data (mode 1)', r'k_igemm<.*, 1>'), ('k_wrw2', r'k_wrw2'),
+for name, pat in (('igemm prologue (mode 2)', r'k_igemm<\d+, \d+, \d+, \d+, \d+, 2[,>]'), ('resident kernel, prologue', r'k_conv1x1_stream<\d+, true'),
+                  ('igemm plain (mode 0)', r'k_igemm<\d+, \d+, \d+, \d+, \d+, 0[,>]'), ('igemm backward-data (mode 1)', r'k_igemm<\d+, \d+, \d+, \d+, \d+, 1[,>]'), ('k_wrw2', r'k_wrw2'),
                   ('k_wrw_reduce', r'k_wrw_reduce'), ('k_bn_bwd_apply', r'k_bn_bwd_apply'), ('k_bn_apply', r'k_bn_apply'), ('max-pool', r'k_maxpool'),
                   ('stem', r'k_stem'), ('resident kernel, other modes', r'k_conv1x1_stream<\d+, false'), ('k_conv1x1_fwd', r'k_conv1x1_fwd')):
   print('  %-32s %.2f ms/step' % (name, tot(pat)))
-pats = [r'k_conv1x1_stream<\d+, true, ', r'k_igemm<\d+, \d+, \d+, \d+, \d+, 2>', r'k_conv1x1_fwd<\d+, true, ']
+pats = [r'k_conv1x1_stream<\d+, true, ', r'k_igemm<\d+, \d+, \d+, \d+, \d+, 2[,>]', r'k_conv1x1_fwd<\d+, true, ']
 t = c = 0
 for r_ in csv.DictReader(open(P('rocprofv3_stats_b256.csv'))):
   if any(re.search(p, r_['Name']) for p in pats):
