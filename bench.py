@@ -343,6 +343,15 @@ def main():
     if sg.state != 'ready':
       sys.stderr.write('bench.py: step graph not recorded (%r): launch-by-launch steps\n' % (sg.error,))
       sg = None
+    else:
+      # torch.cuda.graph() empties the caching allocator before it records: the launch-by-launch steps of the timed region (the ones
+      # whose roofline-region launches are bracketed by events) would pay hipMalloc for every activation again -- 100-280 ms in ONE
+      # step, measured.  Re-grow the ordinary pool here, untimed: suspend, two launch-by-launch steps, resume, one replay.
+      sg.suspend()
+      train_step()
+      train_step()
+      sg.resume()
+      train_step()
   # Self-diagnosis of a host-bound process.  Seven bench processes of round 2 ran at 150 ms instead of
   # 29 ms per step with the same kernels: the caching allocator was going to the driver for every tensor (torch.empty at
   # 185 us) because a reference cycle in the layer executor kept each step's activations alive until Python's cyclic

@@ -363,11 +363,13 @@ int pf_conv2d_bwd_data_strided(const void* dY, const void* Wt, void* dX, const v
  * NHWC activations [imgs][H][W][C], KRSC kernels [N][R][S][C]; pad_h / pad_w are the BEGIN pads (positions outside the image read 0,
  * whatever Ho / Wo say about the end).  A dense layer is the 1x1 convolution of a [imgs][1][1][C] tensor.  Deterministic: one fused
  * multiply-add per term in a fixed order; the backward-filter pixel splits are summed in ascending order.
- * pf_convg_wrw: `slab` = float32 workspace of pf_convg_wrw_splits(...) * N * R * S * C elements; dw [N][R][S][C] in dw_dtype. */
+ * pf_convg_wrw: `slab` = float32 workspace of pf_convg_wrw_splits(...) * N * R * S * C elements; dw [N][R][S][C] in dw_dtype.
+ * pf_convg_fwd / _bwd_data: `slab` (optional, may be null) = float32 workspace of slab_elems elements: an output with fewer than 256
+ * tiles of 64 x 64 (the dense layer) then splits its contraction over up to 16 slabs, summed in ascending order. */
 int pf_convg_fwd(const void* x, const void* w, const float* bias, void* y, int dtype, int imgs, int H, int W, int C, int N, int R,
-                 int S, int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream);
+                 int S, int stride, int pad_h, int pad_w, int Ho, int Wo, float* slab, int64_t slab_elems, void* stream);
 int pf_convg_bwd_data(const void* dy, const void* w, void* dx, int dtype, int imgs, int H, int W, int C, int N, int R, int S,
-                      int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream);
+                      int stride, int pad_h, int pad_w, int Ho, int Wo, float* slab, int64_t slab_elems, void* stream);
 int pf_convg_wrw_splits(int imgs, int C, int N, int R, int S, int Ho, int Wo);
 int pf_convg_wrw(const void* dy, const void* x, void* dw, int dtype, int dw_dtype, float* slab, int imgs, int H, int W, int C, int N,
                  int R, int S, int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream);

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(CG_T) void k_convg(const CgArgs a) {
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
 
   int k_beg = 0, k_end = a.K;
-  if (MODE == 2) {
+  if (MODE == 2 || a.slab != nullptr) {                          // the contraction range of this split
     k_beg = split * a.k_per_split;
     k_end = min(a.K, k_beg + a.k_per_split);
   }
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(CG_T) void k_convg(const CgArgs a) {
   }
 
   // ---- epilogue --------------------------------------------------------------------------------------------------------------
-  if (MODE == 2) {
+  if (MODE == 2 || a.slab != nullptr) {
     float* out = a.slab + (int64_t)split * a.M * a.Nc;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -273,14 +273,57 @@ __global__ __launch_bounds__(CG_T) void k_convg(const CgArgs a) {
   }
 }
 
-// dW[i] = sum over splits (ascending) of slab[s][i]
+// out[i] = sum over splits (ascending) of slab[s][i] (+ bias[i % Nc])
 template <typename T>
-__global__ __launch_bounds__(CG_T) void k_convg_reduce(const float* __restrict__ slab, int splits, int64_t n, T* __restrict__ out) {
+__global__ __launch_bounds__(CG_T) void k_convg_reduce(const float* __restrict__ slab, int splits, int64_t n, T* __restrict__ out,
+                                                       const float* __restrict__ bias, int Nc) {
   for (int64_t i = (int64_t)blockIdx.x * CG_T + threadIdx.x; i < n; i += (int64_t)gridDim.x * CG_T) {
     float s = slab[i];
     for (int k = 1; k < splits; ++k) s = s + slab[(int64_t)k * n + i];
+    if (bias != nullptr) s = s + bias[(int)(i % Nc)];
     cg_st<T>(out + i, s);
   }
+}
+
+// Contraction splits of a forward / backward-data launch whose output has too few tiles to fill the chip (the dense layer: 256 x 1001
+// outputs = 64 tiles, 2048 terms each): 0 = one launch writes the output, > 0 = that many float32 slabs + a fixed-order reduction.
+static int cg_small_splits(int M, int Nc, int K, int64_t slab_elems) {
+  const int64_t tiles = (int64_t)((M + CG_BM - 1) / CG_BM) * ((Nc + CG_BN - 1) / CG_BN);
+  if (tiles >= 256 || K < 512) return 0;
+  int s = (int)((512 + tiles - 1) / tiles);
+  const int max_s = K / 256;
+  if (s > max_s) s = max_s;
+  if (s > 16) s = 16;
+  if (s < 2 || (int64_t)s * M * Nc > slab_elems) return 0;
+  return s;
+}
+
+template <typename T, int MODE>
+static int cg_launch_split(CgArgs& a, bool v4, int dtype_unused, float* slab, int64_t slab_elems, hipStream_t st) {
+  (void)dtype_unused;
+  const int tiles = ((a.M + CG_BM - 1) / CG_BM) * ((a.Nc + CG_BN - 1) / CG_BN);
+  const int splits = (slab != nullptr) ? cg_small_splits(a.M, a.Nc, a.K, slab_elems) : 0;
+  if (splits == 0) {
+    a.slab = nullptr;
+    if (v4) k_convg<T, MODE, true><<<dim3((unsigned)tiles, 1, 1), CG_T, 0, st>>>(a);
+    else k_convg<T, MODE, false><<<dim3((unsigned)tiles, 1, 1), CG_T, 0, st>>>(a);
+    PF_LAUNCH_CHECK();
+    return 0;
+  }
+  int kps = (a.K + splits - 1) / splits;
+  kps = ((kps + CG_BK - 1) / CG_BK) * CG_BK;
+  a.k_per_split = kps;
+  a.slab = slab;
+  const int used = (a.K + kps - 1) / kps;
+  const float* bias = a.bias;
+  a.bias = nullptr;                                            // added once, by the reduction
+  if (v4) k_convg<T, MODE, true><<<dim3((unsigned)tiles, (unsigned)used, 1), CG_T, 0, st>>>(a);
+  else k_convg<T, MODE, false><<<dim3((unsigned)tiles, (unsigned)used, 1), CG_T, 0, st>>>(a);
+  PF_LAUNCH_CHECK();
+  const int64_t n = (int64_t)a.M * a.Nc;
+  k_convg_reduce<T><<<pf_grid_for(n, CG_T), CG_T, 0, st>>>(slab, used, n, reinterpret_cast<T*>(a.Out), bias, a.Nc);
+  PF_LAUNCH_CHECK();
+  return 0;
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
@@ -302,31 +345,32 @@ static int cg_launch(const CgArgs& a, bool v4, dim3 grid, hipStream_t st) {
   return 0;
 }
 
+// slab / slab_elems: optional float32 workspace (null / 0: none).  With one, a launch whose output is too small to fill the chip splits
+// its contraction (see cg_small_splits) -- results are deterministic either way, but differ in summation order between the two forms.
 extern "C" int pf_convg_fwd(const void* x, const void* w, const float* bias, void* y, int dtype, int imgs, int H, int W, int C,
-                            int N, int R, int S, int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream) {
+                            int N, int R, int S, int stride, int pad_h, int pad_w, int Ho, int Wo, float* slab, int64_t slab_elems,
+                            void* stream) {
   if (!cg_geom_ok(imgs, H, W, C, N, R, S, stride, pad_h, pad_w, Ho, Wo)) return (int)hipErrorInvalidValue;
   CgArgs a{};
   a.P = x; a.Q = w; a.Out = y; a.bias = bias;
   a.imgs = imgs; a.H = H; a.W = W; a.C = C; a.N = N; a.R = R; a.S = S; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w; a.Ho = Ho; a.Wo = Wo;
   a.M = imgs * Ho * Wo; a.Nc = N; a.K = R * S * C;
   const bool v4 = (C % 4 == 0) && pf_aligned16(x) && pf_aligned16(w);
-  const dim3 grid((unsigned)(((a.M + CG_BM - 1) / CG_BM) * ((a.Nc + CG_BN - 1) / CG_BN)), 1, 1);
-  if (dtype == PF_F32) return cg_launch<float, 0>(a, v4, grid, (hipStream_t)stream);
-  if (dtype == PF_BF16) return cg_launch<bf16_t, 0>(a, v4, grid, (hipStream_t)stream);
+  if (dtype == PF_F32) return cg_launch_split<float, 0>(a, v4, dtype, slab, slab_elems, (hipStream_t)stream);
+  if (dtype == PF_BF16) return cg_launch_split<bf16_t, 0>(a, v4, dtype, slab, slab_elems, (hipStream_t)stream);
   return (int)hipErrorInvalidValue;
 }
 
 extern "C" int pf_convg_bwd_data(const void* dy, const void* w, void* dx, int dtype, int imgs, int H, int W, int C, int N, int R,
-                                 int S, int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream) {
+                                 int S, int stride, int pad_h, int pad_w, int Ho, int Wo, float* slab, int64_t slab_elems, void* stream) {
   if (!cg_geom_ok(imgs, H, W, C, N, R, S, stride, pad_h, pad_w, Ho, Wo)) return (int)hipErrorInvalidValue;
   CgArgs a{};
   a.P = dy; a.Q = w; a.Out = dx;
   a.imgs = imgs; a.H = H; a.W = W; a.C = C; a.N = N; a.R = R; a.S = S; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w; a.Ho = Ho; a.Wo = Wo;
   a.M = imgs * H * W; a.Nc = C; a.K = R * S * N;
   const bool v4 = (C % 4 == 0) && (N % 4 == 0) && pf_aligned16(dy) && pf_aligned16(w);
-  const dim3 grid((unsigned)(((a.M + CG_BM - 1) / CG_BM) * ((a.Nc + CG_BN - 1) / CG_BN)), 1, 1);
-  if (dtype == PF_F32) return cg_launch<float, 1>(a, v4, grid, (hipStream_t)stream);
-  if (dtype == PF_BF16) return cg_launch<bf16_t, 1>(a, v4, grid, (hipStream_t)stream);
+  if (dtype == PF_F32) return cg_launch_split<float, 1>(a, v4, dtype, slab, slab_elems, (hipStream_t)stream);
+  if (dtype == PF_BF16) return cg_launch_split<bf16_t, 1>(a, v4, dtype, slab, slab_elems, (hipStream_t)stream);
   return (int)hipErrorInvalidValue;
 }
 
@@ -364,8 +408,8 @@ extern "C" int pf_convg_wrw(const void* dy, const void* x, void* dw, int dtype, 
   if (rc != 0) return rc;
   const int64_t n = (int64_t)a.M * a.Nc;
   const int rgrid = pf_grid_for(n, CG_T);
-  if (dw_dtype == PF_F32) k_convg_reduce<float><<<rgrid, CG_T, 0, (hipStream_t)stream>>>(slab, used, n, (float*)dw);
-  else if (dw_dtype == PF_BF16) k_convg_reduce<bf16_t><<<rgrid, CG_T, 0, (hipStream_t)stream>>>(slab, used, n, (bf16_t*)dw);
+  if (dw_dtype == PF_F32) k_convg_reduce<float><<<rgrid, CG_T, 0, (hipStream_t)stream>>>(slab, used, n, (float*)dw, nullptr, 1);
+  else if (dw_dtype == PF_BF16) k_convg_reduce<bf16_t><<<rgrid, CG_T, 0, (hipStream_t)stream>>>(slab, used, n, (bf16_t*)dw, nullptr, 1);
   else return (int)hipErrorInvalidValue;
   PF_LAUNCH_CHECK();
   return 0;

@@ -351,10 +351,16 @@ class Graph:
     self.device = torch.device(device)
     self.compute_dtype = compute_dtype
     self.store = VarStore(scope)
+    self.store.graph = self                    # (the optimiser reaches the executor through its store: side-stream join)
     self.matmul_ops: List[MatmulOp] = []
     self.activation_ops: List[ActivationOp] = []
     self.nets: Dict[str, object] = {}          # cached net objects (tf.AUTO_REUSE)
     self.capturing = False                     # a hipGraph is recording this graph's step (step_graph.py): nothing per-step on the host
+    self._side = None                          # second stream for the backward-filter launches (side_enter)
+    self._side_keep: List = []
+    self._side_used = False
+    self._side_scratch = None
+    self.side_armed = False                    # set by FlatOptimizer.backward around the training backward pass
     self.step_feeders: List = []               # callables run before every replay of a recorded step (per-step host draws)
     self.training = True
     self.frozen = False                        # teacher: BN scale/shift cached
@@ -414,6 +420,34 @@ class Graph:
       self._scratch = torch.empty(max(n_floats, 1 << 20), dtype=torch.float32, device=self.device)
     return self._scratch
 
+  # -- backward-filter launches beside the backward-data chain -----------------------------------------------------------------
+  # dW of a convolution is needed by nobody before the optimiser; dX is needed by the very next kernel.  With one queue the chip
+  # works through dW, dX, dW, dX ... and every launch ends with idle CUs (persistent workgroups own ceil(tiles / slots) tiles;
+  # the BN-backward kernels in between are latency-bound).  The training backward pass (and only it: `side_armed`) therefore issues
+  # its backward-filter launches on a SECOND stream that waits for the main stream at the point of issue; the optimiser joins.
+  # Inputs of a side launch are kept alive until the join (`_side_keep`) -- inside a recorded step the allocator would otherwise hand
+  # their memory to the next main-stream allocation -- and the side launches have their own split-slab scratch.
+  def side_enter(self, *keep):
+    if not (WRW_SIDE and self.side_armed and self.device.type == 'cuda' and self.store.grad_hook is None):
+      return None
+    if self._side is None:
+      self._side = torch.cuda.Stream(device=self.device)
+    self._side.wait_stream(torch.cuda.current_stream(self.device))
+    self._side_keep.append(keep)
+    self._side_used = True
+    return torch.cuda.stream(self._side)
+
+  def side_join(self) -> None:
+    if self._side_used:
+      torch.cuda.current_stream(self.device).wait_stream(self._side)
+      self._side_keep.clear()
+      self._side_used = False
+
+  def scratch_side(self, n_floats: int) -> torch.Tensor:
+    if self._side_scratch is None or self._side_scratch.numel() < n_floats:
+      self._side_scratch = torch.empty(max(n_floats, 1 << 20), dtype=torch.float32, device=self.device)
+    return self._side_scratch
+
   def act_alpha_beta(self) -> torch.Tensor:
     return hip.minmax_decode(self.act_slots)
 
@@ -427,6 +461,10 @@ class Graph:
 # =================================================================================================
 # autograd functions over the HIP kernels
 # =================================================================================================
+
+import contextlib as _contextlib
+_NULLCTX = _contextlib.nullcontext()
+
 
 def _nhwc(x: torch.Tensor) -> torch.Tensor:
   if x.dim() == 4:
@@ -771,14 +809,15 @@ class _FusedConv1x1(torch.autograd.Function):
     dx = dw = None
     if ctx.needs_input_grad[1]:
       S = hip.conv1x1_wrw_splits(M, N, K)
-      ws = graph.scratch((S + 32) * N * K)
       # the kernel's gradient view inside the flat gradient buffer ([N][1][1][K] memory = [N][K]): written
       # directly (each kernel is used once per step; the optimiser zeroes the buffer), no accumulation kernel
       gw = getattr(ctx.w_leaf, 'grad', None)
       direct = (gw is not None and gw.dtype == w2d.dtype and gw.shape == ctx.w_leaf.shape
                 and gw.permute(0, 2, 3, 1).is_contiguous())
       dw2d = gw.permute(0, 2, 3, 1).view(N, K) if direct else torch.empty((N, K), dtype=w2d.dtype, device=x.device)
-      with region('conv1x1_wrw', float((M * K + M * N) * 2)):
+      side = graph.side_enter(dy, x, ss, lazy) if direct else None
+      with (side if side is not None else _NULLCTX), region('conv1x1_wrw', float((M * K + M * N) * 2)):
+        ws = (graph.scratch_side if side is not None else graph.scratch)((S + 32) * N * K)
         hip.conv1x1_wrw(dy, x, dw2d, ws, M, N, K, scale_shift=ss, act=act, slot=lazy.slot if quant else None,
                         bits=lazy.bits if quant else 8, geom=geom)
       dw = None if direct else dw2d.view(N, 1, 1, K).permute(0, 3, 1, 2)       # logical OIHW over KRSC memory
@@ -838,6 +877,7 @@ OWN_CONV2D_BWD_STRIDED = os.environ.get('PF_OWN_CONV2D_BWD_STRIDED', '1') != '0'
 OWN_CONV2D = os.environ.get('PF_OWN_CONV2D', '1') != '0'     # RxS convolutions on pf_igemm.hip (0: MIOpen, for A/B runs)
 OWN_STEM = os.environ.get('PF_OWN_STEM', '1') != '0'         # the 7x7/2 stem on pf_stem.hip (0: MIOpen, for A/B runs)
 OWN_DEPTHWISE = os.environ.get('PF_OWN_DEPTHWISE', '1') != '0'   # depthwise 3x3 on pf_depthwise.hip (0: MIOpen, for A/B runs)
+WRW_SIDE = os.environ.get('PF_WRW_SIDE', '1') != '0'         # backward-filter launches on a second stream beside backward-data (Graph.side_enter)
 OWN_CONV_GENERIC = os.environ.get('PF_OWN_CONV_GENERIC', '1') != '0'   # every other convolution / dense layer on pf_convg.hip (0: MIOpen / rocBLAS)
 DEPTHWISE_ANY_DEVICE = False     # tests: run the depthwise plumbing on CPU tensors (the HIP entry points are emulated there)
 
@@ -897,8 +937,10 @@ class _Conv2dIgemm(torch.autograd.Function):
           direct = (gw is not None and gw.shape == w.shape and gw.permute(0, 2, 3, 1).is_contiguous()
                     and gw.dtype in (torch.float32, torch.bfloat16))
           dwk = gw.permute(0, 2, 3, 1) if direct else torch.empty((N_, R_, S_, C_), dtype=w.dtype, device=x.device)
-          ws = graph.scratch((splits + 32) * N_ * R_ * S_ * C_)
-          hip.conv2d_wrw(dy, x, dwk, ws, B_, H_, W_, C_, N_, R_, S_, stride, pad[0], pad[1], Ho_, Wo_)
+          side = graph.side_enter(dy, x) if direct else None
+          with (side if side is not None else _NULLCTX):
+            ws = (graph.scratch_side if side is not None else graph.scratch)((splits + 32) * N_ * R_ * S_ * C_)
+            hip.conv2d_wrw(dy, x, dwk, ws, B_, H_, W_, C_, N_, R_, S_, stride, pad[0], pad[1], Ho_, Wo_)
           if direct:
             graph.store.notify_grad(ctx.w_var)
           else:
@@ -965,7 +1007,7 @@ class _ConvGeneric(torch.autograd.Function):
     y = torch.empty((B, N, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     bf = None if bias is None else bias.detach().float().contiguous()
     with region('convg_fwd', float((x.numel() + y.numel()) * x.element_size())):
-      hip.convg_fwd(x, wk, bf, y, B, H, Wd, C, N, R, S, stride, pad[0], pad[1], Ho, Wo)
+      hip.convg_fwd(x, wk, bf, y, B, H, Wd, C, N, R, S, stride, pad[0], pad[1], Ho, Wo, slab=graph.scratch(1 << 20))
     ctx.save_for_backward(x, w)
     ctx.meta = (stride, pad, out_hw, graph, bias is not None)
     return y
@@ -986,7 +1028,7 @@ class _ConvGeneric(torch.autograd.Function):
         wk = wk.contiguous().to(x.dtype)
       dx = torch.empty_like(x, memory_format=torch.channels_last)
       with region('convg_bwd_data', float((dy.numel() + dx.numel()) * x.element_size())):
-        hip.convg_bwd_data(dy, wk, dx, B, H, Wd, C, N, R, S, stride, pad[0], pad[1], Ho, Wo)
+        hip.convg_bwd_data(dy, wk, dx, B, H, Wd, C, N, R, S, stride, pad[0], pad[1], Ho, Wo, slab=graph.scratch(1 << 20))
     if ctx.needs_input_grad[1]:
       splits = hip.convg_wrw_splits(B, C, N, R, S, Ho, Wo)
       dwk = torch.empty((N, R, S, C), dtype=w.dtype, device=x.device)

@@ -483,24 +483,24 @@ def conv2d_bwd_data_strided(dY, Wt, dX, B: int, H: int, Wd: int, C: int, N: int,
 # ------------------------------------------------------------------------------------------------
 
 def convg_fwd(X, Wk, bias, Y, B: int, H: int, Wd: int, C: int, N: int, R: int, S: int, stride: int, pad_h: int, pad_w: int,
-              Ho: int, Wo: int) -> None:
+              Ho: int, Wo: int, slab=None) -> None:
   """Y[B][Ho][Wo][N] = conv(X[B][H][Wd][C], Wk[N][R][S][C]) (+ bias[N], float32); pad_*: begin pads."""
   _dev(X)
   if Wk.dtype != X.dtype or Y.dtype != X.dtype or (bias is not None and bias.dtype != torch.float32):
     raise TypeError('convg_fwd: X / Wk / Y share one dtype, the bias is float32')
   _check(_lib.pf_convg_fwd(_ptr(X), _ptr(Wk), _ptr(bias), _ptr(Y), c_int(dtype_code(X)), c_int(B), c_int(H), c_int(Wd), c_int(C),
-                           c_int(N), c_int(R), c_int(S), c_int(stride), c_int(pad_h), c_int(pad_w), c_int(Ho), c_int(Wo), _stream()),
-         'pf_convg_fwd')
+                           c_int(N), c_int(R), c_int(S), c_int(stride), c_int(pad_h), c_int(pad_w), c_int(Ho), c_int(Wo), _ptr(slab),
+                           c_int64(slab.numel() if slab is not None else 0), _stream()), 'pf_convg_fwd')
 
 
 def convg_bwd_data(dY, Wk, dX, B: int, H: int, Wd: int, C: int, N: int, R: int, S: int, stride: int, pad_h: int, pad_w: int,
-                   Ho: int, Wo: int) -> None:
+                   Ho: int, Wo: int, slab=None) -> None:
   _dev(dY)
   if Wk.dtype != dY.dtype or dX.dtype != dY.dtype:
     raise TypeError('convg_bwd_data: dY / Wk / dX share one dtype')
   _check(_lib.pf_convg_bwd_data(_ptr(dY), _ptr(Wk), _ptr(dX), c_int(dtype_code(dY)), c_int(B), c_int(H), c_int(Wd), c_int(C),
                                 c_int(N), c_int(R), c_int(S), c_int(stride), c_int(pad_h), c_int(pad_w), c_int(Ho), c_int(Wo),
-                                _stream()), 'pf_convg_bwd_data')
+                                _ptr(slab), c_int64(slab.numel() if slab is not None else 0), _stream()), 'pf_convg_bwd_data')
 
 
 def convg_wrw_splits(B: int, C: int, N: int, R: int, S: int, Ho: int, Wo: int) -> int:

@@ -61,6 +61,13 @@ def test_convg_forward_backward_data_backward_filter(dtype, imgs, H, W, C, N, R,
     assert err <= tol, '%s: max |err| / max |ref| = %.3e' % (what, err)
   close(y, yr.detach(), 'forward')
   close(dx, xr.grad, 'backward-data')
+  # with a workspace, an output of few tiles (the dense layer) splits its contraction over slabs: same result up to summation order
+  ws = torch.full((1 << 20,), float('nan'), dtype=torch.float32, device='cuda')
+  ys, dxs = torch.full_like(y, float('nan')), torch.full_like(dx, float('nan'))
+  hip.convg_fwd(xs, wk, b, ys, imgs, H, W, C, N, R, R, stride, pad, pad, Ho, Wo, slab=ws)
+  hip.convg_bwd_data(dys, wk, dxs, imgs, H, W, C, N, R, R, stride, pad, pad, Ho, Wo, slab=ws)
+  close(ys, yr.detach(), 'forward (split contraction)')
+  close(dxs, xr.grad, 'backward-data (split contraction)')
   close(dwk.permute(0, 3, 1, 2), wr.grad, 'backward-filter')
   # deterministic: a second call gives the same bits
   y2 = torch.empty_like(y)
