@@ -351,16 +351,10 @@ class Graph:
     self.device = torch.device(device)
     self.compute_dtype = compute_dtype
     self.store = VarStore(scope)
-    self.store.graph = self                    # (the optimiser reaches the executor through its store: side-stream join)
     self.matmul_ops: List[MatmulOp] = []
     self.activation_ops: List[ActivationOp] = []
     self.nets: Dict[str, object] = {}          # cached net objects (tf.AUTO_REUSE)
     self.capturing = False                     # a hipGraph is recording this graph's step (step_graph.py): nothing per-step on the host
-    self._side = None                          # second stream for the backward-filter launches (side_enter)
-    self._side_keep: List = []
-    self._side_used = False
-    self._side_scratch = None
-    self.side_armed = False                    # set by FlatOptimizer.backward around the training backward pass
     self.step_feeders: List = []               # callables run before every replay of a recorded step (per-step host draws)
     self.training = True
     self.frozen = False                        # teacher: BN scale/shift cached
@@ -420,34 +414,6 @@ class Graph:
       self._scratch = torch.empty(max(n_floats, 1 << 20), dtype=torch.float32, device=self.device)
     return self._scratch
 
-  # -- backward-filter launches beside the backward-data chain -----------------------------------------------------------------
-  # dW of a convolution is needed by nobody before the optimiser; dX is needed by the very next kernel.  With one queue the chip
-  # works through dW, dX, dW, dX ... and every launch ends with idle CUs (persistent workgroups own ceil(tiles / slots) tiles;
-  # the BN-backward kernels in between are latency-bound).  The training backward pass (and only it: `side_armed`) therefore issues
-  # its backward-filter launches on a SECOND stream that waits for the main stream at the point of issue; the optimiser joins.
-  # Inputs of a side launch are kept alive until the join (`_side_keep`) -- inside a recorded step the allocator would otherwise hand
-  # their memory to the next main-stream allocation -- and the side launches have their own split-slab scratch.
-  def side_enter(self, *keep):
-    if not (WRW_SIDE and self.side_armed and self.device.type == 'cuda' and self.store.grad_hook is None):
-      return None
-    if self._side is None:
-      self._side = torch.cuda.Stream(device=self.device)
-    self._side.wait_stream(torch.cuda.current_stream(self.device))
-    self._side_keep.append(keep)
-    self._side_used = True
-    return torch.cuda.stream(self._side)
-
-  def side_join(self) -> None:
-    if self._side_used:
-      torch.cuda.current_stream(self.device).wait_stream(self._side)
-      self._side_keep.clear()
-      self._side_used = False
-
-  def scratch_side(self, n_floats: int) -> torch.Tensor:
-    if self._side_scratch is None or self._side_scratch.numel() < n_floats:
-      self._side_scratch = torch.empty(max(n_floats, 1 << 20), dtype=torch.float32, device=self.device)
-    return self._side_scratch
-
   def act_alpha_beta(self) -> torch.Tensor:
     return hip.minmax_decode(self.act_slots)
 
@@ -461,10 +427,6 @@ class Graph:
 # =================================================================================================
 # autograd functions over the HIP kernels
 # =================================================================================================
-
-import contextlib as _contextlib
-_NULLCTX = _contextlib.nullcontext()
-
 
 def _nhwc(x: torch.Tensor) -> torch.Tensor:
   if x.dim() == 4:
@@ -815,9 +777,8 @@ class _FusedConv1x1(torch.autograd.Function):
       direct = (gw is not None and gw.dtype == w2d.dtype and gw.shape == ctx.w_leaf.shape
                 and gw.permute(0, 2, 3, 1).is_contiguous())
       dw2d = gw.permute(0, 2, 3, 1).view(N, K) if direct else torch.empty((N, K), dtype=w2d.dtype, device=x.device)
-      side = graph.side_enter(dy, x, ss, lazy) if direct else None
-      with (side if side is not None else _NULLCTX), region('conv1x1_wrw', float((M * K + M * N) * 2)):
-        ws = (graph.scratch_side if side is not None else graph.scratch)((S + 32) * N * K)
+      with region('conv1x1_wrw', float((M * K + M * N) * 2)):
+        ws = graph.scratch((S + 32) * N * K)
         hip.conv1x1_wrw(dy, x, dw2d, ws, M, N, K, scale_shift=ss, act=act, slot=lazy.slot if quant else None,
                         bits=lazy.bits if quant else 8, geom=geom)
       dw = None if direct else dw2d.view(N, 1, 1, K).permute(0, 3, 1, 2)       # logical OIHW over KRSC memory
@@ -872,12 +833,12 @@ USE_SEG_TRANSPOSE = os.environ.get('PF_SEG_TRANSPOSE', '1') != '0'   # backward-
 OWN_POOL = os.environ.get('PF_OWN_POOL', '1') != '0'         # stem max-pooling on pf_pool.hip (0: aten, for A/B runs)
 # backward-filter of the RxS convolutions on pf_wrw.hip (shared-tile kernel); PF_OWN_CONV2D_WRW=0: MIOpen, for A/B runs
 OWN_CONV2D_WRW = os.environ.get('PF_OWN_CONV2D_WRW', '1') != '0'
-OWN_CONV2D_WRW_MIN_C = int(os.environ.get('PF_OWN_CONV2D_WRW_MIN_C', '128'))   # narrower inputs: MIOpen is faster (measured)
+OWN_CONV2D_WRW_MIN_C = int(os.environ.get('PF_OWN_CONV2D_WRW_MIN_C', '64'))    # (round 3: 128 -- MIOpen was faster at C = 64; round 4, per step in one box: 9 633 vs 9 590 images/s with ours)
 OWN_CONV2D_BWD_STRIDED = os.environ.get('PF_OWN_CONV2D_BWD_STRIDED', '1') != '0'   # strided backward-data by parity classes (0: MIOpen)
 OWN_CONV2D = os.environ.get('PF_OWN_CONV2D', '1') != '0'     # RxS convolutions on pf_igemm.hip (0: MIOpen, for A/B runs)
 OWN_STEM = os.environ.get('PF_OWN_STEM', '1') != '0'         # the 7x7/2 stem on pf_stem.hip (0: MIOpen, for A/B runs)
 OWN_DEPTHWISE = os.environ.get('PF_OWN_DEPTHWISE', '1') != '0'   # depthwise 3x3 on pf_depthwise.hip (0: MIOpen, for A/B runs)
-WRW_SIDE = os.environ.get('PF_WRW_SIDE', '1') != '0'         # backward-filter launches on a second stream beside backward-data (Graph.side_enter)
+CONVG_BF16_NARROW = os.environ.get('PF_CONVG_BF16_NARROW', '0') != '0'
 OWN_CONV_GENERIC = os.environ.get('PF_OWN_CONV_GENERIC', '1') != '0'   # every other convolution / dense layer on pf_convg.hip (0: MIOpen / rocBLAS)
 DEPTHWISE_ANY_DEVICE = False     # tests: run the depthwise plumbing on CPU tensors (the HIP entry points are emulated there)
 
@@ -937,10 +898,8 @@ class _Conv2dIgemm(torch.autograd.Function):
           direct = (gw is not None and gw.shape == w.shape and gw.permute(0, 2, 3, 1).is_contiguous()
                     and gw.dtype in (torch.float32, torch.bfloat16))
           dwk = gw.permute(0, 2, 3, 1) if direct else torch.empty((N_, R_, S_, C_), dtype=w.dtype, device=x.device)
-          side = graph.side_enter(dy, x) if direct else None
-          with (side if side is not None else _NULLCTX):
-            ws = (graph.scratch_side if side is not None else graph.scratch)((splits + 32) * N_ * R_ * S_ * C_)
-            hip.conv2d_wrw(dy, x, dwk, ws, B_, H_, W_, C_, N_, R_, S_, stride, pad[0], pad[1], Ho_, Wo_)
+          ws = graph.scratch((splits + 32) * N_ * R_ * S_ * C_)
+          hip.conv2d_wrw(dy, x, dwk, ws, B_, H_, W_, C_, N_, R_, S_, stride, pad[0], pad[1], Ho_, Wo_)
           if direct:
             graph.store.notify_grad(ctx.w_var)
           else:
@@ -1040,9 +999,15 @@ class _ConvGeneric(torch.autograd.Function):
     return dx, dw, db, None, None, None, None
 
 
-def convg_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
-  return (OWN_CONV_GENERIC and isinstance(x, torch.Tensor) and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)
-          and w.dtype in (torch.float32, torch.bfloat16) and x.numel() > 0)
+def convg_ok(x: torch.Tensor, w: torch.Tensor, dense: bool = False) -> bool:
+  """float32: every convolution and dense layer.  bf16: the dense layer and convolutions over images (C % 8 != 0); a bf16
+  convolution with 16 / 32 / 48 ... input channels (ResNet-20 @ CIFAR-10) is MFMA-shaped work that the vector-ALU kernel runs 2x
+  slower per step than MIOpen (measured, configuration C1: 33 665 vs 66 174 images/s) -- it stays with the library until the
+  implicit-GEMM kernel takes 16-channel k-steps (PF_CONVG_BF16_NARROW=1 forces ours)."""
+  if not (OWN_CONV_GENERIC and isinstance(x, torch.Tensor) and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)
+          and w.dtype in (torch.float32, torch.bfloat16) and x.numel() > 0):
+    return False
+  return x.dtype == torch.float32 or dense or x.shape[1] % 8 != 0 or CONVG_BF16_NARROW
 
 
 def conv_generic(x, w, bias, stride, pad_begin, out_hw, graph):
@@ -1409,7 +1374,7 @@ class Dense:
         raise TapStop()
       return y + self.bias.tensor.to(x.dtype)
     x = materialize(x)
-    if x.dim() == 2 and convg_ok(x, self.kernel.tensor):
+    if x.dim() == 2 and convg_ok(x, self.kernel.tensor, dense=True):
       # tf.layers.dense = the 1x1 convolution of a [B][1][1][in] tensor (+ BiasAdd in the epilogue): pf_convg.hip
       w4 = self.kernel.tensor.view(self.kernel.tensor.shape[0], self.kernel.tensor.shape[1], 1, 1)
       y = _ConvGeneric.apply(x.contiguous().view(x.shape[0], x.shape[1], 1, 1), w4, self.bias.tensor, 1, (0, 0), (1, 1), self.graph)
@@ -1418,7 +1383,7 @@ class Dense:
 
   def plain(self, x: torch.Tensor) -> torch.Tensor:
     """The MatMul op alone (no BiasAdd)."""
-    if x.dim() == 2 and convg_ok(x, self.kernel.tensor):
+    if x.dim() == 2 and convg_ok(x, self.kernel.tensor, dense=True):
       w4 = self.kernel.tensor.view(self.kernel.tensor.shape[0], self.kernel.tensor.shape[1], 1, 1)
       return _ConvGeneric.apply(x.contiguous().view(x.shape[0], x.shape[1], 1, 1), w4, None, 1, (0, 0), (1, 1), self.graph).view(x.shape[0], -1)
     return F.linear(x, self.kernel.tensor)

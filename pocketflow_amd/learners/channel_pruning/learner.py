@@ -312,14 +312,14 @@ class ChannelPrunedLearner(AbstractLearner):  # pylint: disable=too-many-instanc
       loss, metrics = self.calc_loss(y, logits, self.trainable_vars)
       if FLAGS.enbl_dst:
         loss = loss + self.learner_dst.calc_loss(logits, logits_dst)
-    if ahead is not None:
-      ahead.issue()                                 # next batch's teacher forward on the side stream, beside THIS step's backward pass
     self.optimizer.backward(loss)
     lr = self.lrn_rate(self.global_step)
     self.optimizer.weight_decay = g.store.weight_decay
     self.optimizer.compute_gradients()
     self.optimizer.apply_gradients(lr)
     self.global_step += 1
+    if ahead is not None:
+      ahead.issue()                                 # next batch's teacher forward on the side stream: it runs beside the NEXT step's forward pass
     return lr, loss, metrics
 
   def __train_pruned_model(self, finetune=False):

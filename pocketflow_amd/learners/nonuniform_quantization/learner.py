@@ -104,8 +104,6 @@ class NonUniformQuantLearner(AbstractLearner):
       if FLAGS.enbl_dst:
         dst_loss = self.helper_dst.calc_loss(logits, logits_dst)
         loss = loss + dst_loss
-    if ahead is not None:
-      ahead.issue()                                 # next batch's teacher forward on the side stream, beside THIS step's backward pass
     optimizer.backward(loss)
     if FLAGS.nuql_opt_mode in ('cluster', 'both'):
       self.nonuni_quant.codebook_grads()
@@ -114,6 +112,8 @@ class NonUniformQuantLearner(AbstractLearner):
     optimizer.compute_gradients()
     optimizer.apply_gradients(lr)
     self.ft_step += 1
+    if ahead is not None:
+      ahead.issue()                                 # next batch's teacher forward on the side stream: it runs beside the NEXT step's forward pass
     return {'lr': lr, 'dst_loss': dst_loss, 'model_loss': model_loss, 'loss': loss, 'metrics': metrics}
 
   # -- callables handed to the bit optimiser (the reference passes TF ops + sessions) --------------------

@@ -45,10 +45,6 @@ class CudaStreams(object):
   def on_side(self):
     return torch.cuda.stream(self.side)
 
-  def side_waits_for_main(self):
-    """What follows on the side stream starts when the main stream has reached THIS point (the student's forward pass is done)."""
-    self.side.wait_stream(torch.cuda.current_stream(self.device))
-
   def record(self):
     ev = torch.cuda.Event()
     ev.record(self.side)
@@ -67,9 +63,6 @@ class InlineStreams(object):
 
   def on_side(self):
     return contextlib.nullcontext()
-
-  def side_waits_for_main(self):
-    pass
 
   def record(self):
     return None
@@ -99,11 +92,10 @@ class TeacherAhead(object):
     """Fetch batch k+1, upload it and run the teacher over it -- all on the side stream."""
     lrn, st = self.learner, self.streams
     teacher = teacher_of(lrn)
-    # Called between the student's forward pass and its backward pass: the teacher's launches run beside the BACKWARD kernels (more of
-    # them are latency-bound or tile-starved than in the forward pass, and the forward pass -- the roofline region of bench.py -- keeps
-    # the chip to itself).  Round 4's first version issued at the end of the step: the same +6 %, but the student's forward kernels
-    # shared the chip (region 0.39 -> 0.365 of the HBM peak).
-    st.side_waits_for_main()
+    # Called at the END of step k: the launches queue up behind nothing (the side stream never waits for main) and execute while the
+    # main stream works through what the host has already submitted -- in practice beside step k + 1's FORWARD pass.  Round 4 measured
+    # the alternatives in one box (profiles/r04_overlap_ab.txt): beside the forward pass +6 %; started where the forward pass ends
+    # (beside the backward pass, whose kernels fill the chip better) +0.5 %; backward-filter launches on a third stream -2.8 %.
     with st.on_side(), profiling.suspended():
       # the iterator itself may enqueue device work (pinned upload + resize kernel of the TFRecord reader run on the CURRENT stream):
       # it has to be the side stream, or the teacher would read a batch the main stream has not finished writing
@@ -171,7 +163,7 @@ def next_batch(learner):
   from a hipGraph (step_graph.py) gets the graph's static buffers instead."""
   static = getattr(learner, '_static_batch', None)
   if static is not None:
-    return (getattr(learner, '_static_ahead', None),) + tuple(static)
+    return (None,) + tuple(static)
   ahead = of(learner)
   if ahead is not None and ahead.pending is not None:
     return (ahead,) + ahead.take()

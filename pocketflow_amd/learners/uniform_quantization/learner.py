@@ -110,14 +110,14 @@ class UniformQuantLearner(AbstractLearner):
       if FLAGS.enbl_dst:
         dst_loss = self.helper_dst.calc_loss(logits, logits_dst)
         loss = loss + dst_loss
-    if ahead is not None:
-      ahead.issue()                                 # next batch's teacher forward on the side stream, beside THIS step's backward pass
     self.optimizer.backward(loss)
     lr = self.lrn_rate(self.ft_step)
     self.optimizer.weight_decay = g.store.weight_decay
     self.optimizer.compute_gradients()
     self.optimizer.apply_gradients(lr)
     self.ft_step += 1
+    if ahead is not None:
+      ahead.issue()                                 # next batch's teacher forward on the side stream: it runs beside the NEXT step's forward pass
     return {'lr': lr, 'dst_loss': dst_loss, 'model_loss': model_loss, 'loss': loss, 'metrics': metrics}
 
   # -- callables handed to the bit optimiser (the reference passes TF ops + sessions) --------------------

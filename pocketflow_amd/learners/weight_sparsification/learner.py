@@ -88,14 +88,14 @@ class WeightSparseLearner(AbstractLearner):  # pylint: disable=too-many-instance
       loss, metrics = self.calc_loss(y, logits, self.trainable_vars)
       if FLAGS.enbl_dst:
         loss = loss + self.helper_dst.calc_loss(logits, logits_dst)
-    if ahead is not None:
-      ahead.issue()                                 # next batch's teacher forward on the side stream, beside THIS step's backward pass
     self.optimizer.backward(loss)
     lr = self.lrn_rate(self.global_step)
     self.optimizer.weight_decay = g.store.weight_decay
     self.optimizer.compute_gradients()
     self.optimizer.apply_gradients(lr)
     self.global_step += 1
+    if ahead is not None:
+      ahead.issue()                                 # next batch's teacher forward on the side stream: it runs beside the NEXT step's forward pass
     return lr, loss, metrics
 
   def prune_step(self):

@@ -75,16 +75,7 @@ class FlatOptimizer(object):
     followed by compute_gradients() / apply_gradients(): the distributed wrapper overrides it to let the gradient
     exchange start from inside the pass.  Any OTHER backward (layer-wise tuning on rank 0, regression-gradient
     helpers) stays a plain `loss.backward()` and never touches the process group."""
-    g = getattr(self.store, 'graph', None)
-    if g is None:
-      loss.backward()
-      return
-    g.side_armed = True                  # this backward pass may issue its backward-filter launches on the second stream
-    try:
-      loss.backward()
-    finally:
-      g.side_armed = False
-      g.side_join()                      # the optimiser kernel (main stream) reads every dW
+    loss.backward()
 
   def compute_gradients(self) -> None:
     """Gradients already sit in store.w_grad / store.o_grad after backward (single process)."""

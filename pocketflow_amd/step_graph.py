@@ -17,8 +17,8 @@ What changes per step and therefore cannot be a by-value kernel argument:
                                     -> `graph.step_feeders`: callables run before every replay (stream-ordered copies into the
                                        buffer the captured launch reads).
 The frozen teacher's forward pass over the NEXT batch (learners/teacher_ahead.py) is part of the graph as a forked branch: it
-starts where the student's forward pass ends, runs on a second stream beside the backward pass and joins before the tail, where
-`next` becomes `current` (three device copies).
+runs on a second stream from the start of the step (beside the student's forward pass: that is where it pays, measured) and joins
+before the tail, where `next` becomes `current` (three device copies).
 
 Eager steps and graph steps can alternate (`suspend()` / `resume()`): both draw from the same iterator in the same order and hand
 the prefetched batch over through `TeacherAhead.pending`.  Whatever goes wrong while recording (an op that synchronises, a library
@@ -255,24 +255,15 @@ class StepGraph(object):
     g.capturing = True
     cur, nxt = self.cur, self.nxt
 
-    class _Fork(object):
-      """What the step's `ahead.issue()` does while the step is recorded: the teacher's forward over `next` as a forked branch of
-      the graph, starting where the student's forward pass ends (beside its backward pass)."""
-
-      def __init__(self, be):
-        self.be = be
-
-      def issue(self):
-        with self.be.fork(), profiling.suspended():
-          nxt[2].copy_(teacher.calc_logits(None, nxt[0]))
-
     def body(be):
+      if nxt is not None:
+        with be.fork(), profiling.suspended():             # the teacher over `next`, from the START of the step: beside the forward pass
+          nxt[2].copy_(teacher.calc_logits(None, nxt[0]))
       lrn._static_batch = cur
-      lrn._static_ahead = _Fork(be) if nxt is not None else None
       try:
         out = lrn._train_step_eager()
       finally:
-        lrn._static_batch = lrn._static_ahead = None
+        lrn._static_batch = None
       if nxt is not None:
         be.join()
         for dst, src in zip(cur, nxt):

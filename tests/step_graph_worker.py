@@ -41,6 +41,8 @@ def _collect_losses_each_step(lrn, n_steps, suspend_at, graph_mode):
       sg.resume() if sg.suspended else sg.suspend()
     o = lrn.train_step()
     losses.append((o['loss'] if isinstance(o, dict) else o[1]).detach().clone())
+    if os.environ.get('PF_W_DROP_OUT', '1') != '0':
+      o = None                                             # (as bench.py: nothing of a step's autograd graph outlives the step)
   return [float(l) for l in losses]
 
 
@@ -71,8 +73,10 @@ def case_uq_resnet50(tmp_path):
   import pocketflow_amd.learners.distillation_helper  # noqa: F401
   _setup(tmp_path, batch_size=8, batch_size_eval=8, uql_weight_bits=8, uql_activation_bits=8, enbl_dst=True, dst_eval_teacher=False,
          save_path_dst=str(tmp_path / 'models_dst' / 'model.ckpt'), uql_save_quant_model_path=str(tmp_path / 'uql' / 'm.ckpt'),
-         resnet_size=50, nb_classes=1001, image_size=64, compute_dtype='bfloat16', synthetic_pool=5)
-  os.environ['PF_STEP_GRAPH_STRICT'] = '1'
+         resnet_size=50, nb_classes=1001, image_size=64, compute_dtype='bfloat16', synthetic_pool=int(os.environ.get('PF_W_POOL', '5')))
+  torch.backends.cudnn.benchmark = os.environ.get('PF_W_BENCHMARK', '0') != '0'
+  if os.environ.get('PF_W_STRICT', '1') != '0':
+    os.environ['PF_STEP_GRAPH_STRICT'] = '1'
   made = []
 
   def make():
