@@ -352,6 +352,7 @@ def main():
       train_step()
       sg.resume()
       train_step()
+      train_step()
   # Self-diagnosis of a host-bound process.  Seven bench processes of round 2 ran at 150 ms instead of
   # 29 ms per step with the same kernels: the caching allocator was going to the driver for every tensor (torch.empty at
   # 185 us) because a reference cycle in the layer executor kept each step's activations alive until Python's cyclic
@@ -388,16 +389,20 @@ def main():
       with open(os.path.join(out_dir, 'bench_host_bound_profile.txt'), 'w') as f:
         f.write(text)
   n_event = args.steps if sg is None else max(0, min(args.event_steps, args.steps))
-  if sg is not None:
-    sg.suspend()                       # the first n_event timed steps are issued launch by launch, with events around the region
+  # Recorded steps first, the launch-by-launch steps (roofline-region launches bracketed by events) LAST: the replays are submitted in
+  # ~1 ms each, so the host's slower launch-by-launch submission (and the hand-over between the modes, 60-90 ms measured) runs while
+  # the GPU still works through the replays.  The other way round the GPU sat idle through the first launch-by-launch step: 3 ms per
+  # step over a 20-step region.
   profiling.enable(args.roofline_kernel)
+  if sg is not None:
+    profiling.pause()
   sync()
   t0 = time.perf_counter()
   marks = []
   for i in range(args.steps):
-    if sg is not None and i == n_event:
-      profiling.pause()
-      sg.resume()
+    if sg is not None and i == args.steps - n_event:
+      sg.suspend()
+      profiling.unpause()
     train_step()
     marks.append(time.perf_counter())
   sync()
@@ -468,6 +473,7 @@ def main():
         'vs_baseline': None, 'dtype': 'bf16' if args.dtype.startswith('bf') else 'f32', 'data': 'synthetic',
         'value_per_gpu': per_gpu, 'host_submit_ms_per_step': host_ms,
         'host_submit_ms_min_median_max': [host_steps[0], host_steps[len(host_steps) // 2], host_steps[-1]],
+        'host_submit_ms_steps': [round((b - a) * 1e3, 2) for a, b in zip([t0] + marks[:-1], marks)],
         'launch_probe': {'after_warmup': probe_warm, 'after_timed_region': probe_after, 'extra_untimed_steps': 2},
         'memory': {'after_warmup': mem_warm, 'after_timed_region': mem_after},
         'config': {'workload': cfg['workload'].format(**vars(args)), 'name': args.config,

@@ -374,6 +374,15 @@ int pf_convg_wrw_splits(int imgs, int C, int N, int R, int S, int Ho, int Wo);
 int pf_convg_wrw(const void* dy, const void* x, void* dw, int dtype, int dw_dtype, float* slab, int imgs, int H, int W, int C, int N,
                  int R, int S, int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream);
 
+/* ---- R x S convolutions with few input channels (ResNet-20 @ CIFAR-10: resnet_model.py:156-199 with 16 / 32 filters) --------------
+ * bf16, C % 8 == 0.  pf_im2col gathers Xcol[imgs*Ho*Wo][R*S*C] (taps outside the image: zeros) so that the convolution and its two
+ * gradients are 1x1 products on pf_conv1x1_fwd / pf_conv1x1_wrw over Xcol and the [N][R*S*C] view of the KRSC kernel; pf_col2im is
+ * the inverse gather of backward-data (per input pixel: float32 sum of its <= R*S terms in tap order, one rounding). */
+int pf_im2col(const void* x, void* xcol, int imgs, int H, int W, int C, int R, int S, int stride, int pad_h, int pad_w, int Ho, int Wo,
+              void* stream);
+int pf_col2im(const void* dxcol, void* dx, int imgs, int H, int W, int C, int R, int S, int stride, int pad_h, int pad_w, int Ho, int Wo,
+              void* stream);
+
 /* ---- proximal-gradient channel selection of the 'chn-pruned-gpu' learner ----------------------------------------------------------
  * replaces learners/channel_pruning_gpu/learner.py:376-383 (var_prnd_new = var - lr * grad; var_norm = sqrt(reduce_sum(square, axes
  * [0, 1, 3])); threshold = percentile(var_norm, p); shrk_vec = maximum(1 - threshold / var_norm, 0); assign(var_prnd_new * shrk_vec)).

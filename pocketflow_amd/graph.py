@@ -838,6 +838,7 @@ OWN_CONV2D_BWD_STRIDED = os.environ.get('PF_OWN_CONV2D_BWD_STRIDED', '1') != '0'
 OWN_CONV2D = os.environ.get('PF_OWN_CONV2D', '1') != '0'     # RxS convolutions on pf_igemm.hip (0: MIOpen, for A/B runs)
 OWN_STEM = os.environ.get('PF_OWN_STEM', '1') != '0'         # the 7x7/2 stem on pf_stem.hip (0: MIOpen, for A/B runs)
 OWN_DEPTHWISE = os.environ.get('PF_OWN_DEPTHWISE', '1') != '0'   # depthwise 3x3 on pf_depthwise.hip (0: MIOpen, for A/B runs)
+OWN_CONV_IM2COL = os.environ.get('PF_OWN_CONV_IM2COL', '1') != '0'   # few-channel RxS convolutions as im2col + own 1x1 kernels (0: MIOpen)
 CONVG_BF16_NARROW = os.environ.get('PF_CONVG_BF16_NARROW', '0') != '0'
 OWN_CONV_GENERIC = os.environ.get('PF_OWN_CONV_GENERIC', '1') != '0'   # every other convolution / dense layer on pf_convg.hip (0: MIOpen / rocBLAS)
 DEPTHWISE_ANY_DEVICE = False     # tests: run the depthwise plumbing on CPU tensors (the HIP entry points are emulated there)
@@ -1007,12 +1008,74 @@ def convg_ok(x: torch.Tensor, w: torch.Tensor, dense: bool = False) -> bool:
   if not (OWN_CONV_GENERIC and isinstance(x, torch.Tensor) and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)
           and w.dtype in (torch.float32, torch.bfloat16) and x.numel() > 0):
     return False
-  return x.dtype == torch.float32 or dense or x.shape[1] % 8 != 0 or CONVG_BF16_NARROW
+  return (x.dtype == torch.float32 or dense or x.shape[1] % 8 != 0 or CONVG_BF16_NARROW
+          or (x.dim() == 4 and x.shape[2] * x.shape[3] == 1))      # (a convolution over 1 x 1 pixels IS a dense layer: MobileNet's logits)
 
 
 def conv_generic(x, w, bias, stride, pad_begin, out_hw, graph):
   """Dispatch helper: 4-D x (logical NCHW) through _ConvGeneric; works with or without autograd."""
   return _ConvGeneric.apply(_nhwc(x), w, bias, stride, pad_begin, out_hw, graph)
+
+
+class _ConvIm2col(torch.autograd.Function):
+  """y = conv2d(x, W) for few input channels (bf16, C % 8 == 0, C % 64 != 0: ResNet-20 @ CIFAR-10) as im2col + the in-tree 1x1 kernels
+  (pf_im2col.hip): Y = Xcol W2d^T with W2d the [N][R*S*C] view of the KRSC kernel; backward: dXcol = dY W2d, dX = col2im(dXcol),
+  dW2d = dY^T Xcol written straight into the flat gradient buffer.  Xcol is re-gathered in backward (9x the layer's input: not kept)."""
+
+  @staticmethod
+  def forward(ctx, x, w, stride, pad, out_hw, graph, w_var):
+    B, C, H, Wd = x.shape
+    N, _, R, S = w.shape
+    Ho, Wo = out_hw
+    M, K = B * Ho * Wo, R * S * C
+    w2d = w.detach().permute(0, 2, 3, 1).reshape(N, K)
+    xcol = torch.empty((M, K), dtype=x.dtype, device=x.device)
+    y = torch.empty((B, N, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    with region('conv_im2col_fwd', float((x.numel() + 2 * xcol.numel() + y.numel()) * 2)):
+      hip.im2col(x, xcol, B, H, Wd, C, R, S, stride, pad[0], pad[1], Ho, Wo)
+      hip.conv1x1_fwd(xcol, w2d, y, M, N, K)
+    ctx.save_for_backward(x, w)
+    ctx.meta = (stride, pad, out_hw, graph, w_var)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    x, w = ctx.saved_tensors
+    stride, pad, (Ho, Wo), graph, w_var = ctx.meta
+    B, C, H, Wd = x.shape
+    N, _, R, S = w.shape
+    M, K = B * Ho * Wo, R * S * C
+    dy = _nhwc(dy)
+    dx = dw = None
+    w2d = w.detach().permute(0, 2, 3, 1).reshape(N, K)
+    if ctx.needs_input_grad[1]:
+      xcol = torch.empty((M, K), dtype=x.dtype, device=x.device)
+      hip.im2col(x, xcol, B, H, Wd, C, R, S, stride, pad[0], pad[1], Ho, Wo)
+      gw = getattr(w, 'grad', None)
+      direct = (gw is not None and gw.shape == w.shape and gw.permute(0, 2, 3, 1).is_contiguous() and gw.dtype == w.dtype)
+      dw2d = gw.permute(0, 2, 3, 1).reshape(N, K) if direct else torch.empty((N, K), dtype=w.dtype, device=x.device)
+      splits = hip.conv1x1_wrw_splits(M, N, K)
+      with region('conv_im2col_wrw', float((M * K + M * N) * 2)):
+        hip.conv1x1_wrw(dy, xcol, dw2d, graph.scratch((splits + 32) * N * K), M, N, K)
+      if direct:
+        graph.store.notify_grad(w_var)
+      else:
+        dw = dw2d.view(N, R, S, C).permute(0, 3, 1, 2)
+    if ctx.needs_input_grad[0]:
+      dxcol = torch.empty((M, K), dtype=x.dtype, device=x.device)
+      dx = torch.empty_like(x)
+      with region('conv_im2col_bwd_data', float((dy.numel() + 2 * dxcol.numel() + dx.numel()) * 2)):
+        hip.conv1x1_fwd(dy, w2d.t().contiguous(), dxcol, M, K, N)
+        hip.col2im(dxcol, dx, B, H, Wd, C, R, S, stride, pad[0], pad[1], Ho, Wo)
+    return dx, dw, None, None, None, None, None
+
+
+def im2col_conv_ok(x, conv, pad) -> bool:
+  """R x S convolutions the implicit-GEMM kernel does not take for their channel count (cin % 64 != 0) but the 1x1 kernels do."""
+  kh, kw, cin, cout = conv.kernel.ref_shape
+  return (OWN_CONV_IM2COL and conv.k > 1 and conv.bias is None and isinstance(x, torch.Tensor) and fusable_tensor(x) and x.dim() == 4
+          and cin % 8 == 0 and cin % 64 != 0 and cout % 8 == 0 and pad is not None and conv.graph.fuse_conv1x1
+          and x.shape[0] * x.shape[2] * x.shape[3] * kh * kw * cin < (1 << 31))
 
 
 class _StemConv(torch.autograd.Function):
@@ -1206,6 +1269,11 @@ class Conv2D:
     bn_box = getattr(x, '_pf_bn', None)
     if bn_box is not None:
       bn_box['n_consumers'] += 2                 # a consumer that cannot fuse the BN-backward sums
+    if im2col_conv_ok(x, self, sym):
+      Ho = (x.shape[2] + 2 * sym[0] - self.k) // self.stride + 1
+      Wo = (x.shape[3] + 2 * sym[1] - self.k) // self.stride + 1
+      y = _ConvIm2col.apply(_nhwc(x), w, self.stride, sym, (Ho, Wo), self.graph, self.kernel)
+      return y if residual is None else y + residual
     if convg_ok(x, w):
       ph, pw = (pad, pad) if isinstance(pad, int) else pad
       Ho = (x.shape[2] + 2 * ph - self.k) // self.stride + 1

@@ -48,7 +48,7 @@ SYMBOLS = [
     'pf_depthwise_wrw', 'pf_conv2d_stats_groups_geom', 'pf_tuning_reload',
     'pf_adam_flat_dev', 'pf_momentum_flat_dev', 'pf_set_floats',
     'pf_convg_fwd', 'pf_convg_bwd_data', 'pf_convg_wrw_splits', 'pf_convg_wrw', 'pf_conv2d_bwd_data_strided',
-    'pf_prox_groups', 'pf_prox_norms', 'pf_prox_apply',
+    'pf_prox_groups', 'pf_prox_norms', 'pf_prox_apply', 'pf_im2col', 'pf_col2im',
 ]
 
 
@@ -476,6 +476,24 @@ def conv2d_bwd_data_strided(dY, Wt, dX, B: int, H: int, Wd: int, C: int, N: int,
   _check(_lib.pf_conv2d_bwd_data_strided(_ptr(dY), _ptr(Wt), _ptr(dX), _ptr(zero_page(dY.device)), c_int(B), c_int(H), c_int(Wd),
                                          c_int(C), c_int(N), c_int(R), c_int(S), c_int(stride), c_int(pad_h), c_int(pad_w), c_int(Ho),
                                          c_int(Wo), _stream()), 'pf_conv2d_bwd_data_strided')
+
+
+def im2col(X, Xcol, B: int, H: int, Wd: int, C: int, R: int, S: int, stride: int, pad_h: int, pad_w: int, Ho: int, Wo: int) -> None:
+  """Xcol[B*Ho*Wo][R*S*C] <- X[B][H][Wd][C] (bf16, C % 8 == 0; taps outside the image are zeros)."""
+  _dev(X)
+  if X.dtype != torch.bfloat16 or Xcol.dtype != torch.bfloat16 or Xcol.numel() < B * Ho * Wo * R * S * C:
+    raise TypeError('im2col: bf16 tensors, Xcol of B*Ho*Wo*R*S*C elements')
+  _check(_lib.pf_im2col(_ptr(X), _ptr(Xcol), c_int(B), c_int(H), c_int(Wd), c_int(C), c_int(R), c_int(S), c_int(stride), c_int(pad_h),
+                        c_int(pad_w), c_int(Ho), c_int(Wo), _stream()), 'pf_im2col')
+
+
+def col2im(dXcol, dX, B: int, H: int, Wd: int, C: int, R: int, S: int, stride: int, pad_h: int, pad_w: int, Ho: int, Wo: int) -> None:
+  """dX[B][H][Wd][C] <- the gather-sum of dXcol[B*Ho*Wo][R*S*C] (inverse of im2col; bf16)."""
+  _dev(dXcol)
+  if dXcol.dtype != torch.bfloat16 or dX.dtype != torch.bfloat16:
+    raise TypeError('col2im: bf16 tensors')
+  _check(_lib.pf_col2im(_ptr(dXcol), _ptr(dX), c_int(B), c_int(H), c_int(Wd), c_int(C), c_int(R), c_int(S), c_int(stride), c_int(pad_h),
+                        c_int(pad_w), c_int(Ho), c_int(Wo), _stream()), 'pf_col2im')
 
 
 # ------------------------------------------------------------------------------------------------

@@ -71,6 +71,20 @@ def input_spec(model_helper):
   return torch.empty(tuple(images.shape), device='meta')
 
 
+def _detached(out):
+  """The step's return value without its autograd graph.  The backward pass has run; nothing reads the graph afterwards -- but a
+  caller that keeps the previous step's losses while it calls the next step (`log_rslt = self.train_step()` in every train() loop)
+  would keep that step's whole graph alive, and a graph that is alive while the next step is RECORDED into a hipGraph crashed
+  hipStreamEndCapture (round 4, found by bisecting tests/step_graph_worker.py: PF_W_DROP_OUT)."""
+  if torch.is_tensor(out):
+    return out.detach()
+  if isinstance(out, dict):
+    return {k: _detached(v) for k, v in out.items()}
+  if isinstance(out, (tuple, list)):
+    return type(out)(_detached(v) for v in out)
+  return out
+
+
 class AbstractLearner(ABC):  # pylint: disable=too-many-instance-attributes
   """Abstract class for learners: takes a ModelHelper (data pipeline + network definition) and
   either trains (periodically saving checkpoints) or restores and evaluates a model."""
@@ -169,9 +183,9 @@ class AbstractLearner(ABC):  # pylint: disable=too-many-instance-attributes
     """One fine-tune iteration (`sess.run(train_op)` of the reference learners): the learner's `_train_step_eager`, or -- with
     --enbl_step_graph, single process -- the same step replayed from a hipGraph (step_graph.py)."""
     if args or kwargs or not FLAGS.enbl_step_graph or FLAGS.enbl_multi_gpu:
-      return self._train_step_eager(*args, **kwargs)
+      return _detached(self._train_step_eager(*args, **kwargs))
     from pocketflow_amd import step_graph
-    return step_graph.of(self).step()
+    return _detached(step_graph.of(self).step())
 
   def to_device(self, images, labels):
     x = to_device_images(images, self.graph)

@@ -24,6 +24,11 @@ def pause() -> None:
   _paused = True
 
 
+def unpause() -> None:
+  global _paused
+  _paused = False
+
+
 def disable_all() -> None:
   _enabled.clear()
 

@@ -273,6 +273,9 @@ class StepGraph(object):
     pow0 = (opt.beta1_power, opt.beta2_power)
     try:
       self.out = self.backend.capture(body)
+      if self.out is not None:
+        from pocketflow_amd.learners.abstract_learner import _detached
+        self.out = _detached(self.out)                       # static output tensors; the recorded step's Python graph is not needed
     finally:
       g.capturing = False
     # recording executed nothing on the device; undo the host-side bookkeeping of the recorded step

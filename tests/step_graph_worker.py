@@ -1,8 +1,8 @@
 """The recorded-step cases of tests/test_learner_gpu.py, run in a process of their own (python tests/step_graph_worker.py <case> <tmp dir>).
 
-Why a worker process: round 4 saw hipStreamEndCapture crash the interpreter (SIGSEGV inside the HIP runtime while it instantiates the
-captured graph) when these cases ran INSIDE pytest, while the same steps record and replay in bench.py and in this worker -- a crash
-there must cost one test, not the rest of the GPU suite.  Prints one JSON line: {"case", "exact", "losses_eager", "losses_graph", ...}.
+Why a worker process: a crash inside the HIP runtime's graph instantiation (round 4: hipStreamEndCapture died with SIGSEGV whenever the
+PREVIOUS step's autograd graph was still alive while a step was recorded -- the learners now return detached tensors) must cost one
+test, not the rest of the GPU suite.  Prints one JSON line: {"case", "exact", "losses_eager", "losses_graph", ...}.
 """
 import json
 import os
@@ -41,8 +41,7 @@ def _collect_losses_each_step(lrn, n_steps, suspend_at, graph_mode):
       sg.resume() if sg.suspended else sg.suspend()
     o = lrn.train_step()
     losses.append((o['loss'] if isinstance(o, dict) else o[1]).detach().clone())
-    if os.environ.get('PF_W_DROP_OUT', '1') != '0':
-      o = None                                             # (as bench.py: nothing of a step's autograd graph outlives the step)
+    # (`o` stays bound while the next step runs, as in the learners' train() loops: the returned tensors carry no autograd graph)
   return [float(l) for l in losses]
 
 

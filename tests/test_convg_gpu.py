@@ -116,3 +116,39 @@ def test_layers_route_odd_shapes_to_the_general_kernels(tmp_path, dtype, monkeyp
   tol = 1e-4 if dtype == 'float32' else 3e-2
   for a, b in zip(outs[0], outs[1]):
     assert float((a - b).abs().max()) <= tol * (float(b.abs().max()) + 1e-6)
+
+
+@pytest.mark.parametrize('imgs,H,W,C,N,R,stride,pad', [(4, 32, 32, 16, 16, 3, 1, 1), (4, 32, 32, 16, 32, 3, 2, 1), (3, 16, 16, 32, 32, 3, 1, 1),
+                                                        (2, 16, 16, 32, 64, 3, 2, 1), (2, 9, 7, 48, 24, 5, 1, 2)])
+def test_few_channel_convolutions_as_im2col_plus_1x1_kernels(imgs, H, W, C, N, R, stride, pad):
+  """graph._ConvIm2col (pf_im2col.hip + the fused 1x1 kernels): forward, backward-data (col2im gather) and backward-filter of the
+  ResNet-20 convolutions against torch's float32 convolution on the same bf16 values."""
+  import pocketflow_amd.graph as G
+  from pocketflow_amd.graph import Graph, Conv2D
+  g = Graph('model', 'cuda', torch.bfloat16)
+  with g.as_default():
+    conv = Conv2D(g, 'c', C, N, R, stride, padding=pad, use_bias=False)
+  g.finalize(seed=11)
+  gen = torch.Generator().manual_seed(3 + C + H)
+  x = torch.randn((imgs, C, H, W), generator=gen).cuda().bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+  assert G.im2col_conv_ok(x, conv, (pad, pad))
+  with g.as_default():
+    y = conv(x)
+  Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+  dy = torch.randn((imgs, N, Ho, Wo), generator=gen).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+  y.backward(dy)
+  xr = x.detach().float().requires_grad_(True)
+  wr = conv.kernel.tensor.detach().float().requires_grad_(True)
+  yr = F.conv2d(xr, wr, None, stride=stride, padding=pad)
+  yr.backward(dy.float())
+
+  def close(got, ref, what, tol=1.2e-2):
+    got, ref = got.float(), ref.float()
+    assert torch.isfinite(got).all(), what
+    err = float((got - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
+    assert err <= tol, '%s: %.3e' % (what, err)
+  close(y.detach(), yr.detach(), 'forward')
+  close(x.grad, xr.grad, 'backward-data')
+  v = conv.kernel
+  gw = g.store.w_grad[v.offset:v.offset + v.numel].view(N, R, R, C).permute(0, 3, 1, 2)
+  close(gw, wr.grad, 'backward-filter')

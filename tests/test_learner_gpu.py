@@ -235,8 +235,9 @@ def test_bench_two_gpus_over_rccl(tmp_path):
 
 @pytest.mark.parametrize('case', ['uq_resnet50', 'ws_resnet20', 'cp_mobilenet'])
 def test_step_graph_is_the_eager_step(tmp_path, case):
-  """tests/step_graph_worker.py in a process of its own (a crash inside the HIP runtime's graph instantiation -- seen in round 4 when
-  these cases ran inside pytest -- costs this test, not the suite).  The three benchmarked learner kinds: ResNet-50 UQ w8/a8 +
+  """tests/step_graph_worker.py in a process of its own (a crash inside the HIP runtime's graph instantiation costs this test, not the
+  suite; round 4: hipStreamEndCapture died whenever the previous step's autograd graph was still alive during the recording -- the
+  worker keeps each step's result bound while it calls the next step, as the learners' train() loops do).  The three benchmarked learner kinds: ResNet-50 UQ w8/a8 +
   distillation (teacher forked inside the graph, Adam's alpha_t from device memory, graph suspended for two steps), ResNet-20
   weight sparsification (no teacher, Momentum, masks inside the recorded optimiser launch), MobileNet-v1 channel-pruned fine-tune
   (dropout mask through graph.step_feeders).  Recorded run vs launch-by-launch run of a second learner from the same checkpoint:
