@@ -967,7 +967,10 @@ class _ConvGeneric(torch.autograd.Function):
     y = torch.empty((B, N, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     bf = None if bias is None else bias.detach().float().contiguous()
     with region('convg_fwd', float((x.numel() + y.numel()) * x.element_size())):
-      hip.convg_fwd(x, wk, bf, y, B, H, Wd, C, N, R, S, stride, pad[0], pad[1], Ho, Wo, slab=graph.scratch(1 << 20))
+      # (split contraction of small outputs in bf16 only: the float32 parity mode keeps ONE ascending sum per output -- the conditioned
+      # ResNet-50 gradient test moves from 1.7e-3 to 1.9e-2 on its most sensitive BN scale with the dense layer summed in 8 slabs)
+      hip.convg_fwd(x, wk, bf, y, B, H, Wd, C, N, R, S, stride, pad[0], pad[1], Ho, Wo,
+                    slab=graph.scratch(1 << 20) if x.dtype == torch.bfloat16 else None)
     ctx.save_for_backward(x, w)
     ctx.meta = (stride, pad, out_hw, graph, bias is not None)
     return y
@@ -988,7 +991,8 @@ class _ConvGeneric(torch.autograd.Function):
         wk = wk.contiguous().to(x.dtype)
       dx = torch.empty_like(x, memory_format=torch.channels_last)
       with region('convg_bwd_data', float((dy.numel() + dx.numel()) * x.element_size())):
-        hip.convg_bwd_data(dy, wk, dx, B, H, Wd, C, N, R, S, stride, pad[0], pad[1], Ho, Wo, slab=graph.scratch(1 << 20))
+        hip.convg_bwd_data(dy, wk, dx, B, H, Wd, C, N, R, S, stride, pad[0], pad[1], Ho, Wo,
+                           slab=graph.scratch(1 << 20) if x.dtype == torch.bfloat16 else None)
     if ctx.needs_input_grad[1]:
       splits = hip.convg_wrw_splits(B, C, N, R, S, Ho, Wo)
       dwk = torch.empty((N, R, S, C), dtype=w.dtype, device=x.device)

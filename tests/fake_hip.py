@@ -140,6 +140,30 @@ class FakeHip(object):
   def conv1x1_wrw_splits(self, M, N, K):
     return 2
 
+  # -- few-channel RxS convolutions: the gather and its inverse (pf_im2col.hip) ------------------------------------------------
+  @staticmethod
+  def _padded_extent(size, n_out, k, stride, pad):
+    return max(size + pad, (n_out - 1) * stride + k)
+
+  def im2col(self, X, Xcol, B, H, Wd, C, R, S, stride, ph, pw, Ho, Wo):
+    self._n('im2col')
+    import torch.nn.functional as F
+    x = X.detach().permute(0, 2, 3, 1).float()                      # [B][H][W][C]
+    Hp, Wp = self._padded_extent(H, Ho, R, stride, ph), self._padded_extent(Wd, Wo, S, stride, pw)
+    xp = F.pad(x, (0, 0, pw, Wp - pw - Wd, ph, Hp - ph - H))
+    cols = [xp[:, r:r + (Ho - 1) * stride + 1:stride, s:s + (Wo - 1) * stride + 1:stride, :] for r in range(R) for s in range(S)]
+    Xcol.copy_(torch.cat(cols, dim=3).reshape(B * Ho * Wo, R * S * C).to(Xcol.dtype))
+
+  def col2im(self, dXcol, dX, B, H, Wd, C, R, S, stride, ph, pw, Ho, Wo):
+    self._n('col2im')
+    d = dXcol.detach().float().view(B, Ho, Wo, R * S, C)
+    Hp, Wp = self._padded_extent(H, Ho, R, stride, ph), self._padded_extent(Wd, Wo, S, stride, pw)
+    dxp = torch.zeros((B, Hp, Wp, C), dtype=torch.float32)
+    for r in range(R):
+      for s in range(S):
+        dxp[:, r:r + (Ho - 1) * stride + 1:stride, s:s + (Wo - 1) * stride + 1:stride, :] += d[:, :, :, r * S + s, :]
+    dX.copy_(dxp[:, ph:ph + H, pw:pw + Wd, :].permute(0, 3, 1, 2).to(dX.dtype))
+
   @staticmethod
   def _gather(x, K, geom):
     if geom is None:

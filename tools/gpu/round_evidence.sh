@@ -1,8 +1,8 @@
-# Round evidence on the GPU box:  bash tools/gpu/round_evidence.sh [tag]   (tag defaults to r03; outputs gpurun_out/<tag>_*)
+# Round evidence on the GPU box:  bash tools/gpu/round_evidence.sh [tag]   (tag defaults to r04; outputs gpurun_out/<tag>_*)
 # smoke -> full GPU test suite (gradient-parity report lines -> <tag>_parity_report.txt) -> rocprofv3 kernel trace of bench.py
 # (stats + steady-state step table with the idle-gap analysis) -> separate PMC passes (FETCH_SIZE / WRITE_SIZE; never combined
 # with a trace domain) -> the default bench.py line with cpu_baseline -> one bench line per other configuration of SURVEY 8(d)
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -18,15 +18,26 @@ python tools/prof_summary.py $(find /tmp/prof_$TAG -name '*kernel_trace.csv' | h
 cp $(find /tmp/prof_$TAG -name '*kernel_stats.csv' | head -1) gpurun_out/${TAG}_rocprofv3_stats_b256.csv
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 2 --no_cpu_baseline > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 2 --no_cpu_baseline --step_graph 0 > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$c.log 2>&1
   f=$(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1)
   python $GRAFT_REPO_ROOT/tools/pmc_summary.py $f $c --out $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$c.csv | head -8 | cut -c1-160
+done
+# MFMA-busy pass (north_star: "rocprof MFMA-busy"): SQ busy cycles of the matrix pipe beside the SQ / GRBM activity counters, one pass, no
+# trace domain; tools/mfma_busy.py turns it into a per-kernel table (derivation and calibration in its docstring)
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 5 --no_cpu_baseline --step_graph 0 > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_mfma.log 2>&1
+f=$(find /tmp/pmc_mfma -name '*counter_collection.csv' | head -1)
+python $GRAFT_REPO_ROOT/tools/pmc_table.py $f > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_mfma_busy.csv 2>> $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_mfma.log; head -5 $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_mfma_busy.csv | cut -c1-200
+# steady-state kernel tables of the other configurations (is any library kernel left in their steps?)
+for c in c1 c3; do
+  timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_${TAG}_$c -o $c -- python $GRAFT_REPO_ROOT/bench.py --config $c --steps 12 --warmup 5 --no_cpu_baseline --step_graph 0 > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof_$c.log 2>&1
+  marker=k_adam_flat; [ $c = c1 ] && marker=k_momentum_flat
+  python $GRAFT_REPO_ROOT/tools/prof_summary.py $(find /tmp/prof_${TAG}_$c -name '*kernel_trace.csv' | head -1) --steps 4 --marker $marker --out $GRAFT_REPO_ROOT/gpurun_out/${TAG}_step_kernels_$c.csv | head -12 | cut -c1-150
 done
 cd $GRAFT_REPO_ROOT
 PF_BENCH_TRACE_STEPS=1 timeout 900 python bench.py > gpurun_out/${TAG}_bench.log 2>&1; grep -v '"metric"' gpurun_out/${TAG}_bench.log | tail -2 | cut -c1-300; grep '"metric"' gpurun_out/${TAG}_bench.log | cut -c1-2200
 grep '"metric"' gpurun_out/${TAG}_bench.log > gpurun_out/${TAG}_bench.json
 for c in c2a32 c4 c3 c1; do
-  timeout 400 python bench.py --config $c --steps 10 --warmup 4 --no_cpu_baseline > gpurun_out/${TAG}_bench_$c.json 2> gpurun_out/${TAG}_bench_$c.err || tail -3 gpurun_out/${TAG}_bench_$c.err
+  timeout 400 python bench.py --config $c --steps 20 --warmup 5 --no_cpu_baseline > gpurun_out/${TAG}_bench_$c.json 2> gpurun_out/${TAG}_bench_$c.err || tail -3 gpurun_out/${TAG}_bench_$c.err
   python -c "
 import json, sys
 for ln in open(sys.argv[1]):
