@@ -24,7 +24,7 @@ for H, C in ((56, 128), (28, 256), (14, 512)):
   w_ = w.permute(0, 3, 1, 2)
   mi = bench_us(lambda: torch.ops.aten.convolution_backward(dy_, x_, w_, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False]))
   gf = 2.0 * B * Ho * Ho * N * C * 9 / 1e9
-  print('  %3dx%-3d %4d -> %-4d  %8.1f GFLOP            %8.1f (%4.0f TF/s)   %8.1f' % (H, H, C, N, gf, ours, gf / ours * 1e-3 * 1e3, mi))
+  print('  %3dx%-3d %4d -> %-4d  %8.1f GFLOP            %8.1f (%4.0f TF/s)   %8.1f' % (H, H, C, N, gf, ours, gf / ours * 1e3, mi))
 print('dense 2048 -> 1001 at B = %d, us                                   k_convg   k_convg split   rocBLAS' % B)
 x = torch.randn(B, 2048, device='cuda').bfloat16()
 w = (torch.randn(1001, 2048, device='cuda') * 0.02).bfloat16()
