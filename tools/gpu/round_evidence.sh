@@ -34,6 +34,7 @@ for c in c1 c3; do
   python $GRAFT_REPO_ROOT/tools/prof_summary.py $(find /tmp/prof_${TAG}_$c -name '*kernel_trace.csv' | head -1) --steps 4 --marker $marker --out $GRAFT_REPO_ROOT/gpurun_out/${TAG}_step_kernels_$c.csv | head -12 | cut -c1-150
 done
 cd $GRAFT_REPO_ROOT
+cp gpurun_out/${TAG}_pmc_FETCH_SIZE.csv gpurun_out/${TAG}_pmc_WRITE_SIZE.csv profiles/ 2>/dev/null     # bench.py reads roofline.traffic from profiles/
 PF_BENCH_TRACE_STEPS=1 timeout 900 python bench.py > gpurun_out/${TAG}_bench.log 2>&1; grep -v '"metric"' gpurun_out/${TAG}_bench.log | tail -2 | cut -c1-300; grep '"metric"' gpurun_out/${TAG}_bench.log | cut -c1-2200
 grep '"metric"' gpurun_out/${TAG}_bench.log > gpurun_out/${TAG}_bench.json
 for c in c2a32 c4 c3 c1; do
