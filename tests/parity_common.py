@@ -85,7 +85,7 @@ def gradient_report(per, whole_cos, whole_ratio, what):
                                             cosv[len(cosv) // 2], whole_cos, whole_ratio))
   print(line)
   import os
-  out = os.environ.get('PF_PARITY_REPORT')              # tools/gpu/r03_call.sh collects these lines under profiles/
+  out = os.environ.get('PF_PARITY_REPORT')              # tools/gpu/round_evidence.sh collects these lines under profiles/
   if out:
     with open(out, 'a') as f:
       f.write(line + '\n')
