@@ -55,7 +55,7 @@ def parse_args():
   ap.add_argument('--step_graph', type=int, default=None,
                   help='1: the steady-state step is recorded in a hipGraph during the warm-up and replayed (default on ONE GPU; '
                        'pocketflow_amd/step_graph.py); 0: every step is issued launch by launch (default for N > 1)')
-  ap.add_argument('--event_steps', type=int, default=2,
+  ap.add_argument('--event_steps', type=int, default=3,
                   help='with --step_graph 1: this many of the K timed steps run launch by launch, their roofline-region launches '
                        'bracketed by HIP events (a replayed graph cannot carry timing events)')
   ap.add_argument('--no_reexec', action='store_true', help=argparse.SUPPRESS)       # accepted, ignored (older scripts)
@@ -389,6 +389,8 @@ def main():
       with open(os.path.join(out_dir, 'bench_host_bound_profile.txt'), 'w') as f:
         f.write(text)
   n_event = args.steps if sg is None else max(0, min(args.event_steps, args.steps))
+  if sg is not None and sg.nxt is not None and 0 < n_event < 2:
+    n_event = min(2, args.steps)         # (with a teacher branch the first launch-by-launch step is not representative, see `unshared`)
   # Recorded steps first, the launch-by-launch steps (roofline-region launches bracketed by events) LAST: the replays are submitted in
   # ~1 ms each, so the host's slower launch-by-launch submission (and the hand-over between the modes, 60-90 ms measured) runs while
   # the GPU still works through the replays.  The other way round the GPU sat idle through the first launch-by-launch step: 3 ms per
@@ -399,12 +401,15 @@ def main():
   sync()
   t0 = time.perf_counter()
   marks = []
+  rec_marks = []                       # region launches recorded after each launch-by-launch step (recorded-step mode)
   for i in range(args.steps):
     if sg is not None and i == args.steps - n_event:
       sg.suspend()
       profiling.unpause()
     train_step()
     marks.append(time.perf_counter())
+    if sg is not None and i >= args.steps - n_event:
+      rec_marks.append(profiling.count(args.roofline_kernel))
   sync()
   dt = time.perf_counter() - t0
   host_ms = (marks[-1] - t0) * 1e3 / max(1, args.steps)        # host-side submission time per step (GPU-bound when << ms_per_step)
@@ -433,7 +438,20 @@ def main():
                  'buckets': len(red.buckets) if red is not None else None,
                  'buckets_launched_inside_backward': red.n_overlapped if red is not None else None,
                  'allreduce_bytes_per_step': int(st.w_size * el + st.o_size * 4)}
-  n_launch, ms, work = profiling.summary(args.roofline_kernel)
+  # Recorded-step mode with a teacher: the FIRST launch-by-launch step after the hand-over finds its teacher logits ready (the
+  # graph computed them), so its region launches run with the chip to themselves; from the second one on the teacher's forward over
+  # the next batch runs beside the student's forward pass, as it does inside every replayed step.  The second kind is what the
+  # bench's steps look like (and what a rocprofv3 trace of this command averages over): it is `roofline`; the first kind is kept
+  # beside it as `roofline.unshared` (what the kernels do when nothing else is on the chip).
+  unshared = None
+  if sg is not None and sg.nxt is not None and len(rec_marks) >= 2 and rec_marks[0] > 0 and rec_marks[-1] > rec_marks[0]:
+    n_u, ms_u, work_u = profiling.summary(args.roofline_kernel, 0, rec_marks[0])
+    n_launch, ms, work = profiling.summary(args.roofline_kernel, rec_marks[0], None)
+    if ms_u > 0:
+      unshared = {'launches': n_u, 'avg_launch_ms': ms_u / n_u, 'achieved': work_u / (ms_u * 1e-3) / 1e9,
+                  'frac': work_u / (ms_u * 1e-3) / HBM_PEAK}
+  else:
+    n_launch, ms, work = profiling.summary(args.roofline_kernel)
 
   if rank == 0:
     images = args.batch * world * args.steps
@@ -448,7 +466,11 @@ def main():
                 'traffic_source': pmc_traffic_source(),
                 'algorithmic_bytes_per_launch': (work / n_launch) if n_launch else None, 'launches': n_launch,
                 'avg_launch_ms': (ms / n_launch) if n_launch else None,
-                'step_mfma_frac': per_gpu * cfg['flops'] / MFMA_BF16_PEAK}
+                'step_mfma_frac': per_gpu * cfg['flops'] / MFMA_BF16_PEAK,
+                'unshared': unshared,
+                'sharing': ('the teacher branch (forward over the next batch, second stream) runs beside these launches: their durations '
+                            'include the sharing' if getattr(learner, '_teacher_ahead', None) is not None or (sg is not None and sg.nxt is not None)
+                            else 'none')}
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline and cfg['learner'] == 'uniform':   # the oracle timer restates the UQ step
       # the reference path restated on the host cores (oracle/learner_oracle.py), in a child process with a

@@ -94,9 +94,14 @@ def region(name: str, work: float = 0.0):
   return _NOOP if (rec is None or _suspended or _paused) else _Timed(rec, work)
 
 
-def summary(name: str):
-  """(launches, total_ms, total_work) of a region; call after torch.cuda.synchronize()."""
-  rec = _enabled.get(name, [])
+def count(name: str) -> int:
+  """Launches recorded so far (host side; no synchronisation)."""
+  return len(_enabled.get(name, []))
+
+
+def summary(name: str, lo: int = 0, hi: int = None):
+  """(launches, total_ms, total_work) of a region (records lo .. hi); call after torch.cuda.synchronize()."""
+  rec = _enabled.get(name, [])[lo:hi]
   ms = sum(a.elapsed_time(b) for a, b, _ in rec)
   work = sum(w for _, _, w in rec)
   return len(rec), ms, work

@@ -34,9 +34,9 @@ def main():
   for r in rows:
     k = r['kernel']
     try:
-      busy = float(r['mean_SQ_VALU_MFMA_BUSY_CYCLES'])
-      gui = float(r['mean_GRBM_GUI_ACTIVE'])
-    except (KeyError, ValueError):
+      busy = float(r.get('mean_SQ_VALU_MFMA_BUSY_CYCLES', r.get('SQ_VALU_MFMA_BUSY_CYCLES')))      # (pmc_table.py: per-dispatch means)
+      gui = float(r.get('mean_GRBM_GUI_ACTIVE', r.get('GRBM_GUI_ACTIVE')))
+    except (KeyError, ValueError, TypeError):
       continue
     if busy <= 0:
       continue
