@@ -389,12 +389,11 @@ def main():
       with open(os.path.join(out_dir, 'bench_host_bound_profile.txt'), 'w') as f:
         f.write(text)
   n_event = args.steps if sg is None else max(0, min(args.event_steps, args.steps))
-  if sg is not None and sg.nxt is not None and 0 < n_event < 2:
-    n_event = min(2, args.steps)         # (with a teacher branch the first launch-by-launch step is not representative, see `unshared`)
   # Recorded steps first, the launch-by-launch steps (roofline-region launches bracketed by events) LAST: the replays are submitted in
   # ~1 ms each, so the host's slower launch-by-launch submission (and the hand-over between the modes, 60-90 ms measured) runs while
   # the GPU still works through the replays.  The other way round the GPU sat idle through the first launch-by-launch step: 3 ms per
   # step over a 20-step region.
+  profiling.include_side = True
   profiling.enable(args.roofline_kernel)
   if sg is not None:
     profiling.pause()
@@ -438,20 +437,14 @@ def main():
                  'buckets': len(red.buckets) if red is not None else None,
                  'buckets_launched_inside_backward': red.n_overlapped if red is not None else None,
                  'allreduce_bytes_per_step': int(st.w_size * el + st.o_size * 4)}
-  # Recorded-step mode with a teacher: the FIRST launch-by-launch step after the hand-over finds its teacher logits ready (the
-  # graph computed them), so its region launches run with the chip to themselves; from the second one on the teacher's forward over
-  # the next batch runs beside the student's forward pass, as it does inside every replayed step.  The second kind is what the
-  # bench's steps look like (and what a rocprofv3 trace of this command averages over): it is `roofline`; the first kind is kept
-  # beside it as `roofline.unshared` (what the kernels do when nothing else is on the chip).
-  unshared = None
-  if sg is not None and sg.nxt is not None and len(rec_marks) >= 2 and rec_marks[0] > 0 and rec_marks[-1] > rec_marks[0]:
-    n_u, ms_u, work_u = profiling.summary(args.roofline_kernel, 0, rec_marks[0])
-    n_launch, ms, work = profiling.summary(args.roofline_kernel, rec_marks[0], None)
-    if ms_u > 0:
-      unshared = {'launches': n_u, 'avg_launch_ms': ms_u / n_u, 'achieved': work_u / (ms_u * 1e-3) / 1e9,
-                  'frac': work_u / (ms_u * 1e-3) / HBM_PEAK}
-  else:
-    n_launch, ms, work = profiling.summary(args.roofline_kernel)
+  # The region's launches of BOTH streams: the student's (main stream) and -- profiling.include_side -- the teacher's over the next
+  # batch (second stream).  A launch that shares the chip with the other stream takes longer from start to end; that is what a
+  # rocprofv3 kernel trace of this command shows for it too, so the average over both is the figure the trace's average agrees with.
+  n_launch, ms, work = profiling.summary(args.roofline_kernel)
+  n_m, ms_m, work_m = profiling.summary(args.roofline_kernel, side=False)
+  n_s, ms_s, work_s = profiling.summary(args.roofline_kernel, side=True)
+  by_stream = {'main_stream': {'launches': n_m, 'avg_launch_ms': (ms_m / n_m) if n_m else None},
+               'teacher_stream': {'launches': n_s, 'avg_launch_ms': (ms_s / n_s) if n_s else None}}
 
   if rank == 0:
     images = args.batch * world * args.steps
@@ -467,7 +460,7 @@ def main():
                 'algorithmic_bytes_per_launch': (work / n_launch) if n_launch else None, 'launches': n_launch,
                 'avg_launch_ms': (ms / n_launch) if n_launch else None,
                 'step_mfma_frac': per_gpu * cfg['flops'] / MFMA_BF16_PEAK,
-                'unshared': unshared,
+                'by_stream': by_stream,
                 'sharing': ('the teacher branch (forward over the next batch, second stream) runs beside these launches: their durations '
                             'include the sharing' if getattr(learner, '_teacher_ahead', None) is not None or (sg is not None and sg.nxt is not None)
                             else 'none')}

@@ -51,10 +51,10 @@ class _Noop(object):
 
 
 class _Timed(object):
-  __slots__ = ('rec', 'work', 'a')
+  __slots__ = ('rec', 'work', 'a', 'side')
 
   def __init__(self, rec, work):
-    self.rec, self.work, self.a = rec, work, None
+    self.rec, self.work, self.a, self.side = rec, work, None, _in_side > 0
 
   def __enter__(self):
     self.a = torch.cuda.Event(enable_timing=True)
@@ -65,12 +65,15 @@ class _Timed(object):
     if exc_type is None:
       b = torch.cuda.Event(enable_timing=True)
       b.record()
-      self.rec.append((self.a, b, self.work))
+      self.rec.append((self.a, b, self.work, self.side))
     return False
 
 
 _NOOP = _Noop()
 _suspended = 0
+_in_side = 0
+include_side = False       # bench.py: regions entered on the teacher's side stream are recorded too (their event-to-event durations
+#                            include the time-sharing with the main stream -- exactly what a rocprofv3 kernel trace shows for them)
 _paused = False
 
 
@@ -79,13 +82,17 @@ class suspended(object):
   event-to-event interval there is not a kernel's duration, learners/teacher_ahead.py)."""
 
   def __enter__(self):
-    global _suspended
-    _suspended += 1
+    global _suspended, _in_side
+    _in_side += 1
+    if not include_side:
+      _suspended += 1
     return None
 
   def __exit__(self, exc_type, exc, tb):
-    global _suspended
-    _suspended -= 1
+    global _suspended, _in_side
+    _in_side -= 1
+    if not include_side:
+      _suspended -= 1
     return False
 
 
@@ -99,9 +106,10 @@ def count(name: str) -> int:
   return len(_enabled.get(name, []))
 
 
-def summary(name: str, lo: int = 0, hi: int = None):
-  """(launches, total_ms, total_work) of a region (records lo .. hi); call after torch.cuda.synchronize()."""
-  rec = _enabled.get(name, [])[lo:hi]
-  ms = sum(a.elapsed_time(b) for a, b, _ in rec)
-  work = sum(w for _, _, w in rec)
+def summary(name: str, lo: int = 0, hi: int = None, side=None):
+  """(launches, total_ms, total_work) of a region (records lo .. hi; side: None = all, False = main stream only, True = launches
+  issued inside `suspended()` with `include_side`, i.e. the teacher's side stream); call after torch.cuda.synchronize()."""
+  rec = [r for r in _enabled.get(name, [])[lo:hi] if side is None or r[3] == side]
+  ms = sum(r[0].elapsed_time(r[1]) for r in rec)
+  work = sum(r[2] for r in rec)
   return len(rec), ms, work

@@ -36,7 +36,7 @@ def test_bench_main_runs_end_to_end_on_emulated_kernels(monkeypatch, capsys, tmp
   monkeypatch.setattr(bench, 'launch_probe', lambda torch, n=1000: {'host_us_per_launch': 1.0, 'us_per_dispatch': 99.0})
   monkeypatch.setattr(bench, 'memory_snapshot', lambda torch: {'reserved_gb': 0.0, 'segments_allocated': 0})
   monkeypatch.setattr(PR, 'enable', lambda name: None)
-  monkeypatch.setattr(PR, 'summary', lambda name: (72, 7.2, 72 * 3.0e8))
+  monkeypatch.setattr(PR, 'summary', lambda name, lo=0, hi=None, side=None: (72, 7.2, 72 * 3.0e8))
   monkeypatch.setenv('TMPDIR', str(tmp_path))
   monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', config, '--steps', '1', '--warmup', '1', '--batch', '2',
                                     '--image_size', '32', '--dtype', 'float32', '--no_cpu_baseline'] + extra)
