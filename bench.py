@@ -53,8 +53,11 @@ def parse_args():
                        'conv1x1_bwd_data | conv2d_fwd | bn_bwd_apply | bn_bwd_stats | bn_act_quant_apply | bn_stats')
   ap.add_argument('--no_cpu_baseline', action='store_true')
   ap.add_argument('--step_graph', type=int, default=None,
-                  help='1: the steady-state step is recorded in a hipGraph during the warm-up and replayed (default on ONE GPU; '
-                       'pocketflow_amd/step_graph.py); 0: every step is issued launch by launch (default for N > 1)')
+                  help='1: the steady-state step is recorded in a hipGraph during the warm-up and replayed (pocketflow_amd/step_graph.py); '
+                       '0: every step is issued launch by launch (always for N > 1).  Default: recorded when the warm-up shows the step '
+                       'to be HOST-bound (the host needs more than 70 %% of the step time to submit it: ResNet-20 @ CIFAR-10), launch by '
+                       'launch otherwise -- a GPU-bound step gains nothing from the recording (C2: 10 307 vs 10 302 images/s), and a '
+                       'replayed graph cannot carry timing events on ROCm, so only launch-by-launch steps yield per-kernel durations')
   ap.add_argument('--event_steps', type=int, default=3,
                   help='with --step_graph 1: this many of the K timed steps run launch by launch, their roofline-region launches '
                        'bracketed by HIP events (a replayed graph cannot carry timing events)')
@@ -137,7 +140,7 @@ def set_flags(args, tmp, world):
   FLAGS.enbl_dst = cfg['dst']
   FLAGS.dst_eval_teacher = False            # the teacher's one-off evaluation is not part of a step
   FLAGS.synthetic_pool = 2
-  FLAGS.enbl_step_graph = bool(args.step_graph if getattr(args, 'step_graph', None) is not None else world == 1)
+  FLAGS.enbl_step_graph = bool(getattr(args, 'step_graph', None) == 1) and world == 1     # (default: decided after the warm-up, see main)
   FLAGS.save_path = os.path.join(tmp, 'models', 'model.ckpt')
   FLAGS.save_path_dst = os.path.join(tmp, 'models_dst', 'model.ckpt')
   if cfg['model'] != 'mobilenet':
@@ -333,6 +336,17 @@ def main():
   # --step_graph: the recording (three launch-by-launch steps, then one pass of the Python step under stream capture) belongs to
   # the warm-up whatever W is; a learner whose step cannot be recorded says so once and stays launch-by-launch
   sg = None
+  auto_share = None
+  if args.step_graph is None and world == 1:
+    # default: is the step host-bound?  The host's share of two untimed steps from an empty launch queue decides.
+    torch.cuda.synchronize()
+    a0 = time.perf_counter()
+    train_step()
+    train_step()
+    a1 = time.perf_counter()
+    torch.cuda.synchronize()
+    auto_share = (a1 - a0) / max(time.perf_counter() - a0, 1e-9)
+    FLAGS.enbl_step_graph = auto_share > 0.7
   if FLAGS.enbl_step_graph and world == 1:
     from pocketflow_amd import step_graph
     sg = step_graph.of(learner)
@@ -497,7 +511,9 @@ def main():
                    # beside step k's backward; the roofline region then holds the student's launches only
                    'teacher': 'next batch, side stream' if getattr(learner, '_teacher_ahead', None) is not None else 'in line',
                    'step_graph': ({'replayed_steps': args.steps - n_event, 'launch_by_launch_steps_with_events': n_event,
-                                   'teacher_branch': sg.nxt is not None} if sg is not None else None)},
+                                   'teacher_branch': sg.nxt is not None} if sg is not None else None),
+                   'step_graph_default_rule': (None if auto_share is None else
+                                               {'host_share_of_two_warm_steps': auto_share, 'recorded_if_above': 0.7})},
         'roofline': roofline, 'cpu_baseline': cpu_baseline, 'multi_gpu': multi_gpu}
     print(json.dumps(line))
   if world > 1:

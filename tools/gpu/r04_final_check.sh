@@ -1,11 +1,9 @@
-# Round 4, last GPU call: the teacher branch now starts with the step in launch-by-launch mode too (as inside the recorded step); bench.py
-# reports the shared / unshared region separately.  Re-take: learner + distillation tests, the rocprofv3 stats of the bench command, the
-# default bench line with cpu_baseline, the other configurations' lines.
+# Round 4, last GPU call: bench.py as the driver runs it (default rule: recorded only when host-bound), plain and under rocprofv3 --stats,
+# and one line per other configuration.
 TAG=r04
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests/test_learner_gpu.py tests/test_parity_gpu.py -m gpu -q --timeout=900 --tb=short -k "not lenet and not nuq_resnet20" 2>&1 | grep -v amdgpu.ids | tail -6 | cut -c1-300 | tee gpurun_out/${TAG}_pytest_gpu_learners_last.log
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o $TAG -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no_cpu_baseline > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof.log 2>&1
 cd $GRAFT_REPO_ROOT
@@ -16,13 +14,14 @@ timeout 900 python bench.py > gpurun_out/${TAG}_bench.log 2>&1; grep '"metric"' 
 for c in c2a32 c4 c3 c1; do
   timeout 400 python bench.py --config $c --steps 20 --warmup 5 --no_cpu_baseline > gpurun_out/${TAG}_bench_$c.json 2> gpurun_out/${TAG}_bench_$c.err || tail -3 gpurun_out/${TAG}_bench_$c.err
 done
+timeout 400 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --step_graph 1 > gpurun_out/${TAG}_bench_c2_recorded.json 2>/dev/null
 python - <<'PY'
 import json, csv, re
-for name in ('r04_bench_under_rocprof', 'r04_bench', 'r04_bench_c2a32', 'r04_bench_c4', 'r04_bench_c3', 'r04_bench_c1'):
+for name in ('r04_bench_under_rocprof', 'r04_bench', 'r04_bench_c2_recorded', 'r04_bench_c2a32', 'r04_bench_c4', 'r04_bench_c3', 'r04_bench_c1'):
   try:
     d = json.loads([l for l in open('gpurun_out/%s.json' % name) if l.startswith('{')][0])
     r = d['roofline']
-    print(name, round(d['value']), 'img/s', round(d['ms_per_step'], 2), 'ms | region frac', round(r['frac'], 4), 'avg us', round(1e3 * (r['avg_launch_ms'] or 0), 1), 'n', r['launches'], '| unshared', r.get('unshared') and (round(r['unshared']['frac'], 4), round(1e3 * r['unshared']['avg_launch_ms'], 1), r['unshared']['launches']))
+    print(name, round(d['value']), 'img/s', round(d['ms_per_step'], 2), 'ms | host median', round(d['host_submit_ms_min_median_max'][1], 2), '| region frac', round(r['frac'], 4), 'avg us', round(1e3 * (r['avg_launch_ms'] or 0), 1), 'n', r['launches'], '|', d['config'].get('step_graph'), d['config'].get('step_graph_default_rule'))
   except Exception as e:
     print(name, 'failed', e)
 rows = list(csv.DictReader(open('gpurun_out/r04_rocprofv3_stats_b256.csv')))
