@@ -53,11 +53,11 @@ def parse_args():
                        'conv1x1_bwd_data | conv2d_fwd | bn_bwd_apply | bn_bwd_stats | bn_act_quant_apply | bn_stats')
   ap.add_argument('--no_cpu_baseline', action='store_true')
   ap.add_argument('--step_graph', type=int, default=None,
-                  help='1: the steady-state step is recorded in a hipGraph during the warm-up and replayed (pocketflow_amd/step_graph.py); '
-                       '0: every step is issued launch by launch (always for N > 1).  Default: recorded when the warm-up shows the step '
-                       'to be HOST-bound (the host needs more than 70 %% of the step time to submit it: ResNet-20 @ CIFAR-10), launch by '
-                       'launch otherwise -- a GPU-bound step gains nothing from the recording (C2: 10 307 vs 10 302 images/s), and a '
-                       'replayed graph cannot carry timing events on ROCm, so only launch-by-launch steps yield per-kernel durations')
+                  help='1 (default on ONE GPU): the steady-state step is recorded in a hipGraph during the warm-up and replayed '
+                       '(pocketflow_amd/step_graph.py); 0: every step is issued launch by launch (always for N > 1).  The throughput of a '
+                       'GPU-bound step does not depend on it when the host is fast (C2: 10 307 vs 10 302 images/s) but a loaded host '
+                       'cannot slow a recorded step down; a replayed graph cannot carry timing events on ROCm, so the last --event_steps '
+                       'steps are issued launch by launch for the roofline figure')
   ap.add_argument('--event_steps', type=int, default=3,
                   help='with --step_graph 1: this many of the K timed steps run launch by launch, their roofline-region launches '
                        'bracketed by HIP events (a replayed graph cannot carry timing events)')
@@ -346,7 +346,7 @@ def main():
     a1 = time.perf_counter()
     torch.cuda.synchronize()
     auto_share = (a1 - a0) / max(time.perf_counter() - a0, 1e-9)
-    FLAGS.enbl_step_graph = auto_share > 0.7
+    FLAGS.enbl_step_graph = True          # (the measured host share is reported; the recording is the default on one GPU)
   if FLAGS.enbl_step_graph and world == 1:
     from pocketflow_amd import step_graph
     sg = step_graph.of(learner)
@@ -512,8 +512,7 @@ def main():
                    'teacher': 'next batch, side stream' if getattr(learner, '_teacher_ahead', None) is not None else 'in line',
                    'step_graph': ({'replayed_steps': args.steps - n_event, 'launch_by_launch_steps_with_events': n_event,
                                    'teacher_branch': sg.nxt is not None} if sg is not None else None),
-                   'step_graph_default_rule': (None if auto_share is None else
-                                               {'host_share_of_two_warm_steps': auto_share, 'recorded_if_above': 0.7})},
+                   'host_share_of_two_launch_by_launch_steps': auto_share},
         'roofline': roofline, 'cpu_baseline': cpu_baseline, 'multi_gpu': multi_gpu}
     print(json.dumps(line))
   if world > 1:

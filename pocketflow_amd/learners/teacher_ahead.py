@@ -16,8 +16,8 @@ Stream discipline:
   pool; the tensors the main stream will read (x, y, logits) are `record_stream`ed for it, so the caching allocator does not hand
   their memory to a later side-stream allocation while main is still reading them;
 * main waits for ONE event recorded behind the teacher forward before it touches them;
-* the side stream waits for main ONCE per step, at the point of issue (the end of the previous step): the teacher's launches then run
-  beside the next step's forward pass, where the chip has idle CUs; the teacher's weights and scratch were written long before.
+* the side stream never waits for main: the teacher's weights and scratch were written long before (first, in-line teacher
+  forward of step 0), the batch comes from the host.
 The roofline region of bench.py is suspended while the teacher is issued (its launches run beside backward kernels: their
 event-to-event durations are not a kernel's duration any more); the student's launches of the same kernels remain in it.
 """
@@ -99,12 +99,13 @@ class TeacherAhead(object):
     """Fetch batch k+1, upload it and run the teacher over it -- all on the side stream."""
     lrn, st = self.learner, self.streams
     teacher = teacher_of(lrn)
-    # Called at the END of step k, and the side stream waits for the main stream at this point: the teacher's launches over batch
-    # k + 1 start when step k is done, i.e. they run beside step k + 1's FORWARD pass -- exactly where the recorded step forks its
-    # teacher branch (step_graph.py).  Round 4 measured the alternatives in one box (profiles/r04_overlap_ab.txt): beside the forward
-    # pass +6 %; started where the forward pass ends (beside the backward pass, whose kernels fill the chip better) +0.5 %;
-    # backward-filter launches on a third stream -2.8 %.
-    st.side_waits_for_main()
+    # Called at the END of step k; the side stream does NOT wait for the main stream: the launches start as soon as they are issued and
+    # slip into whatever the main stream is executing then (the host is about a step ahead of the GPU).  Round 4 measured the
+    # alternatives (profiles/r04_overlap_ab.txt): this, +6.6 % (9 735 -> 10 379); side stream held until step k is done, so that the
+    # teacher runs beside step k + 1's forward pass as it does inside a RECORDED step (where the two branches genuinely time-share the
+    # chip and it is worth +6 %): -6 % launch by launch (9 251 vs 9 839 recorded in one box -- launch by launch the persistent kernels
+    # of the two streams alternate instead of sharing); teacher beside the backward pass +0.5 %; backward-filter launches on a third
+    # stream -2.8 %.
     with st.on_side(), profiling.suspended():
       # the iterator itself may enqueue device work (pinned upload + resize kernel of the TFRecord reader run on the CURRENT stream):
       # it has to be the side stream, or the teacher would read a batch the main stream has not finished writing
