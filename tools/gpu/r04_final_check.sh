@@ -1,4 +1,4 @@
-# Round 4, last GPU call: bench.py as the driver runs it (default rule: recorded only when host-bound), plain and under rocprofv3 --stats,
+# Round 4, last GPU call: bench.py as the driver runs it (recorded steps), plain and under rocprofv3 --stats,
 # and one line per other configuration.
 TAG=r04
 cd $GRAFT_REPO_ROOT
@@ -14,14 +14,15 @@ timeout 900 python bench.py > gpurun_out/${TAG}_bench.log 2>&1; grep '"metric"' 
 for c in c2a32 c4 c3 c1; do
   timeout 400 python bench.py --config $c --steps 20 --warmup 5 --no_cpu_baseline > gpurun_out/${TAG}_bench_$c.json 2> gpurun_out/${TAG}_bench_$c.err || tail -3 gpurun_out/${TAG}_bench_$c.err
 done
-timeout 400 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --step_graph 1 > gpurun_out/${TAG}_bench_c2_recorded.json 2>/dev/null
+timeout 400 python bench.py --steps 20 --warmup 5 --no_cpu_baseline --step_graph 0 > gpurun_out/${TAG}_bench_c2_launch_by_launch.json 2>/dev/null
+timeout 600 python -m pytest tests/test_learner_gpu.py -m gpu -q --timeout=900 --tb=short 2>&1 | grep -v amdgpu.ids | tail -3 | cut -c1-200
 python - <<'PY'
 import json, csv, re
-for name in ('r04_bench_under_rocprof', 'r04_bench', 'r04_bench_c2_recorded', 'r04_bench_c2a32', 'r04_bench_c4', 'r04_bench_c3', 'r04_bench_c1'):
+for name in ('r04_bench_under_rocprof', 'r04_bench', 'r04_bench_c2_launch_by_launch', 'r04_bench_c2a32', 'r04_bench_c4', 'r04_bench_c3', 'r04_bench_c1'):
   try:
     d = json.loads([l for l in open('gpurun_out/%s.json' % name) if l.startswith('{')][0])
     r = d['roofline']
-    print(name, round(d['value']), 'img/s', round(d['ms_per_step'], 2), 'ms | host median', round(d['host_submit_ms_min_median_max'][1], 2), '| region frac', round(r['frac'], 4), 'avg us', round(1e3 * (r['avg_launch_ms'] or 0), 1), 'n', r['launches'], '|', d['config'].get('step_graph'), d['config'].get('step_graph_default_rule'))
+    print(name, round(d['value']), 'img/s', round(d['ms_per_step'], 2), 'ms | host median', round(d['host_submit_ms_min_median_max'][1], 2), '| region frac', round(r['frac'], 4), 'avg us', round(1e3 * (r['avg_launch_ms'] or 0), 1), 'n', r['launches'], '|', d['config'].get('step_graph'), d['config'].get('host_share_of_two_launch_by_launch_steps'))
   except Exception as e:
     print(name, 'failed', e)
 rows = list(csv.DictReader(open('gpurun_out/r04_rocprofv3_stats_b256.csv')))
