@@ -225,6 +225,10 @@ class StepGraph(object):
     if ahead.pending is not None:
       ahead.drop()
     ahead.pending = (x, y, logits, None, None)
+    # The eager helper's side stream must not run ahead of the replays that are still queued: its next teacher forward would run
+    # CONCURRENTLY with the teacher branch of a replay that has not executed yet -- two forward passes of one frozen network through
+    # the same scratch buffers (seen as a loss mismatch in tests/step_graph_worker.py when the side stream was left free).
+    ahead.streams.side_waits_for_main()
     # a `next` that no replay has consumed yet holds one more batch drawn from the iterator: back it goes, in front of the iterator
     if not self.nxt_stale and self.nxt_raw is not None:
       lrn.__dict__.setdefault('_unget', []).insert(0, self.nxt_raw)
