@@ -459,15 +459,6 @@ def main():
   n_s, ms_s, work_s = profiling.summary(args.roofline_kernel, side=True)
   by_stream = {'main_stream': {'launches': n_m, 'avg_launch_ms': (ms_m / n_m) if n_m else None},
                'teacher_stream': {'launches': n_s, 'avg_launch_ms': (ms_s / n_s) if n_s else None}}
-  # Recorded-step mode with a teacher: the FIRST launch-by-launch step after the hand-over finds its teacher logits ready (the last
-  # replay computed them) and nothing is in flight on the second stream while its forward pass runs -- its main-stream launches are
-  # the region's kernels with the chip to themselves.
-  unshared = None
-  if sg is not None and sg.nxt is not None and len(rec_marks) >= 2:
-    n_u, ms_u, work_u = profiling.summary(args.roofline_kernel, 0, rec_marks[0], side=False)
-    if n_u and ms_u > 0:
-      unshared = {'launches': n_u, 'avg_launch_ms': ms_u / n_u, 'achieved': work_u / (ms_u * 1e-3) / 1e9, 'frac': work_u / (ms_u * 1e-3) / HBM_PEAK,
-                  'what': 'main-stream launches of the first launch-by-launch step: no teacher work in flight beside them'}
 
   if rank == 0:
     images = args.batch * world * args.steps
@@ -484,7 +475,6 @@ def main():
                 'avg_launch_ms': (ms / n_launch) if n_launch else None,
                 'step_mfma_frac': per_gpu * cfg['flops'] / MFMA_BF16_PEAK,
                 'by_stream': by_stream,
-                'unshared': unshared,
                 'sharing': ('the teacher branch (forward over the next batch, second stream) runs beside these launches: their durations '
                             'include the sharing' if getattr(learner, '_teacher_ahead', None) is not None or (sg is not None and sg.nxt is not None)
                             else 'none')}
