@@ -30,7 +30,10 @@ def unpause() -> None:
 
 
 def disable_all() -> None:
+  global include_side, _paused
   _enabled.clear()
+  include_side = False
+  _paused = False
 
 
 def reset() -> None:

@@ -105,6 +105,14 @@ def test_profiling_regions_record_event_pairs_and_cost_nothing_when_disabled(mon
         pass
       assert PR.region('conv1x1_fwd', 7.0) is PR.region('anything')
     assert PR.region('conv1x1_fwd', 7.0) is not PR.region('anything')
+    PR.include_side = True                                                   # bench.py: the side stream's launches are recorded too, tagged
+    with PR.suspended():
+      with PR.region('conv1x1_fwd', 1.0):
+        clock[0] += 50.0
+    PR.include_side = False
+    assert PR.summary('conv1x1_fwd', side=True)[0] == 1 and PR.summary('conv1x1_fwd', side=False)[0] == 2
+    _ENABLED = PR._enabled['conv1x1_fwd']
+    del _ENABLED[-1]                                                         # (the totals below are those of the main-stream launches)
     try:
       with PR.region('conv1x1_fwd', 5.0):
         raise ValueError('launch failed')
