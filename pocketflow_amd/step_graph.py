@@ -151,7 +151,8 @@ class StepGraph(object):
       self.learner.optimizer.hyper_external = False
     if self.state != 'failed':
       self.state, self.n_eager, self.suspended = 'warm', 0, False
-      self.out = self.cur = self.nxt = None
+      self.out = self.cur = self.nxt = self.nxt_raw = self.cur_raw = None
+      self.nxt_stale = False
       self.backend = type(self.backend)(self.learner.device) if isinstance(self.backend, CudaBackend) else InlineBackend()
 
   # -- one step ---------------------------------------------------------------------------------------
