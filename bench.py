@@ -338,7 +338,8 @@ def main():
   sg = None
   auto_share = None
   if args.step_graph is None and world == 1:
-    # default: is the step host-bound?  The host's share of two untimed steps from an empty launch queue decides.
+    # default: the step is recorded; how host-bound it is launch by launch (the host's share of two untimed steps from an empty launch
+    # queue) is measured first and reported in the line (config.host_share_of_two_launch_by_launch_steps)
     torch.cuda.synchronize()
     a0 = time.perf_counter()
     train_step()
