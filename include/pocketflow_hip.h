@@ -384,7 +384,7 @@ int pf_col2im(const void* dxcol, void* dx, int imgs, int H, int W, int C, int R,
               void* stream);
 
 /* ---- proximal-gradient channel selection of the 'chn-pruned-gpu' learner ----------------------------------------------------------
- * replaces learners/channel_pruning_gpu/learner.py:376-383 (var_prnd_new = var - lr * grad; var_norm = sqrt(reduce_sum(square, axes
+ * replaces learners/channel_pruning_gpu/learner.py:379-383 (var_prnd_new = var - lr * grad; var_norm = sqrt(reduce_sum(square, axes
  * [0, 1, 3])); threshold = percentile(var_norm, p); shrk_vec = maximum(1 - threshold / var_norm, 0); assign(var_prnd_new * shrk_vec)).
  * w: float32 master kernel in KRSC storage = [rows = O*R*S][I] with the input channel innermost; g: its gradient (float32 / bf16).
  * pf_prox_norms: norms[I] of W - lr * G (partial: float32 workspace of pf_prox_groups(rows, I) * I elements; deterministic).

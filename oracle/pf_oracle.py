@@ -762,16 +762,17 @@ def krsc_to_hwio(w: np.ndarray) -> np.ndarray:
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
-# 'chn-pruned-gpu': the stochastic proximal-gradient step (learners/channel_pruning_gpu/learner.py:376-383)
+# 'chn-pruned-gpu': the stochastic proximal-gradient step (learners/channel_pruning_gpu/learner.py:379-383)
 # ---------------------------------------------------------------------------------------------------------------------------------
 
 def cpg_proximal_step(w_hwio: np.ndarray, g_hwio: np.ndarray, lrn_rate, prune_perctl) -> Tuple[np.ndarray, np.ndarray, np.float32]:
-  """var_prnd_new = var_prnd - lrn_rate_pgd * grad                                          (:376)
-  var_norm = tf.sqrt(tf.reduce_sum(tf.square(var_prnd_new), axis=[0, 1, 3], keepdims=True))  (:377)
-  threshold = tf.contrib.distributions.percentile(var_norm, prune_perctl)                     (:378, 'nearest')
-  shrk_vec = tf.maximum(1.0 - threshold / var_norm, 0.0)                                     (:379)
-  prune_op = var_prnd.assign(var_prnd_new * shrk_vec)                                        (:380)
-  One float32 rounding per TF op.  Returns (new kernel HWIO, var_norm [I], threshold).  A channel whose norm is exactly 0 under a
+  """var_prnd_new = var_prnd - lrn_rate_pgd * grad                                          (:379)
+  var_norm = tf.sqrt(tf.reduce_sum(tf.square(var_prnd_new), axis=[0, 1, 3], keepdims=True))  (:380)
+  threshold = tf.contrib.distributions.percentile(var_norm, prune_perctl)                     (:381, 'nearest')
+  shrk_vec = tf.maximum(1.0 - threshold / var_norm, 0.0)                                     (:382)
+  prune_op = var_prnd.assign(var_prnd_new * shrk_vec)                                        (:383)
+  One float32 rounding per TF op; pinned by tests/golden/reference_cpg.npz (the five statements executed over oracle/tf_stub.py).
+  Returns (new kernel HWIO, var_norm [I], threshold).  A channel whose norm is exactly 0 under a
   zero threshold gives 0 / 0 in TF (nan * 0-weights = nan); the learner never reaches that state from finite weights with p > 0
   (the threshold is then a positive norm); this restatement maps it to 0 like the product (stated, not pinned)."""
   w = f32(w_hwio)

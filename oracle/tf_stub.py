@@ -201,7 +201,10 @@ def reduce_mean(x, axis=None, keepdims=False, keep_dims=False, name=None, **kw):
 
 
 def _reduce_mean(x, axis=None, keepdims=False): return T(np.mean(_raw(x), axis=tuple(axis) if isinstance(axis, (list, tuple)) else axis, dtype=np.float32, keepdims=keepdims))
-def reduce_sum(x, axis=None, **kw): return T(np.sum(_raw(x), axis=axis, dtype=np.asarray(_raw(x)).dtype))
+def reduce_sum(x, axis=None, keepdims=False, keep_dims=False, **kw):
+  return T(np.sum(_raw(x), axis=tuple(axis) if isinstance(axis, (list, tuple)) else axis, dtype=np.asarray(_raw(x)).dtype,
+                  keepdims=bool(keepdims or keep_dims)))
+def sqrt(x, **kw): return T(np.sqrt(np.asarray(_raw(x))))
 def minimum(a, b, **kw): return T(np.minimum(T._b(a, np.asarray(_raw(b))), T._b(b, np.asarray(_raw(a)))))
 def maximum(a, b, **kw): return T(np.maximum(T._b(a, np.asarray(_raw(b))), T._b(b, np.asarray(_raw(a)))))
 def pow(x, y, **kw): return T(np.power(_raw(x), T._b(y, np.asarray(_raw(x)))))  # noqa: A001

@@ -2,7 +2,7 @@
 // the group-lasso shrinkage of its INPUT channels,
 //     W' = W - lr * G;   n_c = sqrt(sum_{o,r,s} W'[o][r][s][c]^2);   tau = percentile(n, p) (nearest rank);
 //     W  <- W' * max(1 - tau / n_c, 0)
-// (reference learners/channel_pruning_gpu/learner.py:376-383: var_prnd_new / var_norm / threshold / shrk_vec / prune_op; one TF op per
+// (reference learners/channel_pruning_gpu/learner.py:379-383: var_prnd_new / var_norm / threshold / shrk_vec / prune_op; one TF op per
 // rounding: the subtraction, the square, the division, the subtraction from one, the maximum and the product are each rounded once).
 // HBM-bound.  KRSC storage makes the kernel a [rows = O*R*S][I] row-major matrix with the group index c innermost, so the channel
 // norms are COLUMN sums: pass 1 reads W and G once (rows split over G workgroups, per-thread column accumulators, float32 partial

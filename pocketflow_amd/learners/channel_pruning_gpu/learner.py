@@ -79,7 +79,7 @@ def proximal_shrink(w_krsc: torch.Tensor, prune_perctl: float):
 
 
 def proximal_step(w_flat, g_flat, lrn_rate_pgd: float, prune_perctl: float, rows: int, cin: int, ws) -> None:
-  """layer_ops[idx]['prune'] of the reference (:376-380) on the device, in place on the float32 master kernel `w_flat` (KRSC storage =
+  """layer_ops[idx]['prune'] of the reference (:379-383) on the device, in place on the float32 master kernel `w_flat` (KRSC storage =
   [rows][cin]): pf_prox_norms (one read of W and G) -> nearest-rank percentile of the cin norms (pf_kth_largest_nonneg, the index in
   float64 on the float32 percentile as for the weight-sparsification masks) -> pf_prox_apply (one read of W and G, one write of W).
   Until round 4: `proximal_shrink` above, five torch ops."""

@@ -727,7 +727,7 @@ def test_proximal_shrink_against_numpy():
 
 
 def test_cpg_proximal_step_oracle_and_plumbing():
-  """oracle/pf_oracle.py cpg_proximal_step (restating channel_pruning_gpu/learner.py:376-380) against the torch expression the
+  """oracle/pf_oracle.py cpg_proximal_step (restating channel_pruning_gpu/learner.py:379-383) against the torch expression the
   learner used until round 4 (`proximal_shrink`), and the learner's `proximal_step` plumbing (norms -> nearest-rank threshold ->
   shrink) over the emulated entry points."""
   from oracle import pf_oracle as O

@@ -258,3 +258,28 @@ def test_model_loss_and_metrics_match_the_reference_code(arrays, key, bn_filter,
   assert got_keys == sorted(m.keys())
   for k in got_keys:
     assert float(m[k]) == float(arrays['loss/%s/metric/%s' % (key, k)]), k
+
+
+def test_cpg_proximal_step_is_the_reference_statements():
+  """oracle cpg_proximal_step against tests/golden/reference_cpg.npz: the five statements of the reference's `prune` layer op
+  (learners/channel_pruning_gpu/learner.py:379-383) located with `ast` and executed over oracle/tf_stub.py
+  (tests/golden/make_reference_cpg_golden.py).  Bit for bit: new kernel, per-input-channel norms, threshold.  The stub's
+  reduce_sum is NumPy's, so the summation ORDER inside the norm is the stub's, not TensorFlow's; everything else (which axes,
+  which tensor the percentile sees and its 'nearest' index, the shrink expression, one float32 rounding per op) is the
+  reference's code.  The cases hold the two ends (q = 0: one channel zeroed; q = 100: all), a fractional 'nearest' index and
+  a half-to-even one."""
+  with np.load(os.path.join(GOLD, 'reference_cpg.npz')) as z:
+    a = {k: z[k] for k in z.files}
+  with open(os.path.join(GOLD, 'reference_cpg.json')) as f:
+    meta = json.load(f)
+  assert meta['reference'] == 'learners/channel_pruning_gpu/learner.py:379-383' and len(meta['cases']) == 9
+  for i, case in enumerate(meta['cases']):
+    k = 'cpg/%d/' % i
+    new, norm, thr = O.cpg_proximal_step(a[k + 'w'], a[k + 'g'], case['lrn_rate'], case['prune_perctl'])
+    assert new.dtype == np.float32 and new.shape == tuple(case['shape'])
+    assert np.array_equal(norm, a[k + 'norm']), (i, 'norm')
+    assert np.float32(thr) == a[k + 'thr'], (i, 'threshold')
+    assert np.array_equal(new, a[k + 'new']), (i, float(np.max(np.abs(new - a[k + 'new']))))
+    assert int(np.sum(np.all(new == 0, axis=(0, 1, 3)))) == case['channels_zeroed']
+  zeroed = [c['channels_zeroed'] for c in meta['cases']]
+  assert zeroed[1] == 1 and zeroed[2] == meta['cases'][2]['shape'][2]

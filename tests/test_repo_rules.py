@@ -55,7 +55,7 @@ def test_nothing_on_the_gpu_box_reads_the_reference_tree():
       assert 'open(' not in line and 'sys.path' not in line and 'os.path.join' not in line, (os.path.relpath(path, ROOT), line)
   # the fixture generators (build container only) are the one place that opens it
   gens = [os.path.basename(p) for p in _py('tests/golden/*.py')]
-  assert sorted(gens) == ['make_reference_cp_features_golden.py', 'make_reference_flags.py', 'make_reference_golden.py',
+  assert sorted(gens) == ['make_reference_cp_features_golden.py', 'make_reference_cpg_golden.py', 'make_reference_flags.py', 'make_reference_golden.py',
                           'make_reference_image_golden.py', 'make_reference_rl_golden.py']
 
 
