@@ -283,9 +283,10 @@ class StepGraph(object):
         self.out = _detached(self.out)                       # static output tensors; the recorded step's Python graph is not needed
     finally:
       g.capturing = False
-    # recording executed nothing on the device; undo the host-side bookkeeping of the recorded step
-    setattr(lrn, _step_attr(lrn), step0)
-    opt.beta1_power, opt.beta2_power = pow0
+      # recording executed nothing on the device; undo the host-side bookkeeping of the recorded step (also when the recording failed
+      # half-way: the eager path that takes over must continue from the step counter / Adam powers of the last EXECUTED step)
+      setattr(lrn, _step_attr(lrn), step0)
+      opt.beta1_power, opt.beta2_power = pow0
     self.state = 'ready'
     log.info('step graph: recorded the %s step (%s)', type(lrn).__name__, 'teacher forked on a side stream' if nxt is not None else 'single stream')
 

@@ -1018,6 +1018,54 @@ def test_step_graph_control_flow_uq_distillation_on_cpu(cpu_learners, monkeypatc
   assert step_graph.of(lrn).state == 'ready' and step_graph.of(lrn).n_replays == 6 + 2
 
 
+@pytest.mark.parametrize('ahead', ['inline', '0'])
+def test_step_graph_failed_recording_leaves_the_eager_run_untouched(cpu_learners, monkeypatch, ahead):
+  """A recording that fails half-way (a library call that cannot be captured, hipStreamEndCapture refusing the graph): nothing of
+  it executed on the device, so the eager path that takes over has to continue from the step counter and Adam powers of the last
+  executed step, with the batches that were drawn for the static buffers first in line -- same losses and weights as a run that
+  never tried."""
+  FLAGS, fake, tmp = cpu_learners
+  from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
+  from pocketflow_amd.learners.uniform_quantization.learner import UniformQuantLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  from pocketflow_amd import step_graph
+  FLAGS.batch_size, FLAGS.batch_size_eval, FLAGS.nb_classes, FLAGS.resnet_size = 8, 8, 10, 20
+  FLAGS.uql_weight_bits, FLAGS.uql_activation_bits, FLAGS.uql_use_buckets, FLAGS.uql_bucket_type = 8, 8, False, 'channel'
+  FLAGS.enbl_dst, FLAGS.dst_eval_teacher = True, False
+  FLAGS.uql_save_quant_model_path = str(tmp / 'uql' / 'm.ckpt')
+  FLAGS.synthetic_pool = 5
+  monkeypatch.setenv('PF_TEACHER_AHEAD', ahead)
+
+  def make():
+    mh = ModelHelper()
+    create_synthetic_checkpoint(mh)
+    return UniformQuantLearner(None, mh)
+  base, l0 = _run_steps(make, 7, False, monkeypatch, FLAGS=FLAGS)
+
+  class Refusing(step_graph.InlineBackend):
+    def capture(self, body):
+      lrn = self.lrn
+      # what the host side of a captured step does before the capture is refused (no launch of it ever executes)
+      lrn.ft_step += 1
+      lrn.optimizer.beta1_power = np.float32(lrn.optimizer.beta1_power * np.float32(0.9))
+      lrn.optimizer.beta2_power = np.float32(lrn.optimizer.beta2_power * np.float32(0.999))
+      raise RuntimeError('operation not permitted when stream is capturing')
+  monkeypatch.setenv('PF_STEP_GRAPH', 'inline')
+  monkeypatch.delenv('PF_STEP_GRAPH_STRICT', raising=False)
+  FLAGS.enbl_step_graph = True
+  lrn = make()
+  sg = step_graph.of(lrn)
+  sg.backend = Refusing()
+  sg.backend.lrn = lrn
+  l1 = [float(lrn.train_step()['loss'].detach()) for _ in range(7)]
+  assert sg.state == 'failed' and isinstance(sg.error, RuntimeError) and sg.n_replays == 0
+  assert lrn.ft_step == base.ft_step == 7 and not lrn.optimizer.hyper_external and not lrn.graph.capturing
+  assert lrn.optimizer.beta1_power == base.optimizer.beta1_power and lrn.optimizer.beta2_power == base.optimizer.beta2_power
+  assert l0 == l1, (l0, l1)
+  a, b = base.graph.store.export_numpy(), lrn.graph.store.export_numpy()
+  assert all(np.array_equal(a[k], b[k]) for k in a)
+
+
 def test_step_graph_control_flow_ws_on_cpu(cpu_learners, monkeypatch):
   """... a learner without a teacher (no look-ahead batch), Momentum with the learning rate in device memory
   (pf_momentum_flat_dev), a mask refresh between recorded steps (the masks are updated in place: the recording stays valid)."""
