@@ -131,7 +131,9 @@ class TeacherAhead(object):
     the batch train_step would have seen, or the data order differs from the run without this helper)."""
     images, ev = self.pending[4], self.pending[3]
     self.pending = None
-    self.streams.main_waits(ev)
+    if ev is not None:                               # (None: handed over by a suspended step graph, already in main-stream order)
+      self.streams.main_waits(ev)
+    self.n_taken += 1
     return images
 
   def drop(self):
@@ -192,7 +194,11 @@ def next_images(learner):
 
 
 def drop(learner):
-  """Forget the prefetched batch, if any: call where the training iterator is reset or re-built."""
+  """Forget the prefetched batch, if any, and the batches a suspended step graph handed back: call where the training iterator
+  is reset or re-built (they belong to its previous pass)."""
   ahead = getattr(learner, '_teacher_ahead', None)
   if ahead is not None:
     ahead.drop()
+  back = getattr(learner, '_unget', None)
+  if back:
+    del back[:]

@@ -127,6 +127,7 @@ class StepGraph(object):
     self.nxt_raw = None                     # the iterator's (images, labels) behind `nxt` (handed back when the graph is suspended)
     self.nxt_stale = False                  # `nxt` was consumed by a replay: draw the following batch before the next one
     self.cur_raw = None                     # without a teacher: the batch already loaded into `cur` (not yet consumed by a replay)
+    self.cur_images = None                  # with a teacher: the images behind `cur` as the iterator delivered them (teacher_ahead.next_images)
     self.error = None
 
   # -- mode switches --------------------------------------------------------------------------------
@@ -151,7 +152,7 @@ class StepGraph(object):
       self.learner.optimizer.hyper_external = False
     if self.state != 'failed':
       self.state, self.n_eager, self.suspended = 'warm', 0, False
-      self.out = self.cur = self.nxt = self.nxt_raw = self.cur_raw = None
+      self.out = self.cur = self.nxt = self.nxt_raw = self.cur_raw = self.cur_images = None
       self.nxt_stale = False
       self.backend = type(self.backend)(self.learner.device) if isinstance(self.backend, CudaBackend) else InlineBackend()
 
@@ -200,9 +201,12 @@ class StepGraph(object):
       return
     ahead = teacher_ahead.of(lrn)
     if ahead is not None and ahead.pending is not None:
+      self.cur_images = ahead.pending[4]
       x, y, logits = ahead.take()
     else:
-      x, y = self._fetch()
+      raw = teacher_ahead.fetch_raw(lrn)
+      self.cur_images = raw[0]
+      x, y = lrn.to_device(*raw)
       logits = teacher_ahead.teacher_of(lrn).calc_logits(None, x)
     for dst, src in zip(self.cur, (x, y, logits)):
       dst.copy_(src)
@@ -225,7 +229,7 @@ class StepGraph(object):
       ahead = lrn._teacher_ahead = teacher_ahead.TeacherAhead(lrn, teacher_ahead.InlineStreams())
     if ahead.pending is not None:
       ahead.drop()
-    ahead.pending = (x, y, logits, None, None)
+    ahead.pending = (x, y, logits, None, self.cur_images)
     # The eager helper's side stream must not run ahead of the replays that are still queued: its next teacher forward would run
     # CONCURRENTLY with the teacher branch of a replay that has not executed yet -- two forward passes of one frozen network through
     # the same scratch buffers (seen as a loss mismatch in tests/step_graph_worker.py when the side stream was left free).
@@ -243,9 +247,12 @@ class StepGraph(object):
     # static inputs
     ahead = teacher_ahead.of(lrn) if teacher is not None else None
     if ahead is not None and ahead.pending is not None:
+      self.cur_images = ahead.pending[4]
       x, y, logits = ahead.take()
     elif teacher is not None:
-      x, y = self._fetch()
+      raw = teacher_ahead.fetch_raw(lrn)
+      self.cur_images = raw[0]
+      x, y = lrn.to_device(*raw)
       logits = teacher.calc_logits(None, x)
     else:
       self.cur_raw = teacher_ahead.fetch_raw(lrn)            # no look-ahead without a teacher: this batch is the first replay's
@@ -316,6 +323,8 @@ class StepGraph(object):
       setattr(lrn, attr, step + 1)
     self.n_replays += 1
     self.nxt_stale = True                                  # the tail of the replay moved `next` into `current`
+    if self.nxt_raw is not None:
+      self.cur_images = self.nxt_raw[0]
     return _with_lr(self.out, lr)
 
 

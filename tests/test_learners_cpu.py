@@ -953,8 +953,9 @@ def test_teacher_ahead_gives_the_same_steps_on_cpu(cpu_learners, monkeypatch):
   assert h.pending is None and torch.equal(torch.as_tensor(nxt), torch.as_tensor(base.iter_train.batches[base.iter_train.idx % 3][0]))
   assert torch.equal(torch.as_tensor(teacher_ahead.next_images(ahead)), torch.as_tensor(base.iter_train.batches[(base.iter_train.idx + 1) % 3][0]))
   ahead.train_step()
-  h.drop()
-  assert h.pending is None
+  ahead._unget = [('images', 'labels')]                  # what a suspended step graph hands back
+  teacher_ahead.drop(ahead)                             # iterator reset: neither the prefetched batch nor the handed-back ones survive
+  assert h.pending is None and ahead._unget == []
 
 
 def _run_steps(make, n, graph_mode, monkeypatch, suspend_at=(), FLAGS=None):
@@ -1013,6 +1014,12 @@ def test_step_graph_control_flow_uq_distillation_on_cpu(cpu_learners, monkeypatc
   # a change of bit widths voids the recording; the learner warms up and records again
   lrn._UniformQuantLearner__feed([4] * len(lrn.optimal_w_bit_list), lrn.optimal_a_bit_list)
   assert step_graph.of(lrn).state == 'warm'
+  # another consumer of the training iterator (layer-wise tuning follows a bit-width feed) sees the batch the next step would have
+  # seen -- the one the graph held in its static buffers -- and the step after it the following one: the eager run's order
+  from pocketflow_amd.learners import teacher_ahead
+  for _ in range(2):
+    assert torch.equal(torch.as_tensor(teacher_ahead.next_images(lrn)), torch.as_tensor(teacher_ahead.next_images(base)))
+  assert teacher_ahead.of(lrn) is None or teacher_ahead.of(lrn).pending is None
   for _ in range(5):
     lrn.train_step()
   assert step_graph.of(lrn).state == 'ready' and step_graph.of(lrn).n_replays == 6 + 2
