@@ -15,8 +15,11 @@ DepthwiseConv2dNative weight and behind every Relu / Relu6 output
                    `search_matmul_op` / `search_activation_op` enumerate; a learner "rewrites" the
                    graph by assigning bit widths to those ops.
   * layer classes -- Conv2D / DepthwiseConv2D / Dense / BatchNormAct / Activation / pooling, executed
-                   eagerly on HIP streams; the HBM-bound ones call the hand-written kernels through
-                   the C ABI (pocketflow_amd.hip), convolutions go through MIOpen / the MFMA GEMM.
+                   eagerly on HIP streams (or recorded once and replayed, step_graph.py); every layer of the
+                   benchmarked networks calls the hand-written kernels through the C ABI (pocketflow_amd.hip):
+                   the MFMA kernels for the 1x1 / RxS convolutions, pf_convg.hip for every other shape and
+                   for the float32 parity mode.  torch's library convolution is left only for geometries no
+                   benchmarked network has (few-channel RxS convolutions with a bias, the stem's image gradient).
 
 Storage layouts are chosen for the GPU (activations NHWC = torch channels_last, kernels KRSC =
 [cout][kh][kw][cin]); `VarStore.export_numpy` / `load_numpy` speak the reference's layouts (HWIO
@@ -866,7 +869,9 @@ def _run_conv2d(x, w_krsc, stride, pad, want_stats):
 class _Conv2dIgemm(torch.autograd.Function):
   """y = conv2d(x, W) on the implicit-GEMM kernel (pf_conv2d_fwd), x a materialised bf16 NHWC activation.
   Backward-data of stride-1 convolutions runs on the same kernel with the flipped / transposed kernel and reduces the
-  BN-backward sums of x's producer BN in its epilogue; backward-filter and strided backward-data go through MIOpen."""
+  BN-backward sums of x's producer BN in its epilogue; strided backward-data runs on it by output-parity classes
+  (pf_conv2d_bwd_data_strided), backward-filter on pf_wrw.hip (conv2d_wrw).  The library calls that remain below are the A/B
+  switches' other side and geometries outside the kernels' limits (channel counts, 31-bit offsets)."""
 
   @staticmethod
   def forward(ctx, x, w, stride, pad, want_stats, graph, box, bn_box, w_var=None):
