@@ -264,8 +264,8 @@ int pf_conv1x1_wrw(const void* dY, const void* X, void* dW, int dw_dtype, float*
  *   Backward-data of a stride-1 convolution is the same call on dY with the kernel flipped and transposed:
  *   W'[c][r][s][n] = W[n][th-1-r][tw-1-s][c], pad' = th-1-pad.                                                      */
 int pf_conv2d_stats_groups(int M, int N);
-/* the same for a given geometry: 3x3 / stride 1 / pad 1 convolutions run on the halo kernel (pf_conv3x3.hip), whose
- * workgroups walk the padded-flat pixel space -- ask with the SAME arguments as the pf_conv2d_fwd call that follows           */
+/* the same, asked with the arguments of the pf_conv2d_fwd call that follows (rounds 3-4 dispatched some geometries to a second
+ * kernel family with its own group count; since its removal this equals pf_conv2d_stats_groups(imgs * Ho * Wo, N))             */
 int pf_conv2d_stats_groups_geom(int imgs, int H, int Wd, int C, int N, int th, int tw, int stride, int pad_h, int pad_w,
                                 int Ho, int Wo);
 int pf_conv2d_fwd(const void* X, const void* W, void* Y, const void* zero, const void* R, float* partial,

@@ -24,10 +24,8 @@ static void tuning_load() {
   t.conv_bn = env_int("PF_CONV_BN", 0);
   t.conv_igemm = env_int("PF_CONV_IGEMM", 1);
   t.conv_igemm_pro = env_int("PF_CONV_IGEMM_PRO", 1);
-  t.conv3x3_halo = env_int("PF_CONV3X3_HALO", 0);
   t.conv_stream = env_int("PF_CONV_STREAM", 1);
   t.conv_stream_maxsplit = env_int("PF_CONV_STREAM_MAXSPLIT", 2);
-  t.igemm_prow = env_int("PF_IGEMM_PROW", 0);
   t.igemm_pro3 = env_int("PF_IGEMM_PRO3", 1);
   t.igemm_tile_bm = t.igemm_tile_bn = 0;
   const char* e = getenv("PF_IGEMM_TILE");

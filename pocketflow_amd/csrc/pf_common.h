@@ -26,10 +26,9 @@ typedef uint16_t bf16_t;
 struct PfTuning {
   int conv_bn;                    // PF_CONV_BN            0 | 64 | 128
   int conv_igemm, conv_igemm_pro; // PF_CONV_IGEMM[_PRO]   1 (default) | 0
-  int conv3x3_halo;               // PF_CONV3X3_HALO       0 (default) | 1
   int conv_stream;                // PF_CONV_STREAM        1 (default) | 0
   int conv_stream_maxsplit;       // PF_CONV_STREAM_MAXSPLIT  2
-  int igemm_prow, igemm_pro3;     // PF_IGEMM_PROW 0, PF_IGEMM_PRO3 1
+  int igemm_pro3;                 // PF_IGEMM_PRO3         1 (default) | 0
   int igemm_tile_bm, igemm_tile_bn;   // PF_IGEMM_TILE "BMxBN" (0, 0: none)
   int pool3s2;                    // PF_POOL3S2            1 (default) | 0
   int wrw_tr, wrw2, wrw2_target;  // PF_WRW_TR 0, PF_WRW2 1, PF_WRW2_TARGET 0 (= per-shape default)

@@ -93,31 +93,23 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 #define IG_PLAIN 0
 #define IG_BWD 1
 #define IG_PRO 2
-// MODE 3 = IG_PRO with WAVE SPECIALISATION: WM x WN consumer wavefronts (fragment reads + MFMAs only) plus as many PRODUCER
-// wavefronts that issue all LDS-DMA and run the BN / ReLU / fake-quant pass over the input tile of step ks+1 in LDS while
-// the consumers multiply step ks.  Two consumers and one producer per SIMD: the prologue's VALU work (5.5 instructions per
-// element, as long as the MFMAs of the step when one wavefront has to do both -- measured: +23 us on 14x14 1024 -> 256) runs
-// in the shadow of the matrix pipe instead of in its way.  Three stages, one barrier per step, 64 x 64 accumulators per
-// consumer, 12 wavefronts = 3 per SIMD = 168 registers each.
-#define IG_PROW 3
-#define IG_NWP 4                                    // producer wavefronts of the wave-specialised variant (one per SIMD)
+// (A wave-specialised MODE 3 -- producer wavefronts for the LDS-DMA and the prologue pass, consumer wavefronts for the MFMAs -- lived
+// here in rounds 3-4: measured no faster than the single-role three-stage kernel, profiles/r03_pro_bench.txt, and removed.)
 // SUB: the launch walks a sub-grid of a larger kernel buffer and scatters its rows (IgArgs.w_* / o_*: strided backward-data by parity
 // classes).  A template parameter, not a run-time branch: the extra scalar state cost the ordinary kernels 16-24 more spilled SGPRs
 // (v_writelane / v_readlane traffic in the staging code) when it was one.
 template <int BM, int BN, int WM, int WN, int NS, int MODE, bool SUB = false>
-__global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) void k_igemm(const IgArgs a) {
-  constexpr bool WS = (MODE == IG_PROW);
-  constexpr bool BWD = (MODE == IG_BWD), PRO = (MODE == IG_PRO || WS);
-  static_assert(!WS || NS == 3, "the wave-specialised variant is written for the 3-stage ring");
+__global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
+  constexpr bool BWD = (MODE == IG_BWD), PRO = (MODE == IG_PRO);
   static_assert(!PRO || NS == 2 || NS == 3, "the in-LDS prologue pass is written for the 2- and 3-stage rings");
   // PRO with three stages: the loads of step ks+2 travel, the lanes transform their own vectors of step ks+1 in LDS and the
   // matrix cores multiply step ks -- all inside ONE barrier interval (round 2's two-stage form ran them back to back:
   // wait for the loads, transform, barrier, multiply; measured 5.5 k cycles per step against 0.5 k of MFMA issue).
   constexpr bool PRO3 = PRO && NS == 3;
-  constexpr int NWC = WM * WN;                      // consumer wavefronts (all of them unless WS)
-  constexpr int T = 64 * (NWC + (WS ? IG_NWP : 0)); // threads of the workgroup
-  constexpr int TS = WS ? 64 * IG_NWP : 64 * NWC;   // threads that STAGE (WS: the producer wavefronts)
-  constexpr int TE = 64 * NWC;                      // threads of the epilogue row stores (WS: the consumers)
+  constexpr int NWC = WM * WN;                      // wavefronts
+  constexpr int T = 64 * NWC;                       // threads of the workgroup
+  constexpr int TS = T;                             // threads that STAGE
+  constexpr int TE = T;                             // threads of the epilogue row stores
   constexpr int WR = BM / WM, WC = BN / WN;         // wavefront tile: pixels x channels
   constexpr int JM = WR / 16, NI = WC / 16;
   constexpr int AS = BM * 8 / TS, BS = BN * 8 / TS; // 16-byte loads per staging lane and step (input / kernel tile)
@@ -135,8 +127,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);              // scalar: LDS-DMA bases stay in SGPRs
-  const bool prod = WS && wave >= NWC;                                    // WS: producer wavefront (scalar condition)
-  const int swave = prod ? wave - NWC : wave;                             // index among the staging wavefronts
+  const int swave = wave;                                                 // index among the staging wavefronts
   const int cwave = wave % NWC;
   const int wm = cwave / WN, wn = cwave % WN;
   const int l15 = lane & 15, q = lane >> 4;
@@ -189,20 +180,13 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
     boff[i] = (n < a.N) ? (uint32_t)(((int64_t)n * wrow + schunk * 8) * 2) : OOB;
   }
 
-  if (WS && a.partial != nullptr && g >= a.tiles_m) {
-    // a workgroup without a row tile still owns its row of the statistics array (WS writes partial[g] tile by tile)
-    for (int c = tid; c < 4 * BN; c += T) {
-      const int stat = c / BN, col = c - stat * BN;
-      if (n0 + col < a.N) a.partial[((int64_t)g * 4 + stat) * a.N + n0 + col] = (stat < 2) ? 0.f : (stat == 2 ? INFINITY : -INFINITY);
-    }
-  }
   const bool pointwise = a.th == 1 && a.tw == 1 && a.stride == 1 && a.pad_h == 0 && a.pad_w == 0 && a.Ho == a.H && a.Wo == a.Wd;
   // Cross-tile prefetch (three-stage kernels, forward / plain modes): the C staging of the epilogue aliases ring buffers 0 and 1
   // only, so every tile starts its ring at buffer RB0 = 2 and the FIRST stage of the next tile is issued into that buffer right
   // behind the last k-step's barrier -- its latency (~2 us, a seventh of a 4-step tile) travels under the epilogue.  The epilogue
   // of such a kernel touches LDS through the asm helpers only (an ordinary LDS access beside a pending LDS-DMA makes hipcc wait
   // vmcnt(0)) and uses raw barriers.
-  constexpr bool XPRE = !WS && !BWD && NS == 3 && 2 * STAGE >= BM * CS_LD_B * 2;
+  constexpr bool XPRE = !BWD && NS == 3 && 2 * STAGE >= BM * CS_LD_B * 2;
   constexpr int RB0 = XPRE ? 2 : 0;
   // input rows of this lane: byte offset of the top-left input pixel of the receptive field (may lie outside the
   // image: the sum with the tap offset is only used for taps whose bit is set) and the mask of taps inside the image
@@ -217,8 +201,8 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
       if (pointwise) {
         // 1x1, stride 1, no padding (every 1x1 layer of the step): input row == output row, one tap -- no divisions, no tap
         // loop (the generic branch costs ~300 instructions per tile, 5 % of a 4-step tile)
-        if (m < a.M && (!WS || prod)) { pbase[i] = (uint32_t)(m * a.C + schunk * 8) * 2u; pmask[i] = 1u; }
-      } else if (m < a.M && (!WS || prod)) {
+        if (m < a.M) { pbase[i] = (uint32_t)(m * a.C + schunk * 8) * 2u; pmask[i] = 1u; }
+      } else if (m < a.M) {
         const int img = m / hw_o, rem = m - img * hw_o;
         const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
         const int h0 = ho * a.stride - a.pad_h, w0 = wo * a.stride - a.pad_w;
@@ -280,7 +264,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
     // MFMAs (issued in the epilogue they cost 10-13 us per launch on the 14x14 / 7x7 conv3 layers).
     uint2 rr[NI][JM];
     const bool has_r = !BWD && a.R != nullptr;
-    constexpr bool RPRE = !WS && BM * BN <= 128 * 256;                       // larger tiles have no 32 spare registers: load at use
+    constexpr bool RPRE = BM * BN <= 128 * 256;                       // larger tiles have no 32 spare registers: load at use
     auto load_residual = [&]() {
 #pragma unroll
       for (int j = 0; j < JM; ++j) {
@@ -371,74 +355,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
         *p = pro_apply(pro, *p);
       }
     };
-    if constexpr (WS) {
-      // ---- wave-specialised ring: producers stage + transform one step ahead, consumers multiply.  TWO loops with the same
-      // barrier count (not one loop with a role branch inside): register live ranges then end at the role boundary -- the
-      // consumers' accumulators are not live in the producer loop, the producers' staging state not in the consumer loop
-      // (a single loop needed 212 spilled registers at the 168-register budget of 12 wavefronts per CU).
-      if (prod) {
-        stage(0);
-        if (nk > 1) { stage(1); wait_vm<LPS>(); } else wait_vm<0>();
-        transform3(0, 0, 0, AS);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        int tb = 1;                                                         // buffer of step ks+1
-        ibuf = (nk > 1) ? 2 : 1;
-        for (int ks = 0; ks < nk; ++ks) {
-          const bool more = ks + 2 < nk;
-          if (more) { stage(ibuf); ibuf = (ibuf + 1 == NS) ? 0 : ibuf + 1; }
-          if (ks + 1 < nk) {
-            if (more) wait_vm<LPS>(); else wait_vm<0>();                    // own pieces of step ks+1 have landed
-            transform3(tb, ks + 1, 0, AS);
-            tb = (tb + 1 == NS) ? 0 : tb + 1;
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the prologue writes of this wavefront are done
-          __builtin_amdgcn_s_barrier();
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      } else {
-        f32x4 cacc[NI][JM];
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-          for (int j = 0; j < JM; ++j) cacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        __builtin_amdgcn_s_barrier();
-        int cbuf = 0;
-        for (int ks = 0; ks < nk; ++ks) {
-          const unsigned char* As = smem + cbuf * STAGE;
-          const unsigned char* Bs = As + A_BYTES;
-          cbuf = (cbuf + 1 == NS) ? 0 : cbuf + 1;
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk) {
-            const int coff = (((kk * 4 + q) ^ (l15 & 7)) << 4);
-            bf16x8 wf[NI], xf[JM];
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-              wf[i] = *reinterpret_cast<const bf16x8*>(Bs + (wn * WC + i * 16 + l15) * 128 + coff);
-#pragma unroll
-            for (int j = 0; j < JM; ++j)
-              xf[j] = *reinterpret_cast<const bf16x8*>(As + (wm * WR + j * 16 + l15) * 128 + coff);
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-              for (int j = 0; j < JM; ++j)
-                cacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], cacc[i][j], 0, 0, 0);
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the fragment reads of this wavefront are done
-          __builtin_amdgcn_s_barrier();
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        // C tile staging (aliases the ring: every fragment read of the tile is behind the last barrier)
-        if (has_r) { load_residual(); add_residual(cacc); }
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-          for (int j = 0; j < JM; ++j) {
-            const uint2 v = make_uint2(pack_bf16x2(cacc[i][j][0], cacc[i][j][1]), pack_bf16x2(cacc[i][j][2], cacc[i][j][3]));
-            *reinterpret_cast<uint2*>(Cs + (wm * WR + j * 16 + l15) * CS_LD + wn * WC + i * 16 + q * 4) = v;
-          }
-      }
-    } else {
+    {
 #pragma unroll
     for (int d = 0; d < NS - 1; ++d)
       if (d < nk) {
@@ -544,7 +461,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
     }
 
 #if PF_IG_ABLATE >= 4
-    if (!WS) {                                                              // no epilogue: a store that never executes keeps the matrix work alive
+    {                                                                       // no epilogue: a store that never executes keeps the matrix work alive
       if (a.M < 0) {
 #pragma unroll
         for (int i = 0; i < NI; ++i)
@@ -555,7 +472,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
     }
 #endif
     // ---- epilogue of one [BM][BN] tile (C staging aliases the stage buffers: all reads of them are complete) ----
-    if (!WS) {
+    {
     if (has_r) {
       if constexpr (RPRE) add_residual(acc);
       else {
@@ -597,13 +514,9 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
         else *reinterpret_cast<uint2*>(Cs + (wm * WR + j * 16 + l15) * CS_LD + wn * WC + i * 16 + q * 4) = v;
       }
     }
-    if constexpr (WS) {                                                     // per-tile statistics: (re)defined HERE, dead in the role loops
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; st_mn[j] = INFINITY; st_mx[j] = -INFINITY; }
-    }
     // epilogue passes in groups of <= 8 rows per thread: the side vectors (residual / BN input) of a group are all in
     // flight before the group is processed (and before the LDS hand-off for the first group)
-    constexpr int PG = (NP > 8) ? 8 : (WS && NP > 4 ? 4 : NP);
+    constexpr int PG = (NP > 8) ? 8 : NP;
     uint4 rres[PG];
     auto load_side = [&](int p0) {
 #pragma unroll
@@ -613,7 +526,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
         if (m < a.M && n < a.N) rres[p] = *reinterpret_cast<const uint4*>(side + (int64_t)m * a.N + n);
       }
     };
-    const bool etid = !WS || tid < TE;                                      // WS: the producers only keep the barriers company
+    constexpr bool etid = true;                                             // every thread takes part in the row passes
     float bpr[32];                                                          // BWD: this thread's 8 channels of scale | shift | mean | invstd
     if (BWD) {
 #pragma unroll
@@ -696,44 +609,10 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
       out[14] = (uint32_t)__builtin_readcyclecounter();
     }
 #endif
-    if constexpr (WS) {
-      // statistics of THIS tile -> partial[g][4][N] at once (first tile of the workgroup: store, later tiles: combine, in
-      // tile order: deterministic): the 32 accumulator registers are dead while the next tile's main loop runs (the
-      // 64 x 128 accumulators of a consumer leave no room for them)
-      if (a.partial != nullptr) {
-        if (etid) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          red[(0 * RPP + wrw) * BN + wvec * 8 + j] = st_s[j];
-          red[(1 * RPP + wrw) * BN + wvec * 8 + j] = st_q[j];
-          red[(2 * RPP + wrw) * BN + wvec * 8 + j] = st_mn[j];
-          red[(3 * RPP + wrw) * BN + wvec * 8 + j] = st_mx[j];
-        }
-        }
-        __syncthreads();
-        for (int c = tid; c < 4 * BN; c += T) {
-          const int stat = c / BN, col = c - stat * BN;
-          float r = red[(stat * RPP) * BN + col];
-          for (int rr = 1; rr < RPP; ++rr) {
-            const float w = red[(stat * RPP + rr) * BN + col];
-            r = (stat < 2) ? (r + w) : (stat == 2 ? fminf(r, w) : fmaxf(r, w));
-          }
-          if (n0 + col < a.N) {
-            float* dst = a.partial + ((int64_t)g * 4 + stat) * a.N + n0 + col;
-            if (tm != g) {
-              const float o = *dst;
-              r = (stat < 2) ? (o + r) : (stat == 2 ? fminf(o, r) : fmaxf(o, r));
-            }
-            *dst = r;
-          }
-        }
-        __syncthreads();
-      }
-    }
   }
 
   // ---- per-workgroup statistics -> partial[g][stat][N] (fixed order: deterministic) ---------------------------
-  if (!WS && a.partial != nullptr) {
+  if (a.partial != nullptr) {
     // threads with equal column group: RPP row lanes.  Two-level: registers -> LDS [stat][RPP][BN] in chunks that fit
     constexpr int nstat_max = 4;
     const int nstat = BWD ? 2 : 4;
@@ -758,14 +637,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0))) vo
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
-struct IgCfg { int bm, bn, slots; bool pro3, prow; };    // slots: resident workgroups on the chip (256 CUs x workgroups per CU)
-
-static bool ig_prow_enabled() {
-  // =1: the wave-specialised variant (IG_PROW).  Measured in round 3 (profiles/r03_pro_bench.txt, step A/B 9 092 vs 9 199
-  // images/s): no faster than the single-role three-stage kernel -- the prologue's VALU work was not what bounds these
-  // layers (the LDS fill is) -- so it is opt-in; the tests keep it alive.
-  return pf_tuning().igemm_prow != 0;                      // PF_IGEMM_PROW
-}
+struct IgCfg { int bm, bn, slots; bool pro3; };    // slots: resident workgroups on the chip (256 CUs x workgroups per CU)
 
 static bool ig_pro3_enabled() {
   return pf_tuning().igemm_pro3 != 0;                      // PF_IGEMM_PRO3=0: round 2's two-stage prologue kernel (A/B runs)
@@ -778,24 +650,23 @@ static IgCfg ig_pick(int M, int N, bool pro) {
     // prologue variant.  Three stages, 8 wavefronts, one workgroup per CU: 128 x 256 tiles where N allows (the in-LDS
     // prologue pass over the input tile is amortised over 256 output channels), 256 x 128 otherwise.
     if (ig_pro3_enabled()) {
-      const bool prow = ig_prow_enabled();
-      if (N % 256 == 0) return IgCfg{128, 256, 256, true, prow};
-      if (N % 128 == 0) return IgCfg{256, 128, 256, true, prow};
+      if (N % 256 == 0) return IgCfg{128, 256, 256, true};
+      if (N % 128 == 0) return IgCfg{256, 128, 256, true};
     }
-    return IgCfg{128, (N % 128 == 0) ? 128 : 64, 512, false, false};
+    return IgCfg{128, (N % 128 == 0) ? 128 : 64, 512, false};
   }
   {                                                        // PF_IGEMM_TILE, tuning override: "256x128" | "128x128" | "256x64" | "128x64"
     const int bm = pf_tuning().igemm_tile_bm, bn = pf_tuning().igemm_tile_bn;
     if ((bm == 128 || bm == 256) && (bn == 64 || bn == 128 || (bn == 256 && bm == 256)) &&
         (N % bn == 0 || bn == 64))
-      return IgCfg{bm, bn, (bm == 256) ? 256 : 512, false, false};
+      return IgCfg{bm, bn, (bm == 256) ? 256 : 512, false};
   }
   const int bn = (N % 128 == 0) ? 128 : 64;
   // measured on the ResNet-50 shapes at batch 256 (tools/gpu/igemm_bench.py): 128-row tiles with two workgroups per CU
   // (2 LDS stages each) beat 256-row tiles with one workgroup per CU and 3 stages on every shape (e.g. 3x3 C = 256 at
   // 14x14: 85 vs 96 us; 3x3 C = 64 at 56x56: 127 vs 165 us): the second workgroup hides the barrier / DMA waits of the
   // first better than a deeper pipeline does
-  return IgCfg{128, bn, 512, false, false};
+  return IgCfg{128, bn, 512, false};
 }
 
 static int ig_grid(int slots, int tiles_m, int tiles_n, int* G_out) {
@@ -819,8 +690,8 @@ extern "C" int pf_conv2d_stats_groups(int M, int N) { return pf_igemm_stats_grou
 
 template <int BM, int BN, int WM, int WN, int NS, int MODE, bool SUB = false>
 static int ig_launch_t(IgArgs& a, int slots, hipStream_t st) {
-  constexpr bool BWD = (MODE == IG_BWD), PRO3 = ((MODE == IG_PRO || MODE == IG_PROW) && NS == 3);
-  constexpr int THREADS = 64 * (WM * WN + (MODE == IG_PROW ? IG_NWP : 0));
+  constexpr bool BWD = (MODE == IG_BWD), PRO3 = (MODE == IG_PRO && NS == 3);
+  constexpr int THREADS = 64 * WM * WN;
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
   const int grid = ig_grid(slots, a.tiles_m, a.tiles_n, &a.G);
@@ -847,8 +718,6 @@ static int ig_launch(IgArgs& a, hipStream_t st) {
   const IgCfg c = ig_pick(a.M, a.N, pro);
   if (pro) {
     if (a.th * a.tw != 1 || bwd) return (int)hipErrorInvalidValue;
-    if (c.pro3 && c.prow) return (c.bn == 256) ? ig_launch_t<128, 256, 2, 4, 3, IG_PROW>(a, c.slots, st)
-                                               : ig_launch_t<256, 128, 4, 2, 3, IG_PROW>(a, c.slots, st);
     if (c.pro3) return (c.bn == 256) ? ig_launch_t<128, 256, 2, 4, 3, IG_PRO>(a, c.slots, st)
                                      : ig_launch_t<256, 128, 4, 2, 3, IG_PRO>(a, c.slots, st);
     return (c.bn == 128) ? ig_launch_t<128, 128, 2, 2, 2, IG_PRO>(a, c.slots, st) : ig_launch_t<128, 64, 2, 2, 2, IG_PRO>(a, c.slots, st);
@@ -862,17 +731,10 @@ static int ig_launch(IgArgs& a, hipStream_t st) {
 #undef PF_IG
 }
 
-// pf_conv3x3.hip: 3x3 / stride 1 / pad 1 with the input window (halo included) staged once per 64-channel chunk
-int pf_conv3x3_halo_ok(int imgs, int H, int Wd, int C, int N, int th, int tw, int stride, int pad_h, int pad_w, int Ho, int Wo);
-int pf_conv3x3_halo_groups(int imgs, int H, int Wd, int N);
-int pf_conv3x3_halo_launch(const void* X, const void* W, void* Y, const void* R, float* partial, const void* bn_x,
-                           const float* bss, const float* bmi, float b_lo, float b_hi, int imgs, int H, int Wd, int C, int N,
-                           hipStream_t st);
-
 // rows of the [G][.][N] statistics array pf_conv2d_fwd writes for THIS convolution (depends on the kernel it is dispatched to)
 extern "C" int pf_conv2d_stats_groups_geom(int imgs, int H, int Wd, int C, int N, int th, int tw, int stride, int pad_h,
                                            int pad_w, int Ho, int Wo) {
-  if (pf_conv3x3_halo_ok(imgs, H, Wd, C, N, th, tw, stride, pad_h, pad_w, Ho, Wo)) return pf_conv3x3_halo_groups(imgs, H, Wd, N);
+  (void)H; (void)Wd; (void)C; (void)th; (void)tw; (void)stride; (void)pad_h; (void)pad_w;   // (one kernel family since round 4: the geometry does not matter)
   return pf_igemm_stats_groups(imgs * Ho * Wo, N, 0);
 }
 
@@ -893,10 +755,6 @@ extern "C" int pf_conv2d_fwd(const void* X, const void* W, void* Y, const void* 
     return (int)hipErrorInvalidValue;
   if ((int64_t)imgs * H * Wd * C >= ((int64_t)1 << 30) || (int64_t)N * th * tw * C >= ((int64_t)1 << 30) || th * tw > 32)
     return (int)hipErrorInvalidValue;                     // 31-bit byte offsets and a 32-bit tap mask inside the kernel
-  if (pf_conv3x3_halo_ok(imgs, H, Wd, C, N, th, tw, stride, pad_h, pad_w, Ho, Wo))
-    return pf_conv3x3_halo_launch(X, W, Y, R, partial, bn_x, bn_scale_shift, bn_mean_invstd,
-                                  (bn_act == PF_ACT_NONE) ? -INFINITY : 0.0f, (bn_act == PF_ACT_RELU6) ? 6.0f : INFINITY, imgs, H, Wd,
-                                  C, N, (hipStream_t)stream);
   IgArgs a;
   a.X = (const bf16_t*)X; a.W = (const bf16_t*)W; a.Y = (bf16_t*)Y; a.zero = (const bf16_t*)zero;
   a.R = (const bf16_t*)R; a.partial = partial; a.bx = (const bf16_t*)bn_x; a.bss = bn_scale_shift; a.bmi = bn_mean_invstd;

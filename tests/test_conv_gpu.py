@@ -86,7 +86,7 @@ def test_conv1x1_fwd_prologue_matches_standalone_bn_act_quant(hip, act, bits, sh
   _close_bf16(Y, ref, frac_tol=2e-3 if bits is not None else 0.0, what='prologue %s/%s' % (act, bits))
 
 
-# the three-stage prologue kernels of pf_igemm.hip (wave-specialised k_igemm<..,IG_PROW> and single-role k_igemm<..,3,IG_PRO>;
+# the three-stage prologue kernel of pf_igemm.hip (k_igemm<..,3,IG_PRO>;
 # 128 x 256 tiles for N % 256 == 0, 256 x 128 for N % 128 == 0): deep contractions (up to the 2048 channels whose folded constants fill the LDS to its last byte), row tails,
 # persistent workgroups that walk several row tiles, residual + statistics in the epilogue, and PF_IGEMM_PRO3=0 (round 2's
 # two-stage kernel) on the same inputs -- the two must agree to the last bit (same prologue arithmetic, same k order)
@@ -108,16 +108,15 @@ def test_conv1x1_fwd_prologue_three_stage_kernel(hip, M, N, K, act, bits, monkey
   Q = torch.empty_like(X)
   hip.bn_act_quant_apply(X, Q, M, K, ss, act, sl, bits or 8, bits is not None)
   out = {}
-  # 'ws': wave-specialised (4 producer + 8 consumer wavefronts), '3': single-role three-stage kernel, '2': round 2's two-stage kernel
-  for mode, (pro3, prow) in (('ws', ('1', '1')), ('3', ('1', '0')), ('2', ('0', '0'))):
+  # '3': the three-stage kernel (the product), '2': round 2's two-stage kernel
+  for mode, pro3 in (('3', '1'), ('2', '0')):
     monkeypatch.setenv('PF_IGEMM_PRO3', pro3)
-    monkeypatch.setenv('PF_IGEMM_PROW', prow)
     G = hip.conv1x1_stats_groups(M, N, K, prologue=True)
     partial = torch.full((G, 4, N), float('nan'), device='cuda')
     Y = torch.full((M, N), float('nan'), device='cuda', dtype=torch.bfloat16)
     hip.conv1x1_fwd(X, W, Y, M, N, K, R=R, scale_shift=ss, act=act, slot=sl, bits=bits or 8, partial=partial)
     out[mode] = (Y, partial)
-  Y, partial = out['ws']
+  Y, partial = out['3']
   acc = Q.float() @ W.float().t()
   ref = _bf(acc + R.float())                                   # residual on the fp32 accumulators: one rounding
   _close_bf16(Y, ref, frac_tol=2e-3 if bits is not None else 0.0, what='3-stage prologue', scale=acc)
@@ -127,17 +126,16 @@ def test_conv1x1_fwd_prologue_three_stage_kernel(hip, M, N, K, act, bits, monkey
   torch.testing.assert_close(partial[:, 1].sum(0), (y * y).sum(0), rtol=1e-4, atol=1e-2)
   assert torch.equal(partial[:, 2].min(0).values, y.min(0).values)
   assert torch.equal(partial[:, 3].max(0).values, y.max(0).values)
-  assert torch.equal(Y, out['2'][0]) and torch.equal(Y, out['3'][0]), 'the three prologue kernels differ'
+  assert torch.equal(Y, out['2'][0]), 'the two prologue kernels differ'
   # race screen for the cross-tile prefetch of the three-stage kernel (the next tile's first stage lands in ring buffer 2 while
   # the epilogue of this one runs; workgroups walk up to 4 tiles at the larger sizes): repeated launches must agree to the bit
   monkeypatch.setenv('PF_IGEMM_PRO3', '1')
-  monkeypatch.setenv('PF_IGEMM_PROW', '0')
   for _ in range(4):
     Y2 = torch.full((M, N), float('nan'), device='cuda', dtype=torch.bfloat16)
     p2 = torch.full_like(out['3'][1], float('nan'))
     hip.conv1x1_fwd(X, W, Y2, M, N, K, R=R, scale_shift=ss, act=act, slot=sl, bits=bits or 8, partial=p2)
     assert torch.equal(Y2, out['3'][0]) and torch.equal(p2, out['3'][1])
-  for mode in ('3', '2'):                                      # and so do their statistics (different partial layouts, same sums)
+  for mode in ('2',):                                          # and so do their statistics (different partial layouts, same sums)
     torch.testing.assert_close(out[mode][1][:, 0].sum(0), partial[:, 0].sum(0), rtol=1e-5, atol=1e-3)
     assert torch.equal(out[mode][1][:, 2].min(0).values, partial[:, 2].min(0).values)
 

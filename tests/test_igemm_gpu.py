@@ -45,16 +45,14 @@ def _ref(x_nhwc, w_krsc, stride, pad):
                   padding=pad).permute(0, 2, 3, 1)
 
 
-# tile 'halo': the 3x3 / stride 1 / pad 1 kernel of pf_conv3x3.hip (default where it applies); every other value runs the
-# per-tap implicit GEMM of pf_igemm.hip (PF_CONV3X3_HALO=0) with that tile override
-@pytest.mark.parametrize('tile', ['halo', '', '256x128', '128x128', '256x64', '128x64'])
+# tile '': the dispatcher's own choice; every other value is a tile override (PF_IGEMM_TILE) of the per-tap implicit GEMM
+@pytest.mark.parametrize('tile', ['', '256x128', '128x128', '256x64', '128x64'])
 @pytest.mark.parametrize('imgs,H,Wd,C,N,k,stride', [(2, 14, 14, 64, 64, 3, 1), (3, 9, 11, 128, 128, 3, 1),
                                                     (2, 16, 16, 64, 128, 3, 2), (5, 7, 7, 192, 256, 1, 1),
                                                     (1, 20, 12, 64, 72, 3, 1), (40, 28, 28, 128, 128, 3, 1),
                                                     (37, 7, 7, 512, 256, 3, 1), (3, 56, 56, 64, 64, 3, 1), (5, 5, 62, 64, 192, 3, 1)])
 def test_conv2d_fwd_matches_torch(hip, monkeypatch, tile, imgs, H, Wd, C, N, k, stride):
-  monkeypatch.setenv('PF_CONV3X3_HALO', '1' if tile == 'halo' else '0')
-  if tile and tile != 'halo':
+  if tile:
     monkeypatch.setenv('PF_IGEMM_TILE', tile)
   else:
     monkeypatch.delenv('PF_IGEMM_TILE', raising=False)
@@ -75,10 +73,8 @@ def test_conv2d_fwd_asymmetric_window_and_padding(hip):
   _close(y, _bf(_ref(x, w, 1, (2, 0))), 'asymmetric')
 
 
-@pytest.mark.parametrize('halo', ['1', '0'])
 @pytest.mark.parametrize('imgs,H,C,N', [(8, 28, 128, 128), (4, 14, 256, 256), (16, 56, 64, 64), (70, 14, 128, 256), (300, 7, 64, 128)])
-def test_conv2d_fwd_statistics_and_residual(hip, monkeypatch, halo, imgs, H, C, N):
-  monkeypatch.setenv('PF_CONV3X3_HALO', halo)
+def test_conv2d_fwd_statistics_and_residual(hip, imgs, H, C, N):
   g = torch.Generator(device='cuda').manual_seed(C)
   x = _bf(torch.randn(imgs, H, H, C, device='cuda', generator=g))
   w = _bf(torch.randn(N, 3, 3, C, device='cuda', generator=g) * 0.05)
@@ -101,11 +97,9 @@ def test_conv2d_fwd_statistics_and_residual(hip, monkeypatch, halo, imgs, H, C, 
   assert torch.equal(partial, p2)
 
 
-@pytest.mark.parametrize('halo', ['1', '0'])
-def test_conv2d_backward_data_through_flipped_kernel_with_bn_statistics(hip, monkeypatch, halo):
+def test_conv2d_backward_data_through_flipped_kernel_with_bn_statistics(hip):
   """dX = conv(dY, W') with W'[c][r][s][n] = W[n][2-r][2-s][c], pad 1 (stride-1 3x3), against autograd; the BN-backward
   sums of the producer BN in the epilogue against pf_bn_bwd_stats on the stored dX."""
-  monkeypatch.setenv('PF_CONV3X3_HALO', halo)
   imgs, H, C, N = 6, 14, 128, 192
   g = torch.Generator(device='cuda').manual_seed(9)
   x = _bf(torch.randn(imgs, H, H, C, device='cuda', generator=g))

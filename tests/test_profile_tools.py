@@ -124,3 +124,33 @@ def test_profiling_regions_record_event_pairs_and_cost_nothing_when_disabled(mon
     assert PR.summary('conv1x1_fwd') == (0, 0, 0)
   finally:
     PR.disable_all()
+
+
+def test_isa_diff_tells_identical_changed_removed(tmp_path):
+  """tools/isa_diff.py on two hand-made snapshots: label numbering and the per-compilation __hip_cuid symbol do not count, an
+  instruction or a descriptor line does."""
+  def asm(kernels, cuid):
+    out = []
+    for idx, (name, body, vgprs) in enumerate(kernels):
+      out += ['\t.text', '\t.globl\t%s' % name, '%s:                                 ; @%s' % (name, name)]
+      out += ['\ts_load_dword s0, s[4:5], 0x0', '.LBB%d_1:                                ; %%loop' % idx]
+      out += ['\t' + i for i in body] + ['\ts_cbranch_scc1 .LBB%d_1' % idx, '\ts_endpgm', '.Lfunc_end%d:' % idx]
+      out += ['\t.amdhsa_kernel %s' % name, '\t\t.amdhsa_next_free_vgpr %d' % vgprs, '\t.end_amdhsa_kernel']
+    out += ['__hip_cuid_%s:' % cuid, '\t.byte 0', '\t.amdgpu_metadata', 'amdhsa.kernels:', '  - .name: x%s' % cuid, '\t.end_amdgpu_metadata']
+    return '\n'.join(out) + '\n'
+  a, b = tmp_path / 'a', tmp_path / 'b'
+  a.mkdir(); b.mkdir()
+  (a / 'k.s').write_text(asm([('k_same', ['v_add_f32 v0, v1, v2'], 8), ('k_gone', ['v_mov_b32 v0, 0'], 4),
+                              ('k_code', ['v_add_f32 v0, v1, v2'], 8), ('k_regs', ['v_mul_f32 v0, v1, v2'], 8)], 'aaaa'))
+  # k_gone deleted: the remaining kernels move up one label index
+  (b / 'k.s').write_text(asm([('k_same', ['v_add_f32 v0, v1, v2'], 8), ('k_code', ['v_fma_f32 v0, v1, v2, v0'], 8),
+                              ('k_regs', ['v_mul_f32 v0, v1, v2'], 12)], 'bbbb'))
+  (a / 'only_a.s').write_text(asm([('k_x', ['s_nop 0'], 1)], 'cccc'))
+  r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'isa_diff.py'), str(a), str(b)], capture_output=True, text=True)
+  assert r.returncode == 1, r.stdout + r.stderr
+  assert 'identical   1' in r.stdout and 'changed 2' in r.stdout and 'removed 1' in r.stdout and 'added 0' in r.stdout
+  assert 'CHANGED k_code' in r.stdout and 'descriptor same' in r.stdout
+  assert 'CHANGED k_regs' in r.stdout and 'descriptor differs' in r.stdout
+  assert 'removed k_gone' in r.stdout and 'only_a.s' in r.stdout and 'hip_cuid' not in r.stdout
+  r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'isa_diff.py'), str(a), str(a)], capture_output=True, text=True)
+  assert r.returncode == 0 and 'changed 0' in r.stdout

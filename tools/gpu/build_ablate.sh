@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # ablation builds of pf_igemm.hip / pf_wrw.hip for tools/gpu/*_ablate.py (tools only; never linked into the product library).
-# The builds need symbols of other files of the product library (pf_wrw_reduce, the halo kernel's launcher): they LINK against it (their own kernels come first in their
+# The builds need symbols of other files of the product library (pf_wrw_reduce, the tuning switches): they LINK against it (their own kernels come first in their
 # local lookup scope).  Loading the product library RTLD_GLOBAL instead makes the dynamic linker bind the weak template
 # kernel stubs of every ablation build to the PRODUCT's kernels -- round 3 measured the same kernel five times that way.
 set -euo pipefail

@@ -19,7 +19,7 @@ B = int(os.environ.get('B', 256))
 shapes = [(56, 64, 64, 3, 1), (56, 128, 128, 3, 2), (28, 128, 128, 3, 1), (28, 256, 256, 3, 2), (14, 256, 256, 3, 1),
           (14, 512, 512, 3, 2), (7, 512, 512, 3, 1), (14, 1024, 256, 1, 1), (14, 256, 1024, 1, 1), (7, 2048, 512, 1, 1),
           (7, 512, 2048, 1, 1), (28, 512, 128, 1, 1)]
-tiles = ['halo', '256x128', '128x128', '256x64', '128x64']
+tiles = ['256x128', '128x128', '256x64', '128x64']
 print('%-22s | %-44s | miopen fwd | miopen bwd-data | igemm best TF' % ('H,C,N,k,s', 'igemm us by tile ' + ' '.join(tiles)))
 for H, C, N, k, s in shapes:
   g = torch.Generator(device='cuda').manual_seed(H + C + N)
@@ -32,22 +32,14 @@ for H, C, N, k, s in shapes:
   G = 0
   ts = []
   for t in tiles:
-    os.environ['PF_CONV3X3_HALO'] = '1' if t == 'halo' else '0'
+    if N % int(t.split('x')[1]):
+      ts.append(float('nan')); continue
+    os.environ['PF_IGEMM_TILE'] = t
     hip.tuning_reload()          # the library reads its switches once
-    if t == 'halo':
-      os.environ.pop('PF_IGEMM_TILE', None)
-      hip.tuning_reload()          # the library reads its switches once
-      if not (k == 3 and s == 1):
-        ts.append(float('nan')); continue
-    else:
-      if N % int(t.split('x')[1]):
-        ts.append(float('nan')); continue
-      os.environ['PF_IGEMM_TILE'] = t
-      hip.tuning_reload()          # the library reads its switches once
     G = hip.conv2d_stats_groups(M, N, geom=(B, H, H, C, N, k, k, s, pad, pad, Ho, Ho))
     partial = torch.empty(G, 4, N, device='cuda')
     ts.append(timeit(lambda: hip.conv2d_fwd(x, w, y, B, H, H, C, N, k, k, s, pad, pad, Ho, Ho, partial=partial)))
-  os.environ.pop('PF_IGEMM_TILE', None); os.environ.pop('PF_CONV3X3_HALO', None)
+  os.environ.pop('PF_IGEMM_TILE', None)
   hip.tuning_reload()          # the library reads its switches once
   x4 = x.permute(0, 3, 1, 2)
   w4 = w.permute(0, 3, 1, 2)
