@@ -18,6 +18,8 @@ individual TF primitive remain a restatement of TF's published behaviour [3P]:
       q, d in float64; descending sort (top_k); index = round_half_even((d-1) * (1 - q/100)) clipped;
   * tf.losses.softmax_cross_entropy -> mean over the batch of -sum(labels * log_softmax(logits));
   * tf.train.piecewise_constant  -> values[0] for x <= b[0], values[i] for b[i-1] < x <= b[i], ...
+  * tf.reduce_sum                -> np.sum in the operand's dtype (NumPy's pairwise order, not Eigen's), axis list / keepdims honoured;
+    tf.sqrt -> np.sqrt (correctly rounded) -- the proximal step of chn-pruned-gpu, tests/golden/make_reference_cpg_golden.py;
   * gradient_override_map / variable_scope / summaries -> no-ops (forward values only: gradients of
     the reference chain are NOT produced by this stub; the STE rules are pinned by hand-derived
     known answers in tests/test_oracle_kat.py).
