@@ -320,7 +320,7 @@ int pf_conv_stem_wrw(const void* dY, const void* X, void* dW, int dw_dtype, floa
  * (floor(total / 2); the rest behind is implied by Ho / Wo).  C % 8 == 0 and 256 % (C / 8) == 0 (pf_depthwise_supported).
  * pf_depthwise_fwd: partial (may be NULL) receives the per-channel {sum, sum of squares, min, max} of the stored outputs,
  * [G][4][C] with G = pf_depthwise_groups(B, Ho, Wo, C) -- the statistics of the BatchNorm behind the layer (pf_bn_finalize).
- * pf_depthwise_wrw: slabs = workspace of pf_depthwise_groups(B, Ho, Wo, C) * C * 9 floats; fixed-order reduction.        */
+ * pf_depthwise_wrw: slabs = workspace of (pf_depthwise_groups(B, Ho, Wo, C) + 32) * C * 9 floats; fixed-order reduction.  */
 int pf_depthwise_supported(int C, int k, int stride);
 int pf_depthwise_groups(int B, int Ho, int Wo, int C);
 int pf_depthwise_fwd(const void* X, const void* W, void* Y, int dtype, float* partial, int B, int H, int Wd, int C, int k,

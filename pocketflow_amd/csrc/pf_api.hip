@@ -38,6 +38,7 @@ static void tuning_load() {
   t.wrw2 = env_int("PF_WRW2", 1);
   t.wrw2_target = env_int("PF_WRW2_TARGET", 0);
   t.splitk = env_int("PF_IGEMM_SPLITK", 1);
+  t.dw_reduce2 = env_int("PF_DW_REDUCE2", 0);
   g_tuning = t;
   g_tuning_loaded = true;
 }

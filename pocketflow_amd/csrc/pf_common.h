@@ -33,6 +33,7 @@ struct PfTuning {
   int pool3s2;                    // PF_POOL3S2            1 (default) | 0
   int wrw_tr, wrw2, wrw2_target;  // PF_WRW_TR 0, PF_WRW2 1, PF_WRW2_TARGET 0 (= per-shape default)
   int splitk;                     // PF_IGEMM_SPLITK       1 (default) | 0
+  int dw_reduce2;                 // PF_DW_REDUCE2         0 (default) | 1: depthwise backward-filter slabs through pf_wrw_reduce
 };
 const PfTuning& pf_tuning();
 

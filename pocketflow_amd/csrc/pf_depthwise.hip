@@ -329,7 +329,9 @@ extern "C" int pf_depthwise_bwd_data(const void* dY, const void* W, void* dX, in
   return 0;
 }
 
-// dW [C][3][3] (dw_dtype) from dY and X; slabs: pf_depthwise_groups(B, Ho, Wo, C) * C * 9 floats of workspace
+int pf_wrw_reduce(float* workspace, int S, int64_t n, void* dW, int dw_dtype, hipStream_t st);   // pf_conv.hip
+
+// dW [C][3][3] (dw_dtype) from dY and X; slabs: (pf_depthwise_groups(B, Ho, Wo, C) + 32) * C * 9 floats of workspace
 extern "C" int pf_depthwise_wrw(const void* dY, const void* X, void* dW, int dtype, int dw_dtype, float* slabs, int B, int H,
                                 int Wd, int C, int k, int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream) {
   if (!pf_depthwise_supported(C, k, stride)) return (int)hipErrorInvalidValue;
@@ -351,6 +353,12 @@ extern "C" int pf_depthwise_wrw(const void* dY, const void* X, void* dW, int dty
   else return (int)hipErrorInvalidValue;
 #undef PF_DWW
   const int n = C * 9;
+  // PF_DW_REDUCE2=1 (prepared at the end of round 4, NOT yet run on hardware; A/B in the first GPU call of round 5): the slabs go
+  // through the staged reduction of the other backward-filter kernels (pf_wrw_reduce: 64 outputs x 4 interleaved slab lanes per
+  // workgroup, split ranges on gridDim.y, a second launch folds the ranges; fixed order).  k_dw_wrw_reduce below runs ONE thread per
+  // output over all G <= 1024 slabs: C * 9 threads in total, 271 us per launch in profiles/r04_step_kernels_c3.csv (14.6 % of that
+  // step's GPU time for 19 MB of reads).
+  if (pf_tuning().dw_reduce2 != 0) return pf_wrw_reduce(slabs, grid, (int64_t)n, dW, dw_dtype, st);
   if (dw_dtype == PF_F32) k_dw_wrw_reduce<float><<<(n + DW_T - 1) / DW_T, DW_T, 0, st>>>(slabs, grid, n, (float*)dW);
   else if (dw_dtype == PF_BF16) k_dw_wrw_reduce<bf16_t><<<(n + DW_T - 1) / DW_T, DW_T, 0, st>>>(slabs, grid, n, (bf16_t*)dW);
   else return (int)hipErrorInvalidValue;

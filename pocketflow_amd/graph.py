@@ -1370,7 +1370,7 @@ class _Depthwise(torch.autograd.Function):
       dwk = gw if direct else torch.empty(w.shape, dtype=w.dtype, device=x.device)
       G = hip.depthwise_groups(B, Ho, Wo, C)
       with region('depthwise_wrw', float((x.numel() + dy.numel()) * x.element_size())):
-        hip.depthwise_wrw(dy, x, dwk, graph.scratch(G * C * k * k), B, H, W, C, k, stride, ph, pw, Ho, Wo)
+        hip.depthwise_wrw(dy, x, dwk, graph.scratch((G + 32) * C * k * k), B, H, W, C, k, stride, ph, pw, Ho, Wo)
       if direct:
         graph.store.notify_grad(w_var)             # written straight into the flat gradient buffer
       else:

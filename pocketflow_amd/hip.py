@@ -459,8 +459,10 @@ def depthwise_bwd_data(dY, W, dX, B: int, H: int, Wd: int, C: int, k: int, strid
 
 def depthwise_wrw(dY, X, dW, slabs, B: int, H: int, Wd: int, C: int, k: int, stride: int, pad_h: int, pad_w: int, Ho: int,
                   Wo: int) -> None:
-  """dW: [C][k][k], float32 or bf16; slabs: depthwise_groups(B, Ho, Wo, C) * C * k * k floats."""
+  """dW: [C][k][k], float32 or bf16; slabs: (depthwise_groups(B, Ho, Wo, C) + 32) * C * k * k floats."""
   _dev(X)
+  if slabs.dtype != torch.float32 or slabs.numel() < (depthwise_groups(B, Ho, Wo, C) + 32) * C * k * k:
+    raise TypeError('depthwise_wrw: float32 workspace of (groups + 32) * C * k * k elements')
   _check(_lib.pf_depthwise_wrw(_ptr(dY), _ptr(X), _ptr(dW), c_int(dtype_code(X)), c_int(dtype_code(dW)), _ptr(slabs), c_int(B),
                                c_int(H), c_int(Wd), c_int(C), c_int(k), c_int(stride), c_int(pad_h), c_int(pad_w), c_int(Ho),
                                c_int(Wo), _stream()), 'pf_depthwise_wrw')
