@@ -1,0 +1,37 @@
+#!/usr/bin/env bash
+# First GPU call of round 5 (prepared at the end of round 4, when no GPU minutes were left):
+#   gpurun --timeout 1700 -- 'bash tools/gpu/r05_first_call.sh'
+# 1. the whole GPU suite at HEAD (validates the end-of-round-4 clean-up on hardware: kernel machine code is unchanged per
+#    tools/isa_diff.py, the host dispatch lost two dead branches);
+# 2. the prepared, never-run pieces: PF_DW_REDUCE2 (its test, then C3 with and without it);
+# 3. the LDS-DMA fill-rate table (tools/gpu/fill_bench.hip) that decides what the next contraction kernel should look like;
+# 4. the headline line.
+# Everything lands in gpurun_out/r05_first_call/ ; delete this script after use (it stays in the history).
+set -uo pipefail
+cd "$(dirname "$0")/../.."
+OUT=gpurun_out/r05_first_call
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+( time timeout 1000 python -m pytest tests -m gpu -x -q ) > "$OUT/pytest_gpu.log" 2>&1
+tail -3 "$OUT/pytest_gpu.log"
+PF_TEST_PREPARED=1 timeout 240 python -m pytest tests/test_depthwise_gpu.py -m gpu -q > "$OUT/pytest_prepared_dw_reduce2.log" 2>&1
+tail -2 "$OUT/pytest_prepared_dw_reduce2.log"
+timeout 300 bash tools/gpu/fill_bench.sh > /dev/null 2>&1; cp gpurun_out/fill_bench.txt "$OUT/fill_bench.txt" 2>/dev/null
+for v in 0 1 0 1; do
+  echo "PF_DW_REDUCE2=$v" >> "$OUT/c3_dw_reduce2_ab.txt"
+  PF_DW_REDUCE2=$v timeout 200 python bench.py --config c3 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null | tail -1 >> "$OUT/c3_dw_reduce2_ab.txt"
+done
+timeout 300 python bench.py --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null | tail -1 > "$OUT/bench_c2.json"
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob('gpurun_out/r05_first_call/*.txt')) + ['gpurun_out/r05_first_call/bench_c2.json']:
+  for line in open(f):
+    line = line.strip()
+    if line.startswith('{'):
+      try:
+        d = json.loads(line); print(f.split('/')[-1], d.get('value'), d.get('ms_per_step'), (d.get('roofline') or {}).get('frac'))
+      except Exception as e:
+        print(f, 'unparsable', e)
+    elif line.startswith('PF_'):
+      print(line)
+PY
