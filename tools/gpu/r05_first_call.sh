@@ -22,8 +22,8 @@ for v in 0 1 0 1; do
   PF_DW_REDUCE2=$v timeout 200 python bench.py --config c3 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null | tail -1 >> "$OUT/c3_dw_reduce2_ab.txt"
 done
 timeout 300 python bench.py --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null | tail -1 > "$OUT/bench_c2.json"
-timeout 400 python tools/gpu/igemm_bench.py > "$OUT/igemm_layers.txt" 2>&1
-timeout 300 python tools/gpu/depthwise_bench.py > "$OUT/depthwise_layers.txt" 2>&1   # (now with the 256x256 tile column)
+timeout 400 python tools/gpu/igemm_bench.py > "$OUT/igemm_layers.txt" 2>&1   # (now with the 256x256 tile column)
+timeout 300 python tools/gpu/depthwise_bench.py > "$OUT/depthwise_layers.txt" 2>&1
 python - <<'PY'
 import json, glob
 for f in sorted(glob.glob('gpurun_out/r05_first_call/*.txt')) + ['gpurun_out/r05_first_call/bench_c2.json']:
