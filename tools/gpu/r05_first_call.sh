@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # First GPU call of round 5 (prepared at the end of round 4, when no GPU minutes were left):
-#   gpurun --timeout 1700 -- 'bash tools/gpu/r05_first_call.sh'
+#   gpurun --timeout 2400 -- 'bash tools/gpu/r05_first_call.sh'        (typically ~20 min: the suite ~10, the rest ~10)
 # 1. the whole GPU suite at HEAD (validates the end-of-round-4 clean-up on hardware: kernel machine code is unchanged per
 #    tools/isa_diff.py, the host dispatch lost two dead branches);
 # 2. the prepared, never-run pieces: PF_DW_REDUCE2 (its test, then C3 with and without it);
