@@ -94,6 +94,23 @@ xp = F.pad(x, (0, 1, 0, 1)).contiguous(memory_format=torch.channels_last)
 w4 = w.permute(0, 3, 1, 2)
 m_f = bench_us(lambda: F.conv2d(xp, w4, stride=2))
 m_w = bench_us(lambda: torch.ops.aten.convolution_backward(dy, xp, w4, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False]))
+# the same with the channels padded to 4 (PF_CONVG_PAD_C3=1: k_convg's 4-element vector loader), pad copies included
+def padded_fwd():
+  x4 = torch.zeros(B, 4, H, H, device='cuda', dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+  x4[:, :3] = x
+  w4p = torch.zeros(N, 3, 3, 4, device='cuda', dtype=torch.bfloat16)
+  w4p[..., :3] = w
+  hip.convg_fwd(x4, w4p, None, y, B, H, H, 4, N, 3, 3, 2, 0, 0, Ho, Ho)
+  return x4
+
+
+x4 = padded_fwd()
+dwk4 = torch.empty(N, 3, 3, 4, device='cuda', dtype=torch.bfloat16)
+slab4 = torch.empty(hip.convg_wrw_splits(B, 4, N, 3, 3, Ho, Ho) * N * 36, device='cuda')
+p_f = bench_us(padded_fwd)
+p_w = bench_us(lambda: hip.convg_wrw(dy, x4, dwk4, slab4, B, H, H, 4, N, 3, 3, 2, 0, 0, Ho, Ho))
+print('  padded to 4 channels: forward (with the pad copies) %.1f us, backward-filter %.1f us; dW agrees to %.1e' % (
+    p_f, p_w, float((dwk4[..., :3].float() - dwk.float()).abs().max() / (dwk.float().abs().max() + 1e-12))))
 fl = (B * H * H * 3 * 2 + B * Ho * Ho * N * 2) / BW * 1e6
 print('image convolution 3 -> %d, 3x3 / 2 at %d: k_convg forward %.1f us, backward-filter %.1f us; MIOpen %.1f / %.1f; floor %.1f' % (
     N, H, t_f, t_w, m_f, m_w, fl))
