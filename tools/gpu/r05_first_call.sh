@@ -16,6 +16,8 @@ export TMPDIR=/tmp
 tail -3 "$OUT/pytest_gpu.log"
 PF_TEST_PREPARED=1 timeout 240 python -m pytest tests/test_depthwise_gpu.py -m gpu -q > "$OUT/pytest_prepared_dw_reduce2.log" 2>&1
 tail -2 "$OUT/pytest_prepared_dw_reduce2.log"
+PF_TEST_PREPARED=1 timeout 240 python -m pytest tests/test_igemm_gpu.py -m gpu -q -k "256x256" > "$OUT/pytest_prepared_tile256x256.log" 2>&1
+tail -2 "$OUT/pytest_prepared_tile256x256.log"
 timeout 300 bash tools/gpu/fill_bench.sh > /dev/null 2>&1; cp gpurun_out/fill_bench.txt "$OUT/fill_bench.txt" 2>/dev/null
 # PF_CONVG_PAD_C3=1 (image convolutions on k_convg's vector loader): the parity tests of the networks that have one, then C3 with both switches
 PF_CONVG_PAD_C3=1 timeout 400 python -m pytest tests/test_parity_gpu.py tests/test_convg_gpu.py -m gpu -q -k "mobilenet or lenet or cp or convg" > "$OUT/pytest_prepared_pad_c3.log" 2>&1
