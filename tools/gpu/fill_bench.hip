@@ -169,6 +169,69 @@ __global__ __launch_bounds__(64 * WAVES) void k_fill_reg(const FbArgs a) {
   if (a.iters < 0) a.sink[threadIdx.x] = smem[lane];
 }
 
+// Both transports at once: PD LDS-DMA pieces into the ring AND PR 16-byte global loads into registers per wavefront and stage (what a
+// kernel does that keeps the pixel operand in LDS and fetches the kernel operand's fragments straight from L2).  Do the two rates
+// add up, or do they share one path?  The register loads are inline assembly with counted waits of their own: beside a pending
+// LDS-DMA hipcc drains vmcnt(0) for every register-destination load it knows about.
+template <int WAVES, int PD, int PR, bool BARRIER>
+__global__ __launch_bounds__(64 * WAVES) void k_fill_mix(const FbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int PIECE_B = 1024;
+  constexpr int STAGE_B = WAVES * PD * PIECE_B;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const fb_rsrc_t rs = FB_MAKE_RSRC(a.src, a.bytes);
+  const uint32_t mask = a.bytes - 1u;
+  const uint32_t lane_off = (uint32_t)(lane >> 3) * a.row_stride + (uint32_t)((lane & 7) ^ ((lane >> 3) & 7)) * 16u;
+  const uint32_t piece_span = 8u * a.row_stride;
+  auto dma = [&](int it, int buf) {
+    const uint32_t w0 = ((uint32_t)blockIdx.x * 7919u + (uint32_t)it * 104729u) * (uint32_t)(WAVES * (PD + PR));
+#pragma unroll
+    for (int p = 0; p < PD; ++p) {
+      const uint32_t base = ((w0 + (uint32_t)(wave * PD + p)) * piece_span) & mask;
+      FB_LOAD_LDS(rs, smem + buf * STAGE_B + (wave * PD + p) * PIECE_B, 16, (base + lane_off) & mask, 0, 0);
+    }
+  };
+  auto fetch = [&](int it, fb_u32x4 (&r)[PR > 0 ? PR : 1]) {
+    const uint32_t w0 = ((uint32_t)blockIdx.x * 7919u + (uint32_t)it * 104729u) * (uint32_t)(WAVES * (PD + PR)) + (uint32_t)(WAVES * PD);
+#pragma unroll
+    for (int p = 0; p < PR; ++p) {
+      const uint32_t base = ((w0 + (uint32_t)(wave * PR + p)) * piece_span) & mask;
+      const unsigned char* ptr = a.src + ((base + lane_off) & mask);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[p]) : "v"(ptr) : "memory");
+    }
+  };
+  uint32_t acc = 0;
+  auto use = [&](fb_u32x4 (&r)[PR > 0 ? PR : 1]) {
+#pragma unroll
+    for (int p = 0; p < PR; ++p) {
+      asm volatile("" : "+v"(r[p]));                   // (the wait in front of this call covers them; keeps the use behind it)
+      acc ^= r[p][0];
+    }
+  };
+  constexpr int PRA = PR > 0 ? PR : 1;                // (PR == 0: the arrays stay unused)
+  fb_u32x4 ra[PRA], rb[PRA];
+  // iters even, >= 2.  In flight behind the counted wait: the NEXT stage's PD pieces + PR loads.
+  dma(0, 0); fetch(0, ra);
+  int it = 0;
+  for (; it + 2 < a.iters; it += 2) {
+    dma(it + 1, 1); fetch(it + 1, rb);
+    fb_wait_vm<PD + PR>();
+    use(ra);
+    if (BARRIER) __builtin_amdgcn_s_barrier();
+    dma(it + 2, 0); fetch(it + 2, ra);
+    fb_wait_vm<PD + PR>();
+    use(rb);
+    if (BARRIER) __builtin_amdgcn_s_barrier();
+  }
+  dma(it + 1, 1); fetch(it + 1, rb);
+  fb_wait_vm<PD + PR>();
+  use(ra);
+  fb_wait_vm<0>();
+  use(rb);
+  if (a.iters < 0 || acc == 0x9e3779b9u) a.sink[threadIdx.x] = acc + smem[lane];
+}
+
 struct Cfg { const char* name; int waves, stages, pieces, pattern, sz, aux, barrier, reads; };
 
 template <int WAVES, int STAGES, int PIECES, int PATTERN, int SZ, int AUX, bool BARRIER, bool READS>
@@ -219,6 +282,29 @@ static float run_reg(const FbArgs& a, int wgs_per_cu, int cus, double* bytes_out
   return ms;
 }
 
+template <int WAVES, int PD, int PR, bool BARRIER>
+static float run_mix(const FbArgs& a, int wgs_per_cu, int cus, double* bytes_out) {
+  constexpr int STAGE_B = WAVES * PD * 1024;
+  const size_t want = (size_t)(160 * 1024) / (size_t)wgs_per_cu;
+  if ((size_t)2 * STAGE_B > want) return -1.f;
+  const size_t lds = want - 1024;
+  auto kern = k_fill_mix<WAVES, PD, PR, BARRIER>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1.f;
+  const int grid = cus * wgs_per_cu;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  kern<<<grid, 64 * WAVES, lds, 0>>>(a);
+  hipEventRecord(e0, 0);
+  kern<<<grid, 64 * WAVES, lds, 0>>>(a);
+  hipEventRecord(e1, 0);
+  if (hipEventSynchronize(e1) != hipSuccess) return -1.f;
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  *bytes_out = (double)grid * a.iters * (double)(WAVES * (PD + PR) * 1024);
+  return ms;
+}
+
 #define FB_CASE(W, S, P, PAT, SZ, AUX, BAR, RD)                                                                          \
   if (c.waves == W && c.stages == S && c.pieces == P && c.pattern == PAT && c.sz == SZ && c.aux == AUX && c.barrier == BAR && c.reads == RD) \
     return run_one<W, S, P, PAT, SZ, AUX, (BAR != 0), (RD != 0)>(a, wgs_per_cu, cus, bytes_out);
@@ -231,6 +317,13 @@ static float dispatch(const Cfg& c, const FbArgs& a, int wgs_per_cu, int cus, do
   FB_CASE(8, 2, 4, 2, 16, 0, 1, 0) FB_CASE(8, 3, 4, 2, 16, 0, 1, 0) FB_CASE(8, 3, 4, 0, 16, 0, 0, 0)
   FB_CASE(4, 2, 32, 0, 4, 0, 1, 0) FB_CASE(4, 2, 32, 0, 4, 0, 0, 0)
   FB_CASE(4, 2, 4, 2, 16, 0, 1, 0) FB_CASE(4, 4, 4, 2, 16, 0, 1, 0) FB_CASE(4, 4, 4, 2, 16, 0, 0, 0)
+  if (c.stages == -1) {                                // mixed transport: pieces = LDS-DMA pieces, sz = register loads per wavefront and stage
+    if (c.pieces == 4 && c.sz == 4 && c.barrier == 1) return run_mix<4, 4, 4, true>(a, wgs_per_cu, cus, bytes_out);
+    if (c.pieces == 4 && c.sz == 4 && c.barrier == 0) return run_mix<4, 4, 4, false>(a, wgs_per_cu, cus, bytes_out);
+    if (c.pieces == 8 && c.sz == 8 && c.barrier == 1) return run_mix<4, 8, 8, true>(a, wgs_per_cu, cus, bytes_out);
+    if (c.pieces == 4 && c.sz == 0 && c.barrier == 1) return run_mix<4, 4, 0, true>(a, wgs_per_cu, cus, bytes_out);
+    if (c.pieces == 0 && c.sz == 4 && c.barrier == 1) return run_mix<4, 0, 4, true>(a, wgs_per_cu, cus, bytes_out);
+  }
   if (c.stages == 0) {                                 // register-staged: (waves, pieces, pattern, barrier)
     if (c.waves == 4 && c.pieces == 8 && c.pattern == 0 && c.barrier == 1) return run_reg<4, 8, 0, true>(a, wgs_per_cu, cus, bytes_out);
     if (c.waves == 4 && c.pieces == 8 && c.pattern == 2 && c.barrier == 1) return run_reg<4, 8, 2, true>(a, wgs_per_cu, cus, bytes_out);
@@ -273,6 +366,11 @@ int main(int argc, char** argv) {
       {"REGISTER-staged, gather+swizzle, 4w 32K, barrier", 4, 0, 8, 2, 16, 0, 1, 0},
       {"REGISTER-staged, gather+swizzle, 4w 32K, no barrier", 4, 0, 8, 2, 16, 0, 0, 0},
       {"REGISTER-staged, gather+swizzle, 8w 32K, barrier", 8, 0, 4, 2, 16, 0, 1, 0},
+      {"MIXED: 4 LDS-DMA pieces + 4 register loads per wave and stage (16K + 16K), barrier", 4, -1, 4, 2, 4, 0, 1, 0},
+      {"MIXED: 4 LDS-DMA pieces + 4 register loads per wave and stage, no barrier", 4, -1, 4, 2, 4, 0, 0, 0},
+      {"MIXED: 8 + 8 per wave and stage (32K + 32K), barrier", 4, -1, 8, 2, 8, 0, 1, 0},
+      {"MIXED kernel, LDS-DMA half only (4 pieces, 16K), barrier", 4, -1, 4, 2, 0, 0, 1, 0},
+      {"MIXED kernel, register half only (4 loads, 16K, nothing written to LDS), barrier", 4, -1, 0, 2, 4, 0, 1, 0},
   };
   const size_t sets[] = {(size_t)1 << 20, (size_t)4 << 20, (size_t)16 << 20, (size_t)128 << 20, (size_t)1 << 30};
   const uint32_t strides[] = {256u, 2048u};            // 128-channel and 1024-channel bf16 rows
@@ -284,7 +382,7 @@ int main(int argc, char** argv) {
           if (c.pattern == 0 && stride != strides[0]) continue;
           FbArgs a;
           a.src = src; a.bytes = (uint32_t)set; a.row_stride = stride; a.sink = sink;
-          const int stage_b = c.waves * c.pieces * 64 * c.sz;
+          const int stage_b = (c.stages == -1) ? c.waves * (c.pieces + c.sz) * 1024 : c.waves * c.pieces * 64 * c.sz;
           a.iters = (int)(((size_t)96 << 20) / (size_t)stage_b);        // 96 MiB per workgroup
           if (a.iters > 4096) a.iters = 4096;
           a.iters &= ~1;                                                   // (k_fill_reg: an even count)
