@@ -645,7 +645,6 @@ static bool ig_pro3_enabled() {
 
 // ONE decision for the launcher and for the statistics-group query (the [G][.][N] partial array is sized from it)
 static IgCfg ig_pick(int M, int N, bool pro) {
-  (void)M;
   if (pro) {
     // prologue variant.  Three stages, 8 wavefronts, one workgroup per CU: 128 x 256 tiles where N allows (the in-LDS
     // prologue pass over the input tile is amortised over 256 output channels), 256 x 128 otherwise.
@@ -661,6 +660,11 @@ static IgCfg ig_pick(int M, int N, bool pro) {
         (N % bn == 0 || bn == 64))
       return IgCfg{bm, bn, (bm == 256) ? 256 : 512, false};
   }
+  // PF_IGEMM_AUTO256=T (prepared at the end of round 4, never run on hardware): 256 x 256 tiles -- eight wavefronts of 64 x 128, twice
+  // the matrix work per LDS-DMA piece, DESIGN.md section 9 -- where the output has 256-channel tiles and at least T of them (one
+  // workgroup per CU: fewer than ~128 tiles leave most of the chip idle).  The instantiations are the ones PF_IGEMM_TILE=256x256 selects.
+  if (pf_tuning().igemm_auto256 > 0 && N % 256 == 0 && (int64_t)((M + 255) / 256) * (N / 256) >= pf_tuning().igemm_auto256)
+    return IgCfg{256, 256, 256, false};
   const int bn = (N % 128 == 0) ? 128 : 64;
   // measured on the ResNet-50 shapes at batch 256 (tools/gpu/igemm_bench.py): 128-row tiles with two workgroups per CU
   // (2 LDS stages each) beat 256-row tiles with one workgroup per CU and 3 stages on every shape (e.g. 3x3 C = 256 at

@@ -28,6 +28,11 @@ for v in "0 0" "1 0" "0 1" "1 1" "0 0" "1 1"; do
   PF_DW_REDUCE2=$1 PF_CONVG_PAD_C3=$2 timeout 200 python bench.py --config c3 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null | tail -1 >> "$OUT/c3_switches_ab.txt"
 done
 timeout 300 python bench.py --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null | tail -1 > "$OUT/bench_c2.json"
+# PF_IGEMM_AUTO256 (256 x 256 tiles where N % 256 == 0 and >= T tiles): only meaningful if the 256x256 tile test above passed
+for v in 0 128 0 128 64; do
+  echo "PF_IGEMM_AUTO256=$v" >> "$OUT/c2_auto256_ab.txt"
+  PF_IGEMM_AUTO256=$v timeout 200 python bench.py --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null | tail -1 >> "$OUT/c2_auto256_ab.txt"
+done
 timeout 400 python tools/gpu/igemm_bench.py > "$OUT/igemm_layers.txt" 2>&1   # (now with the 256x256 tile column)
 timeout 300 python tools/gpu/depthwise_bench.py > "$OUT/depthwise_layers.txt" 2>&1
 python - <<'PY'
