@@ -34,6 +34,7 @@ static void tuning_load() {
     if (sscanf(e, "%dx%d", &bm, &bn) == 2) { t.igemm_tile_bm = bm; t.igemm_tile_bn = bn; }
   }
   t.igemm_auto256 = env_int("PF_IGEMM_AUTO256", 0);
+  t.igemm_pro256 = env_int("PF_IGEMM_PRO256", 0);
   t.pool3s2 = env_int("PF_POOL3S2", 1);
   t.wrw_tr = env_int("PF_WRW_TR", 0);
   t.wrw2 = env_int("PF_WRW2", 1);

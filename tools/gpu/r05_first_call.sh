@@ -17,6 +17,8 @@ tail -3 "$OUT/pytest_gpu.log"
 PF_TEST_PREPARED=1 timeout 240 python -m pytest tests/test_depthwise_gpu.py -m gpu -q > "$OUT/pytest_prepared_dw_reduce2.log" 2>&1
 tail -2 "$OUT/pytest_prepared_dw_reduce2.log"
 PF_TEST_PREPARED=1 timeout 240 python -m pytest tests/test_igemm_gpu.py -m gpu -q -k "256x256" > "$OUT/pytest_prepared_tile256x256.log" 2>&1
+PF_TEST_PREPARED=1 timeout 300 python -m pytest tests/test_conv_gpu.py -m gpu -q -k "prologue_three_stage" > "$OUT/pytest_prepared_pro256.log" 2>&1
+tail -2 "$OUT/pytest_prepared_pro256.log"
 tail -2 "$OUT/pytest_prepared_tile256x256.log"
 timeout 300 bash tools/gpu/fill_bench.sh > /dev/null 2>&1; cp gpurun_out/fill_bench.txt "$OUT/fill_bench.txt" 2>/dev/null
 # PF_CONVG_PAD_C3=1 (image convolutions on k_convg's vector loader): the parity tests of the networks that have one, then C3 with both switches
@@ -28,10 +30,12 @@ for v in "0 0" "1 0" "0 1" "1 1" "0 0" "1 1"; do
   PF_DW_REDUCE2=$1 PF_CONVG_PAD_C3=$2 timeout 200 python bench.py --config c3 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null | tail -1 >> "$OUT/c3_switches_ab.txt"
 done
 timeout 300 python bench.py --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null | tail -1 > "$OUT/bench_c2.json"
-# PF_IGEMM_AUTO256 (256 x 256 tiles where N % 256 == 0 and >= T tiles): only meaningful if the 256x256 tile test above passed
-for v in 0 128 0 128 64; do
-  echo "PF_IGEMM_AUTO256=$v" >> "$OUT/c2_auto256_ab.txt"
-  PF_IGEMM_AUTO256=$v timeout 200 python bench.py --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null | tail -1 >> "$OUT/c2_auto256_ab.txt"
+# PF_IGEMM_AUTO256 / PF_IGEMM_PRO256 (256 x 256 tiles where N % 256 == 0 and >= T tiles; plain / prologue launches): only meaningful if
+# the two prepared tile tests above passed
+for v in "0 0" "128 0" "0 128" "128 128" "0 0" "128 128" "64 256"; do
+  set -- $v
+  echo "PF_IGEMM_AUTO256=$1 PF_IGEMM_PRO256=$2" >> "$OUT/c2_auto256_ab.txt"
+  PF_IGEMM_AUTO256=$1 PF_IGEMM_PRO256=$2 timeout 200 python bench.py --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null | tail -1 >> "$OUT/c2_auto256_ab.txt"
 done
 timeout 400 python tools/gpu/igemm_bench.py > "$OUT/igemm_layers.txt" 2>&1   # (now with the 256x256 tile column)
 timeout 300 python tools/gpu/depthwise_bench.py > "$OUT/depthwise_layers.txt" 2>&1
