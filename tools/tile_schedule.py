@@ -4,6 +4,7 @@ workgroup is done, and ONE in-order queue cannot start the next kernel on them (
 Dispatch rules as in pf_igemm.hip (ig_pick / ig_grid) and pf_conv_stream.hip (pf_conv_stream_plan).  No GPU.
 
     python tools/tile_schedule.py [batch]
+    python tools/tile_schedule.py [batch] pieces      the LDS-DMA piece model of DESIGN.md section 9 per launch, current tile vs 256 x 256
 """
 import math
 import sys
@@ -24,8 +25,10 @@ def stream_ok(M, N, K):
   return not (nsplit > 2 or (256 % (8 * nsplit)) or nw not in (64, 128, 256) or (nsplit >= 2 and N < 4 * K))
 
 
-def igemm(M, N, pro):
-  if pro:
+def igemm(M, N, pro, force=None):
+  if force is not None:
+    bm, bn, slots = force
+  elif pro:
     bm, bn, slots = (128, 256, 256) if N % 256 == 0 else (256, 128, 256)
   else:
     bm, bn, slots = 128, (128 if N % 128 == 0 else 64), 512
@@ -77,3 +80,35 @@ for name, m, n, k, tile, T, S, avg, rounds, nets in rows:
 for (nm, m, n, k), (cnt, tile, T, S, avg, rounds, idle, nets) in seen.items():
   print('%-30s %8d %5d %5d  %-8s %6d %6d %9.2f %9d %6.1f%%' % ('%s x%d' % (nm, cnt * nets), m, n, k, tile, T, S, avg, rounds, idle * 100))
 print('\nflop-weighted: %.1f %% of the time of these launches is CUs waiting for the busiest one (B = %d)' % (tot_i / (tot_w + tot_i) * 100, B))
+
+
+# ---- the piece model: a CU lands about one 1-KiB LDS-DMA piece per PIECE_CYC cycles whatever issues it; a k-step
+# of a (bm x bn) tile needs (bm + bn) / 8 pieces and bm * bn * 64 / 8192 MFMAs of 16 cycles on 4 SIMDs.  Predicted main-loop time of a
+# launch = busiest CU's tiles x k-steps x max(pieces x PIECE_CYC, MFMA cycles).  Calibrated on one number (the 28x28 3x3 loop: 68 us).
+if len(sys.argv) > 2 and sys.argv[2] == 'pieces':
+  PIECE_CYC, GHZ = 34.0, 2.3
+
+  def model(m, n, k, tile, max_per_cu):
+    bm, bn = (int(v) for v in tile.split('x'))
+    ksteps = k // 64
+    dma = (bm + bn) / 8.0 * PIECE_CYC
+    mfma = bm * bn * 64 / 8192.0 * 16 / 4
+    return max_per_cu * ksteps * max(dma, mfma) / (GHZ * 1e3), dma, mfma
+
+  print('\n%-30s %8s %5s %5s | %-8s %8s %9s | %-8s %8s %9s | %s' % ('launch (x networks)', 'M', 'N', 'K', 'tile', 'max / CU', 'model us', 'tile', 'max / CU',
+                                                                 'model us', 'pieces : MFMA cycles per k-step'))
+  t_cur = t_alt = 0.0
+  for (nm, m, n, k), (cnt, tile, T, S, avg, rounds, idle, nets) in seen.items():
+    pro = 'bwd' not in nm and '3x3' not in nm
+    us, dma, mfma = model(m, n, k, tile, rounds)
+    alt = ('-', 0, us)
+    if n % 256 == 0:
+      t2, T2, S2, avg2, rounds2 = igemm(m, n, pro, force=(256, 256, 256))
+      us2, dma2, mfma2 = model(m, n, k, t2, rounds2)
+      alt = (t2, rounds2, us2)
+    t_cur += us * cnt * nets
+    t_alt += min(us, alt[2]) * cnt * nets
+    print('%-30s %8d %5d %5d | %-8s %8d %9.1f | %-8s %8s %9.1f | %4.0f : %4.0f' % ('%s x%d' % (nm, cnt * nets), m, n, k, tile, rounds, us, alt[0],
+                                                                          alt[1] if alt[1] else '-', alt[2], dma, mfma))
+  print('\nmain loops of these launches per step, model: %.2f ms with the current tiles, %.2f ms taking 256 x 256 wherever the model prefers it'
+        % (t_cur / 1e3, t_alt / 1e3))
