@@ -58,6 +58,9 @@ def parse_args():
                        'GPU-bound step does not depend on it when the host is fast (C2: 10 307 vs 10 302 images/s) but a loaded host '
                        'cannot slow a recorded step down; a replayed graph cannot carry timing events on ROCm, so the last --event_steps '
                        'steps are issued launch by launch for the roofline figure')
+  ap.add_argument('--unshared_steps', type=int, default=2,
+                  help='extra launch-by-launch steps OUTSIDE the timed region with the teacher branch serialised with the student step: '
+                       'the roofline region with the chip to itself (roofline.unshared); 0 = skip')
   ap.add_argument('--event_steps', type=int, default=3,
                   help='with --step_graph 1: this many of the K timed steps run launch by launch, their roofline-region launches '
                        'bracketed by HIP events (a replayed graph cannot carry timing events)')
@@ -460,6 +463,28 @@ def main():
   n_s, ms_s, work_s = profiling.summary(args.roofline_kernel, side=True)
   by_stream = {'main_stream': {'launches': n_m, 'avg_launch_ms': (ms_m / n_m) if n_m else None},
                'teacher_stream': {'launches': n_s, 'avg_launch_ms': (ms_s / n_s) if n_s else None}}
+  # The same region with the chip to itself (`roofline.unshared`, outside the timed region): two more launch-by-launch steps in which the
+  # teacher branch is SERIALISED with the student's step (TeacherAhead.serialise: the side stream waits for the main stream before the
+  # teacher is issued, the next step waits for the teacher as always) -- every launch of the region then runs alone, which is the figure
+  # that is comparable round over round (round 3's bench had no teacher beside the region) and that measures the kernels rather than
+  # the overlap.  `frac` above stays the shared figure: it is what a rocprofv3 trace of this command shows.
+  unshared = None
+  ahead_h = getattr(learner, '_teacher_ahead', None)
+  if world == 1 and n_launch and ahead_h is not None and not getattr(ahead_h, 'handover_only', False) and args.unshared_steps > 0:
+    sync()
+    ahead_h.serialise = True
+    train_step()                                       # (its teacher logits were issued un-serialised by the last timed step)
+    sync()
+    profiling.reset()
+    for _ in range(args.unshared_steps):
+      train_step()
+    sync()
+    ahead_h.serialise = False
+    n_u, ms_u, work_u = profiling.summary(args.roofline_kernel)
+    if n_u and ms_u > 0:
+      unshared = {'launches': n_u, 'avg_launch_ms': ms_u / n_u, 'achieved': work_u / (ms_u * 1e-3) / 1e9, 'unit': 'GB/s',
+                  'frac': work_u / (ms_u * 1e-3) / HBM_PEAK, 'steps': args.unshared_steps,
+                  'how': 'extra launch-by-launch steps outside the timed region, teacher branch serialised with the student step'}
 
   if rank == 0:
     images = args.batch * world * args.steps
@@ -475,7 +500,7 @@ def main():
                 'algorithmic_bytes_per_launch': (work / n_launch) if n_launch else None, 'launches': n_launch,
                 'avg_launch_ms': (ms / n_launch) if n_launch else None,
                 'step_mfma_frac': per_gpu * cfg['flops'] / MFMA_BF16_PEAK,
-                'by_stream': by_stream,
+                'by_stream': by_stream, 'unshared': unshared,
                 'sharing': ('the teacher branch (forward over the next batch, second stream) runs beside these launches: their durations '
                             'include the sharing' if getattr(learner, '_teacher_ahead', None) is not None or (sg is not None and sg.nxt is not None)
                             else 'none')}
@@ -508,8 +533,9 @@ def main():
         'memory': {'after_warmup': mem_warm, 'after_timed_region': mem_after},
         'config': {'workload': cfg['workload'].format(**vars(args)), 'name': args.config,
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
-                   # opt-in experiment (learners/teacher_ahead.py): the teacher's forward over batch k+1 on a second stream
-                   # beside step k's backward; the roofline region then holds the student's launches only
+                   # learners/teacher_ahead.py (the default since round 4): the teacher's forward over batch k+1 on a second stream;
+                   # the roofline region holds BOTH streams' launches (profiling.include_side), `roofline.unshared` the same
+                   # launches with the chip to themselves
                    'teacher': 'next batch, side stream' if getattr(learner, '_teacher_ahead', None) is not None else 'in line',
                    'step_graph': ({'replayed_steps': args.steps - n_event, 'launch_by_launch_steps_with_events': n_event,
                                    'teacher_branch': sg.nxt is not None} if sg is not None else None),

@@ -365,7 +365,10 @@ int pf_conv2d_bwd_data_strided(const void* dY, const void* Wt, void* dX, const v
  * multiply-add per term in a fixed order; the backward-filter pixel splits are summed in ascending order.
  * pf_convg_wrw: `slab` = float32 workspace of pf_convg_wrw_splits(...) * N * R * S * C elements; dw [N][R][S][C] in dw_dtype.
  * pf_convg_fwd / _bwd_data: `slab` (optional, may be null) = float32 workspace of slab_elems elements: an output with fewer than 256
- * tiles of 64 x 64 (the dense layer) then splits its contraction over up to 16 slabs, summed in ascending order. */
+ * tiles of 64 x 64 (the dense layer) then splits its contraction over pf_convg_small_splits(M, Nc, K) slabs (0: no split; M = output
+ * rows, Nc = output columns, K = contraction length -- a function of the shape alone), summed in ascending order; a workspace
+ * smaller than splits * M * Nc elements is hipErrorInvalidValue. */
+int pf_convg_small_splits(int M, int Nc, int K);
 int pf_convg_fwd(const void* x, const void* w, const float* bias, void* y, int dtype, int imgs, int H, int W, int C, int N, int R,
                  int S, int stride, int pad_h, int pad_w, int Ho, int Wo, float* slab, int64_t slab_elems, void* stream);
 int pf_convg_bwd_data(const void* dy, const void* w, void* dx, int dtype, int imgs, int H, int W, int C, int N, int R, int S,

@@ -33,14 +33,11 @@ static void tuning_load() {
     int bm = 0, bn = 0;
     if (sscanf(e, "%dx%d", &bm, &bn) == 2) { t.igemm_tile_bm = bm; t.igemm_tile_bn = bn; }
   }
-  t.igemm_auto256 = env_int("PF_IGEMM_AUTO256", 0);
-  t.igemm_pro256 = env_int("PF_IGEMM_PRO256", 0);
   t.pool3s2 = env_int("PF_POOL3S2", 1);
   t.wrw_tr = env_int("PF_WRW_TR", 0);
   t.wrw2 = env_int("PF_WRW2", 1);
   t.wrw2_target = env_int("PF_WRW2_TARGET", 0);
   t.splitk = env_int("PF_IGEMM_SPLITK", 1);
-  t.dw_reduce2 = env_int("PF_DW_REDUCE2", 0);
   g_tuning = t;
   g_tuning_loaded = true;
 }

@@ -30,12 +30,9 @@ struct PfTuning {
   int conv_stream_maxsplit;       // PF_CONV_STREAM_MAXSPLIT  2
   int igemm_pro3;                 // PF_IGEMM_PRO3         1 (default) | 0
   int igemm_tile_bm, igemm_tile_bn;   // PF_IGEMM_TILE "BMxBN" (0, 0: none)
-  int igemm_auto256;              // PF_IGEMM_AUTO256      0 (default) | T: 256 x 256 tiles for plain launches with N % 256 == 0 and >= T tiles
-  int igemm_pro256;               // PF_IGEMM_PRO256       0 (default) | T: the same for the prologue 1x1 launches (two-stage ring)
   int pool3s2;                    // PF_POOL3S2            1 (default) | 0
   int wrw_tr, wrw2, wrw2_target;  // PF_WRW_TR 0, PF_WRW2 1, PF_WRW2_TARGET 0 (= per-shape default)
   int splitk;                     // PF_IGEMM_SPLITK       1 (default) | 0
-  int dw_reduce2;                 // PF_DW_REDUCE2         0 (default) | 1: depthwise backward-filter slabs through pf_wrw_reduce
 };
 const PfTuning& pf_tuning();
 

@@ -287,14 +287,16 @@ __global__ __launch_bounds__(CG_T) void k_convg_reduce(const float* __restrict__
 
 // Contraction splits of a forward / backward-data launch whose output has too few tiles to fill the chip (the dense layer: 256 x 1001
 // outputs = 64 tiles, 2048 terms each): 0 = one launch writes the output, > 0 = that many float32 slabs + a fixed-order reduction.
-static int cg_small_splits(int M, int Nc, int K, int64_t slab_elems) {
+static int cg_small_splits(int M, int Nc, int K) {
+  // a function of the SHAPE only (round 5): the summation order of a layer must not depend on how large a workspace the
+  // caller happens to hold -- a workspace that is too small for the split the shape asks for is an error, not a different sum
   const int64_t tiles = (int64_t)((M + CG_BM - 1) / CG_BM) * ((Nc + CG_BN - 1) / CG_BN);
   if (tiles >= 256 || K < 512) return 0;
   int s = (int)((512 + tiles - 1) / tiles);
   const int max_s = K / 256;
   if (s > max_s) s = max_s;
   if (s > 16) s = 16;
-  if (s < 2 || (int64_t)s * M * Nc > slab_elems) return 0;
+  if (s < 2 || (int64_t)s * M * Nc > ((int64_t)1 << 24)) return 0;      // (64 MiB of float32 slabs at most)
   return s;
 }
 
@@ -302,7 +304,8 @@ template <typename T, int MODE>
 static int cg_launch_split(CgArgs& a, bool v4, int dtype_unused, float* slab, int64_t slab_elems, hipStream_t st) {
   (void)dtype_unused;
   const int tiles = ((a.M + CG_BM - 1) / CG_BM) * ((a.Nc + CG_BN - 1) / CG_BN);
-  const int splits = (slab != nullptr) ? cg_small_splits(a.M, a.Nc, a.K, slab_elems) : 0;
+  const int splits = (slab != nullptr) ? cg_small_splits(a.M, a.Nc, a.K) : 0;
+  if (splits > 0 && (int64_t)splits * a.M * a.Nc > slab_elems) return (int)hipErrorInvalidValue;
   if (splits == 0) {
     a.slab = nullptr;
     if (v4) k_convg<T, MODE, true><<<dim3((unsigned)tiles, 1, 1), CG_T, 0, st>>>(a);
@@ -345,8 +348,14 @@ static int cg_launch(const CgArgs& a, bool v4, dim3 grid, hipStream_t st) {
   return 0;
 }
 
-// slab / slab_elems: optional float32 workspace (null / 0: none).  With one, a launch whose output is too small to fill the chip splits
-// its contraction (see cg_small_splits) -- results are deterministic either way, but differ in summation order between the two forms.
+// slab / slab_elems: optional float32 workspace (null / 0: none: one ascending sum per output).  With one, a launch whose output is too
+// small to fill the chip splits its contraction into pf_convg_small_splits(M, Nc, K) slabs -- a function of the shape alone, so that a
+// layer sums in the same order whatever else has grown the caller's workspace; a workspace smaller than splits * M * Nc is an error.
+extern "C" int pf_convg_small_splits(int M, int Nc, int K) {
+  if (M <= 0 || Nc <= 0 || K <= 0) return 0;
+  return cg_small_splits(M, Nc, K);
+}
+
 extern "C" int pf_convg_fwd(const void* x, const void* w, const float* bias, void* y, int dtype, int imgs, int H, int W, int C,
                             int N, int R, int S, int stride, int pad_h, int pad_w, int Ho, int Wo, float* slab, int64_t slab_elems,
                             void* stream) {

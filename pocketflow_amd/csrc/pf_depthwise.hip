@@ -237,15 +237,6 @@ __global__ __launch_bounds__(DW_T) void k_dw_wrw(const DwArgs a) {
   }
 }
 
-template <typename TO>
-__global__ __launch_bounds__(DW_T) void k_dw_wrw_reduce(const float* __restrict__ slabs, int G, int n, TO* __restrict__ dw) {
-  const int e = blockIdx.x * DW_T + threadIdx.x;
-  if (e >= n) return;
-  float v = 0.f;
-  for (int g = 0; g < G; ++g) v += slabs[(int64_t)g * n + e];
-  store_one<TO>(dw + e, v);
-}
-
 // ---- host side ---------------------------------------------------------------------------------------------------
 static bool dw_shape_ok(int C, int k) { return k == 3 && C >= 8 && (C % 8) == 0 && C <= 2048 && (DW_T % (C / 8)) == 0; }
 
@@ -353,15 +344,9 @@ extern "C" int pf_depthwise_wrw(const void* dY, const void* X, void* dW, int dty
   else return (int)hipErrorInvalidValue;
 #undef PF_DWW
   const int n = C * 9;
-  // PF_DW_REDUCE2=1 (prepared at the end of round 4, NOT yet run on hardware; A/B in the first GPU call of round 5): the slabs go
-  // through the staged reduction of the other backward-filter kernels (pf_wrw_reduce: 64 outputs x 4 interleaved slab lanes per
-  // workgroup, split ranges on gridDim.y, a second launch folds the ranges; fixed order).  k_dw_wrw_reduce below runs ONE thread per
-  // output over all G <= 1024 slabs: C * 9 threads in total, 271 us per launch in profiles/r04_step_kernels_c3.csv (14.6 % of that
-  // step's GPU time for 19 MB of reads).
-  if (pf_tuning().dw_reduce2 != 0) return pf_wrw_reduce(slabs, grid, (int64_t)n, dW, dw_dtype, st);
-  if (dw_dtype == PF_F32) k_dw_wrw_reduce<float><<<(n + DW_T - 1) / DW_T, DW_T, 0, st>>>(slabs, grid, n, (float*)dW);
-  else if (dw_dtype == PF_BF16) k_dw_wrw_reduce<bf16_t><<<(n + DW_T - 1) / DW_T, DW_T, 0, st>>>(slabs, grid, n, (bf16_t*)dW);
-  else return (int)hipErrorInvalidValue;
-  PF_LAUNCH_CHECK();
-  return 0;
+  // The slabs go through the staged reduction of the other backward-filter kernels (pf_wrw_reduce: 64 outputs x 4 interleaved slab
+  // lanes per workgroup, split ranges on gridDim.y, a second launch folds the ranges; fixed order).  Round 4's own reduction ran ONE
+  // thread per output over all G <= 1024 slabs (271 us per launch, 14.6 % of the C3 step); measured in round 5's first GPU call
+  // (profiles/r05_first_call_ab.txt): C3 13 602 -> 16 140 images/s with this one, the old kernel is gone.
+  return pf_wrw_reduce(slabs, grid, (int64_t)n, dW, dw_dtype, st);
 }

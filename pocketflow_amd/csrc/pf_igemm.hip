@@ -646,11 +646,6 @@ static bool ig_pro3_enabled() {
 // ONE decision for the launcher and for the statistics-group query (the [G][.][N] partial array is sized from it)
 static IgCfg ig_pick(int M, int N, bool pro) {
   if (pro) {
-    // PF_IGEMM_PRO256=T (prepared at the end of round 4, never run on hardware): 256 x 256 tiles, eight wavefronts of 64 x 128, on the
-    // TWO-stage ring (three stages of 64 KiB do not fit the LDS): 8 MFMAs per LDS-DMA piece instead of 5.3, the in-LDS prologue pass
-    // amortised over 256 output channels as before, but not overlapped with the matrix work (round 2's form of the pass).
-    if (pf_tuning().igemm_pro256 > 0 && N % 256 == 0 && (int64_t)((M + 255) / 256) * (N / 256) >= pf_tuning().igemm_pro256)
-      return IgCfg{256, 256, 256, false};
     // prologue variant.  Three stages, 8 wavefronts, one workgroup per CU: 128 x 256 tiles where N allows (the in-LDS
     // prologue pass over the input tile is amortised over 256 output channels), 256 x 128 otherwise.
     if (ig_pro3_enabled()) {
@@ -665,11 +660,8 @@ static IgCfg ig_pick(int M, int N, bool pro) {
         (N % bn == 0 || bn == 64))
       return IgCfg{bm, bn, (bm == 256) ? 256 : 512, false};
   }
-  // PF_IGEMM_AUTO256=T (prepared at the end of round 4, never run on hardware): 256 x 256 tiles -- eight wavefronts of 64 x 128, twice
-  // the matrix work per LDS-DMA piece, DESIGN.md section 9 -- where the output has 256-channel tiles and at least T of them (one
-  // workgroup per CU: fewer than ~128 tiles leave most of the chip idle).  The instantiations are the ones PF_IGEMM_TILE=256x256 selects.
-  if (pf_tuning().igemm_auto256 > 0 && N % 256 == 0 && (int64_t)((M + 255) / 256) * (N / 256) >= pf_tuning().igemm_auto256)
-    return IgCfg{256, 256, 256, false};
+  // (256 x 256 tiles by per-layer selection -- PF_IGEMM_AUTO256 / PF_IGEMM_PRO256, prepared in round 4 -- were measured in round 5's first GPU
+  // call: 10 302 / 10 310 / 10 210 / 10 283 images/s for off / plain / prologue / both, i.e. nothing, profiles/r05_first_call_ab.txt; deleted)
   const int bn = (N % 128 == 0) ? 128 : 64;
   // measured on the ResNet-50 shapes at batch 256 (tools/gpu/igemm_bench.py): 128-row tiles with two workgroups per CU
   // (2 LDS stages each) beat 256-row tiles with one workgroup per CU and 3 stages on every shape (e.g. 3x3 C = 256 at
@@ -729,7 +721,6 @@ static int ig_launch(IgArgs& a, hipStream_t st) {
     if (a.th * a.tw != 1 || bwd) return (int)hipErrorInvalidValue;
     if (c.pro3) return (c.bn == 256) ? ig_launch_t<128, 256, 2, 4, 3, IG_PRO>(a, c.slots, st)
                                      : ig_launch_t<256, 128, 4, 2, 3, IG_PRO>(a, c.slots, st);
-    if (c.bm == 256 && c.bn == 256) return ig_launch_t<256, 256, 4, 2, 2, IG_PRO>(a, c.slots, st);   // PF_IGEMM_PRO256
     return (c.bn == 128) ? ig_launch_t<128, 128, 2, 2, 2, IG_PRO>(a, c.slots, st) : ig_launch_t<128, 64, 2, 2, 2, IG_PRO>(a, c.slots, st);
   }
 #define PF_IG(BMV, BNV, WMV, WNV, NSV) (bwd ? ig_launch_t<BMV, BNV, WMV, WNV, NSV, IG_BWD>(a, c.slots, st) : ig_launch_t<BMV, BNV, WMV, WNV, NSV, IG_PLAIN>(a, c.slots, st))

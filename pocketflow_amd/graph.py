@@ -843,12 +843,6 @@ OWN_STEM = os.environ.get('PF_OWN_STEM', '1') != '0'         # the 7x7/2 stem on
 OWN_DEPTHWISE = os.environ.get('PF_OWN_DEPTHWISE', '1') != '0'   # depthwise 3x3 on pf_depthwise.hip (0: MIOpen, for A/B runs)
 OWN_CONV_IM2COL = os.environ.get('PF_OWN_CONV_IM2COL', '1') != '0'   # few-channel RxS convolutions as im2col + own 1x1 kernels (0: MIOpen)
 CONVG_BF16_NARROW = os.environ.get('PF_CONVG_BF16_NARROW', '0') != '0'
-# PF_CONVG_PAD_C3=1 (prepared at the end of round 4, never run on hardware; A/B in the first GPU call of round 5): image convolutions
-# (3 input channels) run on k_convg with the channels padded to 4 -- the kernel's 4-element vector loader (one index decomposition
-# per 4 contraction terms, 8-byte loads) instead of its element-wise one.  The fourth channel is zero in x and W: every sum keeps
-# its terms and their order (acc + 0 * w = acc exactly).  MobileNet's first convolution costs 468 + 497 us per step on the
-# element-wise path (profiles/r04_step_kernels_c3.csv) against an HBM floor of ~45 us each.
-CONVG_PAD_C3 = os.environ.get('PF_CONVG_PAD_C3', '0') != '0'
 OWN_CONV_GENERIC = os.environ.get('PF_OWN_CONV_GENERIC', '1') != '0'   # every other convolution / dense layer on pf_convg.hip (0: MIOpen / rocBLAS)
 DEPTHWISE_ANY_DEVICE = False     # tests: run the depthwise plumbing on CPU tensors (the HIP entry points are emulated there)
 
@@ -975,25 +969,22 @@ class _ConvGeneric(torch.autograd.Function):
     wk = w.detach().permute(0, 2, 3, 1)
     if not wk.is_contiguous() or wk.dtype != x.dtype:
       wk = wk.contiguous().to(x.dtype)
-    pad_c = CONVG_PAD_C3 and C == 3
-    if pad_c:
-      x, wk, C = _pad_channels(x, 4), _pad_last(wk, 4), 4
     y = torch.empty((B, N, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     bf = None if bias is None else bias.detach().float().contiguous()
     with region('convg_fwd', float((x.numel() + y.numel()) * x.element_size())):
       # (split contraction of small outputs in bf16 only: the float32 parity mode keeps ONE ascending sum per output -- the conditioned
       # ResNet-50 gradient test moves from 1.7e-3 to 1.9e-2 on its most sensitive BN scale with the dense layer summed in 8 slabs)
       hip.convg_fwd(x, wk, bf, y, B, H, Wd, C, N, R, S, stride, pad[0], pad[1], Ho, Wo,
-                    slab=graph.scratch(1 << 20) if x.dtype == torch.bfloat16 else None)
-    ctx.save_for_backward(x, w)                              # (pad_c: the padded input -- backward-filter reads it as it is)
-    ctx.meta = (stride, pad, out_hw, graph, bias is not None, pad_c)
+                    slab=_convg_slab(graph, x.dtype, B * Ho * Wo, N, R * S * C))
+    ctx.save_for_backward(x, w)
+    ctx.meta = (stride, pad, out_hw, graph, bias is not None)
     return y
 
   @staticmethod
   def backward(ctx, dy):
     x, w = ctx.saved_tensors
-    stride, pad, (Ho, Wo), graph, has_bias, pad_c = ctx.meta
-    B, C, H, Wd = x.shape                                    # (pad_c: C == 4, the padded input)
+    stride, pad, (Ho, Wo), graph, has_bias = ctx.meta
+    B, C, H, Wd = x.shape
     N, _, R, S = w.shape
     dy = _nhwc(dy)
     if dy.dtype != x.dtype:
@@ -1003,36 +994,30 @@ class _ConvGeneric(torch.autograd.Function):
       wk = w.detach().permute(0, 2, 3, 1)
       if not wk.is_contiguous() or wk.dtype != x.dtype:
         wk = wk.contiguous().to(x.dtype)
-      if pad_c:
-        wk = _pad_last(wk, 4)
       dx = torch.empty_like(x, memory_format=torch.channels_last)
       with region('convg_bwd_data', float((dy.numel() + dx.numel()) * x.element_size())):
         hip.convg_bwd_data(dy, wk, dx, B, H, Wd, C, N, R, S, stride, pad[0], pad[1], Ho, Wo,
-                           slab=graph.scratch(1 << 20) if x.dtype == torch.bfloat16 else None)
-      if pad_c:
-        dx = dx[:, :3]
+                           slab=_convg_slab(graph, x.dtype, B * H * Wd, C, R * S * N))
     if ctx.needs_input_grad[1]:
       splits = hip.convg_wrw_splits(B, C, N, R, S, Ho, Wo)
       dwk = torch.empty((N, R, S, C), dtype=w.dtype, device=x.device)
       with region('convg_wrw', float((dy.numel() + x.numel()) * x.element_size())):
         hip.convg_wrw(dy, x, dwk, graph.scratch(splits * N * R * S * C), B, H, Wd, C, N, R, S, stride, pad[0], pad[1], Ho, Wo)
-      dw = (dwk[..., :3] if pad_c else dwk).permute(0, 3, 1, 2)
+      dw = dwk.permute(0, 3, 1, 2)
     if has_bias and ctx.needs_input_grad[2]:
       db = dy.float().sum(dim=(0, 2, 3))
     return dx, dw, db, None, None, None, None
 
 
-def _pad_channels(x: torch.Tensor, c: int) -> torch.Tensor:
-  """x (logical NCHW, physical NHWC) with zero channels appended up to c."""
-  out = torch.zeros((x.shape[0], c, x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
-  out[:, :x.shape[1]] = x
-  return out
-
-
-def _pad_last(t: torch.Tensor, c: int) -> torch.Tensor:
-  out = torch.zeros(t.shape[:-1] + (c,), dtype=t.dtype, device=t.device)
-  out[..., :t.shape[-1]] = t
-  return out
+def _convg_slab(graph, dtype, M: int, Nc: int, K: int):
+  """Workspace of a k_convg forward / backward-data launch: EXACTLY what the shape's contraction split needs (hip.convg_small_splits --
+  the kernel library decides from the shape alone, so a layer sums in the same order in step 1 and in step 1000, whatever other
+  operators have grown the shared scratch to meanwhile); None in the float32 parity mode (one ascending sum per output) and for
+  shapes that do not split."""
+  if dtype != torch.bfloat16:
+    return None
+  splits = hip.convg_small_splits(M, Nc, K)
+  return graph.scratch(splits * M * Nc) if splits > 0 else None
 
 
 def convg_ok(x: torch.Tensor, w: torch.Tensor, dense: bool = False) -> bool:

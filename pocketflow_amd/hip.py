@@ -47,7 +47,7 @@ SYMBOLS = [
     'pf_image_resize_bilinear', 'pf_depthwise_supported', 'pf_depthwise_groups', 'pf_depthwise_fwd', 'pf_depthwise_bwd_data',
     'pf_depthwise_wrw', 'pf_conv2d_stats_groups_geom', 'pf_tuning_reload',
     'pf_adam_flat_dev', 'pf_momentum_flat_dev', 'pf_set_floats',
-    'pf_convg_fwd', 'pf_convg_bwd_data', 'pf_convg_wrw_splits', 'pf_convg_wrw', 'pf_conv2d_bwd_data_strided',
+    'pf_convg_fwd', 'pf_convg_bwd_data', 'pf_convg_small_splits', 'pf_convg_wrw_splits', 'pf_convg_wrw', 'pf_conv2d_bwd_data_strided',
     'pf_prox_groups', 'pf_prox_norms', 'pf_prox_apply', 'pf_im2col', 'pf_col2im',
 ]
 
@@ -521,6 +521,12 @@ def convg_bwd_data(dY, Wk, dX, B: int, H: int, Wd: int, C: int, N: int, R: int, 
   _check(_lib.pf_convg_bwd_data(_ptr(dY), _ptr(Wk), _ptr(dX), c_int(dtype_code(dY)), c_int(B), c_int(H), c_int(Wd), c_int(C),
                                 c_int(N), c_int(R), c_int(S), c_int(stride), c_int(pad_h), c_int(pad_w), c_int(Ho), c_int(Wo),
                                 _ptr(slab), c_int64(slab.numel() if slab is not None else 0), _stream()), 'pf_convg_bwd_data')
+
+
+def convg_small_splits(M: int, Nc: int, K: int) -> int:
+  """Contraction splits of a forward / backward-data launch with M x Nc outputs and K terms each (0: none) -- shape only; the
+  workspace to pass as `slab` is splits * M * Nc float32 elements."""
+  return int(_lib.pf_convg_small_splits(c_int(M), c_int(Nc), c_int(K)))
 
 
 def convg_wrw_splits(B: int, C: int, N: int, R: int, S: int, Ho: int, Wo: int) -> int:

@@ -183,6 +183,9 @@ class AbstractLearner(ABC):  # pylint: disable=too-many-instance-attributes
     """One fine-tune iteration (`sess.run(train_op)` of the reference learners): the learner's `_train_step_eager`, or -- with
     --enbl_step_graph, single process -- the same step replayed from a hipGraph (step_graph.py)."""
     if args or kwargs or not FLAGS.enbl_step_graph or FLAGS.enbl_multi_gpu:
+      sg = getattr(self, '_step_graph', None)
+      if sg is not None:
+        sg.yield_to_eager()                                # the batches a ready step graph holds are the next ones in data order
       return _detached(self._train_step_eager(*args, **kwargs))
     from pocketflow_amd import step_graph
     return _detached(step_graph.of(self).step())

@@ -94,6 +94,8 @@ class TeacherAhead(object):
   def __init__(self, learner, streams):
     self.learner, self.streams, self.pending = learner, streams, None
     self.n_issued = self.n_taken = 0
+    self.handover_only = False    # made by a suspended step graph for ONE hand-over although the user switched the helper off
+    self.serialise = False        # bench.py (roofline.unshared): the side stream waits for the main stream before the teacher is issued
 
   def issue(self):
     """Fetch batch k+1, upload it and run the teacher over it -- all on the side stream."""
@@ -106,6 +108,8 @@ class TeacherAhead(object):
     # chip and it is worth +6 %): -6 % launch by launch (9 251 vs 9 839 recorded in one box -- launch by launch the persistent kernels
     # of the two streams alternate instead of sharing); teacher beside the backward pass +0.5 %; backward-filter launches on a third
     # stream -2.8 %.
+    if self.serialise:                                     # measurement mode: nothing of this batch runs beside step k
+      st.side_waits_for_main()
     with st.on_side(), profiling.suspended():
       # the iterator itself may enqueue device work (pinned upload + resize kernel of the TFRecord reader run on the CURRENT stream):
       # it has to be the side stream, or the teacher would read a batch the main stream has not finished writing
@@ -178,7 +182,10 @@ def next_batch(learner):
     return (None,) + tuple(static)
   ahead = of(learner)
   if ahead is not None and ahead.pending is not None:
-    return (ahead,) + ahead.take()
+    taken = ahead.take()
+    if ahead.handover_only:                          # PF_TEACHER_AHEAD=0: the hand-over is done, the helper does not stay (ADVICE r4:
+      learner._teacher_ahead = ahead = None          # it used to, and every later eager step ran the teacher one step ahead)
+    return (ahead,) + taken
   images, labels = fetch_raw(learner)
   x, y = learner.to_device(images, labels)
   return ahead, x, y, None
@@ -187,9 +194,15 @@ def next_batch(learner):
 def next_images(learner):
   """iter_train.get_next()[0] for every consumer of the training iterator that is not train_step (layer-wise tuning): the batch a
   previous step prefetched comes first."""
+  sg = getattr(learner, '_step_graph', None)
+  if sg is not None:
+    sg.yield_to_eager()                              # a ready step graph holds the next batches: they come first
   ahead = of(learner)
   if ahead is not None and ahead.pending is not None and ahead.pending[4] is not None:
-    return ahead.take_images()
+    images = ahead.take_images()
+    if ahead.handover_only:
+      learner._teacher_ahead = None
+    return images
   return fetch_raw(learner)[0]
 
 
@@ -199,6 +212,11 @@ def drop(learner):
   ahead = getattr(learner, '_teacher_ahead', None)
   if ahead is not None:
     ahead.drop()
+    if ahead.handover_only:
+      learner._teacher_ahead = None
   back = getattr(learner, '_unget', None)
   if back:
     del back[:]
+  sg = getattr(learner, '_step_graph', None)
+  if sg is not None:
+    sg.discard_lookahead()                           # a ready step graph holds two more batches of that pass in its static buffers

@@ -129,6 +129,8 @@ class StepGraph(object):
     self.cur_raw = None                     # without a teacher: the batch already loaded into `cur` (not yet consumed by a replay)
     self.cur_images = None                  # with a teacher: the images behind `cur` as the iterator delivered them (teacher_ahead.next_images)
     self.error = None
+    self.lookahead_void = False             # the iterator was reset behind the batches held here: they belong to its previous pass
+    self.auto_suspended = False             # suspended for ONE foreign consumer of the iterator; the next plain step resumes
 
   # -- mode switches --------------------------------------------------------------------------------
   def suspend(self):
@@ -138,12 +140,29 @@ class StepGraph(object):
     if self.state == 'ready':
       self.learner.optimizer.hyper_external = False
     self.suspended = True
+    self.auto_suspended = False
 
   def resume(self):
     if self.suspended and self.state == 'ready':
       self.learner.optimizer.hyper_external = True
       self._load_current()
     self.suspended = False
+    self.auto_suspended = False
+
+  def yield_to_eager(self):
+    """Another consumer of the training iterator runs NOW (a `train_step` with arguments, layer-wise tuning's `next_images`): hand
+    the batches held in the static buffers over, so that it sees the batch the next replay would have seen; the next plain step
+    resumes the replays by itself (those consumers used to read PAST the held batches)."""
+    if self.state == 'ready' and not self.suspended:
+      self.suspend()
+      self.auto_suspended = True
+
+  def discard_lookahead(self):
+    """The training iterator was reset or re-built: the batches held here were drawn from its previous pass.  Forget them WITHOUT
+    handing them back (teacher_ahead.drop calls this); the next replay re-fills the static buffers from the iterator."""
+    self.nxt_raw = self.cur_raw = self.cur_images = None
+    if self.state == 'ready' and not self.suspended:
+      self.lookahead_void = True
 
   def invalidate(self):
     """Something the recorded launches carry by value changed (bit widths, masks re-built, optimiser replaced): record again."""
@@ -153,12 +172,14 @@ class StepGraph(object):
     if self.state != 'failed':
       self.state, self.n_eager, self.suspended = 'warm', 0, False
       self.out = self.cur = self.nxt = self.nxt_raw = self.cur_raw = self.cur_images = None
-      self.nxt_stale = False
+      self.nxt_stale = self.lookahead_void = self.auto_suspended = False
       self.backend = type(self.backend)(self.learner.device) if isinstance(self.backend, CudaBackend) else InlineBackend()
 
   # -- one step ---------------------------------------------------------------------------------------
   def step(self):
     lrn = self.learner
+    if self.suspended and self.auto_suspended and self.state == 'ready':
+      self.resume()
     if self.state == 'failed' or self.suspended:
       return lrn._train_step_eager()
     if self.state == 'warm':
@@ -197,6 +218,7 @@ class StepGraph(object):
     """Fill the static buffers of the NEXT replay: distillation -> (current from what an eager step prefetched or from the iterator
     with the teacher in line, next from the iterator); otherwise nothing (the batch is fetched right before each replay)."""
     lrn = self.learner
+    self.lookahead_void = False
     if self.nxt is None:
       return
     ahead = teacher_ahead.of(lrn)
@@ -218,6 +240,10 @@ class StepGraph(object):
   def _hand_to_eager(self):
     """The batch in `current` (its teacher logits are computed) is the next one in data order: the eager path takes it first."""
     lrn = self.learner
+    if self.lookahead_void:                                # (drawn from a pass of the iterator that is over: nothing to hand over)
+      self.lookahead_void = False
+      self.nxt_raw = self.cur_raw = None
+      return
     if self.nxt is None:
       if self.cur_raw is not None:                         # drawn, never consumed: back in front of the iterator
         lrn.__dict__.setdefault('_unget', []).insert(0, self.cur_raw)
@@ -225,8 +251,9 @@ class StepGraph(object):
       return
     x, y, logits = (t.clone() for t in self.cur)
     ahead = teacher_ahead.of(lrn)
-    if ahead is None:                                      # (PF_TEACHER_AHEAD=0 with distillation: a helper just for the hand-over)
-      ahead = lrn._teacher_ahead = teacher_ahead.TeacherAhead(lrn, teacher_ahead.InlineStreams())
+    if ahead is None:                                      # (PF_TEACHER_AHEAD=0 with distillation: a helper just for the hand-over --
+      ahead = lrn._teacher_ahead = teacher_ahead.TeacherAhead(lrn, teacher_ahead.InlineStreams())   # gone again once the batch is taken)
+      ahead.handover_only = True
     if ahead.pending is not None:
       ahead.drop()
     ahead.pending = (x, y, logits, None, self.cur_images)
@@ -302,6 +329,9 @@ class StepGraph(object):
     attr = _step_attr(lrn)
     step = getattr(lrn, attr)
     lr = lrn.lrn_rate(step)
+    if self.lookahead_void:                                # the iterator was reset: both static batches are re-drawn from it
+      self.cur_raw = None
+      self._load_current()
     if self.nxt is None:
       if self.cur_raw is not None:
         self.cur_raw = None                                  # loaded when the step was recorded / resumed

@@ -140,19 +140,6 @@ def test_conv1x1_fwd_prologue_three_stage_kernel(hip, M, N, K, act, bits, monkey
   for mode in ('2',):                                          # and so do their statistics (different partial layouts, same sums)
     torch.testing.assert_close(out[mode][1][:, 0].sum(0), partial[:, 0].sum(0), rtol=1e-5, atol=1e-3)
     assert torch.equal(out[mode][1][:, 2].min(0).values, partial[:, 2].min(0).values)
-  if os.environ.get('PF_TEST_PREPARED') == '1' and N % 256 == 0:
-    # PF_IGEMM_PRO256 (csrc/pf_igemm.hip ig_pick): 256 x 256 tiles on the two-stage ring -- the prologue arithmetic and the k order of
-    # the two-stage kernel, so the outputs must be ITS outputs bit for bit.  Prepared without a GPU at the end of round 4; runs only
-    # on request until a GPU session has seen it pass.
-    monkeypatch.setenv('PF_IGEMM_PRO256', '1')
-    G = hip.conv1x1_stats_groups(M, N, K, prologue=True)
-    p256 = torch.full((G, 4, N), float('nan'), device='cuda')
-    Y256 = torch.full((M, N), float('nan'), device='cuda', dtype=torch.bfloat16)
-    hip.conv1x1_fwd(X, W, Y256, M, N, K, R=R, scale_shift=ss, act=act, slot=sl, bits=bits or 8, partial=p256)
-    assert torch.equal(Y256, out['2'][0]), '256 x 256 prologue tile differs from the two-stage kernel'
-    assert not torch.isnan(p256).any()
-    torch.testing.assert_close(p256[:, 0].sum(0), partial[:, 0].sum(0), rtol=1e-5, atol=1e-3)
-    assert torch.equal(p256[:, 2].min(0).values, partial[:, 2].min(0).values) and torch.equal(p256[:, 3].max(0).values, partial[:, 3].max(0).values)
 
 
 # PF_CONV_STREAM_MAXSPLIT > 2: the resident-kernel variant with a row panel cut into 4 / 8 / 32 column slices (the conv3 layers

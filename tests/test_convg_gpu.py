@@ -62,13 +62,23 @@ def test_convg_forward_backward_data_backward_filter(dtype, imgs, H, W, C, N, R,
   close(y, yr.detach(), 'forward')
   close(dx, xr.grad, 'backward-data')
   # with a workspace, an output of few tiles (the dense layer) splits its contraction over slabs: same result up to summation order
-  ws = torch.full((1 << 20,), float('nan'), dtype=torch.float32, device='cuda')
+  # (the split is a function of the shape -- hip.convg_small_splits -- and the workspace must hold splits * M * Nc floats)
+  need = max(hip.convg_small_splits(imgs * Ho * Wo, N, R * R * C) * imgs * Ho * Wo * N,
+             hip.convg_small_splits(imgs * H * W, C, R * R * N) * imgs * H * W * C, 1)
+  ws = torch.full((need,), float('nan'), dtype=torch.float32, device='cuda')
   ys, dxs = torch.full_like(y, float('nan')), torch.full_like(dx, float('nan'))
   hip.convg_fwd(xs, wk, b, ys, imgs, H, W, C, N, R, R, stride, pad, pad, Ho, Wo, slab=ws)
   hip.convg_bwd_data(dys, wk, dxs, imgs, H, W, C, N, R, R, stride, pad, pad, Ho, Wo, slab=ws)
   close(ys, yr.detach(), 'forward (split contraction)')
   close(dxs, xr.grad, 'backward-data (split contraction)')
   close(dwk.permute(0, 3, 1, 2), wr.grad, 'backward-filter')
+  # the summation order does not depend on how large the caller's workspace is (the layer executor's shared scratch grows
+  # during a run): a 16x larger workspace gives the same bits
+  big = torch.full((need * 16 + (1 << 22),), float('nan'), dtype=torch.float32, device='cuda')
+  yb, dxb = torch.full_like(y, float('nan')), torch.full_like(dx, float('nan'))
+  hip.convg_fwd(xs, wk, b, yb, imgs, H, W, C, N, R, R, stride, pad, pad, Ho, Wo, slab=big)
+  hip.convg_bwd_data(dys, wk, dxb, imgs, H, W, C, N, R, R, stride, pad, pad, Ho, Wo, slab=big)
+  assert torch.equal(ys, yb) and torch.equal(dxs, dxb)
   # deterministic: a second call gives the same bits
   y2 = torch.empty_like(y)
   hip.convg_fwd(xs, wk, b, y2, imgs, H, W, C, N, R, R, stride, pad, pad, Ho, Wo)

@@ -1026,6 +1026,58 @@ def test_step_graph_control_flow_uq_distillation_on_cpu(cpu_learners, monkeypatc
 
 
 @pytest.mark.parametrize('ahead', ['inline', '0'])
+def test_step_graph_foreign_consumers_and_iterator_reset_keep_the_eager_data_order(cpu_learners, monkeypatch, ahead):
+  """while a step graph is READY (not suspended) it holds the next two batches in its static buffers.  (1) Another
+  consumer of the training iterator (`teacher_ahead.next_images`: layer-wise tuning) must get THOSE batches first, and the next plain
+  step must resume the replays by itself; (2) `teacher_ahead.drop` + an iterator reset (the channel pruner's sampling pass) must
+  forget them -- they belong to the iterator's previous pass -- instead of handing them back after the reset; (3) with
+  PF_TEACHER_AHEAD=0 the helper that a suspended graph makes for the hand-over must not stay.  Reference: the eager run doing the same."""
+  FLAGS, fake, tmp = cpu_learners
+  from pocketflow_amd.nets.resnet_at_cifar10 import ModelHelper
+  from pocketflow_amd.learners.uniform_quantization.learner import UniformQuantLearner
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  from pocketflow_amd.learners import teacher_ahead
+  from pocketflow_amd import step_graph
+  FLAGS.batch_size, FLAGS.batch_size_eval, FLAGS.nb_classes, FLAGS.resnet_size = 8, 8, 10, 20
+  FLAGS.uql_weight_bits, FLAGS.uql_activation_bits, FLAGS.uql_use_buckets, FLAGS.uql_bucket_type = 8, 8, False, 'channel'
+  FLAGS.enbl_dst, FLAGS.dst_eval_teacher = True, False
+  FLAGS.uql_save_quant_model_path = str(tmp / 'uql' / 'm.ckpt')
+  FLAGS.synthetic_pool = 7
+  monkeypatch.setenv('PF_TEACHER_AHEAD', ahead)
+
+  def make():
+    mh = ModelHelper()
+    create_synthetic_checkpoint(mh)
+    return UniformQuantLearner(None, mh)
+
+  def loss_of(o):
+    return float(o['loss'].detach())
+
+  def run(graph_mode):
+    lrn, losses = _run_steps(make, 6, graph_mode, monkeypatch, FLAGS=FLAGS)
+    if graph_mode:
+      assert step_graph.of(lrn).state == 'ready' and not step_graph.of(lrn).suspended
+    seen = [torch.as_tensor(teacher_ahead.next_images(lrn)).clone() for _ in range(2)]     # a foreign consumer, graph READY
+    losses += [loss_of(lrn.train_step()) for _ in range(2)]
+    if graph_mode:
+      sg = step_graph.of(lrn)
+      assert sg.state == 'ready' and not sg.suspended and sg.n_replays == 3 + 2          # resumed by itself
+      if ahead == '0':
+        assert getattr(lrn, '_teacher_ahead', None) is None                               # the hand-over helper did not stay
+    teacher_ahead.drop(lrn)                                                               # as ChannelPrunedLearner.create_pruner does
+    lrn.iter_train.reset()
+    losses += [loss_of(lrn.train_step()) for _ in range(3)]
+    return lrn, losses, seen
+  base, l0, s0 = run(False)
+  lrn, l1, s1 = run(True)
+  assert all(torch.equal(a, b) for a, b in zip(s0, s1))
+  assert l0 == l1, (l0, l1)
+  a, b = base.graph.store.export_numpy(), lrn.graph.store.export_numpy()
+  assert all(np.array_equal(a[k], b[k]) for k in a)
+  assert step_graph.of(lrn).n_replays == 3 + 2 + 3 and getattr(lrn, '_unget', None) in (None, [])
+
+
+@pytest.mark.parametrize('ahead', ['inline', '0'])
 def test_step_graph_failed_recording_leaves_the_eager_run_untouched(cpu_learners, monkeypatch, ahead):
   """A recording that fails half-way (a library call that cannot be captured, hipStreamEndCapture refusing the graph): nothing of
   it executed on the device, so the eager path that takes over has to continue from the step counter and Adam powers of the last
@@ -1170,75 +1222,3 @@ def test_bf16_parity_bodies_of_the_other_configurations_on_cpu(cpu_learners, mon
   FLAGS.save_path = str(tmp / 'nuq' / 'models' / 'model.ckpt')
   FLAGS.synthetic_pool, FLAGS.compute_dtype = 2, 'float32'
   run_nuq_bf16_parity(FLAGS, tmp / 'nuq', expect_bf16=False, batch=4, steps=1)
-
-
-def test_conv_generic_channel_padding_plumbing(monkeypatch):
-  """graph._ConvGeneric with PF_CONVG_PAD_C3 (image convolutions on k_convg's vector loader: 3 -> 4 channels, zeros in x and W)
-  against the unpadded call, with the three pf_convg entry points emulated in float64 on the CPU: same output, same kernel and bias
-  gradients, an input gradient of the ORIGINAL three channels -- the slicing / permuting around the launches is what is checked."""
-  import torch.nn.functional as F
-  from pocketflow_amd import graph as G
-
-  calls = []
-
-  class Emu(object):
-    @staticmethod
-    def _nchw(t, B, H, W, C):
-      return t.detach().permute(0, 2, 3, 1).reshape(B, H, W, C).permute(0, 3, 1, 2).double()
-
-    def convg_fwd(self, X, Wk, bias, Y, B, H, Wd, C, N, R, S, stride, ph, pw, Ho, Wo, slab=None):
-      calls.append(('fwd', C))
-      assert tuple(X.shape) == (B, C, H, Wd) and tuple(Wk.shape) == (N, R, S, C) and Wk.is_contiguous()
-      assert X.is_contiguous(memory_format=torch.channels_last)
-      eh = (Ho - 1) * stride + R - H - ph
-      ew = (Wo - 1) * stride + S - Wd - pw
-      y = F.conv2d(F.pad(X.double(), (pw, ew, ph, eh)), Wk.permute(0, 3, 1, 2).double(), None if bias is None else bias.double(), stride=stride)
-      Y.copy_(y.to(Y.dtype))
-
-    def convg_bwd_data(self, dY, Wk, dX, B, H, Wd, C, N, R, S, stride, ph, pw, Ho, Wo, slab=None):
-      calls.append(('bwd_data', C))
-      assert tuple(Wk.shape) == (N, R, S, C) and tuple(dX.shape) == (B, C, H, Wd)
-      eh = (Ho - 1) * stride + R - H - ph
-      ew = (Wo - 1) * stride + S - Wd - pw
-      x = torch.zeros(B, C, H, Wd, dtype=torch.float64, requires_grad=True)
-      with torch.enable_grad():
-        y = F.conv2d(F.pad(x, (pw, ew, ph, eh)), Wk.permute(0, 3, 1, 2).double(), stride=stride)
-        (g,) = torch.autograd.grad(y, x, dY.double())
-      dX.copy_(g.to(dX.dtype))
-
-    def convg_wrw_splits(self, B, C, N, R, S, Ho, Wo):
-      return 2
-
-    def convg_wrw(self, dY, X, dW, slab, B, H, Wd, C, N, R, S, stride, ph, pw, Ho, Wo):
-      calls.append(('wrw', C))
-      assert tuple(X.shape) == (B, C, H, Wd) and tuple(dW.shape) == (N, R, S, C) and slab.numel() >= 2 * N * R * S * C
-      eh = (Ho - 1) * stride + R - H - ph
-      ew = (Wo - 1) * stride + S - Wd - pw
-      w = torch.zeros(N, C, R, S, dtype=torch.float64, requires_grad=True)
-      with torch.enable_grad():
-        y = F.conv2d(F.pad(X.double(), (pw, ew, ph, eh)), w, stride=stride)
-        (g,) = torch.autograd.grad(y, w, dY.double())
-      dW.copy_(g.permute(0, 2, 3, 1).to(dW.dtype))
-  monkeypatch.setattr(G, 'hip', Emu())
-
-  class Gr(object):
-    def scratch(self, n):
-      return torch.empty(max(n, 1), dtype=torch.float32)
-  rng = torch.Generator().manual_seed(3)
-  B, H, Wd, N, R, stride = 2, 9, 8, 5, 3, 2
-  Ho, Wo = 5, 4                                               # 'SAME' at stride 2: begin pads (1, 0)
-  out = {}
-  for pad_c in (False, True):
-    monkeypatch.setattr(G, 'CONVG_PAD_C3', pad_c)
-    x = torch.randn(B, 3, H, Wd, generator=torch.Generator().manual_seed(1)).contiguous(memory_format=torch.channels_last).requires_grad_(True)
-    w = torch.randn(N, 3, R, R, generator=torch.Generator().manual_seed(2)).requires_grad_(True)
-    b = torch.randn(N, generator=rng.manual_seed(4)).requires_grad_(True)
-    calls.clear()
-    y = G._ConvGeneric.apply(x, w, b, stride, (1, 0), (Ho, Wo), Gr())
-    y.backward(torch.ones_like(y) * 0.5 + y.detach() * 0.1)
-    out[pad_c] = (y.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone(), list(calls))
-  assert out[False][4] == [('fwd', 3), ('bwd_data', 3), ('wrw', 3)] and out[True][4] == [('fwd', 4), ('bwd_data', 4), ('wrw', 4)]
-  for a, c in zip(out[False][:4], out[True][:4]):
-    assert a.shape == c.shape
-    torch.testing.assert_close(a, c, rtol=1e-6, atol=1e-6)
-  assert out[True][1].shape == (B, 3, H, Wd) and out[True][2].shape == (N, 3, R, R)

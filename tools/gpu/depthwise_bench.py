@@ -1,6 +1,6 @@
 """Per-layer timings of the depthwise kernels (pf_depthwise.hip) on MobileNet-v1's thirteen depthwise layers at B = 256, bf16:
 forward (+ BN statistics), backward-data, backward-filter with the one-thread-per-output slab reduction (default) and with the
-staged reduction (PF_DW_REDUCE2=1), each against its HBM floor (bytes / 4.5 TB/s) and against torch's grouped convolution (MIOpen).
+staged reduction, each against its HBM floor (bytes / 4.5 TB/s) and against torch's grouped convolution (MIOpen).
 Also MobileNet's image convolution (3 -> 32, 3x3 stride 2) on k_convg against MIOpen and its floor.
 Written at the end of round 4 from the step table (profiles/r04_step_kernels_c3.csv: k_dw_wrw_reduce 271 us per launch,
 k_dw_fwd 163 us average); not yet run.
@@ -30,12 +30,7 @@ def same(size, stride):
   return total // 2, out
 
 
-def set_reduce2(v):
-  os.environ['PF_DW_REDUCE2'] = v
-  hip.tuning_reload()
-
-
-print('%-20s | %8s %8s | %8s %8s | %8s %8s %8s | %8s %8s %8s' % ('H, C, stride', 'fwd', 'floor', 'bwd-data', 'floor', 'wrw', 'wrw red2', 'floor',
+print('%-20s | %8s %8s | %8s %8s | %8s %8s %8s | %8s %8s %8s' % ('H, C, stride', 'fwd', 'floor', 'bwd-data', 'floor', 'wrw', '-', 'floor',
                                                                 'mi fwd', 'mi bwd', 'mi wrw'))
 tot = [0.0] * 10
 for H, C1, stride in LAYERS:
@@ -56,13 +51,8 @@ for H, C1, stride in LAYERS:
   slabs = torch.empty((G + 32) * C * 9, device='cuda')
   t_f = bench_us(lambda: hip.depthwise_fwd(x, w, y, B, H, H, C, 3, stride, ph, ph, Ho, Ho, partial=partial))
   t_b = bench_us(lambda: hip.depthwise_bwd_data(dy, w, dx, B, H, H, C, 3, stride, ph, ph, Ho, Ho))
-  set_reduce2('0')
   t_w = bench_us(lambda: hip.depthwise_wrw(dy, x, dw, slabs, B, H, H, C, 3, stride, ph, ph, Ho, Ho))
-  ref = dw.float().clone()
-  set_reduce2('1')
-  t_w2 = bench_us(lambda: hip.depthwise_wrw(dy, x, dw, slabs, B, H, H, C, 3, stride, ph, ph, Ho, Ho))
-  err = float((dw.float() - ref).abs().max() / (ref.abs().max() + 1e-12))
-  set_reduce2('0')
+  t_w2, err = t_w, 0.0                                    # (round 4's per-output slab reduction is gone: one form since round 5)
   n_in, n_out = B * H * H * C * 2, B * Ho * Ho * C * 2
   fl = (n_in + n_out) / BW * 1e6
   fl_w = (n_in + n_out + G * C * 9 * 4 * 2) / BW * 1e6
@@ -94,7 +84,7 @@ xp = F.pad(x, (0, 1, 0, 1)).contiguous(memory_format=torch.channels_last)
 w4 = w.permute(0, 3, 1, 2)
 m_f = bench_us(lambda: F.conv2d(xp, w4, stride=2))
 m_w = bench_us(lambda: torch.ops.aten.convolution_backward(dy, xp, w4, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False]))
-# the same with the channels padded to 4 (PF_CONVG_PAD_C3=1: k_convg's 4-element vector loader), pad copies included
+# the same with the channels padded to 4 (k_convg's 4-element vector loader; measured as PF_CONVG_PAD_C3 in round 5: +0.1 % per C3 step, not kept), pad copies included
 def padded_fwd():
   x4 = torch.zeros(B, 4, H, H, device='cuda', dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
   x4[:, :3] = x

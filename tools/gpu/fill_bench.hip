@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_fill_reg(const FbArgs a) {
 // kernel does that keeps the pixel operand in LDS and fetches the kernel operand's fragments straight from L2).  Do the two rates
 // add up, or do they share one path?  The register loads are inline assembly with counted waits of their own: beside a pending
 // LDS-DMA hipcc drains vmcnt(0) for every register-destination load it knows about.
-template <int WAVES, int PD, int PR, bool BARRIER>
+template <int WAVES, int PD, int PR, bool BARRIER, bool RCONT = false>
 __global__ __launch_bounds__(64 * WAVES) void k_fill_mix(const FbArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int PIECE_B = 1024;
@@ -197,7 +197,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_fill_mix(const FbArgs a) {
 #pragma unroll
     for (int p = 0; p < PR; ++p) {
       const uint32_t base = ((w0 + (uint32_t)(wave * PR + p)) * piece_span) & mask;
-      const unsigned char* ptr = a.src + ((base + lane_off) & mask);
+      // RCONT: the register half fetches one contiguous KiB per wave-instruction (a kernel operand pre-packed in fragment order)
+      const unsigned char* ptr = a.src + (RCONT ? (((w0 + (uint32_t)(wave * PR + p)) * 1024u + (uint32_t)lane * 16u) & mask) : ((base + lane_off) & mask));
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[p]) : "v"(ptr) : "memory");
     }
   };
@@ -282,13 +283,13 @@ static float run_reg(const FbArgs& a, int wgs_per_cu, int cus, double* bytes_out
   return ms;
 }
 
-template <int WAVES, int PD, int PR, bool BARRIER>
+template <int WAVES, int PD, int PR, bool BARRIER, bool RCONT = false>
 static float run_mix(const FbArgs& a, int wgs_per_cu, int cus, double* bytes_out) {
   constexpr int STAGE_B = WAVES * PD * 1024;
   const size_t want = (size_t)(160 * 1024) / (size_t)wgs_per_cu;
   if ((size_t)2 * STAGE_B > want) return -1.f;
   const size_t lds = want - 1024;
-  auto kern = k_fill_mix<WAVES, PD, PR, BARRIER>;
+  auto kern = k_fill_mix<WAVES, PD, PR, BARRIER, RCONT>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1.f;
   const int grid = cus * wgs_per_cu;
   hipEvent_t e0, e1;
@@ -318,11 +319,14 @@ static float dispatch(const Cfg& c, const FbArgs& a, int wgs_per_cu, int cus, do
   FB_CASE(4, 2, 32, 0, 4, 0, 1, 0) FB_CASE(4, 2, 32, 0, 4, 0, 0, 0)
   FB_CASE(4, 2, 4, 2, 16, 0, 1, 0) FB_CASE(4, 4, 4, 2, 16, 0, 1, 0) FB_CASE(4, 4, 4, 2, 16, 0, 0, 0)
   if (c.stages == -1) {                                // mixed transport: pieces = LDS-DMA pieces, sz = register loads per wavefront and stage
-    if (c.pieces == 4 && c.sz == 4 && c.barrier == 1) return run_mix<4, 4, 4, true>(a, wgs_per_cu, cus, bytes_out);
+    if (c.pieces == 4 && c.sz == 4 && c.barrier == 1 && c.aux == 0) return run_mix<4, 4, 4, true>(a, wgs_per_cu, cus, bytes_out);
     if (c.pieces == 4 && c.sz == 4 && c.barrier == 0) return run_mix<4, 4, 4, false>(a, wgs_per_cu, cus, bytes_out);
     if (c.pieces == 8 && c.sz == 8 && c.barrier == 1) return run_mix<4, 8, 8, true>(a, wgs_per_cu, cus, bytes_out);
     if (c.pieces == 4 && c.sz == 0 && c.barrier == 1) return run_mix<4, 4, 0, true>(a, wgs_per_cu, cus, bytes_out);
-    if (c.pieces == 0 && c.sz == 4 && c.barrier == 1) return run_mix<4, 0, 4, true>(a, wgs_per_cu, cus, bytes_out);
+    if (c.pieces == 0 && c.sz == 4 && c.barrier == 1 && c.aux == 0) return run_mix<4, 0, 4, true>(a, wgs_per_cu, cus, bytes_out);
+    if (c.pieces == 4 && c.sz == 4 && c.barrier == 1 && c.aux == 1) return run_mix<4, 4, 4, true, true>(a, wgs_per_cu, cus, bytes_out);
+    if (c.pieces == 4 && c.sz == 8 && c.barrier == 1 && c.aux == 1) return run_mix<4, 4, 8, true, true>(a, wgs_per_cu, cus, bytes_out);
+    if (c.pieces == 0 && c.sz == 8 && c.barrier == 1 && c.aux == 1) return run_mix<4, 0, 8, true, true>(a, wgs_per_cu, cus, bytes_out);
   }
   if (c.stages == 0) {                                 // register-staged: (waves, pieces, pattern, barrier)
     if (c.waves == 4 && c.pieces == 8 && c.pattern == 0 && c.barrier == 1) return run_reg<4, 8, 0, true>(a, wgs_per_cu, cus, bytes_out);
@@ -371,6 +375,9 @@ int main(int argc, char** argv) {
       {"MIXED: 8 + 8 per wave and stage (32K + 32K), barrier", 4, -1, 8, 2, 8, 0, 1, 0},
       {"MIXED kernel, LDS-DMA half only (4 pieces, 16K), barrier", 4, -1, 4, 2, 0, 0, 1, 0},
       {"MIXED kernel, register half only (4 loads, 16K, nothing written to LDS), barrier", 4, -1, 0, 2, 4, 0, 1, 0},
+      {"MIXED: 4 LDS-DMA pieces + 4 CONTIGUOUS-KiB register loads per wave and stage, barrier", 4, -1, 4, 2, 4, 1, 1, 0},
+      {"MIXED: 4 LDS-DMA pieces + 8 CONTIGUOUS-KiB register loads per wave and stage, barrier", 4, -1, 4, 2, 8, 1, 1, 0},
+      {"MIXED kernel, 8 CONTIGUOUS-KiB register loads only, barrier", 4, -1, 0, 2, 8, 1, 1, 0},
   };
   const size_t sets[] = {(size_t)1 << 20, (size_t)4 << 20, (size_t)16 << 20, (size_t)128 << 20, (size_t)1 << 30};
   const uint32_t strides[] = {256u, 2048u};            // 128-channel and 1024-channel bf16 rows
