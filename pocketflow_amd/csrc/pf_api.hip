@@ -38,6 +38,8 @@ static void tuning_load() {
   t.wrw2 = env_int("PF_WRW2", 1);
   t.wrw2_target = env_int("PF_WRW2_TARGET", 0);
   t.splitk = env_int("PF_IGEMM_SPLITK", 1);
+  t.igemm_pp = env_int("PF_IGEMM_PP", 0);
+  t.igemm_pp_bm = env_int("PF_IGEMM_PP_BM", 0);
   g_tuning = t;
   g_tuning_loaded = true;
 }

@@ -24,47 +24,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
-
-// The buffer-descriptor type exists only in the device pass; the host pass (which merely emits the launch stub) still has
-// to parse the kernel body -- without this the host pass silently DROPS the stubs and the library fails to load.
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef __amdgpu_buffer_rsrc_t pf_rsrc_t;
-#define PF_MAKE_RSRC(p, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(p), (short)0, (int)(bytes), 0x00020000)
-#define PF_BUFFER_LOAD_LDS16(rs, lds, voff, soff) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds), 16, voff, soff, 0, 0)
-#else
-typedef int pf_rsrc_t;
-#define PF_MAKE_RSRC(p, bytes) 0
-#define PF_BUFFER_LOAD_LDS16(rs, lds, voff, soff) ((void)(rs), (void)(lds), (void)(voff), (void)(soff))
-#endif
-
-struct IgArgs {
-  const bf16_t* X;      // [rows_in][C]
-  const bf16_t* W;      // [N][taps][C]
-  bf16_t* Y;            // [M][N]
-  const bf16_t* zero;   // unused by the kernel (padding taps read zeros through the buffer bounds check); kept in the ABI
-  uint32_t x_bytes, w_bytes;   // sizes of X / W in bytes (buffer descriptors)
-  const bf16_t* R;      // residual [M][N] or null
-  float* partial;       // statistics [G][4][N] (or [G][2][N] with bx) or null
-  const bf16_t* bx;     // BN-backward statistics mode: the BN's input x [M][N]
-  const float* bss;     // its scale | shift [2][N]
-  const float* bmi;     // its mean | invstd [2][N]
-  float b_lo, b_hi;
-  const float* ss;      // PRO: scale | shift [2][C] of the producer BN
-  const uint32_t* slot; // PRO: activation range (null: no fake-quant)
-  float kq, act_lo, act_hi;
-  int M, N, C;
-  int th, tw;           // taps
-  int H, Wd, Ho, Wo, stride, pad_h, pad_w;
-  int tiles_m, tiles_n, G;
-  // sub-filter walk (strided backward-data by output-parity classes, pf_conv2d_bwd_data_strided): the th x tw taps of THIS launch are
-  // taps (w_r0 + r * w_rs, w_s0 + s * w_ss) of a kernel buffer whose rows hold w_taps_full taps, w_S of them per kernel row.
-  // A plain convolution walks its own kernel: w_r0 = w_s0 = 0, w_rs = w_ss = 1, w_S = tw, w_taps_full = th * tw.
-  int w_r0, w_rs, w_s0, w_ss, w_S, w_taps_full;
-  // output scatter: row (img, i, j) of the launch's [Ho x Wo] grid is stored at pixel (i * o_sub + o_y, j * o_sub + o_x) of an
-  // [o_H x o_W] image (o_sub = 0: off, rows are stored where they are)
-  int o_sub, o_y, o_x, o_H, o_W;
-};
+#include "pf_igemm.h"
 
 // Ablation builds for tools/gpu/igemm_ablate.py ONLY (never in libpocketflow_hip.so): -DPF_IG_ABLATE=1 drops the MFMAs and
 // their fragment reads (what is left is the LDS-DMA fill + barriers), =2 drops the LDS-DMA (matrix work + fragment reads +
@@ -86,13 +46,6 @@ struct IgArgs {
 #define PF_IG_STAMP(k) do { } while (0)
 #endif
 
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// MODE 0: plain (+ residual / statistics), 1: backward-data with BN-backward sums, 2: producer's BN + act + fake-quant
-// prologue on the input operand (1x1 only: padding taps would need Q = 0, not Q(0))
-#define IG_PLAIN 0
-#define IG_BWD 1
-#define IG_PRO 2
 // (A wave-specialised MODE 3 -- producer wavefronts for the LDS-DMA and the prologue pass, consumer wavefronts for the MFMAs -- lived
 // here in rounds 3-4: measured no faster than the single-role three-stage kernel, profiles/r03_pro_bench.txt, and removed.)
 // SUB: the launch walks a sub-grid of a larger kernel buffer and scatters its rows (IgArgs.w_* / o_*: strided backward-data by parity
@@ -680,7 +633,13 @@ static int ig_grid(int slots, int tiles_m, int tiles_n, int* G_out) {
   return G * tiles_n;
 }
 
+// pf_igemm_pp.hip: the ping-pong kernel for plain / backward-data launches
+bool pf_igemm_pp_takes(int M, int N);
+int pf_igemm_pp_stats_groups(int M, int N);
+int pf_igemm_pp_launch(IgArgs& a, hipStream_t st);
+
 int pf_igemm_stats_groups(int M, int N, int pro) {
+  if (!pro && pf_igemm_pp_takes(M, N)) return pf_igemm_pp_stats_groups(M, N);
   const IgCfg c = ig_pick(M, N, pro != 0);
   int G;
   ig_grid(c.slots, (M + c.bm - 1) / c.bm, (N + c.bn - 1) / c.bn, &G);
@@ -716,6 +675,7 @@ static int ig_launch_t(IgArgs& a, int slots, hipStream_t st) {
 
 static int ig_launch(IgArgs& a, hipStream_t st) {
   const bool bwd = a.bx != nullptr, pro = a.ss != nullptr;
+  if (!pro && pf_igemm_pp_takes(a.M, a.N)) return pf_igemm_pp_launch(a, st);
   const IgCfg c = ig_pick(a.M, a.N, pro);
   if (pro) {
     if (a.th * a.tw != 1 || bwd) return (int)hipErrorInvalidValue;
@@ -767,7 +727,7 @@ extern "C" int pf_conv2d_fwd(const void* X, const void* W, void* Y, const void* 
   a.x_bytes = (uint32_t)((int64_t)imgs * H * Wd * C * 2);
   a.w_bytes = (uint32_t)((int64_t)N * th * tw * C * 2);
   a.w_r0 = 0; a.w_rs = 1; a.w_s0 = 0; a.w_ss = 1; a.w_S = tw; a.w_taps_full = th * tw;
-  a.o_sub = 0; a.o_y = 0; a.o_x = 0; a.o_H = 0; a.o_W = 0;
+  a.o_sub = 0; a.o_y = 0; a.o_x = 0; a.o_H = 0; a.o_W = 0; a.pp_bm = 0;
   return ig_launch(a, (hipStream_t)stream);
 }
 
@@ -805,7 +765,7 @@ extern "C" int pf_conv2d_bwd_data_strided(const void* dY, const void* Wt, void* 
       a.w_r0 = (R - 1 - r1) - (th - 1) * stride; a.w_rs = stride;
       a.w_s0 = (S - 1 - s1) - (tw - 1) * stride; a.w_ss = stride;
       a.w_S = S; a.w_taps_full = R * S;
-      a.o_sub = stride; a.o_y = ay; a.o_x = ax; a.o_H = H; a.o_W = Wd;
+      a.o_sub = stride; a.o_y = ay; a.o_x = ax; a.o_H = H; a.o_W = Wd; a.pp_bm = 0;
       // (the two plain tile configurations the dispatcher picks for these shapes, with the sub-grid walk compiled in)
       const int rc = (C % 128 == 0) ? ig_launch_t<128, 128, 2, 2, 2, IG_PLAIN, true>(a, 512, (hipStream_t)stream)
                                     : ig_launch_t<128, 64, 2, 2, 2, IG_PLAIN, true>(a, 512, (hipStream_t)stream);
@@ -840,6 +800,6 @@ int pf_igemm_conv1x1(const void* X, const void* W, void* Y, const void* R, float
   a.x_bytes = (uint32_t)(rows_in * K * 2);
   a.w_bytes = (uint32_t)((int64_t)N * K * 2);
   a.w_r0 = 0; a.w_rs = 1; a.w_s0 = 0; a.w_ss = 1; a.w_S = 1; a.w_taps_full = 1;
-  a.o_sub = 0; a.o_y = 0; a.o_x = 0; a.o_H = 0; a.o_W = 0;
+  a.o_sub = 0; a.o_y = 0; a.o_x = 0; a.o_H = 0; a.o_W = 0; a.pp_bm = 0;
   return ig_launch(a, st);
 }

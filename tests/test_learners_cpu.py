@@ -147,6 +147,16 @@ def test_bf16_parity_body_on_cpu(cpu_learners):
   run_bf16_fused_parity(FLAGS, tmp, steps=1, expect_bf16=False)
 
 
+def test_bf16_parity_body_through_recorded_steps_on_cpu(cpu_learners, monkeypatch):
+  """The same body with the trajectory running through the recorded step (in-line stand-in for the hipGraph): three launch-by-launch
+  steps, then replays, compared with the oracle step by step; weights, BN statistics and the teacher-labelled evaluation afterwards."""
+  FLAGS, fake, tmp = cpu_learners
+  monkeypatch.setenv('PF_STEP_GRAPH', 'inline')
+  monkeypatch.setenv('PF_STEP_GRAPH_STRICT', '1')
+  from parity_common import run_bf16_fused_parity
+  run_bf16_fused_parity(FLAGS, tmp, steps=5, expect_bf16=False, step_graph=True)
+
+
 def test_uq_resnet20_distillation_on_cpu(cpu_learners):
   FLAGS, fake, tmp = cpu_learners
   from oracle.learner_oracle import OracleLearner

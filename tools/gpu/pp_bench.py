@@ -1,0 +1,61 @@
+"""The ping-pong implicit-GEMM kernel (pf_igemm_pp.hip, PF_IGEMM_PP) against the per-tap kernels (pf_igemm.hip) on the ResNet-50 B = 256
+shapes that go through pf_conv2d_fwd / the plain 1x1 products: forward with the statistics epilogue, per row-tile height; bit
+equality of the outputs; TFLOP/s = 2 M N K / time (hipGraph replay: no host launch overhead in the numbers)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from pocketflow_amd import hip
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _timing import gpu_time_us as timeit
+
+B = int(os.environ.get('B', 256))
+# (H, C, N, k, stride)
+shapes = [(56, 64, 64, 3, 1), (28, 128, 128, 3, 1), (14, 256, 256, 3, 1), (7, 512, 512, 3, 1), (56, 128, 128, 3, 2), (28, 256, 256, 3, 2),
+          (14, 512, 512, 3, 2), (14, 1024, 256, 1, 1), (14, 256, 1024, 1, 1), (7, 2048, 512, 1, 1), (7, 512, 2048, 1, 1), (28, 512, 128, 1, 1)]
+if os.environ.get('PP_SHAPES'):
+  shapes = [tuple(int(v) for v in s.split(',')) for s in os.environ['PP_SHAPES'].split(';')]
+bms = os.environ.get('PP_BMS', 'auto,256,208,192,128').split(',')
+
+
+def setenv(**kw):
+  for k, v in kw.items():
+    if v is None:
+      os.environ.pop(k, None)
+    else:
+      os.environ[k] = str(v)
+  hip.tuning_reload()
+
+
+print('%-20s | %9s | %-50s | %9s' % ('H,C,N,k,s', 'per-tap us', 'ping-pong us by row-tile height ' + ' '.join(bms), 'best TF'))
+for H, C, N, k, s in shapes:
+  g = torch.Generator(device='cuda').manual_seed(H + C + N)
+  x = torch.randn(B, H, H, C, device='cuda', generator=g).bfloat16()
+  w = (torch.randn(N, k, k, C, device='cuda', generator=g) * 0.05).bfloat16()
+  pad = (k - 1) // 2
+  Ho = (H + 2 * pad - k) // s + 1
+  M = B * Ho * Ho
+  geom = (B, H, H, C, N, k, k, s, pad, pad, Ho, Ho)
+
+  def run(y, stats=True):
+    G = hip.conv2d_stats_groups(M, N, geom=geom)
+    partial = torch.empty(G, 4, N, device='cuda') if stats else None
+    t = timeit(lambda: hip.conv2d_fwd(x, w, y, B, H, H, C, N, k, k, s, pad, pad, Ho, Ho, partial=partial))
+    return t, partial
+  setenv(PF_IGEMM_PP=0, PF_IGEMM_PP_BM=None)
+  y0 = torch.empty(B, Ho, Ho, N, device='cuda', dtype=torch.bfloat16)
+  t0, p0 = run(y0)
+  ts, same = [], True
+  for bm in bms:
+    setenv(PF_IGEMM_PP=2, PF_IGEMM_PP_BM=None if bm == 'auto' else bm)
+    y1 = torch.full((B, Ho, Ho, N), float('nan'), device='cuda', dtype=torch.bfloat16)
+    t1, p1 = run(y1)
+    ts.append(t1)
+    same = same and bool(torch.equal(y0, y1))
+    ok_stats = bool(torch.allclose(p0[:, 0].sum(0), p1[:, 0].sum(0), rtol=1e-4, atol=5e-2)) and bool(torch.equal(p0[:, 3].max(0).values, p1[:, 3].max(0).values))
+    same = same and ok_stats
+  setenv(PF_IGEMM_PP=2, PF_IGEMM_PP_BM=None)
+  t_ns, _ = run(torch.empty_like(y0), stats=False)
+  fl = 2.0 * M * N * C * k * k
+  print('%-20s | %9.1f | %-50s | %6.0f TF | no-stats %6.1f us | %s' % ('%d,%d,%d,%d,%d' % (H, C, N, k, s), t0, ' '.join('%7.1f' % t for t in ts), fl / min(ts) * 1e-6, t_ns,
+                                                                    'same bits + statistics' if same else 'OUTPUTS DIFFER'))
+setenv(PF_IGEMM_PP=None, PF_IGEMM_PP_BM=None)
