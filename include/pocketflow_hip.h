@@ -258,14 +258,16 @@ int pf_conv1x1_wrw(const void* dY, const void* X, void* dW, int dw_dtype, float*
  *   X [imgs][H][Wd][C] bf16 NHWC, W [N][th][tw][C] bf16 (KRSC), Y [imgs][Ho][Wo][N] bf16; taps outside the image read
  *   zeros (`zero`: >= 128 zero bytes in device memory, 16-byte aligned).  C % 64 == 0, N % 8 == 0.
  *   Epilogue: R != NULL adds a residual [M][N]; partial != NULL receives per-channel {sum, sumsq, min, max} of the stored
- *   values as [G][4][N], G = pf_conv2d_stats_groups(M, N), M = imgs*Ho*Wo (layout of pf_bn_finalize, pivot 0); with
+ *   values as [G][4][N], G = pf_conv2d_stats_groups_geom(<the arguments of this call>), M = imgs*Ho*Wo (layout of
+ *   pf_bn_finalize, pivot 0); with
  *   bn_x != NULL instead the BN-backward sums {sum dy, sum dy*xhat} [G][2][N] of the BN whose input is bn_x [M][N]
  *   (dy = Y * act'(scale*x + shift)), as pf_conv1x1_bwd_data_bnstats.
  *   Backward-data of a stride-1 convolution is the same call on dY with the kernel flipped and transposed:
  *   W'[c][r][s][n] = W[n][th-1-r][tw-1-s][c], pad' = th-1-pad.                                                      */
+/* rows G of the statistics array for a 1x1 product of M x N outputs (DEPRECATED for R x S convolutions: the kernel -- per-tap or,
+ * since round 5, the ping-pong kernel pf_igemm_pp.hip for 3x3 windows with >= 18 k-steps -- and with it G depends on the window) */
 int pf_conv2d_stats_groups(int M, int N);
-/* the same, asked with the arguments of the pf_conv2d_fwd call that follows (rounds 3-4 dispatched some geometries to a second
- * kernel family with its own group count; since its removal this equals pf_conv2d_stats_groups(imgs * Ho * Wo, N))             */
+/* rows G for the pf_conv2d_fwd call with these arguments: the ONLY valid query for R x S convolutions                          */
 int pf_conv2d_stats_groups_geom(int imgs, int H, int Wd, int C, int N, int th, int tw, int stride, int pad_h, int pad_w,
                                 int Ho, int Wo);
 int pf_conv2d_fwd(const void* X, const void* W, void* Y, const void* zero, const void* R, float* partial,

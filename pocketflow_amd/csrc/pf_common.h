@@ -33,7 +33,7 @@ struct PfTuning {
   int pool3s2;                    // PF_POOL3S2            1 (default) | 0
   int wrw_tr, wrw2, wrw2_target;  // PF_WRW_TR 0, PF_WRW2 1, PF_WRW2_TARGET 0 (= per-shape default)
   int splitk;                     // PF_IGEMM_SPLITK       1 (default) | 0
-  int igemm_pp;                   // PF_IGEMM_PP           plain / backward-data implicit GEMMs on the ping-pong kernel: 0 never | 1 by size | 2 every shape it computes (tests)
+  int igemm_pp;                   // PF_IGEMM_PP           plain / backward-data implicit GEMMs on the ping-pong kernel: 0 never (default) | 1 where it measured faster per layer | 2 every shape it computes (tests)
   int igemm_pp_bm;                // PF_IGEMM_PP_BM        0 (default: per launch) | 16 .. 256: its row-tile height (tests, sweeps)
 };
 const PfTuning& pf_tuning();

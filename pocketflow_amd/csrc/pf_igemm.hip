@@ -634,18 +634,24 @@ static int ig_grid(int slots, int tiles_m, int tiles_n, int* G_out) {
 }
 
 // pf_igemm_pp.hip: the ping-pong kernel for plain / backward-data launches
-bool pf_igemm_pp_takes(int M, int N);
+bool pf_igemm_pp_takes(int M, int N, int taps, int C);
 int pf_igemm_pp_stats_groups(int M, int N);
 int pf_igemm_pp_launch(IgArgs& a, hipStream_t st);
 
-int pf_igemm_stats_groups(int M, int N, int pro) {
-  if (!pro && pf_igemm_pp_takes(M, N)) return pf_igemm_pp_stats_groups(M, N);
+// taps, C: the window and the input channels of the launch (1, K for the 1x1 products)
+int pf_igemm_stats_groups_geom(int M, int N, int pro, int taps, int C) {
+  if (!pro && pf_igemm_pp_takes(M, N, taps, C)) return pf_igemm_pp_stats_groups(M, N);
   const IgCfg c = ig_pick(M, N, pro != 0);
   int G;
   ig_grid(c.slots, (M + c.bm - 1) / c.bm, (N + c.bn - 1) / c.bn, &G);
   return G;
 }
 
+// (M, N) alone: the 1x1 reading -- what pf_conv1x1_stats_groups_k answers for the products it routes here.  K is not known to this
+// entry point; the ping-pong kernel's default selection takes no 1x1 product, and under PF_IGEMM_PP=2 (tests) every K % 64 == 0 does.
+int pf_igemm_stats_groups(int M, int N, int pro) { return pf_igemm_stats_groups_geom(M, N, pro, 1, 64); }
+
+/* deprecated for RxS convolutions: use pf_conv2d_stats_groups_geom (the kernel, and with it the row count, depends on the window) */
 extern "C" int pf_conv2d_stats_groups(int M, int N) { return pf_igemm_stats_groups(M, N, 0); }
 
 template <int BM, int BN, int WM, int WN, int NS, int MODE, bool SUB = false>
@@ -675,7 +681,7 @@ static int ig_launch_t(IgArgs& a, int slots, hipStream_t st) {
 
 static int ig_launch(IgArgs& a, hipStream_t st) {
   const bool bwd = a.bx != nullptr, pro = a.ss != nullptr;
-  if (!pro && pf_igemm_pp_takes(a.M, a.N)) return pf_igemm_pp_launch(a, st);
+  if (!pro && pf_igemm_pp_takes(a.M, a.N, a.th * a.tw, a.C)) return pf_igemm_pp_launch(a, st);
   const IgCfg c = ig_pick(a.M, a.N, pro);
   if (pro) {
     if (a.th * a.tw != 1 || bwd) return (int)hipErrorInvalidValue;
@@ -695,8 +701,8 @@ static int ig_launch(IgArgs& a, hipStream_t st) {
 // rows of the [G][.][N] statistics array pf_conv2d_fwd writes for THIS convolution (depends on the kernel it is dispatched to)
 extern "C" int pf_conv2d_stats_groups_geom(int imgs, int H, int Wd, int C, int N, int th, int tw, int stride, int pad_h,
                                            int pad_w, int Ho, int Wo) {
-  (void)H; (void)Wd; (void)C; (void)th; (void)tw; (void)stride; (void)pad_h; (void)pad_w;   // (one kernel family since round 4: the geometry does not matter)
-  return pf_igemm_stats_groups(imgs * Ho * Wo, N, 0);
+  (void)H; (void)Wd; (void)stride; (void)pad_h; (void)pad_w;   // (round 5: the window and the channel count select between the per-tap and the ping-pong kernel)
+  return pf_igemm_stats_groups_geom(imgs * Ho * Wo, N, 0, th * tw, C);
 }
 
 // forward convolution (or any implicit GEMM of that form).  X [img][H][Wd][C], W [N][th][tw][C], Y [img][Ho][Wo][N].

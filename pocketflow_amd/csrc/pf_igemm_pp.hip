@@ -58,7 +58,8 @@ template <typename F, int... I> __device__ __forceinline__ void pp_static_for_im
 template <int N, typename F> __device__ __forceinline__ void pp_static_for(F&& f) { pp_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
 
 // -DPP_ABLATE=n (tools/gpu/build_variant.sh, never in libpocketflow_hip.so; results are garbage by design): 1 = no LDS-DMA in the main
-// loop, 2 = no fragment reads, 3 = neither (MFMAs, waits and barriers only: what the schedule itself costs).
+// loop, 2 = no fragment reads, 3 = neither (MFMAs, waits and barriers only: what the schedule itself costs), 4 = no LDS-DMA of the INPUT
+// operand (kernel pieces and all fragment reads remain: the main loop of a kernel that stages an input window once for all taps).
 #ifndef PP_ABLATE
 #define PP_ABLATE 0
 #endif
@@ -67,8 +68,12 @@ template <int N, typename F> __device__ __forceinline__ void pp_static_for(F&& f
 #ifdef PP_TIMING
 #define PP_STAMP(ph) do { if (tm_rec && tm_k < 12) { const uint32_t t_ = (uint32_t)__builtin_readcyclecounter(); \
     if (lane == 0) asm volatile("ds_write_b32 %0, %1" : : "v"(tm_base + (uint32_t)((tm_k * 8 + (ph)) * 4)), "v"(t_) : "memory"); } } while (0)
+// tile-level stamps (row 12 of the table): 0 tile starts, 1 pipeline filled (first fragments read), 2 main loop done, 3 epilogue done
+#define PP_STAMP_T(i) do { if (tm_rec) { const uint32_t t_ = (uint32_t)__builtin_readcyclecounter(); \
+    if (lane == 0) asm volatile("ds_write_b32 %0, %1" : : "v"(tm_base + (uint32_t)((96 + (i)) * 4)), "v"(t_) : "memory"); } } while (0)
 #else
 #define PP_STAMP(ph) do { } while (0)
+#define PP_STAMP_T(i) do { } while (0)
 #endif
 
 template <int BN, int MODE>
@@ -177,6 +182,9 @@ __global__ __launch_bounds__(512) void k_igemm_pp(const IgArgs a) {
     if (a.M >= 0) return;
 #endif
     if constexpr (P < AS) {
+#if PP_ABLATE == 4
+      if (a.M >= 0) return;
+#endif
       if constexpr (P < JN_) {
         const uint32_t voff = ((pmask[P] >> s_tap) & 1u) ? (pbase[P] + st_tapoff) : OOB;
         PF_BUFFER_LOAD_LDS16(rsX, smem + st_bofs + (P * 64 + wave * 8) * 128, voff, 0);
@@ -218,6 +226,7 @@ __global__ __launch_bounds__(512) void k_igemm_pp(const IgArgs a) {
       else wait_vm<2 * NP>();
     };
     const int m0 = tm * bm;
+    PP_STAMP_T(0);
     if (!pre) setup_tile(m0);
 
     f32x4 acc[NI][JA];
@@ -314,11 +323,14 @@ __global__ __launch_bounds__(512) void k_igemm_pp(const IgArgs a) {
     load_phase(YES, NO, ring(0), 0);
     frags_wait();
     phase_end();
-    // Steady state.  Stage s is issued three steps ahead by both groups: group 0 in interval 2s - 5, group 1 in interval 2s - 4; it is
-    // read in intervals 2s - 1 (group 0) and 2s (group 1), so every wavefront's pieces must have landed before the barrier that ends
-    // interval 2s - 2: group 0 waits for them at the end of its MFMA phase 2s - 2 (3 intervals after the issue), group 1 at the end of
-    // its load phase 2s - 2 (2 intervals) -- each with a COUNTED vmcnt that leaves its newest batch in flight.  The ring buffer of
-    // stage s is the one of stage s - 3, last read in interval 2s - 6.
+    PP_STAMP_T(1);
+    // Steady state: two workgroup barriers per k-step, one behind every interval.  Stage s is issued three steps ahead by both groups:
+    // group 0 in interval 2s - 5, group 1 in interval 2s - 4; it is read in intervals 2s - 1 (group 0) and 2s (group 1), so every
+    // wavefront's pieces must have landed before the barrier that ends interval 2s - 2: group 0 waits for them at the end of its MFMA
+    // phase 2s - 2 (3 intervals after the issue), group 1 at the end of its load phase 2s - 2 (2 intervals) -- each with a COUNTED
+    // vmcnt that leaves its newest batch in flight.  The ring buffer of stage s is the one of stage s - 3, last read in interval 2s - 6.
+    // (A schedule with ONE barrier per k-step -- the mid-step barrier only enforces the alternation, no memory ordering needs it -- was
+    // measured too: no faster, profiles/r05_pp_timeline_v3.txt: the k-step is bound by the LDS / L1 work, not by barrier skew.)
     if (grp == 0) {
       for (int k = 0; k < nk; ++k) {
 #ifdef PP_TIMING
@@ -365,6 +377,7 @@ __global__ __launch_bounds__(512) void k_igemm_pp(const IgArgs a) {
       }
     }
     // every fragment read and every LDS-DMA of the tile is complete here, for both groups: the ring is free
+    PP_STAMP_T(2);
 
     // ---- epilogue ----
     if (!BWD && a.R != nullptr) {                               // residual on the fp32 accumulators: ONE rounding to bf16
@@ -529,6 +542,7 @@ __global__ __launch_bounds__(512) void k_igemm_pp(const IgArgs a) {
     // the wavefront regions are free for the next tile's stages when EVERY wavefront is through with its region
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     phase_end();
+    PP_STAMP_T(3);
   };
   for (int tm = g; tm < a.tiles_m; tm += a.G) {
 #ifdef PP_TIMING
@@ -604,13 +618,21 @@ static PpPlan pp_plan(int M, int N) {
   return p;
 }
 
-// Does the ping-pong kernel take this plain / backward-data launch?  A function of (M, N) only: the statistics-group query that sizes
-// the [G][.][N] array has nothing else.  PF_IGEMM_PP=0: never (A/B runs); =2: every shape it can compute (tests).
-bool pf_igemm_pp_takes(int M, int N) {
+// Does the ping-pong kernel take this plain / backward-data launch?  A function of what the statistics-group query knows as well
+// (M, N, taps, C): the [G][.][N] array is sized from the same decision.  PF_IGEMM_PP=0 (DEFAULT): never; =2: every shape it can
+// compute (tests); =1: where it measured faster than the per-tap kernels LAYER BY LAYER on the ResNet-50 shapes at batch 256, three
+// boxes (profiles/r05_pp_bench_v{1,2,3}.txt): the RxS convolutions with at least 18 k-steps and 128-channel column tiles -- 3x3 at
+// 28 x 28 and below, forward and backward-data, stride 1 and 2: -3 ... -10 % -- and NOT the 1x1 products (4-32 k-steps per tile: the
+// per-tile cost of one workgroup per CU is not amortised, +0 ... +20 %) nor the 64-channel layers at 56 x 56 (+5 %).
+// Why it is not the default: in the STEP that selection is 2.2 % SLOWER (10 054 / 10 039 vs 9 836 / 9 810 images/s, one box,
+// profiles/r05_pp_step_ab.txt).  The student's forward pass shares the chip with the teacher branch on a second stream; a kernel
+// that holds a whole CU's LDS (144 KiB, one workgroup per CU) leaves no room for the other stream's workgroups beside it, while the
+// per-tap kernels (two workgroups of 64 KiB per CU) interleave with them -- the overlap is worth more than the kernel's own gain.
+bool pf_igemm_pp_takes(int M, int N, int taps, int C) {
   const int mode = pf_tuning().igemm_pp;
-  if (mode == 0 || (N % 64) != 0 || pf_tuning().igemm_tile_bm != 0) return false;   // (a PF_IGEMM_TILE override asks for a per-tap kernel)
+  if (mode == 0 || (N % 64) != 0 || (C % 64) != 0 || pf_tuning().igemm_tile_bm != 0) return false;   // (a PF_IGEMM_TILE override asks for a per-tap kernel)
   if (mode == 2) return true;
-  return (int64_t)M * N >= ((int64_t)1 << 21);                  // at least ~64 tiles of 256 x 128: smaller products stay on the per-tap kernels
+  return taps >= 9 && (N % 128) == 0 && (int64_t)taps * C >= 1152 && (int64_t)M * N >= ((int64_t)1 << 21);
 }
 
 int pf_igemm_pp_stats_groups(int M, int N) { return pp_plan(M, N).G; }

@@ -15,7 +15,9 @@ B = int(os.environ.get('B', 256))
 shapes = [(28, 128, 128, 3, 1), (14, 256, 256, 3, 1), (14, 1024, 256, 1, 1)]
 if os.environ.get('PP_SHAPES'):
   shapes = [tuple(int(v) for v in s.split(',')) for s in os.environ['PP_SHAPES'].split(';')]
-names = ['mfma issue', 'vmcnt wait', 'barrier', '-', 'reads+dma', 'waits', 'barrier']   # (group 1 waits for its LDS-DMA in 'waits', group 0 in 'vmcnt wait')
+# stamps of a k-step (v3 schedule, one barrier per k-step): 0 MFMA phase starts, 1 MFMAs issued, 2 own LDS-DMA wait passed (group 0),
+# 3 barrier passed (group 0), 5 reads + pieces issued (group 0) / load phase issued (group 1, taken at the start of the NEXT iteration),
+# 6 waits passed (group 1), 7 barrier passed (group 1)
 for H, C, N, k, s in shapes:
   x = torch.randn(B, H, H, C, device='cuda').bfloat16()
   w = (torch.randn(N, k, k, C, device='cuda') * 0.05).bfloat16()
@@ -31,13 +33,17 @@ for H, C, N, k, s in shapes:
   torch.cuda.synchronize()
   t = out.cpu().numpy().astype('int64').reshape(8, 16, 8) & 0xFFFFFFFF
   print('== %d,%d,%d,%d,%d  (G = %d)' % (H, C, N, k, s, G))
-  print('%-6s %-4s | %s | step' % ('wave', 'k', ' '.join('%10s' % n for n in names)))
-  for wave in (0, 1, 2, 4, 5, 6):
+  for wave in (0, 4):
+    tt = [int(v) for v in t[wave, 12][:4]]
+    if tt[0]:
+      print('wave %d tile: pipeline fill %d | main loop %d | epilogue %d cycles' % (wave, (tt[1] - tt[0]) & 0xFFFFFFFF, (tt[2] - tt[1]) & 0xFFFFFFFF, (tt[3] - tt[2]) & 0xFFFFFFFF))
+  for wave in (0, 2, 4, 6):
+    base = None
     for ks in range(2, 8):
       row = t[wave, ks]
       if row[0] == 0:
         continue
-      d = [(int(row[i + 1]) - int(row[i])) & 0xFFFFFFFF for i in range(7)]
-      nxt = t[wave, ks + 1][0]
-      step = ((int(nxt) - int(row[0])) & 0xFFFFFFFF) if nxt else 0
-      print('%-6d %-4d | %s | %6d' % (wave, ks, ' '.join('%10d' % v for v in d), step))
+      if base is None:
+        base = int(min(v for v in row if v))
+      ev = sorted((int(v) - base, i) for i, v in enumerate(row) if v)
+      print('wave %d k %d | ' % (wave, ks) + '  '.join('%d@%d' % (i, tt) for tt, i in ev))
