@@ -316,6 +316,19 @@ int pf_conv_stem_wrw_slabs(int imgs, int H, int Wd);
 int pf_conv_stem_wrw(const void* dY, const void* X, void* dW, int dw_dtype, float* workspace, int imgs, int H, int Wd,
                      void* stream);
 
+/* ---- the MobileNet-v1 stem (round 5): 3x3 / stride 2 convolution of a 3-channel image to 16 or 32 channels, 'SAME' padding -----
+ * replaces the first slim.conv2d of utils/external/mobilenet_v1.py:233-262 (conv_defs[0] = Conv(kernel=[3, 3], stride=2, depth=32);
+ * depth multipliers 1.0 and 0.5) and its Conv2DBackpropFilter.  X [imgs][H][Wd][3] bf16 (NHWC), W [N][3][3][3] bf16 (KRSC),
+ * Y / dY [imgs][Ho][Wo][N] bf16.  pad_h / pad_w are TensorFlow's FRONT pads (0 | 1); positions behind the image read zeros
+ * (no padded copy of the image).  Wd even, Wo % 16 == 0 (pf_conv_stem3_supported).  Backward-filter: dW in dw_dtype, deterministic;
+ * workspace (pf_conv_stem3_wrw_slabs(...) + 32) * N * 27 floats (0 slabs: unsupported shape).                              */
+int pf_conv_stem3_supported(int H, int Wd, int C, int N, int k, int stride, int pad_h, int pad_w, int Ho, int Wo);
+int pf_conv_stem3_fwd(const void* X, const void* W, void* Y, int imgs, int H, int Wd, int N, int pad_h, int pad_w, int Ho, int Wo,
+                      void* stream);
+int pf_conv_stem3_wrw_slabs(int imgs, int H, int Wd, int N, int pad_h, int pad_w, int Ho, int Wo);
+int pf_conv_stem3_wrw(const void* dY, const void* X, void* dW, int dw_dtype, float* workspace, int imgs, int H, int Wd, int N,
+                      int pad_h, int pad_w, int Ho, int Wo, void* stream);
+
 /* ---- K12 (MobileNet): depthwise 3x3 convolutions, NHWC float32 / bf16, kernel [C][3][3] in the activation dtype ----------
  * replaces DepthwiseConv2dNative / ...BackpropInput / ...BackpropFilter behind slim.separable_conv2d(num_outputs=None)
  * (utils/external/mobilenet_v1.py:264-292).  stride 1 | 2; pad_h / pad_w are TensorFlow's FRONT pads of 'SAME'

@@ -24,6 +24,49 @@
 #define DW_T 256
 #define DW_PW 4
 
+// Round 5: every activation load of these kernels goes through a buffer descriptor with a per-lane BYTE offset, and a position
+// outside the image gets an offset outside the buffer -- the hardware returns zeros, no branch.  Rounds 3-4 wrote
+// `if (inside) load8(...) else zeros` per vector: hipcc turns that into a branch around every load with `s_waitcnt vmcnt(0)` behind
+// it (cdna_hip_programming.md, "per-element register-or-load select"), i.e. 18 DEPENDENT round trips to L2 / HBM per strip of four
+// output pixels -- the kernels ran at 2.5-2.9x their HBM floor (profiles/r05_depthwise_layers_before.txt), latency-bound at two
+// wavefronts per SIMD.  Now the 18 (+ 4) loads of a strip are issued back to back and waited for once.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t dw_rsrc_t;
+#define DW_MAKE_RSRC(p, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(p), (short)0, (int)(bytes), 0x00020000)
+typedef uint32_t dw_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 dw_load16(dw_rsrc_t rs, uint32_t off) {
+  const dw_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+#else
+typedef int dw_rsrc_t;
+#define DW_MAKE_RSRC(p, bytes) 0
+__device__ __forceinline__ uint4 dw_load16(dw_rsrc_t, uint32_t) { return make_uint4(0, 0, 0, 0); }
+#endif
+#define DW_OOB 0x80000000u
+
+// eight consecutive channels of one pixel as they sit in memory: one 16-byte vector (bf16) or two (float32)
+template <typename T> struct DwRaw;
+template <> struct DwRaw<bf16_t> { uint4 a; };
+template <> struct DwRaw<float> { uint4 a, b; };
+template <typename T> __device__ __forceinline__ void dw_fetch(dw_rsrc_t rs, uint32_t off, DwRaw<T>& r);
+template <> __device__ __forceinline__ void dw_fetch<bf16_t>(dw_rsrc_t rs, uint32_t off, DwRaw<bf16_t>& r) { r.a = dw_load16(rs, off); }
+template <> __device__ __forceinline__ void dw_fetch<float>(dw_rsrc_t rs, uint32_t off, DwRaw<float>& r) {
+  r.a = dw_load16(rs, off);
+  r.b = dw_load16(rs, off == DW_OOB ? DW_OOB : off + 16u);
+}
+template <typename T> __device__ __forceinline__ void dw_unpack(const DwRaw<T>& r, float* o);
+template <> __device__ __forceinline__ void dw_unpack<bf16_t>(const DwRaw<bf16_t>& r, float* o) {
+  o[0] = __uint_as_float(r.a.x << 16); o[1] = __uint_as_float(r.a.x & 0xFFFF0000u);
+  o[2] = __uint_as_float(r.a.y << 16); o[3] = __uint_as_float(r.a.y & 0xFFFF0000u);
+  o[4] = __uint_as_float(r.a.z << 16); o[5] = __uint_as_float(r.a.z & 0xFFFF0000u);
+  o[6] = __uint_as_float(r.a.w << 16); o[7] = __uint_as_float(r.a.w & 0xFFFF0000u);
+}
+template <> __device__ __forceinline__ void dw_unpack<float>(const DwRaw<float>& r, float* o) {
+  o[0] = __uint_as_float(r.a.x); o[1] = __uint_as_float(r.a.y); o[2] = __uint_as_float(r.a.z); o[3] = __uint_as_float(r.a.w);
+  o[4] = __uint_as_float(r.b.x); o[5] = __uint_as_float(r.b.y); o[6] = __uint_as_float(r.b.z); o[7] = __uint_as_float(r.b.w);
+}
+
 struct DwArgs {
   const void* x;       // fwd: input; bwd-data: dy; wrw: x
   const void* w;       // [C][3][3] in the activation dtype, always the forward kernel (`flip` reverses the tap order)
@@ -34,6 +77,7 @@ struct DwArgs {
   int flip;            // forward kernel used as stride-1 backward-data: taps read in reverse order
   int strips_w;        // strips per output row
   int64_t total;       // strips in the tensor
+  uint32_t x_bytes, dy_bytes;   // sizes of the tensors behind `x` / `dy` (buffer descriptors; < 2^31)
 };
 
 template <typename T> __device__ __forceinline__ float dw_round(float v);
@@ -46,7 +90,7 @@ __global__ __launch_bounds__(DW_T) void k_dw_fwd(const DwArgs a) {
   __shared__ float red[4 * DW_T * 8];
   const int C8 = a.C >> 3, SPB = DW_T / C8;
   const int cg = threadIdx.x % C8, sl = threadIdx.x / C8;
-  const T* __restrict__ x = (const T*)a.x;
+  const dw_rsrc_t rsx = DW_MAKE_RSRC(a.x, a.x_bytes);
   const T* __restrict__ w = (const T*)a.w;
   T* __restrict__ y = (T*)a.y;
   float wr[9][8];
@@ -68,21 +112,25 @@ __global__ __launch_bounds__(DW_T) void k_dw_fwd(const DwArgs a) {
     for (int p = 0; p < DW_PW; ++p)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[p][j] = 0.f;
+    // all 3 x NV vectors of the strip are requested before the first one is used (positions outside the image: zeros)
+    DwRaw<T> raw[3][NV];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const int hi = ho * ST + r - a.ph;
-      if ((unsigned)hi >= (unsigned)a.H) continue;
-      const T* row = x + ((int64_t)(b * a.H + hi) * a.W) * a.C + cg * 8;
-      float v[NV][8];
+      const bool rok = (unsigned)hi < (unsigned)a.H;
+      const uint32_t rbase = (uint32_t)((((int64_t)(b * a.H + hi) * a.W) * a.C + cg * 8) * (int)sizeof(T));
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int wi = wo0 * ST - a.pw + i;
-        if ((unsigned)wi < (unsigned)a.W) load8<T>(row + (int64_t)wi * a.C, v[i]);
-        else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
-        }
+        const bool ok = rok && (unsigned)wi < (unsigned)a.W;
+        dw_fetch<T>(rsx, ok ? rbase + (uint32_t)(wi * a.C * (int)sizeof(T)) : DW_OOB, raw[r][i]);
       }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      float v[NV][8];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) dw_unpack<T>(raw[r][i], v[i]);
 #pragma unroll
       for (int p = 0; p < DW_PW; ++p)
 #pragma unroll
@@ -133,7 +181,7 @@ template <typename T>
 __global__ __launch_bounds__(DW_T) void k_dw_bwd_data(const DwArgs a) {
   const int C8 = a.C >> 3, SPB = DW_T / C8;
   const int cg = threadIdx.x % C8, sl = threadIdx.x / C8;
-  const T* __restrict__ dy = (const T*)a.x;
+  const dw_rsrc_t rsy = DW_MAKE_RSRC(a.x, a.x_bytes);
   const T* __restrict__ w = (const T*)a.w;
   T* __restrict__ dx = (T*)a.y;
   float wr[9][8];
@@ -146,26 +194,30 @@ __global__ __launch_bounds__(DW_T) void k_dw_bwd_data(const DwArgs a) {
     const int wi = (int)(pix % a.W);
     const int64_t t = pix / a.W;
     const int hi = (int)(t % a.H), b = (int)(t / a.H);
+    // the nine candidate taps, requested at once: a tap that does not hit an output pixel reads zeros
+    DwRaw<T> raw[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int th = hi + a.ph - r;
+      const int ho = th / a.stride;
+      const bool rok = th >= 0 && (th - ho * a.stride) == 0 && ho < a.Ho;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int tw = wi + a.pw - s;
+        const int wo = tw / a.stride;
+        const bool ok = rok && tw >= 0 && (tw - wo * a.stride) == 0 && wo < a.Wo;
+        dw_fetch<T>(rsy, ok ? (uint32_t)((((int64_t)(b * a.Ho + ho) * a.Wo + wo) * a.C + cg * 8) * (int)sizeof(T)) : DW_OOB, raw[r * 3 + s]);
+      }
+    }
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int th = hi + a.ph - r;
-      if (th < 0 || th % a.stride) continue;
-      const int ho = th / a.stride;
-      if (ho >= a.Ho) continue;
+    for (int t9 = 0; t9 < 9; ++t9) {
+      float g[8];
+      dw_unpack<T>(raw[t9], g);
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int tw = wi + a.pw - s;
-        if (tw < 0 || tw % a.stride) continue;
-        const int wo = tw / a.stride;
-        if (wo >= a.Wo) continue;
-        float g[8];
-        load8<T>(dy + ((int64_t)(b * a.Ho + ho) * a.Wo + wo) * a.C + cg * 8, g);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = fmaf(g[j], wr[r * 3 + s][j], acc[j]);
-      }
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(g[j], wr[t9][j], acc[j]);
     }
     store8<T>(dx + pix * a.C + cg * 8, acc);
   }
@@ -177,8 +229,8 @@ __global__ __launch_bounds__(DW_T) void k_dw_wrw(const DwArgs a) {
   __shared__ float red[DW_T * 8];                       // one tap at a time: [SPB][C]
   const int C8 = a.C >> 3, SPB = DW_T / C8;
   const int cg = threadIdx.x % C8, sl = threadIdx.x / C8;
-  const T* __restrict__ x = (const T*)a.x;
-  const T* __restrict__ dy = (const T*)a.dy;
+  const dw_rsrc_t rsx = DW_MAKE_RSRC(a.x, a.x_bytes);
+  const dw_rsrc_t rsy = DW_MAKE_RSRC(a.dy, a.dy_bytes);
   float acc[9][8];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -190,30 +242,31 @@ __global__ __launch_bounds__(DW_T) void k_dw_wrw(const DwArgs a) {
     const int64_t t = strip / a.strips_w;
     const int ho = (int)(t % a.Ho), b = (int)(t / a.Ho);
     const int wo0 = sw * DW_PW;
-    float g[DW_PW][8];
+    // the 4 gradient vectors and the 3 x NV input vectors of the strip, requested at once
+    DwRaw<T> graw[DW_PW], raw[3][NV];
 #pragma unroll
-    for (int p = 0; p < DW_PW; ++p) {
-      if (wo0 + p < a.Wo) load8<T>(dy + ((int64_t)(b * a.Ho + ho) * a.Wo + wo0 + p) * a.C + cg * 8, g[p]);
-      else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) g[p][j] = 0.f;
-      }
-    }
+    for (int p = 0; p < DW_PW; ++p)
+      dw_fetch<T>(rsy, (wo0 + p < a.Wo) ? (uint32_t)((((int64_t)(b * a.Ho + ho) * a.Wo + wo0 + p) * a.C + cg * 8) * (int)sizeof(T)) : DW_OOB, graw[p]);
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const int hi = ho * ST + r - a.ph;
-      if ((unsigned)hi >= (unsigned)a.H) continue;
-      const T* row = x + ((int64_t)(b * a.H + hi) * a.W) * a.C + cg * 8;
-      float v[NV][8];
+      const bool rok = (unsigned)hi < (unsigned)a.H;
+      const uint32_t rbase = (uint32_t)((((int64_t)(b * a.H + hi) * a.W) * a.C + cg * 8) * (int)sizeof(T));
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int wi = wo0 * ST - a.pw + i;
-        if ((unsigned)wi < (unsigned)a.W) load8<T>(row + (int64_t)wi * a.C, v[i]);
-        else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
-        }
+        const bool ok = rok && (unsigned)wi < (unsigned)a.W;
+        dw_fetch<T>(rsx, ok ? rbase + (uint32_t)(wi * a.C * (int)sizeof(T)) : DW_OOB, raw[r][i]);
       }
+    }
+    float g[DW_PW][8];
+#pragma unroll
+    for (int p = 0; p < DW_PW; ++p) dw_unpack<T>(graw[p], g[p]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      float v[NV][8];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) dw_unpack<T>(raw[r][i], v[i]);
 #pragma unroll
       for (int p = 0; p < DW_PW; ++p)
 #pragma unroll
@@ -257,6 +310,15 @@ extern "C" int pf_depthwise_groups(int B, int Ho, int Wo, int C) {
   return dw_groups(total, C);
 }
 
+// sizes of the tensors the kernels read through buffer descriptors (31-bit byte offsets: 0x80000000 is the "outside" offset)
+static bool dw_set_bytes(DwArgs& a, int dtype, int64_t x_elems, int64_t dy_elems) {
+  const int64_t sz = (dtype == PF_F32) ? 4 : 2;
+  if (x_elems * sz >= ((int64_t)1 << 31) || dy_elems * sz >= ((int64_t)1 << 31)) return false;
+  a.x_bytes = (uint32_t)(x_elems * sz);
+  a.dy_bytes = (uint32_t)(dy_elems * sz);
+  return true;
+}
+
 static int dw_fill(DwArgs& a, int B, int H, int W, int C, int Ho, int Wo, int stride, int ph, int pw) {
   if (B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || ph < 0 || pw < 0 || ph > 2 || pw > 2) return (int)hipErrorInvalidValue;
   a.B = B; a.H = H; a.W = W; a.C = C; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.ph = ph; a.pw = pw;
@@ -274,6 +336,7 @@ extern "C" int pf_depthwise_fwd(const void* X, const void* W, void* Y, int dtype
   const int r = dw_fill(a, B, H, Wd, C, Ho, Wo, stride, pad_h, pad_w);
   if (r) return r;
   a.x = X; a.w = W; a.y = Y; a.dy = nullptr; a.partial = partial;
+  if (!dw_set_bytes(a, dtype, (int64_t)B * H * Wd * C, 0)) return (int)hipErrorInvalidValue;
   const int grid = dw_groups(a.total, C);
   hipStream_t st = (hipStream_t)stream;
 #define PF_DW(TT)                                                                     \
@@ -301,6 +364,7 @@ extern "C" int pf_depthwise_bwd_data(const void* dY, const void* W, void* dX, in
     const int r1 = dw_fill(a, B, Ho, Wo, C, H, Wd, 1, 2 - pad_h, 2 - pad_w);
     if (r1) return r1;
     a.x = dY; a.w = W; a.y = dX; a.dy = nullptr; a.partial = nullptr; a.flip = 1;
+    if (!dw_set_bytes(a, dtype, (int64_t)B * Ho * Wo * C, 0)) return (int)hipErrorInvalidValue;
     const int grid1 = dw_groups(a.total, C);
     if (dtype == PF_F32) k_dw_fwd<float, 1><<<grid1, DW_T, 0, st>>>(a);
     else if (dtype == PF_BF16) k_dw_fwd<bf16_t, 1><<<grid1, DW_T, 0, st>>>(a);
@@ -311,6 +375,7 @@ extern "C" int pf_depthwise_bwd_data(const void* dY, const void* W, void* dX, in
   const int r = dw_fill(a, B, H, Wd, C, Ho, Wo, stride, pad_h, pad_w);
   if (r) return r;
   a.x = dY; a.w = W; a.y = dX; a.dy = nullptr; a.partial = nullptr;
+  if (!dw_set_bytes(a, dtype, (int64_t)B * Ho * Wo * C, 0)) return (int)hipErrorInvalidValue;
   const int64_t npix = (int64_t)B * H * Wd;
   const int grid = dw_groups(npix, C);
   if (dtype == PF_F32) k_dw_bwd_data<float><<<grid, DW_T, 0, st>>>(a);
@@ -332,6 +397,7 @@ extern "C" int pf_depthwise_wrw(const void* dY, const void* X, void* dW, int dty
   const int r = dw_fill(a, B, H, Wd, C, Ho, Wo, stride, pad_h, pad_w);
   if (r) return r;
   a.x = X; a.w = nullptr; a.y = nullptr; a.dy = dY; a.partial = slabs;
+  if (!dw_set_bytes(a, dtype, (int64_t)B * H * Wd * C, (int64_t)B * Ho * Wo * C)) return (int)hipErrorInvalidValue;
   const int grid = dw_groups(a.total, C);
   hipStream_t st = (hipStream_t)stream;
 #define PF_DWW(TT)                                                                    \

@@ -1141,6 +1141,60 @@ class _StemConv(torch.autograd.Function):
     return dx, dw, None, None
 
 
+class _Stem3Conv(torch.autograd.Function):
+  """The MobileNet-v1 stem (3x3 / stride 2, 3 -> 16 | 32 channels, TensorFlow 'SAME' padding given by its FRONT pads) on
+  pf_conv_stem3_fwd / pf_conv_stem3_wrw: no padded copy of the image (round 4 ran this layer on the general kernel over
+  F.pad(image): 361 + 878 us per step against 148 / 119 us for MIOpen).  The image needs no gradient."""
+
+  @staticmethod
+  def forward(ctx, x, w, graph, w_var, pads, out_hw):
+    B, _, H, Wd = x.shape
+    N = w.shape[0]
+    Ho, Wo = out_hw
+    y = torch.empty((B, N, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    with region('conv_stem_fwd', float((x.numel() + y.numel()) * 2)):
+      hip.conv_stem3_fwd(x, w.detach().permute(0, 2, 3, 1), y, B, H, Wd, N, pads[0], pads[1], Ho, Wo)
+    ctx.save_for_backward(x, w)
+    ctx.meta = (graph, w_var, pads, out_hw)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    x, w = ctx.saved_tensors
+    graph, w_var, pads, (Ho, Wo) = ctx.meta
+    dy = _nhwc(dy)
+    dw = None
+    if ctx.needs_input_grad[1]:
+      B, _, H, Wd = x.shape
+      N = w.shape[0]
+      S = hip.conv_stem3_wrw_slabs(B, H, Wd, N, pads[0], pads[1], Ho, Wo)
+      if S <= 0:
+        raise RuntimeError('pf_conv_stem3_wrw does not take the shape its forward kernel took')
+      with region('conv_stem_wrw', float((x.numel() + dy.numel()) * 2)):
+        gw = getattr(w, 'grad', None)
+        direct = (gw is not None and gw.shape == w.shape and gw.permute(0, 2, 3, 1).is_contiguous()
+                  and gw.dtype in (torch.float32, torch.bfloat16))
+        dwk = gw.permute(0, 2, 3, 1) if direct else torch.empty((N, 3, 3, 3), dtype=w.dtype, device=x.device)
+        hip.conv_stem3_wrw(dy, x, dwk, graph.scratch((S + 32) * N * 27), B, H, Wd, N, pads[0], pads[1], Ho, Wo)
+        if direct:
+          graph.store.notify_grad(w_var)
+        else:
+          dw = dwk.permute(0, 3, 1, 2)
+    if ctx.needs_input_grad[0]:
+      raise RuntimeError('the MobileNet stem kernels compute no image gradient')
+    return None, dw, None, None, None, None
+
+
+def own_stem3_ok(x, conv, front_pads, out_hw) -> bool:
+  """The MobileNet stem on pf_stem3.hip: bf16 NHWC image batch, 3 -> 16 | 32 channels, 3x3 / stride 2, no bias, no image gradient."""
+  return (OWN_STEM and conv.bias is None and isinstance(x, torch.Tensor) and fusable_tensor(x) and x.dim() == 4 and conv.k == 3
+          and conv.graph.fuse_conv1x1 and not x.requires_grad and x.is_contiguous(memory_format=torch.channels_last)
+          and hip.conv_stem3_supported(x.shape[2], x.shape[3], x.shape[1], conv.kernel.ref_shape[3], conv.k, conv.stride,
+                                       front_pads[0], front_pads[1], out_hw[0], out_hw[1])
+          and hip.conv_stem3_wrw_slabs(x.shape[0], x.shape[2], x.shape[3], conv.kernel.ref_shape[3], front_pads[0], front_pads[1],
+                                       out_hw[0], out_hw[1]) > 0)
+
+
 def own_stem_ok(x, conv, pad) -> bool:
   return (OWN_STEM and conv.bias is None and isinstance(x, torch.Tensor) and fusable_tensor(x) and x.dim() == 4
           and pad is not None and pad[0] == pad[1] and conv.graph.fuse_conv1x1
@@ -1258,6 +1312,15 @@ class Conv2D:
     elif self.padding == 'SAME' and self.k > 1:
       ph = _same_pads(x.shape[2], self.k, self.stride)
       pw = _same_pads(x.shape[3], self.k, self.stride)
+      if residual is None and x.shape[1] == 3 and self.k == 3 and self.stride == 2:
+        out_hw = (-(-x.shape[2] // 2), -(-x.shape[3] // 2))
+        if own_stem3_ok(x, self, (ph[0], pw[0]), out_hw):    # the MobileNet stem: asymmetric 'SAME' pads without a padded image copy
+          if torch.is_grad_enabled() and w.requires_grad:
+            return _Stem3Conv.apply(x, w, self.graph, self.kernel, (ph[0], pw[0]), out_hw)
+          y = torch.empty((x.shape[0], w.shape[0]) + out_hw, dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+          hip.conv_stem3_fwd(x, w.detach().permute(0, 2, 3, 1), y, x.shape[0], x.shape[2], x.shape[3], w.shape[0], ph[0], pw[0],
+                             out_hw[0], out_hw[1])
+          return y
       if ph[0] == ph[1] and pw[0] == pw[1]:
         pad = (ph[0], pw[0])
         sym = pad

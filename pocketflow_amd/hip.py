@@ -49,6 +49,7 @@ SYMBOLS = [
     'pf_adam_flat_dev', 'pf_momentum_flat_dev', 'pf_set_floats',
     'pf_convg_fwd', 'pf_convg_bwd_data', 'pf_convg_small_splits', 'pf_convg_wrw_splits', 'pf_convg_wrw', 'pf_conv2d_bwd_data_strided',
     'pf_prox_groups', 'pf_prox_norms', 'pf_prox_apply', 'pf_im2col', 'pf_col2im',
+    'pf_conv_stem3_supported', 'pf_conv_stem3_fwd', 'pf_conv_stem3_wrw_slabs', 'pf_conv_stem3_wrw',
 ]
 
 
@@ -579,6 +580,30 @@ def conv_stem_wrw(dY, X, dW, workspace, imgs: int, H: int, Wd: int) -> None:
   _dev(dY)
   _check(_lib.pf_conv_stem_wrw(_ptr(dY), _ptr(X), _ptr(dW), c_int(dtype_code(dW)), _ptr(workspace), c_int(imgs), c_int(H),
                                c_int(Wd), _stream()), 'pf_conv_stem_wrw')
+
+
+def conv_stem3_supported(H: int, Wd: int, C: int, N: int, k: int, stride: int, pad_h: int, pad_w: int, Ho: int, Wo: int) -> bool:
+  return bool(_lib.pf_conv_stem3_supported(c_int(H), c_int(Wd), c_int(C), c_int(N), c_int(k), c_int(stride), c_int(pad_h), c_int(pad_w),
+                                           c_int(Ho), c_int(Wo)))
+
+
+def conv_stem3_fwd(X, W, Y, imgs: int, H: int, Wd: int, N: int, pad_h: int, pad_w: int, Ho: int, Wo: int) -> None:
+  """The MobileNet stem.  X: NHWC memory [imgs][H][Wd][3] bf16, W: KRSC memory [N][3][3][3] bf16, Y: [imgs][Ho][Wo][N] bf16;
+  pad_h / pad_w: FRONT pads of 'SAME'."""
+  _dev(X)
+  _check(_lib.pf_conv_stem3_fwd(_ptr(X), _ptr(W), _ptr(Y), c_int(imgs), c_int(H), c_int(Wd), c_int(N), c_int(pad_h), c_int(pad_w),
+                                c_int(Ho), c_int(Wo), _stream()), 'pf_conv_stem3_fwd')
+
+
+def conv_stem3_wrw_slabs(imgs: int, H: int, Wd: int, N: int, pad_h: int, pad_w: int, Ho: int, Wo: int) -> int:
+  return int(_lib.pf_conv_stem3_wrw_slabs(c_int(imgs), c_int(H), c_int(Wd), c_int(N), c_int(pad_h), c_int(pad_w), c_int(Ho), c_int(Wo)))
+
+
+def conv_stem3_wrw(dY, X, dW, workspace, imgs: int, H: int, Wd: int, N: int, pad_h: int, pad_w: int, Ho: int, Wo: int) -> None:
+  """dW: KRSC memory [N][3][3][3] float32 / bf16; workspace: float32, (conv_stem3_wrw_slabs(...) + 32) * N * 27 elements."""
+  _dev(dY)
+  _check(_lib.pf_conv_stem3_wrw(_ptr(dY), _ptr(X), _ptr(dW), c_int(dtype_code(dW)), _ptr(workspace), c_int(imgs), c_int(H), c_int(Wd),
+                                c_int(N), c_int(pad_h), c_int(pad_w), c_int(Ho), c_int(Wo), _stream()), 'pf_conv_stem3_wrw')
 
 
 # ------------------------------------------------------------------------------------------------

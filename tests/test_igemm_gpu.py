@@ -325,3 +325,64 @@ def test_conv2d_backward_data_of_strided_convolutions_by_parity_classes(hip, img
   dx2 = torch.empty_like(dx)
   hip.conv2d_bwd_data_strided(dy, wb, dx2, imgs, H, Wd, C, N, k, k, stride, pad, pad, Ho, Wo)
   assert torch.equal(dx, dx2)
+
+# ---- the MobileNet stem (pf_stem3.hip) --------------------------------------------------------------------------------
+def _same(size, k=3, stride=2):
+  out = -(-size // stride)
+  total = max((out - 1) * stride + k - size, 0)
+  return total // 2, total - total // 2, out
+
+
+@pytest.mark.parametrize('N', [32, 16])
+@pytest.mark.parametrize('imgs,H,Wd', [(3, 64, 64), (2, 224, 224), (1, 38, 96), (5, 63, 64), (130, 32, 64), (2, 17, 32)])
+def test_conv_stem3_fwd_matches_torch(hip, imgs, H, Wd, N):
+  """3x3 / stride 2, TensorFlow 'SAME' (asymmetric on even sizes: nothing in front, one row / column behind; symmetric on odd ones),
+  3 -> 16 | 32 channels: against float32 torch on the explicitly padded image -- borders on all sides, a partial last strip of
+  output rows, more (image, strip) items than workgroups, an asymmetric random kernel, repeated calls into a poisoned buffer."""
+  (ph, ph1, Ho), (pw, pw1, Wo) = _same(H), _same(Wd)
+  assert hip.conv_stem3_supported(H, Wd, 3, N, 3, 2, ph, pw, Ho, Wo) and not hip.conv_stem3_supported(H, Wd, 4, N, 3, 2, ph, pw, Ho, Wo)
+  g = torch.Generator(device='cuda').manual_seed(H + Wd + imgs + N)
+  x = _bf(torch.randn(imgs, H, Wd, 3, device='cuda', generator=g))
+  w = _bf(torch.randn(N, 3, 3, 3, device='cuda', generator=g) * 0.2)
+  xp = F.pad(x.float().permute(0, 3, 1, 2), (pw, pw1, ph, ph1))
+  ref = _bf(F.conv2d(xp, w.float().permute(0, 3, 1, 2), stride=2).permute(0, 2, 3, 1))
+  assert ref.shape == (imgs, Ho, Wo, N)
+  for rep in range(2):
+    y = torch.full((imgs, Ho, Wo, N), float('nan'), device='cuda', dtype=torch.bfloat16)
+    hip.conv_stem3_fwd(x, w, y, imgs, H, Wd, N, ph, pw, Ho, Wo)
+    _close(y, ref, 'stem3 %dx%dx%d N=%d call %d' % (imgs, H, Wd, N, rep))
+  # one-hot probes: every (tap, channel) weight must meet exactly its input element
+  x1 = torch.zeros(1, 32, 32, 3, device='cuda', dtype=torch.bfloat16)
+  x1[0, 10, 13, 1] = 1.0
+  x1[0, 31, 31, 2] = 1.0                                  # the last pixel: only reached through the padding behind the image
+  y1 = torch.empty(1, 16, 16, N, device='cuda', dtype=torch.bfloat16)
+  hip.conv_stem3_fwd(x1, w, y1, 1, 32, 32, N, 0, 0, 16, 16)
+  r1 = _bf(F.conv2d(F.pad(x1.float().permute(0, 3, 1, 2), (0, 1, 0, 1)), w.float().permute(0, 3, 1, 2), stride=2).permute(0, 2, 3, 1))
+  assert torch.equal(y1, r1)
+
+
+@pytest.mark.parametrize('dw_dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('N', [32, 16])
+@pytest.mark.parametrize('imgs,H,Wd', [(3, 64, 64), (2, 224, 224), (1, 38, 96), (5, 63, 64), (130, 32, 64)])
+def test_conv_stem3_wrw_matches_autograd(hip, imgs, H, Wd, N, dw_dtype):
+  """Backward-filter of the MobileNet stem against aten's float32 convolution_backward on the same bf16 operands (explicitly padded
+  image): an odd number of output rows (a half-empty last strip), more items than workgroups, border taps, both gradient dtypes;
+  bit-reproducible (fixed-order slab reduction)."""
+  (ph, ph1, Ho), (pw, pw1, Wo) = _same(H), _same(Wd)
+  S = hip.conv_stem3_wrw_slabs(imgs, H, Wd, N, ph, pw, Ho, Wo)
+  assert S > 0
+  g = torch.Generator(device='cuda').manual_seed(H * 3 + Wd + imgs + N)
+  x = _bf(torch.randn(imgs, H, Wd, 3, device='cuda', generator=g))
+  dy = _bf(torch.randn(imgs, Ho, Wo, N, device='cuda', generator=g) * 0.1)
+  xp = F.pad(x.float().permute(0, 3, 1, 2), (pw, pw1, ph, ph1))
+  ref = torch.ops.aten.convolution_backward(dy.float().permute(0, 3, 1, 2), xp, torch.zeros(N, 3, 3, 3, device='cuda'), None, [2, 2], [0, 0],
+                                            [1, 1], False, [0, 0], 1, [False, True, False])[1].permute(0, 2, 3, 1)
+  outs = []
+  for rep in range(2):
+    ws = torch.full(((S + 32) * N * 27,), float('nan'), device='cuda')
+    dw = torch.full((N, 3, 3, 3), float('nan'), device='cuda', dtype=dw_dtype)
+    hip.conv_stem3_wrw(dy, x, dw, ws, imgs, H, Wd, N, ph, pw, Ho, Wo)
+    outs.append(dw.float())
+  scale = float(ref.abs().max())
+  torch.testing.assert_close(outs[0], ref, rtol=2e-2 if dw_dtype == torch.bfloat16 else 2e-3, atol=(8e-3 if dw_dtype == torch.bfloat16 else 2e-3) * scale)
+  assert torch.equal(outs[0], outs[1])
