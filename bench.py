@@ -53,8 +53,8 @@ def parse_args():
                        'conv1x1_bwd_data | conv2d_fwd | bn_bwd_apply | bn_bwd_stats | bn_act_quant_apply | bn_stats')
   ap.add_argument('--no_cpu_baseline', action='store_true')
   ap.add_argument('--step_graph', type=int, default=None,
-                  help='1 (default on ONE GPU): the steady-state step is recorded in a hipGraph during the warm-up and replayed '
-                       '(pocketflow_amd/step_graph.py); 0: every step is issued launch by launch (always for N > 1).  The throughput of a '
+                  help='1 (default): the steady-state step is recorded in a hipGraph during the warm-up and replayed '
+                       '(pocketflow_amd/step_graph.py; N > 1: two graphs around the gradient-exchange calls); 0: every step is issued launch by launch.  The throughput of a '
                        'GPU-bound step does not depend on it when the host is fast (C2: 10 307 vs 10 302 images/s) but a loaded host '
                        'cannot slow a recorded step down; a replayed graph cannot carry timing events on ROCm, so the last --event_steps '
                        'steps are issued launch by launch for the roofline figure')
@@ -143,7 +143,7 @@ def set_flags(args, tmp, world):
   FLAGS.enbl_dst = cfg['dst']
   FLAGS.dst_eval_teacher = False            # the teacher's one-off evaluation is not part of a step
   FLAGS.synthetic_pool = 2
-  FLAGS.enbl_step_graph = bool(getattr(args, 'step_graph', None) == 1) and world == 1     # (default: decided after the warm-up, see main)
+  FLAGS.enbl_step_graph = bool(getattr(args, 'step_graph', None) == 1)     # (default: decided after the warm-up, see main)
   FLAGS.save_path = os.path.join(tmp, 'models', 'model.ckpt')
   FLAGS.save_path_dst = os.path.join(tmp, 'models_dst', 'model.ckpt')
   if cfg['model'] != 'mobilenet':
@@ -340,7 +340,8 @@ def main():
   # the warm-up whatever W is; a learner whose step cannot be recorded says so once and stays launch-by-launch
   sg = None
   auto_share = None
-  if args.step_graph is None and world == 1:
+  recorded_choice = None
+  if args.step_graph is None and (world == 1 or os.environ.get('PF_STEP_GRAPH_DIST', '1') != '0'):
     # default: the step is recorded; how host-bound it is launch by launch (the host's share of two untimed steps from an empty launch
     # queue) is measured first and reported in the line (config.host_share_of_two_launch_by_launch_steps)
     torch.cuda.synchronize()
@@ -350,16 +351,27 @@ def main():
     a1 = time.perf_counter()
     torch.cuda.synchronize()
     auto_share = (a1 - a0) / max(time.perf_counter() - a0, 1e-9)
-    FLAGS.enbl_step_graph = True          # (the measured host share is reported; the recording is the default on one GPU)
-  if FLAGS.enbl_step_graph and world == 1:
+    FLAGS.enbl_step_graph = True          # (the measured host share is reported; the recording is the default)
+  if FLAGS.enbl_step_graph:
+    # N > 1: every rank records its own two graphs around the gradient-exchange calls (step_graph.CudaBackend.cut).  Every
+    # rank makes the same number of train_step calls whether its recording succeeded or not (a call that records also executes
+    # one step), and whether the job stays on the recorded step is decided together.
     from pocketflow_amd import step_graph
     sg = step_graph.of(learner)
     extra = 0
     while sg.state == 'warm' and extra < 8:
       train_step()
       extra += 1
-    if sg.state != 'ready':
+    ready = sg.state == 'ready'
+    if world > 1:
+      flag = torch.tensor([1.0 if ready else 0.0], device='cuda')
+      dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+      if ready and float(flag.item()) == 0.0:
+        sg.suspend()                       # another rank could not record: this one goes back to launch-by-launch steps with it
+        ready = False
+    if not ready:
       sys.stderr.write('bench.py: step graph not recorded (%r): launch-by-launch steps\n' % (sg.error,))
+      FLAGS.enbl_step_graph = False
       sg = None
     else:
       # torch.cuda.graph() empties the caching allocator before it records: the launch-by-launch steps of the timed region (the ones
@@ -371,6 +383,37 @@ def main():
       sg.resume()
       train_step()
       train_step()
+      if world > 1:
+        # N > 1: the job stays on the recorded step only where it is not slower than launch-by-launch steps ON THIS JOB -- decided
+        # together from the slowest rank's times.  (The recorded step trades the overlap of the exchange with the backward pass
+        # for ~700 fewer host launches per step; which one wins depends on the host and the links.  With two ranks sharing ONE GPU
+        # over gloo, the test hook, replays were measured 10-20x SLOWER: the exchange call waits 80-900 ms,
+        # profiles/r05_recorded_step_two_ranks.txt.)
+        def step_seconds(n):
+          sync()
+          t = time.perf_counter()
+          for _ in range(n):
+            train_step()
+          sync()
+          return (time.perf_counter() - t) / n
+        t_rec = step_seconds(2)
+        sg.suspend()
+        train_step()                       # (the hand-over between the modes is not part of either figure)
+        t_lbl = step_seconds(2)
+        both = torch.tensor([t_rec, t_lbl], dtype=torch.float64, device='cuda')
+        dist.all_reduce(both, op=dist.ReduceOp.MAX)
+        t_rec, t_lbl = (float(v) for v in both.tolist())
+        recorded_choice = {'graphs': len(sg.backend.graphs), 'exchange_calls_between_graphs': len(sg.backend.actions),
+                           'replay_ms_per_step': t_rec * 1e3, 'launch_by_launch_ms_per_step': t_lbl * 1e3,
+                           'kept': bool(t_rec <= 1.1 * t_lbl)}
+        if recorded_choice['kept']:
+          sg.resume()
+          train_step()
+          train_step()
+        else:
+          recorded_choice['replayed_steps'] = sg.n_replays
+          FLAGS.enbl_step_graph = False
+          sg = None
   # Self-diagnosis of a host-bound process.  Seven bench processes of round 2 ran at 150 ms instead of
   # 29 ms per step with the same kernels: the caching allocator was going to the driver for every tensor (torch.empty at
   # 185 us) because a reference cycle in the layer executor kept each step's activations alive until Python's cyclic
@@ -454,7 +497,9 @@ def main():
     multi_gpu = {'backend': dist.get_backend(), 'params_identical_across_ranks': all(bool(torch.equal(sigs[0], x)) for x in sigs),
                  'buckets': len(red.buckets) if red is not None else None,
                  'buckets_launched_inside_backward': red.n_overlapped if red is not None else None,
-                 'allreduce_bytes_per_step': int(st.w_size * el + st.o_size * 4)}
+                 'allreduce_bytes_per_step': int(st.w_size * el + st.o_size * 4),
+                 'recorded_step': (dict(recorded_choice, replayed_steps=sg.n_replays) if sg is not None and recorded_choice is not None
+                                   else recorded_choice)}
   # The region's launches of BOTH streams: the student's (main stream) and -- profiling.include_side -- the teacher's over the next
   # batch (second stream).  A launch that shares the chip with the other stream takes longer from start to end; that is what a
   # rocprofv3 kernel trace of this command shows for it too, so the average over both is the figure the trace's average agrees with.

@@ -167,6 +167,10 @@ class GradReducer(object):
     self.armed = False         # in-backward launching is OPT-IN per step: arm() ... backward ... disarm() / finish()
     store.grad_hook = self._on_grad
     self.n_overlapped = 0      # buckets launched from inside backward in the last cycle (diagnostics / tests)
+    # While the learner's step is recorded in hipGraphs (step_graph.py): the backend whose `cut(action)` takes the exchange -- the
+    # staging copies are captured, the all-reduces stay host calls BETWEEN the two graphs of the chain, made again in every
+    # replay.  None (and outside a capture): collectives are issued on the spot.
+    self.recorder = None
 
   def _build_buckets(self, bucket_elems: int) -> None:
     ws = sorted([v for v in self.store.vars if v.group == 'W' and v.trainable], key=lambda v: v.offset)
@@ -205,12 +209,22 @@ class GradReducer(object):
         self._stage_o = buf
     return buf
 
-  def _launch(self, b: int) -> None:
+  def _stage_bucket(self, b: int):
+    """Widen bucket b into the staging buffer (stream-ordered copy); -> the call that all-reduces it."""
     lo, hi, _ = self.buckets[b]
-    stage = self._stage('w')
-    stage[lo:hi].copy_(self.store.w_grad[lo:hi])
-    self.handles.append(dist.all_reduce(stage[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+    piece = self._stage('w')[lo:hi]
+    piece.copy_(self.store.w_grad[lo:hi])
     self.launched[b] = True
+    return lambda: self.handles.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True))
+
+  def _launch(self, b: int) -> None:
+    self._stage_bucket(b)()
+
+  def _recording(self) -> bool:
+    """The step is being captured into hipGraphs right now (step_graph.CudaBackend): nothing may go out from inside the backward
+    pass -- a capture ended and re-begun from a gradient hook replayed garbage in one bucket from the second replay on (measured,
+    profiles/r05_recorded_step_two_ranks.txt) -- so the whole exchange of a recorded step is made in finish(), between TWO graphs."""
+    return self.recorder is not None and getattr(self.recorder, 'capturing', False)
 
   def arm(self) -> None:
     """Allow bucket all-reduces to be launched from inside the NEXT backward pass.  Every rank must run that backward
@@ -227,7 +241,7 @@ class GradReducer(object):
     self.armed = False
 
   def _on_grad(self, var) -> None:
-    if not (self.overlap and self._active()) or var.group != 'W':
+    if not (self.overlap and self._active()) or var.group != 'W' or self._recording():
       return
     if not self.armed:
       # a gradient produced OUTSIDE the armed pass while buckets of this cycle are already in flight (a second,
@@ -268,18 +282,28 @@ class GradReducer(object):
       self.handles = []
       self.launched = [False] * len(self.buckets)
       n_over = 0
+    calls = []
     if st.w_size:
-      for b in range(len(self.buckets)):
-        if not self.launched[b]:
-          self._launch(b)
+      calls = [self._stage_bucket(b) for b in range(len(self.buckets)) if not self.launched[b]]
     w_src = self._stage('w') if st.w_size else st.w_grad
     o_src = st.o_grad
     if st.o_size:
       o_src = self._stage('o')
       o_src.copy_(st.o_grad)
-      self.handles.append(dist.all_reduce(o_src, op=dist.ReduceOp.SUM, async_op=True))
-    for h in self.handles:
-      h.wait()
+    o_piece = o_src if st.o_size else None
+
+    def exchange():            # what is left of the step's exchange: the buckets not launched from inside backward, the small buffer;
+      for call in calls:       # then every collective of the step is waited for
+        call()
+      if o_piece is not None:
+        self.handles.append(dist.all_reduce(o_piece, op=dist.ReduceOp.SUM, async_op=True))
+      for h in self.handles:
+        h.wait()
+      self.handles = []
+    if self.recorder is not None:
+      self.recorder.cut(exchange)       # recorded step: a host call between the two graphs of the chain, made again in every replay
+    else:
+      exchange()
     self._reset_cycle()
     self.n_overlapped = n_over
     return w_src, o_src, 1.0 / dist.get_world_size()

@@ -1,4 +1,4 @@
-"""The steady-state fine-tune step recorded ONCE in a hipGraph and replayed (`--enbl_step_graph`; single process).
+"""The steady-state fine-tune step recorded ONCE in a hipGraph and replayed (`--enbl_step_graph`).
 
 Why.  A step of this engine is 300-700 kernel launches issued from Python: 10 ms of host time for ResNet-50 (the GPU needs 24 ms:
 fine), 4.4 ms for ResNet-20 @ CIFAR-10 (the GPU needs less: the step is HOST-bound, profiles/r03_host_overhead_c1.txt) and 15 ms for
@@ -41,20 +41,80 @@ log = logging.getLogger('pocketflow_amd')
 
 
 class CudaBackend(object):
-  """torch.cuda.CUDAGraph is a hipGraph on ROCm."""
+  """torch.cuda.CUDAGraph is a hipGraph on ROCm.
 
-  def __init__(self, device):
+  One process: the step is ONE graph.  Several ranks (`segmented`): the step is TWO graphs around the gradient exchange --
+  `cut(action)`, called by optim.GradReducer.finish() behind the recorded backward pass and the captured staging copies of the
+  gradient buckets, ends the graph under capture, notes `action` (the all-reduces of the step: ordinary host-side RCCL calls,
+  then the wait for them) and starts the next graph (the optimiser update and the tail) in the same memory pool; a replay is
+  graph 0, action, graph 1 -- three host calls plus a handful of collectives instead of ~700 launches (Horovod's all-reduce
+  lives inside the reference's compiled train graph the same way: utils/multi_gpu_wrapper.py:83-98,
+  learners/uniform_quantization/learner.py:246).  The collectives themselves are NOT captured: RCCL runs them on its own stream,
+  ordered behind graph 0 by the usual event hand-shake of an asynchronous collective, so nothing here depends on graph support
+  inside RCCL.  What a recorded step gives up is the overlap of the exchange with the rest of the backward pass (the
+  launch-by-launch step keeps it): cutting from the gradient hooks INSIDE the captured backward pass was built first and
+  replayed garbage in one bucket from the second replay on (profiles/r05_recorded_step_two_ranks.txt); with the cut behind
+  backward the recorded and the launch-by-launch run agree.  Segmented captures run in thread-local capture mode (the process
+  group's watchdog thread polls events of earlier collectives; a global-mode capture would be invalidated by it) with the backward
+  pass on the calling thread, as do the launch-by-launch steps before them (`warm`)."""
+
+  def __init__(self, device, segmented=False):
     self.device = device
+    self.segmented = segmented
     self.graph = torch.cuda.CUDAGraph()
+    self.graphs = [self.graph]              # the step in replay order: graphs[0], actions[0], graphs[1], ...
+    self.actions = []
     self.side = torch.cuda.Stream(device=device)
     self._joined = True
+    self.capturing = False
 
   def capture(self, body):
     torch.cuda.synchronize(self.device)
-    with torch.cuda.graph(self.graph):
-      out = body(self)
+    if not self.segmented:
+      with torch.cuda.graph(self.graph):
+        out = body(self)
+    else:
+      out = self._capture_segments(body)
     torch.cuda.synchronize(self.device)
     return out
+
+  def _capture_segments(self, body):
+    torch.cuda.empty_cache()
+    stream = torch.cuda.Stream(device=self.device)
+    with torch.cuda.stream(stream), torch.autograd.set_multithreading_enabled(False):
+      self.graph.capture_begin(capture_error_mode='thread_local')
+      self.capturing = True
+      try:
+        out = body(self)
+      except BaseException:
+        self.capturing = False
+        try:
+          self.graphs[-1].capture_end()
+        except Exception:        # pylint: disable=broad-except
+          pass                    # (the capture is already invalid: the first error is the one to report)
+        raise
+      self.capturing = False
+      self.graphs[-1].capture_end()
+    return out
+
+  def warm(self):
+    """Context of the launch-by-launch steps that precede a segmented recording: their backward pass runs on the calling thread
+    too.  aten's per-thread library handles (hipBLASLt creates one on a thread's first matrix product, which allocates) must
+    exist on the thread that will capture: created inside the capture they end it with hipErrorStreamCaptureUnsupported."""
+    return torch.autograd.set_multithreading_enabled(False) if self.segmented else contextlib.nullcontext()
+
+  def cut(self, action):
+    """End the graph under capture here; `action()` runs on the host between the two graphs in every replay.  Outside a capture
+    (launch-by-launch steps of a learner whose step is also recorded) the action simply runs."""
+    if not self.capturing:
+      action()
+      return
+    self.join()                             # a forked branch must have joined before a capture ends
+    self.graphs[-1].capture_end()
+    self.actions.append(action)
+    g = torch.cuda.CUDAGraph()
+    g.capture_begin(pool=self.graph.pool(), capture_error_mode='thread_local')
+    self.graphs.append(g)
 
   @contextlib.contextmanager
   def fork(self):
@@ -70,7 +130,10 @@ class CudaBackend(object):
       self._joined = True
 
   def replay(self):
-    self.graph.replay()
+    for i, g in enumerate(self.graphs):
+      g.replay()
+      if i < len(self.actions):
+        self.actions[i]()
     return None
 
   def recover(self):
@@ -93,6 +156,12 @@ class InlineBackend(object):
 
   def join(self):
     pass
+
+  def warm(self):
+    return contextlib.nullcontext()
+
+  def cut(self, action):
+    action()
 
   def replay(self):
     return self.body(self)
@@ -173,7 +242,7 @@ class StepGraph(object):
       self.state, self.n_eager, self.suspended = 'warm', 0, False
       self.out = self.cur = self.nxt = self.nxt_raw = self.cur_raw = self.cur_images = None
       self.nxt_stale = self.lookahead_void = self.auto_suspended = False
-      self.backend = type(self.backend)(self.learner.device) if isinstance(self.backend, CudaBackend) else InlineBackend()
+      self.backend = _new_backend(self.learner)
 
   # -- one step ---------------------------------------------------------------------------------------
   def step(self):
@@ -185,7 +254,8 @@ class StepGraph(object):
     if self.state == 'warm':
       if self.n_eager < self.WARM:
         self.n_eager += 1
-        return lrn._train_step_eager()
+        with self.backend.warm():
+          return lrn._train_step_eager()
       try:
         self._record()
       except Exception as e:        # pylint: disable=broad-except
@@ -293,6 +363,9 @@ class StepGraph(object):
     opt.hyper_external = True
     g.capturing = True
     cur, nxt = self.cur, self.nxt
+    red = _reducer_of(lrn)
+    if red is not None:
+      red.recorder = self.backend                            # the exchange goes out through backend.cut(): between the two graphs
 
     def body(be):
       if nxt is not None:
@@ -315,6 +388,10 @@ class StepGraph(object):
       if self.out is not None:
         from pocketflow_amd.learners.abstract_learner import _detached
         self.out = _detached(self.out)                       # static output tensors; the recorded step's Python graph is not needed
+    except BaseException:
+      if red is not None:
+        red.recorder = None
+      raise
     finally:
       g.capturing = False
       # recording executed nothing on the device; undo the host-side bookkeeping of the recorded step (also when the recording failed
@@ -322,7 +399,9 @@ class StepGraph(object):
       setattr(lrn, _step_attr(lrn), step0)
       opt.beta1_power, opt.beta2_power = pow0
     self.state = 'ready'
-    log.info('step graph: recorded the %s step (%s)', type(lrn).__name__, 'teacher forked on a side stream' if nxt is not None else 'single stream')
+    log.info('step graph: recorded the %s step (%s%s)', type(lrn).__name__, 'teacher forked on a side stream' if nxt is not None else 'single stream',
+             '; %d graphs around %d gradient-exchange calls' % (len(self.backend.graphs), len(self.backend.actions))
+             if getattr(self.backend, 'actions', None) else '')
 
   def _replay(self):
     lrn = self.learner
@@ -358,15 +437,24 @@ class StepGraph(object):
     return _with_lr(self.out, lr)
 
 
+def _reducer_of(learner):
+  """The learner's gradient exchange when there is one to make (several ranks): optim.GradReducer, else None."""
+  red = getattr(learner.optimizer, 'reducer', None)
+  return red if red is not None and red._active() else None       # pylint: disable=protected-access
+
+
+def _new_backend(learner):
+  if os.environ.get('PF_STEP_GRAPH') == 'inline':
+    return InlineBackend()
+  if torch.device(learner.device).type == 'cuda':
+    return CudaBackend(learner.device, segmented=_reducer_of(learner) is not None)
+  return None
+
+
 def of(learner) -> StepGraph:
   sg = getattr(learner, '_step_graph', None)
   if sg is None:
-    if os.environ.get('PF_STEP_GRAPH') == 'inline':
-      backend = InlineBackend()
-    elif torch.device(learner.device).type == 'cuda':
-      backend = CudaBackend(learner.device)
-    else:
-      backend = None
+    backend = _new_backend(learner)
     sg = learner._step_graph = StepGraph(learner, backend)
     if backend is None:
       sg.state = 'failed'                                  # no HIP device: eager

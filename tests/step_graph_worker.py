@@ -32,14 +32,46 @@ def _setup(tmp_path, **kw):
 RESULT = {}
 
 
+SIGNATURES = {}
+
+
+def _signature(lrn):
+  """Diagnostics (PF_W_DIAG=1): checksums of the reduced gradient buckets and of the flat buffers after a step."""
+  st = lrn.graph.store
+  red = getattr(st, 'reducer', None)
+  sig = {'w_master': float(st.w_master.double().abs().sum()), 'o_master': float(st.o_master.double().abs().sum()),
+         'state': float(st.state.double().abs().sum())}
+  if red is not None and red._stage_w is not None:
+    sig['buckets'] = [[float(red._stage_w[lo:hi].double().sum()), float(red._stage_w[lo:hi].double().abs().sum())] for lo, hi, _ in red.buckets]
+    if red._stage_o is not None:
+      sig['o_stage'] = float(red._stage_o.double().abs().sum())
+    sig['vars'] = {v.name: float(red._stage_w[v.offset:v.offset + v.numel].double().abs().sum()) for v in st.vars if v.group == 'W' and v.trainable}
+    sig['local'] = dict(getattr(red, '_diag_local', {}))
+  return sig
+
+
 def _collect_losses_each_step(lrn, n_steps, suspend_at, graph_mode):
   from pocketflow_amd import step_graph
   losses = []
+  diag = os.environ.get('PF_W_DIAG') == '1'
+  red0 = getattr(lrn.graph.store, 'reducer', None)
+  if diag and red0 is not None:
+    fin0 = red0.finish
+
+    def fin():
+      if not lrn.graph.capturing:
+        st = lrn.graph.store
+        red0._diag_local = {v.name: float(st.w_grad[v.offset:v.offset + v.numel].double().abs().sum()) for v in st.vars if v.group == 'W' and v.trainable}
+      return fin0()
+    red0.finish = fin
   for i in range(n_steps):
     if graph_mode and i in suspend_at:
       sg = step_graph.of(lrn)
       sg.resume() if sg.suspended else sg.suspend()
     o = lrn.train_step()
+    if diag:
+      torch.cuda.synchronize()
+      SIGNATURES.setdefault('graph' if graph_mode else 'eager', []).append(_signature(lrn))
     losses.append((o['loss'] if isinstance(o, dict) else o[1]).detach().clone())
     # (`o` stays bound while the next step runs, as in the learners' train() loops: the returned tensors carry no autograd graph)
   return [float(l) for l in losses]
@@ -51,6 +83,17 @@ def _assert_same_run(a, b, la, lb, what, loss_rtol=1e-4, param_atol=2e-3):
   solver differently under stream capture: measured 1e-5 relative on a ResNet-20 loss) is held to `loss_rtol` / `param_atol`.
   Whether the run WAS bit-identical is printed."""
   sa, sb = a.graph.store, b.graph.store
+  if SIGNATURES:
+    for i, (e, g) in enumerate(zip(SIGNATURES['eager'], SIGNATURES['graph'])):
+      print('DIAG rank %s step %d loss %.9g | %.9g %s' % (os.environ.get('RANK', '0'), i, la[i], lb[i], 'SAME' if e == g else 'DIFFERENT'))
+      if e != g:
+        ev, gv, el, gl = e.pop('vars', {}), g.pop('vars', {}), e.pop('local', {}), g.pop('local', {})
+        print('DIAG   eager %s' % json.dumps(e))
+        print('DIAG   graph %s' % json.dumps(g))
+        bad = [k for k in ev if ev[k] != gv.get(k)]
+        print('DIAG   reduced gradients that differ: %d of %d: %s' % (len(bad), len(ev), ' '.join('%s(%.3e)' % (k.split('/', 1)[-1], abs(ev[k] - gv[k]) / max(abs(ev[k]), 1e-30)) for k in bad[:12])))
+        badl = [k for k in el if el[k] != gl.get(k)]
+        print('DIAG   local gradients that differ: %d of %d: %s' % (len(badl), len(el), ' '.join('%s(%.3e)' % (k.split('/', 1)[-1], abs(el[k] - gl[k]) / max(abs(el[k]), 1e-30)) for k in badl[:12])))
   worst = max(float((x - y).abs().max()) for x, y in ((sa.w_master, sb.w_master), (sa.o_master, sb.o_master), (sa.state, sb.state)))
   exact = la == lb and worst == 0.0
   RESULT.update(what=what, exact=bool(exact), losses_eager=la, losses_graph=lb, max_parameter_difference=worst)
@@ -59,7 +102,7 @@ def _assert_same_run(a, b, la, lb, what, loss_rtol=1e-4, param_atol=2e-3):
   return exact
 
 
-def case_uq_resnet50(tmp_path):
+def case_uq_resnet50(tmp_path, ranks=1, batch=8, image=64):
   """BASELINE configs[2] shrunk (ResNet-v2-50 @64, batch 8, UQ w8/a8 + distillation, bf16 fused path): 9 steps launch by launch
   vs 3 eager + recording + replays with the graph suspended for steps 6-7.  The teacher's forward over the next batch is a forked
   branch of the graph; Adam's alpha_t comes from device memory.  Same batches in the same order, deterministic kernels: the losses
@@ -70,9 +113,9 @@ def case_uq_resnet50(tmp_path):
   from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
   from pocketflow_amd import step_graph
   import pocketflow_amd.learners.distillation_helper  # noqa: F401
-  _setup(tmp_path, batch_size=8, batch_size_eval=8, uql_weight_bits=8, uql_activation_bits=8, enbl_dst=True, dst_eval_teacher=False,
+  _setup(tmp_path, batch_size=batch, batch_size_eval=batch, uql_weight_bits=8, uql_activation_bits=8, enbl_dst=True, dst_eval_teacher=False,
          save_path_dst=str(tmp_path / 'models_dst' / 'model.ckpt'), uql_save_quant_model_path=str(tmp_path / 'uql' / 'm.ckpt'),
-         resnet_size=50, nb_classes=1001, image_size=64, compute_dtype='bfloat16', synthetic_pool=int(os.environ.get('PF_W_POOL', '5')))
+         resnet_size=50, nb_classes=1001, image_size=image, compute_dtype='bfloat16', synthetic_pool=int(os.environ.get('PF_W_POOL', '5')))
   torch.backends.cudnn.benchmark = os.environ.get('PF_W_BENCHMARK', '0') != '0'
   if os.environ.get('PF_W_STRICT', '1') != '0':
     os.environ['PF_STEP_GRAPH_STRICT'] = '1'
@@ -81,7 +124,10 @@ def case_uq_resnet50(tmp_path):
   def make():
     mh = ModelHelper()
     if not made:
-      create_synthetic_checkpoint(mh)
+      if ranks == 1 or torch.distributed.get_rank() == 0:
+        create_synthetic_checkpoint(mh)                      # (several ranks: one scratch directory, written by rank 0)
+      if ranks > 1:
+        torch.distributed.barrier()
     made.append(1)
     return UniformQuantLearner(None, mh)
   # (the recorded run first: round 4 saw hipStreamEndCapture crash when ANOTHER learner with live side-stream work existed in the
@@ -192,10 +238,49 @@ def case_cp_mobilenet(tmp_path):
       assert np.all(w[:, :, ~keep_in, :] == 0) and np.all(w[:, :, :, ~keep_out] == 0), op.name
 
 
-CASES = {'uq_resnet50': case_uq_resnet50, 'ws_resnet20': case_ws_resnet20, 'cp_mobilenet': case_cp_mobilenet}
+def case_uq_resnet50_two_ranks(tmp_path):
+  """case_uq_resnet50 under torch.distributed.run with TWO ranks on one GPU (PF_DIST_BACKEND=gloo, PF_SINGLE_DEVICE=1: RCCL refuses
+  duplicate devices): --enbl_multi_gpu, so the recorded step is TWO hipGraphs around the gradient exchange (step_graph.CudaBackend.cut,
+  made by optim.GradReducer.finish() behind the captured backward pass).  At 224 x 224 with 48 images per rank every launch of the
+  step is a kernel of this library (at 64 x 64 some backward-filter shapes fall back to MIOpen, whose choice depends on the
+  allocator's state: two launch-by-launch runs then differ in a few gradients by 1e-8 .. 3e-5, which Adam amplifies), so recorded
+  and launch-by-launch runs must agree bit for bit on each rank, and the ranks stay in lock-step."""
+  import torch.distributed as dist
+  from pocketflow_amd.flags import FLAGS
+  from pocketflow_amd import step_graph
+  from pocketflow_amd.utils.multi_gpu_wrapper import MultiGpuWrapper as mgw
+  import pocketflow_amd.learners.abstract_learner  # noqa: F401
+  FLAGS.enbl_multi_gpu = True
+  mgw.init()
+  rank = mgw.rank()
+  os.environ.setdefault('PF_ALLREDUCE_BUCKET', str(6 << 20))
+  made = {}
+  orig = step_graph.StepGraph._record
+
+  def spy(self):
+    orig(self)
+    made['graphs'], made['actions'] = len(self.backend.graphs), len(self.backend.actions)
+  step_graph.StepGraph._record = spy
+  case_uq_resnet50(tmp_path, ranks=2, batch=int(os.environ.get('PF_W_BATCH', '48')), image=int(os.environ.get('PF_W_IMAGE', '224')))
+  assert made['graphs'] == 2 and made['actions'] == 1, made
+  RESULT.update(rank=rank, **made)
+  sig = torch.tensor([RESULT['losses_graph'][-1]], dtype=torch.float64)
+  both = [torch.zeros_like(sig) for _ in range(2)]
+  dist.all_gather(both, sig)
+  assert float(both[0]) != float(both[1]), both                # per-rank data ...
+  RESULT['last_loss_of_each_rank'] = [float(t) for t in both]
+  dist.barrier()
+  if rank != 0:
+    RESULT.clear()                                             # one result line (rank 0's)
+  dist.destroy_process_group()
+
+
+CASES = {'uq_resnet50': case_uq_resnet50, 'ws_resnet20': case_ws_resnet20, 'cp_mobilenet': case_cp_mobilenet,
+         'uq_resnet50_two_ranks': case_uq_resnet50_two_ranks}
 
 if __name__ == '__main__':
   case, tmp = sys.argv[1], pathlib.Path(sys.argv[2])
   CASES[case](tmp)
-  RESULT['case'] = case
-  print('STEP_GRAPH_RESULT ' + json.dumps(RESULT))
+  if RESULT:
+    RESULT['case'] = case
+    print('STEP_GRAPH_RESULT ' + json.dumps(RESULT))

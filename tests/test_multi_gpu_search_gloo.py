@@ -314,3 +314,87 @@ def test_fused_path_launches_every_bucket_from_inside_backward(tmp_path):
     assert rec['buckets'] >= 3, rec
     assert rec['n_overlapped'] == rec['buckets'], rec
     assert all(all(l) and not dirty for l, dirty in rec['at_finish']), rec
+
+
+# -- the recorded step with two ranks: two "graphs" around the gradient-exchange calls (step_graph.CudaBackend.cut) ------
+def _recorded_worker(rank, world, port, out_dir, dst):
+  os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world),
+                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), PF_ALLREDUCE_BUCKET=str(1 << 16),
+                    PF_STEP_GRAPH='inline', PF_STEP_GRAPH_STRICT='1')
+  torch.set_num_threads(2)
+  _patch_cpu()
+  import pocketflow_amd.learners.distillation_helper  # noqa: F401
+  import pocketflow_amd.learners.learner_utils  # noqa: F401
+  import pocketflow_amd.nets.resnet_at_cifar10 as net
+  from pocketflow_amd import step_graph
+  from pocketflow_amd.flags import FLAGS
+  from pocketflow_amd.learners.learner_utils import create_synthetic_checkpoint
+  from pocketflow_amd.learners.uniform_quantization.learner import UniformQuantLearner
+  from pocketflow_amd.utils.multi_gpu_wrapper import MultiGpuWrapper as mgw
+  import torch.distributed as dist
+  FLAGS.enbl_multi_gpu = True
+  FLAGS.save_path = os.path.join(out_dir, 'models', 'model.ckpt')
+  FLAGS.save_path_dst = os.path.join(out_dir, 'models_dst', 'model.ckpt')
+  FLAGS.uql_save_quant_model_path = os.path.join(out_dir, 'uql', 'm.ckpt')
+  FLAGS.synthetic_pool, FLAGS.compute_dtype = 3, 'float32'
+  FLAGS.batch_size, FLAGS.batch_size_eval, FLAGS.nb_classes, FLAGS.resnet_size = 4, 4, 10, 20
+  FLAGS.uql_weight_bits, FLAGS.uql_activation_bits, FLAGS.enbl_dst, FLAGS.dst_eval_teacher = 8, 8, bool(dst), False
+  mgw.init()
+  mh = net.ModelHelper()
+  if rank == 0:
+    create_synthetic_checkpoint(mh)
+  dist.barrier()
+  calls = []
+  orig_all_reduce = dist.all_reduce
+
+  def counting_all_reduce(t, *a, **k):
+    calls.append(int(t.numel()))
+    return orig_all_reduce(t, *a, **k)
+  dist.all_reduce = counting_all_reduce
+
+  def run(recorded):
+    FLAGS.enbl_step_graph = recorded
+    lrn = UniformQuantLearner(None, mh)
+    lrn.ops['bcast']()
+    losses, per_step = [], []
+    for i in range(9):
+      if recorded and i in (6, 8):                         # replays -> two launch-by-launch steps -> replays again
+        sg = step_graph.of(lrn)
+        sg.resume() if sg.suspended else sg.suspend()
+      n0 = len(calls)
+      losses.append(float(lrn.train_step()['loss'].detach()))
+      per_step.append(calls[n0:])
+    return lrn, losses, per_step
+  b, lb, cb = run(True)
+  a, la, ca = run(False)
+  sg = step_graph.of(b)
+  red = b.graph.store.reducer
+  assert sg.state == 'ready' and sg.error is None and sg.n_replays == 9 - 3 - 2, (sg.state, sg.error, sg.n_replays)
+  assert red.recorder is sg.backend and len(red.buckets) >= 3 and red.n_overlapped > 0
+  assert ca == cb and all(len(c) == len(red.buckets) + 1 for c in ca), (ca, cb)    # the same collectives in the same order, every step
+  sa, sb = a.graph.store, b.graph.store
+  assert la == lb, (la, lb)
+  for x, y in ((sa.w_master, sb.w_master), (sa.o_master, sb.o_master), (sa.state, sb.state)):
+    assert torch.equal(x, y)
+  gathered = [torch.zeros_like(sb.w_master) for _ in range(world)]
+  dist.all_gather(gathered, sb.w_master)
+  assert all(torch.equal(gathered[0], t) for t in gathered)                         # the replicas stay in lock-step
+  with open(os.path.join(out_dir, 'recorded%d.json' % rank), 'w') as f:
+    json.dump({'losses': lb, 'buckets': len(red.buckets), 'n_overlapped': red.n_overlapped, 'replays': sg.n_replays}, f)
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('dst', [0, 1])
+def test_recorded_step_with_two_ranks_is_the_launch_by_launch_step(tmp_path, dst):
+  """--enbl_step_graph together with --enbl_multi_gpu (reference: Horovod's all-reduce is part of the compiled train graph,
+  utils/multi_gpu_wrapper.py:83-98): with the in-line stand-in of the graph backend the recorded body IS re-executed, so what
+  this holds is the control flow around it -- GradReducer hands every collective to backend.cut(), recorded steps and
+  launch-by-launch steps alternate (suspend / resume), and a run of 3 eager + recording + replays gives bit for bit the losses,
+  parameters, Adam slots and BN statistics of 9 launch-by-launch steps on both ranks, with the same collectives in the same order."""
+  world = 2
+  mp.spawn(_recorded_worker, args=(world, _free_port(), str(tmp_path), dst), nprocs=world, join=True)
+  recs = [json.load(open(tmp_path / ('recorded%d.json' % r))) for r in range(world)]
+  assert recs[0]['losses'] != recs[1]['losses']                                     # per-rank data
+  assert all(r['replays'] == 4 and r['n_overlapped'] > 0 for r in recs), recs

@@ -4,8 +4,10 @@ EVERY input and are the same ones the GPU parity tests use at full size (tests/t
 disagreement between the two would show on the CPU first.  Runs without a GPU."""
 import numpy as np
 import pytest
-from hypothesis import given, settings, strategies as st
-from hypothesis.extra import numpy as hnp
+
+pytest.importorskip('hypothesis')         # (a test-only dependency: the rest of the suite must not fail at collection without it)
+from hypothesis import given, settings, strategies as st   # noqa: E402
+from hypothesis.extra import numpy as hnp                  # noqa: E402
 
 from oracle import pf_oracle as O
 
