@@ -1,8 +1,8 @@
-# Round evidence on the GPU box:  bash tools/gpu/round_evidence.sh [tag]   (tag defaults to r04; outputs gpurun_out/<tag>_*)
+# Round evidence on the GPU box:  bash tools/gpu/round_evidence.sh [tag]   (tag defaults to r05; outputs gpurun_out/<tag>_*)
 # smoke -> full GPU test suite (gradient-parity report lines -> <tag>_parity_report.txt) -> rocprofv3 kernel trace of bench.py
 # (stats + steady-state step table with the idle-gap analysis) -> separate PMC passes (FETCH_SIZE / WRITE_SIZE; never combined
 # with a trace domain) -> the default bench.py line with cpu_baseline -> one bench line per other configuration of SURVEY 8(d)
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -27,6 +27,8 @@ done
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 5 --no_cpu_baseline --step_graph 0 > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_mfma.log 2>&1
 f=$(find /tmp/pmc_mfma -name '*counter_collection.csv' | head -1)
 python $GRAFT_REPO_ROOT/tools/pmc_table.py $f > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_mfma_busy.csv 2>> $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_mfma.log; head -5 $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_mfma_busy.csv | cut -c1-200
+# per-kernel table + the whole-step derivation (busy cycles per dispatch x calls per step of the kernel trace above)
+python $GRAFT_REPO_ROOT/tools/mfma_busy.py $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_mfma_busy.csv $GRAFT_REPO_ROOT/gpurun_out/${TAG}_step_kernels_b256.csv > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_mfma_busy.txt 2>&1; tail -7 $GRAFT_REPO_ROOT/gpurun_out/${TAG}_mfma_busy.txt | cut -c1-200
 # steady-state kernel tables of the other configurations (is any library kernel left in their steps?)
 for c in c1 c3; do
   timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_${TAG}_$c -o $c -- python $GRAFT_REPO_ROOT/bench.py --config $c --steps 12 --warmup 5 --no_cpu_baseline --step_graph 0 > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof_$c.log 2>&1

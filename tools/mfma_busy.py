@@ -49,6 +49,34 @@ def main():
   print('%-64s %6s %14s %14s %10s %12s' % ('kernel', 'disp', 'MFMA busy cyc', 'GUI active', 'util', 'util @2.4GHz'))
   for _, k, d, busy, gui, util, util_t in out:
     print('%-64s %6d %14.0f %14.0f %9.1f%% %11.1f%%' % (k[:64], d, busy, gui, 100 * util, 100 * util_t))
+  if dur:
+    # The WHOLE step: every kernel's per-dispatch busy cycles x its calls per step (step table), against 1024 SIMDs x the step's
+    # time.  Two denominators: the step's wall time (what "fraction of the MFMA roofline" means for the job) and the GPU-busy time
+    # (kernel time summed over both streams); the clock is the nominal 2.4 GHz, an upper bound (1.9-2.3 GHz under matrix load), so
+    # both figures are LOWER bounds of the pipe's busy fraction at the real clock.
+    wall = gpu_busy = None
+    for ln in open(sys.argv[2]):
+      if ln.startswith('"# steady state') or ln.startswith('# steady state'):
+        import re
+        m = re.search(r'wall ([0-9.]+) ms/step, GPU busy ([0-9.]+) ms/step', ln)
+        if m:
+          wall, gpu_busy = float(m.group(1)), float(m.group(2))
+    tot = 0.0
+    missing = []
+    for _, k, d, busy, gui, util, util_t in out:
+      if k in dur:
+        tot += busy * dur[k][0]
+      else:
+        missing.append(k)
+    print()
+    print('whole step: sum over kernels of (MFMA busy cycles per dispatch x calls per step) = %.4e SIMD-cycles per step' % tot)
+    if wall:
+      print('  / (1024 SIMDs x %.3f ms wall x 2.4 GHz)     = %.1f %% of the matrix pipes busy over the step' % (wall, 100 * tot / (1024 * wall * 1e-3 * 2.4e9)))
+      print('  / (1024 SIMDs x %.3f ms GPU-busy x 2.4 GHz) = %.1f %%' % (gpu_busy, 100 * tot / (1024 * gpu_busy * 1e-3 * 2.4e9)))
+      print('  (a 16x16x32 bf16 MFMA holds its pipe 16 cycles for 16 384 flop: the same figure from the flops is')
+      print('   flops per step / 16 384 x 16 / (1024 x wall x 2.4e9) = roofline.step_mfma_frac of bench.py, which divides by the 2.5 PFLOP/s peak)')
+    if missing:
+      print('  kernels with MFMA cycles in the PMC pass but absent from the step table (not counted): %s' % ', '.join(m[:40] for m in missing[:6]))
 
 
 if __name__ == '__main__':
