@@ -2,14 +2,19 @@
 # smoke -> full GPU test suite (gradient-parity report lines -> <tag>_parity_report.txt) -> rocprofv3 kernel trace of bench.py
 # (stats + steady-state step table with the idle-gap analysis) -> separate PMC passes (FETCH_SIZE / WRITE_SIZE; never combined
 # with a trace domain) -> the default bench.py line with cpu_baseline -> one bench line per other configuration of SURVEY 8(d)
+# second argument: all (default) | suite (smoke + tests only) | profiles (everything behind the tests) -- two calls when GPU minutes are short
 TAG=${1:-r05}
+PART=${2:-all}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
+if [ $PART != profiles ]; then
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | cut -c1-300
 rm -f gpurun_out/${TAG}_parity_report.txt
-PF_PARITY_REPORT=$GRAFT_REPO_ROOT/gpurun_out/${TAG}_parity_report.txt timeout 2400 python -m pytest tests -m gpu -q --timeout=900 --tb=line 2>&1 | tail -12 | cut -c1-300 > gpurun_out/${TAG}_pytest_gpu.log
+PF_PARITY_REPORT=$GRAFT_REPO_ROOT/gpurun_out/${TAG}_parity_report.txt timeout 2400 python -m pytest tests -m gpu -q --timeout=900 --tb=line --durations=8 2>&1 | tail -24 | cut -c1-300 > gpurun_out/${TAG}_pytest_gpu.log
 cat gpurun_out/${TAG}_pytest_gpu.log
+fi
+[ $PART = suite ] && exit 0
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o $TAG -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no_cpu_baseline > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof.log 2>&1
 cd $GRAFT_REPO_ROOT
