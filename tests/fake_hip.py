@@ -320,6 +320,35 @@ class FakeHip(object):
     y = F.conv2d(X.float(), W.float().permute(0, 3, 1, 2), stride=2, padding=3)
     _rows(Y, 64).copy_(y.permute(0, 2, 3, 1).reshape(-1, 64))
 
+  # -- the MobileNet stem (pf_stem3.hip): 3x3 / stride 2 with TensorFlow 'SAME' padding given by its FRONT pads -------------
+  def conv_stem3_supported(self, H, Wd, C, N, k, stride, pad_h, pad_w, Ho, Wo):
+    return (C == 3 and N in (16, 32) and k == 3 and stride == 2 and H > 0 and 32 <= Wd <= 1024 and Wd % 2 == 0 and pad_h in (0, 1)
+            and pad_w in (0, 1) and Wo > 0 and Wo % 16 == 0 and Ho > 0 and 2 * Wo <= Wd + 2 and 2 * (Ho - 1) - pad_h < H)
+
+  def conv_stem3_wrw_slabs(self, imgs, H, Wd, N, pad_h, pad_w, Ho, Wo):
+    return 2 if self.conv_stem3_supported(H, Wd, 3, N, 3, 2, pad_h, pad_w, Ho, Wo) else 0
+
+  @staticmethod
+  def _stem3_padded(X, H, Wd, pad_h, pad_w, Ho, Wo):
+    import torch.nn.functional as F
+    back_h = max((Ho - 1) * 2 + 3 - H - pad_h, 0)
+    back_w = max((Wo - 1) * 2 + 3 - Wd - pad_w, 0)
+    return F.pad(X.float(), (pad_w, back_w, pad_h, back_h))
+
+  def conv_stem3_fwd(self, X, W, Y, imgs, H, Wd, N, pad_h, pad_w, Ho, Wo):
+    self._n('conv_stem3_fwd')
+    import torch.nn.functional as F
+    y = F.conv2d(self._stem3_padded(X, H, Wd, pad_h, pad_w, Ho, Wo), W.float().permute(0, 3, 1, 2), stride=2)[:, :, :Ho, :Wo]
+    _rows(Y, N).copy_(y.permute(0, 2, 3, 1).reshape(-1, N))
+
+  def conv_stem3_wrw(self, dY, X, dW, workspace, imgs, H, Wd, N, pad_h, pad_w, Ho, Wo):
+    self._n('conv_stem3_wrw')
+    xp = self._stem3_padded(X, H, Wd, pad_h, pad_w, Ho, Wo)
+    w0 = torch.zeros(N, 3, 3, 3)
+    g = torch.ops.aten.convolution_backward(dY.float(), xp, w0, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1,
+                                            [False, True, False])[1]
+    dW.copy_(g.permute(0, 2, 3, 1))
+
 
 
 # =================================================================================================

@@ -34,12 +34,6 @@ f=$(find /tmp/pmc_mfma -name '*counter_collection.csv' | head -1)
 python $GRAFT_REPO_ROOT/tools/pmc_table.py $f > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_mfma_busy.csv 2>> $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_mfma.log; head -5 $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_mfma_busy.csv | cut -c1-200
 # per-kernel table + the whole-step derivation (busy cycles per dispatch x calls per step of the kernel trace above)
 python $GRAFT_REPO_ROOT/tools/mfma_busy.py $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_mfma_busy.csv $GRAFT_REPO_ROOT/gpurun_out/${TAG}_step_kernels_b256.csv > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_mfma_busy.txt 2>&1; tail -7 $GRAFT_REPO_ROOT/gpurun_out/${TAG}_mfma_busy.txt | cut -c1-200
-# steady-state kernel tables of the other configurations (is any library kernel left in their steps?)
-for c in c1 c3; do
-  timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_${TAG}_$c -o $c -- python $GRAFT_REPO_ROOT/bench.py --config $c --steps 12 --warmup 5 --no_cpu_baseline --step_graph 0 > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof_$c.log 2>&1
-  marker=k_adam_flat; [ $c = c1 ] && marker=k_momentum_flat
-  python $GRAFT_REPO_ROOT/tools/prof_summary.py $(find /tmp/prof_${TAG}_$c -name '*kernel_trace.csv' | head -1) --steps 4 --marker $marker --out $GRAFT_REPO_ROOT/gpurun_out/${TAG}_step_kernels_$c.csv | head -12 | cut -c1-150
-done
 cd $GRAFT_REPO_ROOT
 cp gpurun_out/${TAG}_pmc_FETCH_SIZE.csv gpurun_out/${TAG}_pmc_WRITE_SIZE.csv profiles/ 2>/dev/null     # bench.py reads roofline.traffic from profiles/
 PF_BENCH_TRACE_STEPS=1 timeout 900 python bench.py > gpurun_out/${TAG}_bench.log 2>&1; grep -v '"metric"' gpurun_out/${TAG}_bench.log | tail -2 | cut -c1-300; grep '"metric"' gpurun_out/${TAG}_bench.log | cut -c1-2200
@@ -53,3 +47,11 @@ for ln in open(sys.argv[1]):
         d = json.loads(ln); print(sys.argv[2], round(d['value']), 'img/s', round(d['ms_per_step'], 2), 'ms/step', d['config'].get('workload', '')[:90])
 " gpurun_out/${TAG}_bench_$c.json $c
 done
+cd /tmp
+# steady-state kernel tables of the other configurations (is any library kernel left in their steps?)
+for c in c1 c3; do
+  timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_${TAG}_$c -o $c -- python $GRAFT_REPO_ROOT/bench.py --config $c --steps 12 --warmup 5 --no_cpu_baseline --step_graph 0 > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof_$c.log 2>&1
+  marker=k_adam_flat; [ $c = c1 ] && marker=k_momentum_flat
+  python $GRAFT_REPO_ROOT/tools/prof_summary.py $(find /tmp/prof_${TAG}_$c -name '*kernel_trace.csv' | head -1) --steps 4 --marker $marker --out $GRAFT_REPO_ROOT/gpurun_out/${TAG}_step_kernels_$c.csv | head -12 | cut -c1-150
+done
+cd $GRAFT_REPO_ROOT
