@@ -53,6 +53,14 @@ def main():
     marks = [e for s, e, n in rows if args.marker_fallback in n]
     # two launches per step in that case (W and O buffers)
     marks = marks[1::2]
+  # several marker launches per step (the optimiser updates the kernel buffer and the small buffer back to back; C3's table of
+  # round 4 was per HALF step because of it): keep the last mark of every cluster -- marks closer than a quarter of a typical step
+  # (the median of the larger half of the distances between neighbours) belong to one step
+  if len(marks) > 2:
+    dist = sorted(b - a for a, b in zip(marks[:-1], marks[1:]))
+    upper = dist[len(dist) // 2:]
+    near = upper[len(upper) // 2] / 4.0
+    marks = [m for i, m in enumerate(marks) if i == len(marks) - 1 or marks[i + 1] - m > near]
   K = min(args.steps, len(marks) - 1)
   if K < 1:
     sys.exit('marker kernel %r not found often enough' % args.marker)
