@@ -42,6 +42,53 @@ def test_prof_summary_takes_exactly_k_steps(tmp_path):
   assert float(rows['k_adam_flat<unsigned short, true>'][2]) == 1.0
 
 
+def test_prof_summary_groups_two_optimiser_launches_per_step(tmp_path):
+  """Adam updates the kernel buffer and the small buffer back to back: with `--marker k_adam_flat` both launches match, and the
+  window must still be K STEPS wide (round 4's C3 table was per half step: 9.5 instead of 18.9 ms)."""
+  p = tmp_path / 'c3_kernel_trace.csv'
+  t = 1000
+  with open(p, 'w', newline='') as f:
+    w = csv.writer(f)
+    w.writerow(['Kind', 'Kernel_Name', 'Start_Timestamp', 'End_Timestamp'])
+    for step in range(7):
+      for _ in range(5):
+        w.writerow(['KERNEL_DISPATCH', 'void k_dw_fwd<unsigned short, 1>(DwArgs)', t, t + 4000])
+        t += 5000
+      for buf in ('unsigned short', 'float'):
+        w.writerow(['KERNEL_DISPATCH', 'void k_adam_flat<%s, true>(AdamArgs)' % buf, t, t + 1000])
+        t += 1200
+  out = _run('prof_summary.py', str(p), '--steps', '4', '--marker', 'k_adam_flat')
+  parsed = list(csv.reader(out.strip().splitlines()))
+  assert parsed[0][0].startswith('# steady state over 4 steps: wall 0.027 ms/step')       # 5 x 5 us + 2 x 1.2 us per step
+  row = [r for r in parsed if r and r[0].startswith('k_dw_fwd')][0]
+  assert float(row[2]) == 5.0                                                               # calls per STEP, not per half step
+  adam = [r for r in parsed if r and r[0].startswith('k_adam_flat')]
+  assert sum(float(r[2]) for r in adam) == 2.0
+
+
+def test_mfma_busy_whole_step_derivation(tmp_path):
+  """tools/mfma_busy.py: per-kernel utilisation from one PMC table and, with a step table, the whole-step figure =
+  sum(busy cycles per dispatch x calls per step) / (1024 SIMDs x step time x 2.4 GHz) (the derivation must be
+  reproducible from the committed CSVs)."""
+  pmc = tmp_path / 'pmc.csv'
+  with open(pmc, 'w', newline='') as f:
+    w = csv.writer(f)
+    w.writerow(['kernel', 'dispatches', 'GRBM_GUI_ACTIVE', 'SQ_BUSY_CYCLES', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_WAVE_CYCLES'])
+    w.writerow(['k_a', 10, 8.0e5, 1e6, 2.4576e7, 1e8])          # 2.4576e7 / (1024 x 8e5 / 8) = 24 %
+    w.writerow(['k_b', 4, 8.0e5, 1e6, 0, 1e8])                  # no matrix work: not listed
+  steps = tmp_path / 'steps.csv'
+  with open(steps, 'w', newline='') as f:
+    w = csv.writer(f)
+    w.writerow(['# steady state over 4 steps: wall 10.000 ms/step, GPU busy 8.000 ms/step'])
+    w.writerow(['kernel', 'category', 'calls_per_step', 'avg_us', 'ms_per_step', 'pct_of_busy'])
+    w.writerow(['k_a', 'pocketflow_hip', '100.00', '50.00', '5.0000', '62.5'])
+  out = _run('mfma_busy.py', str(pmc), str(steps))
+  assert 'k_a' in out and 'k_b' not in out.split('whole step')[0]
+  assert '24.0%' in out
+  # 2.4576e7 x 100 = 2.4576e9 SIMD-cycles per step; / (1024 x 10 ms x 2.4e9) = 10.0 %, / (1024 x 8 ms x 2.4e9) = 12.5 %
+  assert '2.4576e+09 SIMD-cycles per step' in out and '= 10.0 % of the matrix pipes' in out and '= 12.5 %' in out
+
+
 def test_pmc_table_reads_raw_and_its_own_output(tmp_path):
   raw = tmp_path / 'x_counter_collection.csv'
   with open(raw, 'w', newline='') as f:
