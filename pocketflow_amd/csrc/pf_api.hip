@@ -50,3 +50,23 @@ const PfTuning& pf_tuning() {
 }
 
 extern "C" int pf_tuning_reload(void) { tuning_load(); return 0; }
+
+// ---- per-(device, kernel) dynamic-LDS ceiling (declared in pf_common.h) --------------------------------------------------------
+#include <map>
+#include <mutex>
+#include <utility>
+int pf_require_lds(const void* fn, size_t lds) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, size_t> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = done[std::make_pair(dev, fn)];
+  if (lds > have) {
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    have = lds;
+  }
+  return 0;
+}

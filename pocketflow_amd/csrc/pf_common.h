@@ -19,6 +19,11 @@
 
 typedef uint16_t bf16_t;
 
+// hipFuncAttributeMaxDynamicSharedMemorySize of `fn` raised to at least `lds` bytes ON THE CURRENT DEVICE (the attribute is per
+// device; launches that need more than 64 KiB of LDS fail without it).  Cached per (device, function) behind a mutex: a process that
+// drives a second GPU, or launches first from another thread, is configured too (the caches were process-wide statics).
+int pf_require_lds(const void* fn, size_t lds);
+
 // ---- tuning / A-B switches (host) --------------------------------------------------------------
 // Every PF_* environment switch of the launchers is read ONCE, on first use, into this struct (pf_api.hip): a launcher and the
 // workspace-size query that precedes it always see the same decision, and no launch pays for getenv / atoi / sscanf.  Tools and

@@ -373,13 +373,7 @@ static int stream_launch_t(const ConvArgs& a, int nsplit, hipStream_t st) {
   const int JM = (NW == 256) ? 1 : 2, RS = 16 * JM;
   const size_t aux_fl = PRO ? 2 * (size_t)a.K : (BWD ? 4 * (size_t)NW : 0);
   const size_t lds = (size_t)NW * a.K * 2 + aux_fl * 4 + (size_t)ST_WAVES * RS * (NW + 8) * 2;
-  static size_t configured = 0;
-  if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv1x1_stream<NW, PRO, BWD, MAP>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    configured = lds;
-  }
+  if (int e = pf_require_lds(reinterpret_cast<const void*>(&k_conv1x1_stream<NW, PRO, BWD, MAP>), lds)) return e;
   k_conv1x1_stream<NW, PRO, BWD, MAP><<<ST_GRID, ST_THREADS, lds, st>>>(a, nsplit);
   PF_LAUNCH_CHECK();
   return 0;

@@ -666,14 +666,8 @@ static int ig_launch_t(IgArgs& a, int slots, hipStream_t st) {
   constexpr size_t base = (ring > ctile ? ring : ctile);
   const size_t lds = base + (BWD ? 4 * BN * 4 : 0) + (PRO3 ? 2 * (size_t)a.C * 4 : 0);
   if (PRO3 && a.C > CV_MAXK) return (int)hipErrorInvalidValue;
-  static bool configured = false;
-  if (!configured) {
-    const size_t lds_max = base + (BWD ? 4 * BN * 4 : 0) + (PRO3 ? 2 * (size_t)CV_MAXK * 4 : 0);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<BM, BN, WM, WN, NS, MODE, SUB>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-    if (e != hipSuccess) return (int)e;
-    configured = true;
-  }
+  const size_t lds_max = base + (BWD ? 4 * BN * 4 : 0) + (PRO3 ? 2 * (size_t)CV_MAXK * 4 : 0);
+  if (int e = pf_require_lds(reinterpret_cast<const void*>(&k_igemm<BM, BN, WM, WN, NS, MODE, SUB>), lds_max)) return e;
   k_igemm<BM, BN, WM, WN, NS, MODE, SUB><<<grid, THREADS, lds, st>>>(a);
   PF_LAUNCH_CHECK();
   return 0;

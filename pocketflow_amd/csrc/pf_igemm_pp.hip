@@ -645,12 +645,7 @@ static int pp_launch_t(IgArgs& a, const PpPlan& p, hipStream_t st) {
 #else
   constexpr size_t lds = 3 * (size_t)(256 + BN) * 128;           // the ring; wavefront regions and the statistics scratch alias it
 #endif
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm_pp<BN, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    configured = true;
-  }
+  if (int e = pf_require_lds(reinterpret_cast<const void*>(&k_igemm_pp<BN, MODE>), lds)) return e;
   a.tiles_m = p.tiles_m; a.tiles_n = p.tiles_n; a.G = p.G; a.pp_bm = p.bm;
   k_igemm_pp<BN, MODE><<<p.grid, 512, lds, st>>>(a);
   PF_LAUNCH_CHECK();

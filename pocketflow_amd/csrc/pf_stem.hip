@@ -153,13 +153,7 @@ extern "C" int pf_conv_stem_fwd(const void* X, const void* W, void* Y, int imgs,
   a.rsb = (Wd + 8) * 8;
   const size_t lds = (size_t)ST_WL_BYTES + (size_t)ST_IROWS * a.rsb;
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
-  static size_t configured = 0;
-  if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem7x7_fwd),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    configured = lds;
-  }
+  if (int e = pf_require_lds(reinterpret_cast<const void*>(&k_stem7x7_fwd), lds)) return e;
   const int grid = a.n_items < 512 ? a.n_items : 512;
   k_stem7x7_fwd<<<grid, ST_THREADS, lds, (hipStream_t)stream>>>(a);
   PF_LAUNCH_CHECK();
@@ -343,13 +337,7 @@ extern "C" int pf_conv_stem_wrw(const void* dY, const void* X, void* dW, int dw_
   a.rsb = (Wd + 8) * 8;
   a.dy_bytes = (int)((int64_t)imgs * a.Ho * a.Wo * ST_N * 2);
   const size_t lds = (size_t)SW_IROWS * a.rsb + (size_t)SW_OROWS * a.Wo * ST_N * 2;
-  static size_t configured = 0;
-  if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem7x7_wrw),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    configured = lds;
-  }
+  if (int e = pf_require_lds(reinterpret_cast<const void*>(&k_stem7x7_wrw), lds)) return e;
   k_stem7x7_wrw<<<S, ST_THREADS, lds, (hipStream_t)stream>>>(a);
   PF_LAUNCH_CHECK();
   return pf_wrw_reduce(workspace, S, (int64_t)ST_N * 147, dW, dw_dtype, (hipStream_t)stream);

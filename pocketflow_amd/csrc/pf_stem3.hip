@@ -165,12 +165,7 @@ extern "C" int pf_conv_stem3_fwd(const void* X, const void* W, void* Y, int imgs
   const size_t lds = (size_t)N * S3_R * 64 + (size_t)S3_IROWS * a.rsb + 16;
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   const void* fn = (N == 32) ? reinterpret_cast<const void*>(&k_stem3x3_fwd<2>) : reinterpret_cast<const void*>(&k_stem3x3_fwd<1>);
-  static size_t configured[2] = {0, 0};
-  if (lds > configured[N == 32]) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    configured[N == 32] = lds;
-  }
+  if (int e = pf_require_lds(fn, lds)) return e;
   const int grid = a.n_items < 1024 ? a.n_items : 1024;
   if (N == 32) k_stem3x3_fwd<2><<<grid, S3_THREADS, lds, (hipStream_t)stream>>>(a);
   else k_stem3x3_fwd<1><<<grid, S3_THREADS, lds, (hipStream_t)stream>>>(a);
@@ -317,12 +312,7 @@ extern "C" int pf_conv_stem3_wrw(const void* dY, const void* X, void* dW, int dw
   a.dy_bytes = (int)((int64_t)imgs * Ho * Wo * N * 2);
   const size_t lds = (size_t)S3W_IROWS * a.rsb + (size_t)S3W_OROWS * Wo * N * 2 + 16;
   const void* fn = (N == 32) ? reinterpret_cast<const void*>(&k_stem3x3_wrw<2>) : reinterpret_cast<const void*>(&k_stem3x3_wrw<1>);
-  static size_t configured[2] = {0, 0};
-  if (lds > configured[N == 32]) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    configured[N == 32] = lds;
-  }
+  if (int e = pf_require_lds(fn, lds)) return e;
   if (N == 32) k_stem3x3_wrw<2><<<S, S3_THREADS, lds, (hipStream_t)stream>>>(a);
   else k_stem3x3_wrw<1><<<S, S3_THREADS, lds, (hipStream_t)stream>>>(a);
   PF_LAUNCH_CHECK();

@@ -258,13 +258,7 @@ static int wrw_tr_launch_t(const WrwArgs& a, int grid, hipStream_t st) {
   const size_t ring = 4 * (size_t)3 * ((4 * NB + 16) * 256);
   const size_t red = (size_t)4 * NB * 4 * 64 * 16;
   const size_t lds = ring > red ? ring : red;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wrw_tr<BN, PRO, MAP>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    configured = true;
-  }
+  if (int e = pf_require_lds(reinterpret_cast<const void*>(&k_wrw_tr<BN, PRO, MAP>), lds)) return e;
   k_wrw_tr<BN, PRO, MAP><<<grid, 256, lds, st>>>(a);
   PF_LAUNCH_CHECK();
   return 0;
@@ -681,13 +675,7 @@ int pf_wrw2_splits(int M, int N, int C, int taps) {
 template <int TN, int TK, int WTN, int WTK, bool PRO, int MAPM>
 static int wrw2_launch_t(const Wrw2Args& a, int grid, hipStream_t st) {
   const size_t lds = 3 * (size_t)(4 * (TN / 16) * 256 + 4 * (TK / 16) * 256) + 1024;   // three stages + the 1 KiB sink
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wrw2<TN, TK, WTN, WTK, PRO, MAPM>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    configured = true;
-  }
+  if (int e = pf_require_lds(reinterpret_cast<const void*>(&k_wrw2<TN, TK, WTN, WTK, PRO, MAPM>), lds)) return e;
   k_wrw2<TN, TK, WTN, WTK, PRO, MAPM><<<grid, 64 * (TN / WTN) * (TK / WTK), lds, st>>>(a);
   PF_LAUNCH_CHECK();
   return 0;

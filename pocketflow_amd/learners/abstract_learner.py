@@ -182,8 +182,9 @@ class AbstractLearner(ABC):  # pylint: disable=too-many-instance-attributes
   def train_step(self, *args, **kwargs):
     """One fine-tune iteration (`sess.run(train_op)` of the reference learners): the learner's `_train_step_eager`, or -- with
     --enbl_step_graph -- the same step replayed from a hipGraph (step_graph.py; with --enbl_multi_gpu two graphs around the
-    gradient-exchange calls, PF_STEP_GRAPH_DIST=0 keeps a multi-rank job launch by launch)."""
-    if args or kwargs or not FLAGS.enbl_step_graph or (FLAGS.enbl_multi_gpu and os.environ.get('PF_STEP_GRAPH_DIST', '1') == '0'):
+    gradient-exchange calls; OPT-IN there, PF_STEP_GRAPH_DIST=1, until the two-graph chain has run over RCCL on two or more GPUs --
+    the builder's boxes have one; bench.py opts in by itself and keeps the recorded step only where it is not slower)."""
+    if args or kwargs or not FLAGS.enbl_step_graph or (FLAGS.enbl_multi_gpu and os.environ.get('PF_STEP_GRAPH_DIST', '0') == '0'):
       sg = getattr(self, '_step_graph', None)
       if sg is not None:
         sg.yield_to_eager()                                # the batches a ready step graph holds are the next ones in data order

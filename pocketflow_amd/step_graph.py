@@ -238,6 +238,9 @@ class StepGraph(object):
     if self.state == 'ready':
       self.suspend()
       self.learner.optimizer.hyper_external = False
+    red = _reducer_of(self.learner)
+    if red is not None:
+      red.recorder = None                    # (the old backend must not outlive its graphs inside the store-wide reducer: ADVICE r5)
     if self.state != 'failed':
       self.state, self.n_eager, self.suspended = 'warm', 0, False
       self.out = self.cur = self.nxt = self.nxt_raw = self.cur_raw = self.cur_images = None
@@ -264,6 +267,9 @@ class StepGraph(object):
         lrn._static_batch = None
         lrn.optimizer.hyper_external = False
         lrn.graph.capturing = False
+        red = _reducer_of(lrn)
+        if red is not None:
+          red.recorder = None
         try:
           self.backend.recover()
           if self.cur is not None:
@@ -271,10 +277,37 @@ class StepGraph(object):
         except Exception as e2:     # pylint: disable=broad-except
           log.warning('step graph: clean-up after the failed recording: %s', e2)
         log.warning('step graph: recording failed (%s: %s) -- the learner stays on the eager path', type(e).__name__, e)
-        if os.environ.get('PF_STEP_GRAPH_STRICT'):
+        if os.environ.get('PF_STEP_GRAPH_STRICT') and _reducer_of(lrn) is None:
           raise
+      if not self._ranks_agree():
         return lrn._train_step_eager()
     return self._replay()
+
+  def _ranks_agree(self) -> bool:
+    """Several ranks: the job stays on the recorded step only if EVERY rank recorded it.  A rank that fell back alone
+    would send its bucket all-reduces from the backward hooks in completion order while the others issue buckets 0..n-1 from
+    finish() between their two graphs -- collectives of different order and size across ranks.  Every rank reaches this point in
+    the same step (WARM eager steps, then the recording attempt), so the MIN all-reduce of the success flag pairs up.  Returns
+    whether this rank replays."""
+    lrn = self.learner
+    ok = self.state == 'ready'
+    if _reducer_of(lrn) is None:
+      return ok
+    import torch.distributed as dist
+    flag = torch.tensor([1.0 if ok else 0.0], device=lrn.device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if float(flag.item()) >= 1.0:
+      return True
+    if ok:                                                   # another rank could not record: back to launch-by-launch steps with it
+      log.warning('step graph: another rank could not record its step -- every rank stays on the eager path')
+      self.suspend()
+      self.state = 'failed'
+      red = _reducer_of(lrn)
+      if red is not None:
+        red.recorder = None
+    elif os.environ.get('PF_STEP_GRAPH_STRICT') and self.error is not None:
+      raise self.error
+    return False
 
   # -- internals ---------------------------------------------------------------------------------------
   def _fetch(self, keep_raw=False):

@@ -58,7 +58,13 @@ def test_bench_main_runs_end_to_end_on_emulated_kernels(monkeypatch, capsys, tmp
           'c4': 'NonUniformQuantLearner 4-bit'}[config]
   assert want in line['config']['workload'], line['config']['workload']
   r = line['roofline']
-  assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and r['launches'] == 72
+  # headline: the MFMA roofline north_star names (whole-step FLOPs / step time / dense bf16 peak); the HBM-bound region measured launch
+  # by launch is a sub-block, the figure with the chip to itself first
+  assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and r['traffic'] is None
+  assert abs(r['frac'] - r['step_mfma_frac']) < 1e-12 and abs(r['achieved'] * 1e12 - line['value'] * bench.CONFIGS[config]['flops']) < 1e-3 * r['achieved'] * 1e12
+  h = r['hbm_region']
+  assert h['bound'] == 'hbm' and h['unit'] == 'GB/s' and list(h)[-2:] == ['unshared', 'shared'] and h['shared']['launches'] == 72
+  assert abs(h['shared']['frac'] - h['shared']['achieved'] / h['peak']) < 1e-9
   assert line['launch_probe']['after_warmup']['us_per_dispatch'] == 99.0 and 'memory' in line
   assert 'host-bound process' in err and 'tottime' in err          # the self-diagnosis printed its profile
 

@@ -271,7 +271,7 @@ def test_step_graph_with_two_ranks_is_two_graphs_around_the_exchange(tmp_path):
   import subprocess
   import sys
   worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'step_graph_worker.py')
-  env = dict(os.environ, PF_DIST_BACKEND='gloo', PF_SINGLE_DEVICE='1', TMPDIR=str(tmp_path))
+  env = dict(os.environ, PF_DIST_BACKEND='gloo', PF_SINGLE_DEVICE='1', TMPDIR=str(tmp_path), PF_STEP_GRAPH_DIST='1')   # (opt-in for library users since round 6)
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
          '--master-port', '29547', worker, 'uq_resnet50_two_ranks', str(tmp_path)]
   r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)

@@ -175,3 +175,64 @@ def test_bf16_sum_of_8_ranks_is_why_the_reduction_is_float32():
   e32 = float((ring32.double() - exact).abs().max()) / scale
   assert e32 < 1e-5, e32
   assert 1e-3 < e16 < 5e-2, e16                             # ~2^-8 per hop: above the 1e-3 parity bar of north_star
+
+
+def _agree_worker(rank, world, port, fail_rank):
+  sys.path.insert(0, ROOT)
+  os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  import contextlib
+  import types
+  import torch.distributed as dist
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  from pocketflow_amd import step_graph as SG
+
+  class Red(object):
+    recorder = 'the backend of the recording'
+
+    def _active(self):
+      return True
+
+  class Opt(object):
+    reducer, hyper_external = Red(), False
+
+  class Gr(object):
+    capturing = False
+
+  class Lrn(object):
+    optimizer, graph, device = Opt(), Gr(), 'cpu'
+
+    def _train_step_eager(self):
+      return 'eager'
+
+  class Be(object):
+    def warm(self):
+      return contextlib.nullcontext()
+
+    def recover(self):
+      pass
+  sg = SG.StepGraph(Lrn(), Be())
+
+  def rec(self):
+    if rank == fail_rank:
+      raise RuntimeError('this rank cannot capture')
+    self.state = 'ready'
+  sg._record = types.MethodType(rec, sg)
+  sg._replay = lambda: 'replay'
+  outs = [sg.step() for _ in range(SG.StepGraph.WARM + 2)]
+  if fail_rank is None:
+    assert outs == ['eager'] * SG.StepGraph.WARM + ['replay'] * 2 and sg.state == 'ready', (rank, outs, sg.state)
+  else:
+    # EVERY rank stays launch by launch -- also the one whose recording succeeded -- and the reducer forgets the backend
+    assert outs == ['eager'] * (SG.StepGraph.WARM + 2) and sg.state == 'failed', (rank, outs, sg.state)
+    assert Lrn.optimizer.reducer.recorder is None
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('fail_rank', [1, None])
+def test_recorded_step_is_kept_only_if_every_rank_recorded_it(fail_rank):
+  """with --enbl_step_graph a multi-rank job decides TOGETHER whether it replays (MIN all-reduce of the success
+  flag right after the recording attempt, step_graph.StepGraph._ranks_agree): a rank that fell back alone would issue its bucket
+  all-reduces in another order and size than the ranks that replay."""
+  mp.spawn(_agree_worker, args=(2, _free_port(), fail_rank), nprocs=2, join=True)

@@ -42,6 +42,30 @@ def test_prof_summary_takes_exactly_k_steps(tmp_path):
   assert float(rows['k_adam_flat<unsigned short, true>'][2]) == 1.0
 
 
+def test_prof_summary_keeps_the_launch_probe_of_bench_py_out_of_the_window(tmp_path):
+  """bench.py runs 1000 empty launches (aten add_ on 64 floats) between two of its last steps: the window is the K consecutive
+  steps with the smallest wall time, so the probe's step stays outside (rounds 1-5 reported it as 250 aten launches per step)."""
+  p = tmp_path / 'x_kernel_trace.csv'
+  t = 1000
+  with open(p, 'w', newline='') as f:
+    w = csv.writer(f)
+    w.writerow(['Kind', 'Kernel_Name', 'Start_Timestamp', 'End_Timestamp'])
+    for step in range(9):
+      if step == 7:
+        for _ in range(100):
+          w.writerow(['KERNEL_DISPATCH', 'void at::native::vectorized_elementwise_kernel<4, at::native::CUDAFunctorOnSelf_add<float>, std::array<char*, 2ul> >', t, t + 100])
+          t += 300
+      for _ in range(3):
+        w.writerow(['KERNEL_DISPATCH', 'void k_igemm<128, 128, 2, 2, 2, 1>(IgArgs)', t, t + 2000])
+        t += 2500
+      w.writerow(['KERNEL_DISPATCH', 'void k_adam_flat<unsigned short, true>(AdamArgs)', t, t + 1000])
+      t += 1500
+  out = _run('prof_summary.py', str(p), '--steps', '4')
+  assert 'CUDAFunctorOnSelf_add' not in out
+  parsed = list(csv.reader(out.strip().splitlines()))
+  assert parsed[0][0].startswith('# steady state over 4 steps: wall 0.009 ms/step')
+
+
 def test_prof_summary_groups_two_optimiser_launches_per_step(tmp_path):
   """Adam updates the kernel buffer and the small buffer back to back: with `--marker k_adam_flat` both launches match, and the
   window must still be K STEPS wide (round 4's C3 table was per half step: 9.5 instead of 18.9 ms)."""

@@ -13,16 +13,18 @@ def line(path):
 
 d = line(P('bench.json'))
 r = d['roofline']
-print('default: %.0f images/s, %.2f ms/step | roofline %.0f GB/s = %.3f of peak, %d launches, %.1f us avg | traffic %s | cpu_baseline %.2f img/s (%s) | host submit %s'
-      % (d['value'], d['ms_per_step'], r['achieved'], r['frac'], r['launches'], r['avg_launch_ms'] * 1e3,
-         ('%.1f MB' % (r['traffic'] / 1e6)) if r.get('traffic') else None, d['cpu_baseline']['value'], d['cpu_baseline']['sample'][-45:-20],
+h = r.get('hbm_region')                       # round 6 on: MFMA headline, the HBM region as a sub-block (rounds 1-5: the block itself)
+sh = h['shared'] if h else r
+print('default: %.0f images/s, %.2f ms/step | step MFMA fraction %.3f | HBM region shared %.0f GB/s = %.3f of peak, %d launches, %.1f us avg; unshared %s | traffic %s | cpu_baseline %.2f img/s (%s) | host submit %s'
+      % (d['value'], d['ms_per_step'], r['step_mfma_frac'], sh['achieved'], sh['frac'], sh['launches'], sh['avg_launch_ms'] * 1e3,
+         ('%.3f' % (h or r)['unshared']['frac']) if (h or r).get('unshared') else None,
+         ('%.1f MB' % ((h or r)['traffic'] / 1e6)) if (h or r).get('traffic') else None, d['cpu_baseline']['value'], d['cpu_baseline']['sample'][-45:-20],
          [round(v, 1) for v in d['host_submit_ms_min_median_max']]))
-print('step MFMA fraction %.3f' % r['step_mfma_frac'])
 for c in ('c1', 'c2a32', 'c3', 'c4'):
   if os.path.exists(P('bench_%s.json' % c)):
     x = line(P('bench_%s.json' % c))
-    print('%s: %.0f images/s, %.2f ms/step, roofline frac %.3f (%s), host submit median %.1f ms'
-          % (c, x['value'], x['ms_per_step'], x['roofline']['frac'], x['roofline']['kernel'][:24], x['host_submit_ms_min_median_max'][1]))
+    print('%s: %.0f images/s, %.2f ms/step, step MFMA fraction %.3f, host submit median %.1f ms'
+          % (c, x['value'], x['ms_per_step'], x['roofline']['step_mfma_frac'], x['host_submit_ms_min_median_max'][1]))
 rows = list(csv.reader(open(P('step_kernels_b256.csv'))))
 for r_ in rows[:12]:
   if r_ and r_[0].startswith('#') and ('steady' in r_[0] or 'idle' in r_[0] or 'category' in r_[0]):

@@ -64,7 +64,11 @@ def main():
   K = min(args.steps, len(marks) - 1)
   if K < 1:
     sys.exit('marker kernel %r not found often enough' % args.marker)
-  t0, t1 = marks[-K - 1], marks[-1]
+  # the K CONSECUTIVE steps with the smallest wall time: bench.py runs a 1000-launch empty-kernel probe (`launch_probe`: aten add_ on
+  # 64 floats) and mode hand-overs between some of its steps -- the LAST K steps of the trace (rounds 1-5) contained that probe, which
+  # showed as "250 aten add_ launches per step" in the step tables (they were never part of a step)
+  best = min(range(K, len(marks)), key=lambda i: marks[i] - marks[i - K])
+  t0, t1 = marks[best - K], marks[best]
   agg = defaultdict(lambda: [0, 0])
   busy = 0
   for s, e, n in rows:
