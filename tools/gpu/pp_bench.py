@@ -44,18 +44,28 @@ for H, C, N, k, s in shapes:
   setenv(PF_IGEMM_PP=0, PF_IGEMM_PP_BM=None)
   y0 = torch.empty(B, Ho, Ho, N, device='cuda', dtype=torch.bfloat16)
   t0, p0 = run(y0)
-  ts, same = [], True
+  ts, same, detail = [], True, []
   for bm in bms:
     setenv(PF_IGEMM_PP=2, PF_IGEMM_PP_BM=None if bm == 'auto' else bm)
     y1 = torch.full((B, Ho, Ho, N), float('nan'), device='cuda', dtype=torch.bfloat16)
     t1, p1 = run(y1)
     ts.append(t1)
-    same = same and bool(torch.equal(y0, y1))
-    ok_stats = bool(torch.allclose(p0[:, 0].sum(0), p1[:, 0].sum(0), rtol=1e-4, atol=5e-2)) and bool(torch.equal(p0[:, 3].max(0).values, p1[:, 3].max(0).values))
-    same = same and ok_stats
+    ok_y = bool(torch.equal(y0, y1))
+    # statistics: the two kernels fold different partial groupings, so their float32 sums agree up to the accumulation order --
+    # measured against the float64 sum of the stored tile, relative to sum |y| (round 5's bar was `allclose(rtol 1e-4, atol 5e-2)`
+    # on sums of 802 816 terms: row 1 of profiles/r05_pp_bench_v3.txt read OUTPUTS DIFFER without saying which of the two it was)
+    ref = y0.double().reshape(-1, N)
+    s64, a64 = ref.sum(0), ref.abs().sum(0)
+    e0 = float(((p0[:, 0].double().sum(0) - s64).abs() / a64).max())
+    e1 = float(((p1[:, 0].double().sum(0) - s64).abs() / a64).max())
+    ok_stats = e1 <= 1e-5 and bool(torch.equal(p0[:, 3].max(0).values, p1[:, 3].max(0).values)) and bool(torch.equal(p0[:, 2].min(0).values, p1[:, 2].min(0).values))
+    if not (ok_y and ok_stats):
+      detail.append('bm=%s: y %s (%d elements), statistics sum error / sum|y| per-tap %.1e ping-pong %.1e, abs diff of the sums %.3g' % (
+          bm, 'equal' if ok_y else 'DIFFERS', int((y0 != y1).sum()), e0, e1, float((p0[:, 0].sum(0) - p1[:, 0].sum(0)).abs().max())))
+    same = same and ok_y and ok_stats
   setenv(PF_IGEMM_PP=2, PF_IGEMM_PP_BM=None)
   t_ns, _ = run(torch.empty_like(y0), stats=False)
   fl = 2.0 * M * N * C * k * k
   print('%-20s | %9.1f | %-50s | %6.0f TF | no-stats %6.1f us | %s' % ('%d,%d,%d,%d,%d' % (H, C, N, k, s), t0, ' '.join('%7.1f' % t for t in ts), fl / min(ts) * 1e-6, t_ns,
-                                                                    'same bits + statistics' if same else 'OUTPUTS DIFFER'))
+                                                                    'same bits + statistics' if same else 'OUTPUTS DIFFER: ' + '; '.join(detail)))
 setenv(PF_IGEMM_PP=None, PF_IGEMM_PP_BM=None)
