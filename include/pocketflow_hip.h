@@ -62,6 +62,12 @@ int pf_version(void);
 /* The launchers' PF_* tuning / A-B environment switches are read once, on first use (csrc/pf_api.hip, struct PfTuning); a tool or
  * test that changes one in-process calls this to have them read again.  No reference counterpart (tuning service). */
 int pf_tuning_reload(void);
+/* Share of the chip, in 1/1000, that the PERSISTENT contraction launches (pf_conv1x1_fwd, pf_conv2d_fwd) issued from now on may
+ * occupy: their grids are scaled by it (1000 = the whole chip, the default).  The distillation teacher's forward pass
+ * (learners/distillation_helper.py:60-84 of the reference) runs on a second stream beside the student's step; issued at a reduced
+ * share it leaves whole CUs to the student's one-workgroup-per-CU kernels instead of alternating with them.  A launch that writes a
+ * statistics array must be sized (pf_*_stats_groups*) under the same share.  Returns the previous value.  Process-wide. */
+int pf_set_grid_share(int permille);
 
 /* ---- K1: min/max calibration -------------------------------------------------------------
  * replaces tf.reduce_max / tf.reduce_min (+stop_gradient) of __scale,

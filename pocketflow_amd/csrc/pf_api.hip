@@ -70,3 +70,13 @@ int pf_require_lds(const void* fn, size_t lds) {
   }
   return 0;
 }
+
+// ---- share of the chip for persistent launches (pf_set_grid_share) -----------------------------------------------------------------
+#include <atomic>
+static std::atomic<int> g_grid_share{1000};
+int pf_grid_share() { return g_grid_share.load(std::memory_order_relaxed); }
+extern "C" int pf_set_grid_share(int permille) {
+  if (permille < 1) permille = 1;
+  if (permille > 1000) permille = 1000;
+  return g_grid_share.exchange(permille);
+}

@@ -24,6 +24,13 @@ typedef uint16_t bf16_t;
 // drives a second GPU, or launches first from another thread, is configured too (the caches were process-wide statics).
 int pf_require_lds(const void* fn, size_t lds);
 
+// pf_set_grid_share (include/pocketflow_hip.h): `slots` resident workgroups scaled to the current share of the chip
+int pf_grid_share();
+static inline int pf_share_slots(int slots) {
+  const int sh = pf_grid_share();
+  return (sh >= 1000) ? slots : (int)(((int64_t)slots * sh + 999) / 1000);
+}
+
 // ---- tuning / A-B switches (host) --------------------------------------------------------------
 // Every PF_* environment switch of the launchers is read ONCE, on first use, into this struct (pf_api.hip): a launcher and the
 // workspace-size query that precedes it always see the same decision, and no launch pays for getenv / atoi / sscanf.  Tools and

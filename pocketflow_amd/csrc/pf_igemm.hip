@@ -624,7 +624,7 @@ static IgCfg ig_pick(int M, int N, bool pro) {
 }
 
 static int ig_grid(int slots, int tiles_m, int tiles_n, int* G_out) {
-  int G = slots / tiles_n;
+  int G = pf_share_slots(slots) / tiles_n;
   G = (G / 8) * 8;
   if (G < 8) G = 8;
   const int need = ((tiles_m + 7) / 8) * 8;

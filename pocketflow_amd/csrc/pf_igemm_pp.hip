@@ -630,7 +630,8 @@ static PpPlan pp_plan(int M, int N) {
 // per-tap kernels (two workgroups of 64 KiB per CU) interleave with them -- the overlap is worth more than the kernel's own gain.
 bool pf_igemm_pp_takes(int M, int N, int taps, int C) {
   const int mode = pf_tuning().igemm_pp;
-  if (mode == 0 || (N % 64) != 0 || (C % 64) != 0 || pf_tuning().igemm_tile_bm != 0) return false;   // (a PF_IGEMM_TILE override asks for a per-tap kernel)
+  if (mode == 0 || (N % 64) != 0 || (C % 64) != 0 || pf_tuning().igemm_tile_bm != 0) return false;
+  if (mode != 2 && pf_grid_share() < 1000) return false;   // a launch at a reduced share of the chip (the teacher's) stays on the per-tap kernels, two workgroups per CU   // (a PF_IGEMM_TILE override asks for a per-tap kernel)
   if (mode == 2) return true;
   return taps >= 9 && (N % 128) == 0 && (int64_t)taps * C >= 1152 && (int64_t)M * N >= ((int64_t)1 << 21);
 }

@@ -64,7 +64,7 @@ class CudaBackend(object):
     self.graph = torch.cuda.CUDAGraph()
     self.graphs = [self.graph]              # the step in replay order: graphs[0], actions[0], graphs[1], ...
     self.actions = []
-    self.side = torch.cuda.Stream(device=device)
+    self.side = teacher_ahead.make_side_stream(device)
     self._joined = True
     self.capturing = False
 
@@ -403,7 +403,8 @@ class StepGraph(object):
     def body(be):
       if nxt is not None:
         with be.fork(), profiling.suspended():             # the teacher over `next`, from the START of the step: beside the forward pass
-          nxt[2].copy_(teacher.calc_logits(None, nxt[0]))
+          with teacher_ahead.share_of_chip():
+            nxt[2].copy_(teacher.calc_logits(None, nxt[0]))
       lrn._static_batch = cur
       try:
         out = lrn._train_step_eager()

@@ -386,3 +386,33 @@ def test_conv_stem3_wrw_matches_autograd(hip, imgs, H, Wd, N, dw_dtype):
   scale = float(ref.abs().max())
   torch.testing.assert_close(outs[0], ref, rtol=2e-2 if dw_dtype == torch.bfloat16 else 2e-3, atol=(8e-3 if dw_dtype == torch.bfloat16 else 2e-3) * scale)
   assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('share', [0.5, 0.25, 0.05])
+def test_reduced_grid_share_gives_the_same_bits(hip, share):
+  """pf_set_grid_share: the persistent contraction launches at a reduced share of the chip (the teacher's forward beside the student's
+  step) walk the same tiles with fewer workgroups -- same bits; statistics arrays are sized under the same share."""
+  g = torch.Generator(device='cuda').manual_seed(17)
+  # 3x3 (per-tap implicit GEMM), statistics epilogue
+  imgs, H, C, N = 24, 28, 128, 128
+  x = _bf(torch.randn(imgs, H, H, C, device='cuda', generator=g))
+  w = _bf(torch.randn(N, 3, 3, C, device='cuda', generator=g) * 0.05)
+  y0 = _run(hip, x, w, 1, (1, 1))
+  with hip.grid_share(share):
+    G = hip.conv2d_stats_groups(imgs * H * H, N, geom=(imgs, H, H, C, N, 3, 3, 1, 1, 1, H, H))
+    partial = torch.full((G, 4, N), float('nan'), device='cuda')
+    y1 = _run(hip, x, w, 1, (1, 1), partial=partial)
+  assert torch.equal(y0, y1) and not torch.isnan(partial).any()
+  torch.testing.assert_close(partial[:, 0].sum(0), y1.float().reshape(-1, N).sum(0), rtol=1e-4, atol=2e-2)
+  # 1x1: the resident-kernel variant (M >= 4096, K * N small), the prologue kernel of pf_igemm.hip (deep K) and the tiled kernel
+  for M, N1, K in ((20000, 256, 64), (9000, 256, 1024), (3000, 128, 96)):
+    X = _bf(torch.randn(M, K, device='cuda', generator=g))
+    W = _bf(torch.randn(N1, K, device='cuda', generator=g) * 0.1)
+    ss = torch.stack([torch.rand(K, device='cuda', generator=g) + 0.5, torch.randn(K, device='cuda', generator=g)])
+    Y0 = torch.empty(M, N1, device='cuda', dtype=torch.bfloat16)
+    hip.conv1x1_fwd(X, W, Y0, M, N1, K, scale_shift=ss, act='Relu')
+    Y1 = torch.full_like(Y0, float('nan'))
+    with hip.grid_share(share):
+      hip.conv1x1_fwd(X, W, Y1, M, N1, K, scale_shift=ss, act='Relu')
+    assert torch.equal(Y0, Y1), (M, N1, K)
+  assert hip.grid_share(1.0).permille == 1000
