@@ -62,12 +62,6 @@ int pf_version(void);
 /* The launchers' PF_* tuning / A-B environment switches are read once, on first use (csrc/pf_api.hip, struct PfTuning); a tool or
  * test that changes one in-process calls this to have them read again.  No reference counterpart (tuning service). */
 int pf_tuning_reload(void);
-/* Share of the chip, in 1/1000, that the PERSISTENT contraction launches (pf_conv1x1_fwd, pf_conv2d_fwd) issued from now on may
- * occupy: their grids are scaled by it (1000 = the whole chip, the default).  The distillation teacher's forward pass
- * (learners/distillation_helper.py:60-84 of the reference) runs on a second stream beside the student's step; issued at a reduced
- * share it leaves whole CUs to the student's one-workgroup-per-CU kernels instead of alternating with them.  A launch that writes a
- * statistics array must be sized (pf_*_stats_groups*) under the same share.  Returns the previous value.  Process-wide. */
-int pf_set_grid_share(int permille);
 
 /* ---- K1: min/max calibration -------------------------------------------------------------
  * replaces tf.reduce_max / tf.reduce_min (+stop_gradient) of __scale,
@@ -271,7 +265,7 @@ int pf_conv1x1_wrw(const void* dY, const void* X, void* dW, int dw_dtype, float*
  *   Backward-data of a stride-1 convolution is the same call on dY with the kernel flipped and transposed:
  *   W'[c][r][s][n] = W[n][th-1-r][tw-1-s][c], pad' = th-1-pad.                                                      */
 /* rows G of the statistics array for a 1x1 product of M x N outputs (DEPRECATED for R x S convolutions: the kernel -- per-tap or,
- * since round 5, the ping-pong kernel pf_igemm_pp.hip for 3x3 windows with >= 18 k-steps -- and with it G depends on the window) */
+ * and with it G depends on the geometry) */
 int pf_conv2d_stats_groups(int M, int N);
 /* rows G for the pf_conv2d_fwd call with these arguments: the ONLY valid query for R x S convolutions                          */
 int pf_conv2d_stats_groups_geom(int imgs, int H, int Wd, int C, int N, int th, int tw, int stride, int pad_h, int pad_w,

@@ -38,8 +38,6 @@ static void tuning_load() {
   t.wrw2 = env_int("PF_WRW2", 1);
   t.wrw2_target = env_int("PF_WRW2_TARGET", 0);
   t.splitk = env_int("PF_IGEMM_SPLITK", 1);
-  t.igemm_pp = env_int("PF_IGEMM_PP", 0);
-  t.igemm_pp_bm = env_int("PF_IGEMM_PP_BM", 0);
   g_tuning = t;
   g_tuning_loaded = true;
 }
@@ -69,14 +67,4 @@ int pf_require_lds(const void* fn, size_t lds) {
     have = lds;
   }
   return 0;
-}
-
-// ---- share of the chip for persistent launches (pf_set_grid_share) -----------------------------------------------------------------
-#include <atomic>
-static std::atomic<int> g_grid_share{1000};
-int pf_grid_share() { return g_grid_share.load(std::memory_order_relaxed); }
-extern "C" int pf_set_grid_share(int permille) {
-  if (permille < 1) permille = 1;
-  if (permille > 1000) permille = 1000;
-  return g_grid_share.exchange(permille);
 }

@@ -24,13 +24,6 @@ typedef uint16_t bf16_t;
 // drives a second GPU, or launches first from another thread, is configured too (the caches were process-wide statics).
 int pf_require_lds(const void* fn, size_t lds);
 
-// pf_set_grid_share (include/pocketflow_hip.h): `slots` resident workgroups scaled to the current share of the chip
-int pf_grid_share();
-static inline int pf_share_slots(int slots) {
-  const int sh = pf_grid_share();
-  return (sh >= 1000) ? slots : (int)(((int64_t)slots * sh + 999) / 1000);
-}
-
 // ---- tuning / A-B switches (host) --------------------------------------------------------------
 // Every PF_* environment switch of the launchers is read ONCE, on first use, into this struct (pf_api.hip): a launcher and the
 // workspace-size query that precedes it always see the same decision, and no launch pays for getenv / atoi / sscanf.  Tools and
@@ -45,8 +38,6 @@ struct PfTuning {
   int pool3s2;                    // PF_POOL3S2            1 (default) | 0
   int wrw_tr, wrw2, wrw2_target;  // PF_WRW_TR 0, PF_WRW2 1, PF_WRW2_TARGET 0 (= per-shape default)
   int splitk;                     // PF_IGEMM_SPLITK       1 (default) | 0
-  int igemm_pp;                   // PF_IGEMM_PP           plain / backward-data implicit GEMMs on the ping-pong kernel: 0 never (default) | 1 where it measured faster per layer | 2 every shape it computes (tests)
-  int igemm_pp_bm;                // PF_IGEMM_PP_BM        0 (default: per launch) | 16 .. 256: its row-tile height (tests, sweeps)
 };
 const PfTuning& pf_tuning();
 

@@ -304,7 +304,7 @@ static int conv_bn_of(int N) {
 
 static int conv_fwd_grid(int tiles_m, int tiles_n, int* G_out) {
   // ~2 workgroups per CU (256 CUs); G is a multiple of 8 so that a row panel's column tiles share an XCD
-  int G = pf_share_slots(512) / tiles_n;
+  int G = 512 / tiles_n;
   G = (G / 8) * 8;
   if (G < 8) G = 8;
   const int need = ((tiles_m + 7) / 8) * 8;

@@ -366,13 +366,7 @@ int pf_conv_stream_plan(int M, int N, int K, int* nw_out) {
   return nsplit;
 }
 
-// persistent workgroups of a launch: ST_GRID scaled to the current share of the chip (pf_set_grid_share), a multiple of 8 x nsplit
-static int stream_grid(int nsplit) {
-  int grid = (pf_share_slots(ST_GRID) / (8 * nsplit)) * (8 * nsplit);
-  return grid < 8 * nsplit ? 8 * nsplit : grid;
-}
-
-int pf_conv_stream_groups(int nsplit) { return stream_grid(nsplit) / nsplit; }
+int pf_conv_stream_groups(int nsplit) { return ST_GRID / nsplit; }
 
 template <int NW, bool PRO, bool BWD, bool MAP>
 static int stream_launch_t(const ConvArgs& a, int nsplit, hipStream_t st) {
@@ -380,7 +374,7 @@ static int stream_launch_t(const ConvArgs& a, int nsplit, hipStream_t st) {
   const size_t aux_fl = PRO ? 2 * (size_t)a.K : (BWD ? 4 * (size_t)NW : 0);
   const size_t lds = (size_t)NW * a.K * 2 + aux_fl * 4 + (size_t)ST_WAVES * RS * (NW + 8) * 2;
   if (int e = pf_require_lds(reinterpret_cast<const void*>(&k_conv1x1_stream<NW, PRO, BWD, MAP>), lds)) return e;
-  k_conv1x1_stream<NW, PRO, BWD, MAP><<<stream_grid(nsplit), ST_THREADS, lds, st>>>(a, nsplit);
+  k_conv1x1_stream<NW, PRO, BWD, MAP><<<ST_GRID, ST_THREADS, lds, st>>>(a, nsplit);
   PF_LAUNCH_CHECK();
   return 0;
 }

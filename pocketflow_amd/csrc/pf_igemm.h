@@ -1,4 +1,4 @@
-// Shared by the implicit-GEMM kernels (pf_igemm.hip: the per-tap kernels; pf_igemm_pp.hip: the ping-pong kernel): argument block,
+// Shared by the implicit-GEMM kernels (pf_igemm.hip): argument block,
 // buffer-descriptor / LDS-DMA macros, counted waits, mode constants.
 #pragma once
 #include "pf_conv_common.h"
@@ -43,9 +43,6 @@ struct IgArgs {
   // output scatter: row (img, i, j) of the launch's [Ho x Wo] grid is stored at pixel (i * o_sub + o_y, j * o_sub + o_x) of an
   // [o_H x o_W] image (o_sub = 0: off, rows are stored where they are)
   int o_sub, o_y, o_x, o_H, o_W;
-  // ping-pong kernel (pf_igemm_pp.hip): pixel rows per tile, a multiple of 16 in [16, 256] chosen per launch so that the row tiles
-  // divide evenly over the resident workgroups (unused by the per-tap kernels)
-  int pp_bm;
 };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }

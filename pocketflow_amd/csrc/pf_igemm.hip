@@ -624,7 +624,7 @@ static IgCfg ig_pick(int M, int N, bool pro) {
 }
 
 static int ig_grid(int slots, int tiles_m, int tiles_n, int* G_out) {
-  int G = pf_share_slots(slots) / tiles_n;
+  int G = slots / tiles_n;
   G = (G / 8) * 8;
   if (G < 8) G = 8;
   const int need = ((tiles_m + 7) / 8) * 8;
@@ -633,22 +633,16 @@ static int ig_grid(int slots, int tiles_m, int tiles_n, int* G_out) {
   return G * tiles_n;
 }
 
-// pf_igemm_pp.hip: the ping-pong kernel for plain / backward-data launches
-bool pf_igemm_pp_takes(int M, int N, int taps, int C);
-int pf_igemm_pp_stats_groups(int M, int N);
-int pf_igemm_pp_launch(IgArgs& a, hipStream_t st);
-
 // taps, C: the window and the input channels of the launch (1, K for the 1x1 products)
 int pf_igemm_stats_groups_geom(int M, int N, int pro, int taps, int C) {
-  if (!pro && pf_igemm_pp_takes(M, N, taps, C)) return pf_igemm_pp_stats_groups(M, N);
+  (void)taps; (void)C;
   const IgCfg c = ig_pick(M, N, pro != 0);
   int G;
   ig_grid(c.slots, (M + c.bm - 1) / c.bm, (N + c.bn - 1) / c.bn, &G);
   return G;
 }
 
-// (M, N) alone: the 1x1 reading -- what pf_conv1x1_stats_groups_k answers for the products it routes here.  K is not known to this
-// entry point; the ping-pong kernel's default selection takes no 1x1 product, and under PF_IGEMM_PP=2 (tests) every K % 64 == 0 does.
+// (M, N) alone: the 1x1 reading -- what pf_conv1x1_stats_groups_k answers for the products it routes here
 int pf_igemm_stats_groups(int M, int N, int pro) { return pf_igemm_stats_groups_geom(M, N, pro, 1, 64); }
 
 /* deprecated for RxS convolutions: use pf_conv2d_stats_groups_geom (the kernel, and with it the row count, depends on the window) */
@@ -675,7 +669,6 @@ static int ig_launch_t(IgArgs& a, int slots, hipStream_t st) {
 
 static int ig_launch(IgArgs& a, hipStream_t st) {
   const bool bwd = a.bx != nullptr, pro = a.ss != nullptr;
-  if (!pro && pf_igemm_pp_takes(a.M, a.N, a.th * a.tw, a.C)) return pf_igemm_pp_launch(a, st);
   const IgCfg c = ig_pick(a.M, a.N, pro);
   if (pro) {
     if (a.th * a.tw != 1 || bwd) return (int)hipErrorInvalidValue;
@@ -695,7 +688,7 @@ static int ig_launch(IgArgs& a, hipStream_t st) {
 // rows of the [G][.][N] statistics array pf_conv2d_fwd writes for THIS convolution (depends on the kernel it is dispatched to)
 extern "C" int pf_conv2d_stats_groups_geom(int imgs, int H, int Wd, int C, int N, int th, int tw, int stride, int pad_h,
                                            int pad_w, int Ho, int Wo) {
-  (void)H; (void)Wd; (void)stride; (void)pad_h; (void)pad_w;   // (round 5: the window and the channel count select between the per-tap and the ping-pong kernel)
+  (void)H; (void)Wd; (void)stride; (void)pad_h; (void)pad_w;
   return pf_igemm_stats_groups_geom(imgs * Ho * Wo, N, 0, th * tw, C);
 }
 
@@ -727,7 +720,7 @@ extern "C" int pf_conv2d_fwd(const void* X, const void* W, void* Y, const void* 
   a.x_bytes = (uint32_t)((int64_t)imgs * H * Wd * C * 2);
   a.w_bytes = (uint32_t)((int64_t)N * th * tw * C * 2);
   a.w_r0 = 0; a.w_rs = 1; a.w_s0 = 0; a.w_ss = 1; a.w_S = tw; a.w_taps_full = th * tw;
-  a.o_sub = 0; a.o_y = 0; a.o_x = 0; a.o_H = 0; a.o_W = 0; a.pp_bm = 0;
+  a.o_sub = 0; a.o_y = 0; a.o_x = 0; a.o_H = 0; a.o_W = 0;
   return ig_launch(a, (hipStream_t)stream);
 }
 
@@ -765,7 +758,7 @@ extern "C" int pf_conv2d_bwd_data_strided(const void* dY, const void* Wt, void* 
       a.w_r0 = (R - 1 - r1) - (th - 1) * stride; a.w_rs = stride;
       a.w_s0 = (S - 1 - s1) - (tw - 1) * stride; a.w_ss = stride;
       a.w_S = S; a.w_taps_full = R * S;
-      a.o_sub = stride; a.o_y = ay; a.o_x = ax; a.o_H = H; a.o_W = Wd; a.pp_bm = 0;
+      a.o_sub = stride; a.o_y = ay; a.o_x = ax; a.o_H = H; a.o_W = Wd;
       // (the two plain tile configurations the dispatcher picks for these shapes, with the sub-grid walk compiled in)
       const int rc = (C % 128 == 0) ? ig_launch_t<128, 128, 2, 2, 2, IG_PLAIN, true>(a, 512, (hipStream_t)stream)
                                     : ig_launch_t<128, 64, 2, 2, 2, IG_PLAIN, true>(a, 512, (hipStream_t)stream);
@@ -800,6 +793,6 @@ int pf_igemm_conv1x1(const void* X, const void* W, void* Y, const void* R, float
   a.x_bytes = (uint32_t)(rows_in * K * 2);
   a.w_bytes = (uint32_t)((int64_t)N * K * 2);
   a.w_r0 = 0; a.w_rs = 1; a.w_s0 = 0; a.w_ss = 1; a.w_S = 1; a.w_taps_full = 1;
-  a.o_sub = 0; a.o_y = 0; a.o_x = 0; a.o_H = 0; a.o_W = 0; a.pp_bm = 0;
+  a.o_sub = 0; a.o_y = 0; a.o_x = 0; a.o_H = 0; a.o_W = 0;
   return ig_launch(a, st);
 }

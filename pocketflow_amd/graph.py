@@ -750,7 +750,7 @@ class _FusedConv1x1(torch.autograd.Function):
   """y = conv1x1(Q(x), W) [+ residual], Q = the producer BN's normalise/act/fake-quant (prologue)."""
 
   @staticmethod
-  def forward(ctx, x, w, residual, lazy, want_stats, stride, graph, box, w_var=None):
+  def forward(ctx, x, w, residual, lazy, want_stats, stride, graph, box, w_var=None, bn_box=None):
     w2d = w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], w.shape[1])      # [N][K] (KRSC, R=S=1)
     res = _nhwc(residual) if residual is not None else None
     y = _run_conv1x1(x, w2d, lazy, res, want_stats, stride)
@@ -758,6 +758,7 @@ class _FusedConv1x1(torch.autograd.Function):
     ctx.meta = (lazy, stride, graph, residual is not None, w.shape)
     ctx.w_leaf = w
     ctx.w_var = w_var
+    ctx.bn_box = bn_box                       # x is the materialised output of that BatchNormAct (None: lazy or no BN in front)
     box.append(getattr(y, '_pf_stats', None))
     return y
 
@@ -810,8 +811,16 @@ class _FusedConv1x1(torch.autograd.Function):
               and lazy.n_grad_consumers == 2)
       second = join and lazy.pending is not None
       res = lazy.pending if (second and geom is None) else None
-      with region('conv1x1_bwd_data', float((M * K * (2 if (fuse_stats or res is not None) else 1) + M * N) * 2)):
-        if fuse_stats:
+      bb = ctx.bn_box
+      fuse_box = (FUSE_BN_BWD_STATS and lazy is None and bb is not None and bb.get('n_consumers') == 1 and geom is None
+                  and bb.get('act') in ('Relu', 'Relu6') and bb['x'].shape == x.shape)
+      with region('conv1x1_bwd_data', float((M * K * (2 if (fuse_stats or fuse_box or res is not None) else 1) + M * N) * 2)):
+        if fuse_box:
+          G = hip.conv1x1_stats_groups(M, K, N)
+          partial = torch.empty((G, 2, K), dtype=torch.float32, device=x.device)
+          hip.conv1x1_bwd_data_bnstats(dy, wt, dx, bb['x'], bb['scale_shift'], bb['mean_invstd'], bb['act'], partial, M, N, K)
+          bb['bwd_stats'] = (partial, G, dx.data_ptr())
+        elif fuse_stats:
           G = hip.conv1x1_stats_groups(M, K, N)
           partial = torch.empty((G, 2, K), dtype=torch.float32, device=x.device)
           hip.conv1x1_bwd_data_bnstats(dy, wt, dx, x, lazy.scale_shift, lazy.mean_invstd, lazy.act, partial, M, N, K)
@@ -827,7 +836,7 @@ class _FusedConv1x1(torch.autograd.Function):
           if res is None:
             dx = dx + lazy.pending              # the second one is the strided one: no residual operand under a row map
           lazy.pending = None
-    return dx, dw, (dy if has_res else None), None, None, None, None, None, None
+    return dx, dw, (dy if has_res else None), None, None, None, None, None, None, None
 
 
 # two fused consumers of one activation: join their input gradients inside the second backward-data kernel (0: autograd add)
@@ -1286,16 +1295,20 @@ class Conv2D:
       return _tapped(self, materialize(x), residual)
     if fused_conv1x1_ok(x, self):
       lazy = x if isinstance(x, LazyAct) else None
+      bn_box = None
       if lazy is not None:
         lazy.n_consumers += 1
       elif getattr(x, '_pf_bn', None) is not None:
-        x._pf_bn['n_consumers'] += 2             # a materialised BN output read by a 1x1: its BN-backward sums are not fused
+        # a MATERIALISED BN output read by a 1x1 (round 6: bn3 of the deep stages, PF_BN3_MATERIALIZE_MIN_C): a single stride-1
+        # consumer reduces the BN-backward sums in its backward-data epilogue, as the 3x3 convolutions do
+        bn_box = x._pf_bn
+        bn_box['n_consumers'] += 1 if self.stride == 1 else 2
       xin = lazy.x if lazy is not None else _nhwc(x)
       if torch.is_grad_enabled() and (xin.requires_grad or w.requires_grad):
         box = []
         if lazy is not None and xin.requires_grad:
           lazy.n_grad_consumers += 1
-        y = _FusedConv1x1.apply(xin, w, residual, lazy, want_stats, self.stride, self.graph, box, self.kernel)
+        y = _FusedConv1x1.apply(xin, w, residual, lazy, want_stats, self.stride, self.graph, box, self.kernel, bn_box)
         if box and box[0] is not None:
           y._pf_stats = box[0]
         return y

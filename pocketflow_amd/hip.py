@@ -49,7 +49,7 @@ SYMBOLS = [
     'pf_adam_flat_dev', 'pf_momentum_flat_dev', 'pf_set_floats',
     'pf_convg_fwd', 'pf_convg_bwd_data', 'pf_convg_small_splits', 'pf_convg_wrw_splits', 'pf_convg_wrw', 'pf_conv2d_bwd_data_strided',
     'pf_prox_groups', 'pf_prox_norms', 'pf_prox_apply', 'pf_im2col', 'pf_col2im',
-    'pf_conv_stem3_supported', 'pf_conv_stem3_fwd', 'pf_conv_stem3_wrw_slabs', 'pf_conv_stem3_wrw', 'pf_set_grid_share',
+    'pf_conv_stem3_supported', 'pf_conv_stem3_fwd', 'pf_conv_stem3_wrw_slabs', 'pf_conv_stem3_wrw',
 ]
 
 
@@ -123,22 +123,6 @@ def version() -> int:
 def tuning_reload() -> None:
   """The launchers read their PF_* tuning switches once; tools / tests that change one in-process call this afterwards."""
   _check(_lib.pf_tuning_reload(), 'pf_tuning_reload')
-
-
-class grid_share(object):
-  """`with hip.grid_share(0.33): ...` -- the persistent contraction launches issued inside occupy at most that share of the chip
-  (pf_set_grid_share; the teacher's forward pass beside the student's step).  Also what a stream capture records for them."""
-
-  def __init__(self, share: float):
-    self.permille = max(1, min(1000, int(round(share * 1000))))
-
-  def __enter__(self):
-    self.prev = int(_lib.pf_set_grid_share(c_int(self.permille)))
-    return self
-
-  def __exit__(self, *exc):
-    _lib.pf_set_grid_share(c_int(self.prev))
-    return False
 
 
 # ------------------------------------------------------------------------------------------------

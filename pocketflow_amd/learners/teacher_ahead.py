@@ -35,52 +35,12 @@ def enabled() -> bool:
   return os.environ.get('PF_TEACHER_AHEAD', '1') not in ('', '0')
 
 
-def share_of_chip():
-  """Context manager for the teacher's forward pass where it runs BESIDE the student's step (side stream / forked branch of the
-  recorded step): its persistent contraction launches are issued at PF_TEACHER_SHARE of the chip (hip.grid_share; 1 = unchanged)."""
-  share = float(os.environ.get('PF_TEACHER_SHARE', '1'))
-  if share >= 1.0:
-    return contextlib.nullcontext()
-  from pocketflow_amd import hip
-  return hip.grid_share(share)
-
-
-_masked_streams = []           # (raw stream handles are owned here: an ExternalStream does not destroy its stream)
-
-
-def make_side_stream(device):
-  """The second HIP stream of the distillation step.  PF_TEACHER_CU_MASK = "xcd:<n>" (experiment): a stream whose
-  queue is restricted to n of the 8 XCDs (hipExtStreamCreateWithCUMask; the runtime deals the bits of a CU mask round-robin over
-  the XCDs -- bit i belongs to XCD i % 8 -- so whole XCDs are the bits with i % 8 < n).  Measured in round 6
-  (profiles/r06_teacher_share_ab.txt); the mask belongs to the stream's hardware queue, so the launches of a REPLAYED hipGraph, which
-  run on the runtime's own streams, do not carry it."""
-  spec = os.environ.get('PF_TEACHER_CU_MASK', '')
-  if not spec.startswith('xcd:'):
-    return torch.cuda.Stream(device=device)
-  import ctypes
-  n_xcd = max(1, min(8, int(spec[4:])))
-  n_cu = torch.cuda.get_device_properties(device).multi_processor_count
-  words = (n_cu + 31) // 32
-  mask = (ctypes.c_uint32 * words)()
-  for i in range(n_cu):
-    if i % 8 < n_xcd:
-      mask[i // 32] |= 1 << (i % 32)
-  lib = ctypes.CDLL('libamdhip64.so')
-  handle = ctypes.c_void_p()
-  with torch.cuda.device(device):
-    err = lib.hipExtStreamCreateWithCUMask(ctypes.byref(handle), ctypes.c_uint32(words), mask)
-  if err != 0:
-    raise RuntimeError('hipExtStreamCreateWithCUMask failed with %d' % err)
-  _masked_streams.append(handle)
-  return torch.cuda.ExternalStream(handle.value, device=device)
-
-
 class CudaStreams(object):
   """The HIP side of the helper (torch.cuda is HIP on ROCm)."""
 
   def __init__(self, device):
     self.device = device
-    self.side = make_side_stream(device)
+    self.side = torch.cuda.Stream(device=device)
 
   def on_side(self):
     return torch.cuda.stream(self.side)
@@ -155,8 +115,7 @@ class TeacherAhead(object):
       # it has to be the side stream, or the teacher would read a batch the main stream has not finished writing
       images, labels = fetch_raw(lrn)
       x, y = lrn.to_device(images, labels)
-      with share_of_chip():
-        logits = teacher.calc_logits(None, x)
+      logits = teacher.calc_logits(None, x)
       ev = st.record()
     for t in (images, x, y, logits):
       st.hand_to_main(t)

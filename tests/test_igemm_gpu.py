@@ -46,7 +46,7 @@ def _ref(x_nhwc, w_krsc, stride, pad):
 
 
 # tile '': the dispatcher's own choice; every other value is a tile override (PF_IGEMM_TILE) of the per-tap implicit GEMM
-# ('256x256': eight wavefronts of 64 x 128, reachable through PF_IGEMM_TILE only; first run on hardware in round 5: 9 cases passed)
+# ('256x256': eight wavefronts of 64 x 128, reachable through PF_IGEMM_TILE only)
 @pytest.mark.parametrize('tile', ['', '256x128', '128x128', '256x64', '128x64', '256x256'])
 @pytest.mark.parametrize('imgs,H,Wd,C,N,k,stride', [(2, 14, 14, 64, 64, 3, 1), (3, 9, 11, 128, 128, 3, 1),
                                                     (2, 16, 16, 64, 128, 3, 2), (5, 7, 7, 192, 256, 1, 1),
@@ -63,101 +63,6 @@ def test_conv2d_fwd_matches_torch(hip, monkeypatch, tile, imgs, H, Wd, C, N, k, 
   pad = ((k - 1) // 2, (k - 1) // 2)
   y = _run(hip, x, w, stride, pad)
   _close(y, _bf(_ref(x, w, stride, pad)), 'fwd %s' % tile)
-
-
-# ---- the ping-pong kernel (pf_igemm_pp.hip): PF_IGEMM_PP=2 sends every plain / backward-data launch with N % 64 == 0 to it ----
-# bm: row-tile height (PF_IGEMM_PP_BM; '' = the launcher's own choice): one fragment row (16), uneven fragment counts per wavefront
-# row (80, 208), full tiles (256), heights that leave the last input piece half empty
-@pytest.mark.parametrize('bm', ['', '16', '80', '128', '208', '256'])
-@pytest.mark.parametrize('imgs,H,Wd,C,N,k,stride', [(2, 14, 14, 64, 64, 3, 1), (3, 9, 11, 128, 128, 3, 1), (2, 16, 16, 64, 128, 3, 2),
-                                                    (5, 7, 7, 192, 256, 1, 1), (40, 28, 28, 128, 128, 3, 1), (37, 7, 7, 512, 256, 3, 1),
-                                                    (3, 56, 56, 64, 64, 3, 1), (5, 5, 62, 64, 192, 3, 1), (9, 14, 14, 64, 384, 1, 1)])
-def test_conv2d_fwd_pingpong_matches_torch(hip, monkeypatch, bm, imgs, H, Wd, C, N, k, stride):
-  monkeypatch.delenv('PF_IGEMM_TILE', raising=False)
-  monkeypatch.setenv('PF_IGEMM_PP', '2')
-  if bm:
-    monkeypatch.setenv('PF_IGEMM_PP_BM', bm)
-  else:
-    monkeypatch.delenv('PF_IGEMM_PP_BM', raising=False)
-  g = torch.Generator(device='cuda').manual_seed(H * Wd + C + N)
-  x = _bf(torch.randn(imgs, H, Wd, C, device='cuda', generator=g))
-  w = _bf(torch.randn(N, k, k, C, device='cuda', generator=g) * 0.05)
-  pad = ((k - 1) // 2, (k - 1) // 2)
-  ref = _bf(_ref(x, w, stride, pad))
-  for rep in range(2):                                      # (a second launch into a poisoned buffer: a race would rarely repeat itself)
-    y = _run(hip, x, w, stride, pad)
-    _close(y, ref, 'ping-pong fwd bm=%s call %d' % (bm, rep))
-  # the per-tap kernel computes the same sums in the same k order: identical bits
-  monkeypatch.setenv('PF_IGEMM_PP', '0')
-  y0 = _run(hip, x, w, stride, pad)
-  assert torch.equal(y, y0), 'ping-pong and per-tap kernels differ in %d elements' % int((y != y0).sum())
-
-
-@pytest.mark.parametrize('bm', ['', '48', '208'])
-@pytest.mark.parametrize('imgs,H,C,N', [(8, 28, 128, 128), (4, 14, 256, 256), (16, 56, 64, 64), (70, 14, 128, 256), (300, 7, 64, 128)])
-def test_conv2d_fwd_pingpong_statistics_and_residual(hip, monkeypatch, bm, imgs, H, C, N):
-  monkeypatch.setenv('PF_IGEMM_PP', '2')
-  if bm:
-    monkeypatch.setenv('PF_IGEMM_PP_BM', bm)
-  g = torch.Generator(device='cuda').manual_seed(C)
-  x = _bf(torch.randn(imgs, H, H, C, device='cuda', generator=g))
-  w = _bf(torch.randn(N, 3, 3, C, device='cuda', generator=g) * 0.05)
-  M = imgs * H * H
-  G = hip.conv2d_stats_groups(M, N, geom=(imgs, H, H, C, N, 3, 3, 1, 1, 1, H, H))
-  partial = torch.full((G, 4, N), float('nan'), device='cuda')
-  r = _bf(torch.randn(M, N, device='cuda', generator=g))
-  y = _run(hip, x, w, 1, (1, 1), R=r, partial=partial)
-  ref = _bf(_ref(x, w, 1, (1, 1)).float().reshape(M, N) + r.float())       # fp32 sum, ONE rounding (accumulator-level add)
-  _close(y.reshape(M, N), ref, 'residual')
-  yf = y.float().reshape(M, N)
-  assert not torch.isnan(partial).any()
-  torch.testing.assert_close(partial[:, 0].sum(0), yf.sum(0), rtol=1e-4, atol=2e-2)
-  torch.testing.assert_close(partial[:, 1].sum(0), (yf * yf).sum(0), rtol=1e-4, atol=2e-2)
-  assert torch.equal(partial[:, 2].min(0).values, yf.min(0).values)
-  assert torch.equal(partial[:, 3].max(0).values, yf.max(0).values)
-  p2 = torch.full_like(partial, float('nan'))
-  y2 = _run(hip, x, w, 1, (1, 1), R=r, partial=p2)
-  assert torch.equal(partial, p2) and torch.equal(y, y2)                  # deterministic (fixed-order folds)
-
-
-@pytest.mark.parametrize('bm', ['', '112'])
-def test_conv2d_backward_data_pingpong_with_bn_statistics(hip, monkeypatch, bm):
-  """The backward-data launch (flipped kernel, BN-backward sums of the producer BN in the epilogue) on the ping-pong kernel: against
-  autograd, against pf_bn_bwd_stats over the stored dX, and against the per-tap kernel (same dX bits)."""
-  monkeypatch.setenv('PF_IGEMM_PP', '2')
-  if bm:
-    monkeypatch.setenv('PF_IGEMM_PP_BM', bm)
-  imgs, H, C, N = 6, 14, 128, 192
-  g = torch.Generator(device='cuda').manual_seed(9)
-  x = _bf(torch.randn(imgs, H, H, C, device='cuda', generator=g))
-  w = _bf(torch.randn(N, 3, 3, C, device='cuda', generator=g) * 0.05)
-  dy = _bf(torch.randn(imgs, H, H, N, device='cuda', generator=g) * 0.1)
-  xt = x.float().permute(0, 3, 1, 2).requires_grad_(True)
-  F.conv2d(xt, w.float().permute(0, 3, 1, 2), padding=1).backward(dy.float().permute(0, 3, 1, 2))
-  ref = xt.grad.permute(0, 2, 3, 1)
-  wb = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()            # [C][3][3][N]
-  M = imgs * H * H
-  bnx = _bf(torch.randn(M, C, device='cuda', generator=g))
-  ss = torch.stack([torch.rand(C, device='cuda', generator=g) + 0.5, torch.randn(C, device='cuda', generator=g) * 0.3])
-  mi = torch.stack([torch.randn(C, device='cuda', generator=g) * 0.1, torch.rand(C, device='cuda', generator=g) + 0.5])
-  G = hip.conv2d_stats_groups(M, C, geom=(imgs, H, H, N, C, 3, 3, 1, 1, 1, H, H))
-  partial = torch.full((G, 2, C), float('nan'), device='cuda')
-  dx = _run(hip, dy, wb, 1, (1, 1), partial=partial, bn_x=bnx, bn_scale_shift=ss, bn_mean_invstd=mi, bn_act='Relu')
-  _close(dx, _bf(ref), 'bwd-data')
-  nblk = 16
-  ref_partial = torch.empty(nblk * 2 * C, device='cuda')
-  hip.bn_bwd_stats(dx.reshape(M, C), bnx, M, C, ss, mi, 'Relu', ref_partial, nblk)
-  dgamma, dbeta = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
-  hip.bn_bwd_finalize(ref_partial, nblk, C, dgamma, dbeta)
-  dg2, db2 = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
-  hip.bn_bwd_finalize(partial, G, C, dg2, db2)
-  torch.testing.assert_close(db2, dbeta, rtol=1e-4, atol=1e-3)
-  torch.testing.assert_close(dg2, dgamma, rtol=1e-4, atol=1e-3)
-  monkeypatch.setenv('PF_IGEMM_PP', '0')
-  G0 = hip.conv2d_stats_groups(M, C, geom=(imgs, H, H, N, C, 3, 3, 1, 1, 1, H, H))
-  p0 = torch.full((G0, 2, C), float('nan'), device='cuda')
-  dx0 = _run(hip, dy, wb, 1, (1, 1), partial=p0, bn_x=bnx, bn_scale_shift=ss, bn_mean_invstd=mi, bn_act='Relu')
-  assert torch.equal(dx, dx0)
 
 
 def test_conv2d_fwd_asymmetric_window_and_padding(hip):
@@ -386,33 +291,3 @@ def test_conv_stem3_wrw_matches_autograd(hip, imgs, H, Wd, N, dw_dtype):
   scale = float(ref.abs().max())
   torch.testing.assert_close(outs[0], ref, rtol=2e-2 if dw_dtype == torch.bfloat16 else 2e-3, atol=(8e-3 if dw_dtype == torch.bfloat16 else 2e-3) * scale)
   assert torch.equal(outs[0], outs[1])
-
-
-@pytest.mark.parametrize('share', [0.5, 0.25, 0.05])
-def test_reduced_grid_share_gives_the_same_bits(hip, share):
-  """pf_set_grid_share: the persistent contraction launches at a reduced share of the chip (the teacher's forward beside the student's
-  step) walk the same tiles with fewer workgroups -- same bits; statistics arrays are sized under the same share."""
-  g = torch.Generator(device='cuda').manual_seed(17)
-  # 3x3 (per-tap implicit GEMM), statistics epilogue
-  imgs, H, C, N = 24, 28, 128, 128
-  x = _bf(torch.randn(imgs, H, H, C, device='cuda', generator=g))
-  w = _bf(torch.randn(N, 3, 3, C, device='cuda', generator=g) * 0.05)
-  y0 = _run(hip, x, w, 1, (1, 1))
-  with hip.grid_share(share):
-    G = hip.conv2d_stats_groups(imgs * H * H, N, geom=(imgs, H, H, C, N, 3, 3, 1, 1, 1, H, H))
-    partial = torch.full((G, 4, N), float('nan'), device='cuda')
-    y1 = _run(hip, x, w, 1, (1, 1), partial=partial)
-  assert torch.equal(y0, y1) and not torch.isnan(partial).any()
-  torch.testing.assert_close(partial[:, 0].sum(0), y1.float().reshape(-1, N).sum(0), rtol=1e-4, atol=2e-2)
-  # 1x1: the resident-kernel variant (M >= 4096, K * N small), the prologue kernel of pf_igemm.hip (deep K) and the tiled kernel
-  for M, N1, K in ((20000, 256, 64), (9000, 256, 1024), (3000, 128, 96)):
-    X = _bf(torch.randn(M, K, device='cuda', generator=g))
-    W = _bf(torch.randn(N1, K, device='cuda', generator=g) * 0.1)
-    ss = torch.stack([torch.rand(K, device='cuda', generator=g) + 0.5, torch.randn(K, device='cuda', generator=g)])
-    Y0 = torch.empty(M, N1, device='cuda', dtype=torch.bfloat16)
-    hip.conv1x1_fwd(X, W, Y0, M, N1, K, scale_shift=ss, act='Relu')
-    Y1 = torch.full_like(Y0, float('nan'))
-    with hip.grid_share(share):
-      hip.conv1x1_fwd(X, W, Y1, M, N1, K, scale_shift=ss, act='Relu')
-    assert torch.equal(Y0, Y1), (M, N1, K)
-  assert hip.grid_share(1.0).permille == 1000

@@ -1,10 +1,11 @@
+# (RECORD of what ran: the switches PF_TEACHER_SHARE / PF_TEACHER_CU_MASK / PF_IGEMM_PP it sets were deleted with the losing code after this call;
+#  results: profiles/r06_teacher_share_ab.txt, profiles/r06_bn_bwd_apply_fold_ceiling.txt)
 # Round 6, GPU call 2: VERDICT r5 next #3 -- partition the chip between student and teacher, then dispatch or delete the ping-pong kernel.
 # One box, every configuration the same command: python bench.py --steps 20 --warmup 5 --no_cpu_baseline  (recorded step; images/s).
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 O=gpurun_out
-timeout 600 python -m pytest tests/test_igemm_gpu.py -m gpu -q -k "reduced_grid_share" --tb=short 2>&1 | tail -5
 run() {  # label, env...
   label=$1; shift
   v=$(env "$@" timeout 400 python bench.py --steps 20 --warmup 5 --no_cpu_baseline 2>$O/r06_ab_err.txt | python -c "
