@@ -236,6 +236,15 @@ int pf_conv1x1_stats_groups_k(int M, int N, int K, int prologue);
 int pf_conv1x1_fwd(const void* X, const void* W, void* Y, const void* R, const float* scale_shift,
                    int act, const uint32_t* slot, int bits, float* partial, int M, int N, int K,
                    int Ho, int Wo, int H, int Wd, int stride, int ymap, void* stream);
+/* pf_conv1x1_fwd with the CONSUMER's inference-mode BN + activation folded into the epilogue (round 6):
+ *   Y[m][n] = bf16( act_out( out_scale[n] * bf16(conv)[m][n] + out_shift[n] ) ),  out_scale_shift = [2][N] float32
+ * -- bit for bit what pf_bn_act_quant_apply(quantize = 0) makes of the stored convolution output, without the write + read of
+ * that output in between.  No residual, no statistics.  Used by forward_eval networks: tf.layers.batch_normalization(training=False)
+ * behind a convolution (utils/external/resnet_model.py:55-66 under the distillation teacher, learners/distillation_helper.py:60-84).
+ * Shapes outside the fused kernels run the plain launch and the stand-alone pass in place (same result). */
+int pf_conv1x1_fwd_affine(const void* X, const void* W, void* Y, const float* scale_shift, int act,
+                          const float* out_scale_shift, int out_act, int M, int N, int K, int Ho, int Wo, int H, int Wd,
+                          int stride, void* stream);
 /* backward-data of a stride-1 1x1 convolution, dQ[M][K] = dY[M][N] * W[N][K] (Wt = transposed kernel [K][N]),
  * with the statistics pass of the BN backward of the layer that produced Q fused into the epilogue
  * (replaces FusedBatchNormGrad's reduction over dy, utils/external/resnet_model.py:55-62):
@@ -264,8 +273,8 @@ int pf_conv1x1_wrw(const void* dY, const void* X, void* dW, int dw_dtype, float*
  *   (dy = Y * act'(scale*x + shift)), as pf_conv1x1_bwd_data_bnstats.
  *   Backward-data of a stride-1 convolution is the same call on dY with the kernel flipped and transposed:
  *   W'[c][r][s][n] = W[n][th-1-r][tw-1-s][c], pad' = th-1-pad.                                                      */
-/* rows G of the statistics array for a 1x1 product of M x N outputs (DEPRECATED for R x S convolutions: the kernel -- per-tap or,
- * and with it G depends on the geometry) */
+/* rows G of the statistics array for a 1x1 product of M x N outputs (DEPRECATED for R x S convolutions: the tile, and with it G,
+ * depends on the geometry) */
 int pf_conv2d_stats_groups(int M, int N);
 /* rows G for the pf_conv2d_fwd call with these arguments: the ONLY valid query for R x S convolutions                          */
 int pf_conv2d_stats_groups_geom(int imgs, int H, int Wd, int C, int N, int th, int tw, int stride, int pad_h, int pad_w,
@@ -274,6 +283,10 @@ int pf_conv2d_fwd(const void* X, const void* W, void* Y, const void* zero, const
                   const void* bn_x, const float* bn_scale_shift, const float* bn_mean_invstd, int bn_act,
                   int imgs, int H, int Wd, int C, int N, int th, int tw, int stride, int pad_h, int pad_w,
                   int Ho, int Wo, void* stream);
+/* pf_conv2d_fwd with the consumer's inference-mode BN + activation folded into the epilogue: see pf_conv1x1_fwd_affine */
+int pf_conv2d_fwd_affine(const void* X, const void* W, void* Y, const void* zero, const float* out_scale_shift, int out_act,
+                         int imgs, int H, int Wd, int C, int N, int th, int tw, int stride, int pad_h, int pad_w, int Ho, int Wo,
+                         void* stream);
 
 /* pf_conv2d_wrw: backward-filter of the same convolutions (Conv2DBackpropFilter), dW[n][r][s][c] = sum_m dY[m][n] *
  * X[pix(m, r, s)][c], dW float32 or bf16 in KRSC layout; deterministic (fixed-order reductions, no atomics).

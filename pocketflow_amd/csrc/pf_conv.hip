@@ -333,7 +333,7 @@ int pf_igemm_stats_groups(int M, int N, int pro);           // the launcher's ow
 int pf_igemm_conv1x1(const void* X, const void* W, void* Y, const void* R, float* partial, const void* bn_x,
                      const float* bss, const float* bmi, float b_lo, float b_hi, const float* scale_shift,
                      const uint32_t* slot, float kq, float act_lo, float act_hi, int M, int N, int K, int Ho, int Wo,
-                     int H, int Wd, int stride, hipStream_t st);
+                     int H, int Wd, int stride, const float* oss, int oact, hipStream_t st);
 // Which 1x1 shapes go to the direct-to-LDS staged kernel (after the resident-kernel variant had its pick).  Measured
 // (tools/gpu/igemm_bench.py, conv_bench2.py): prologue-free GEMMs win from K = 512 up; with the prologue the in-LDS pass
 // behind asynchronous staging beats the register-staged tiles of this file on every shape it was tried on.
@@ -353,7 +353,9 @@ extern "C" int pf_conv1x1_stats_groups_k(int M, int N, int K, int prologue) {
 static int conv_fwd_launch(const void* X, const void* W, void* Y, const void* R, const float* scale_shift,
                            int act, const uint32_t* slot, int bits, float* partial, int M, int N, int K,
                            int Ho, int Wo, int H, int Wd, int stride, int ymap, const void* bx,
-                           const float* bss, const float* bmi, int bact, void* stream) {
+                           const float* bss, const float* bmi, int bact, void* stream, const float* oss = nullptr,
+                           int oact = PF_ACT_NONE) {
+  if (oss != nullptr && (R != nullptr || partial != nullptr || bx != nullptr || ymap)) return (int)hipErrorInvalidValue;
   if (M <= 0 || N <= 0 || K <= 0 || (K % 8) || (N % 8)) return (int)hipErrorInvalidValue;
   if (!pf_aligned16(X) || !pf_aligned16(W) || !pf_aligned16(Y) || (R && !pf_aligned16(R)))
     return (int)hipErrorInvalidValue;
@@ -371,6 +373,7 @@ static int conv_fwd_launch(const void* X, const void* W, void* Y, const void* R,
   a.bx = (const bf16_t*)bx; a.bss = bss; a.bmi = bmi;
   a.b_lo = (bact == PF_ACT_NONE) ? -INFINITY : 0.0f;
   a.b_hi = (bact == PF_ACT_RELU6) ? 6.0f : INFINITY;
+  a.oss = oss; a.oact = oact;
   if (bx != nullptr && (R != nullptr || partial == nullptr || bss == nullptr || bmi == nullptr || stride != 1 ||
                         !pf_aligned16(bx)))
     return (int)hipErrorInvalidValue;
@@ -387,8 +390,16 @@ static int conv_fwd_launch(const void* X, const void* W, void* Y, const void* R,
   }
   if (!ymap && conv_use_igemm(pro, K)) {
     const int r = pf_igemm_conv1x1(X, W, Y, R, partial, bx, bss, bmi, a.b_lo, a.b_hi, scale_shift, slot, a.kq, a.act_lo,
-                                   a.act_hi, M, N, K, Ho, Wo, H, Wd, stride, st);
+                                   a.act_hi, M, N, K, Ho, Wo, H, Wd, stride, oss, oact, st);
     if (r >= 0) return r;
+  }
+  if (oss != nullptr) {
+    // no kernel with the folded pass took the shape: the plain launch, then the stand-alone pass IN PLACE (same result, one more
+    // read + write of Y)
+    const int r = conv_fwd_launch(X, W, Y, R, scale_shift, act, slot, bits, partial, M, N, K, Ho, Wo, H, Wd, stride, ymap, bx, bss,
+                                  bmi, bact, stream);
+    if (r != 0) return r;
+    return pf_bn_act_quant_apply(Y, Y, PF_BF16, M, N, oss, oact, nullptr, 8, 0, stream);
   }
   const bool map = stride != 1;
 #define PF_CV(BNV)                                                                             \
@@ -410,6 +421,18 @@ extern "C" int pf_conv1x1_fwd(const void* X, const void* W, void* Y, const void*
                               int Ho, int Wo, int H, int Wd, int stride, int ymap, void* stream) {
   return conv_fwd_launch(X, W, Y, R, scale_shift, act, slot, bits, partial, M, N, K, Ho, Wo, H, Wd, stride, ymap,
                          nullptr, nullptr, nullptr, PF_ACT_NONE, stream);
+}
+
+// pf_conv1x1_fwd with the CONSUMER's inference-mode BN + activation folded into the row pass of the epilogue (round 6):
+// Y = act_out(out_scale[n] * bf16(conv) + out_shift[n]) -- what pf_bn_act_quant_apply (quantize = 0) would make of the stored
+// output, bit for bit, without the write + read of the raw output in between.  No residual, no statistics (an inference-mode
+// BN needs none).  The teacher of the distillation step (learners/distillation_helper.py:60-84: forward_eval) runs through it.
+extern "C" int pf_conv1x1_fwd_affine(const void* X, const void* W, void* Y, const float* scale_shift, int act,
+                                     const float* out_scale_shift, int out_act, int M, int N, int K, int Ho, int Wo, int H,
+                                     int Wd, int stride, void* stream) {
+  if (out_scale_shift == nullptr) return (int)hipErrorInvalidValue;
+  return conv_fwd_launch(X, W, Y, nullptr, scale_shift, act, nullptr, 8, nullptr, M, N, K, Ho, Wo, H, Wd, stride, 0,
+                         nullptr, nullptr, nullptr, PF_ACT_NONE, stream, out_scale_shift, out_act);
 }
 
 // backward-data of a stride-1 1x1 convolution, dQ[M][K] = dY[M][N] * W[N][K] (Wt = the transposed kernel

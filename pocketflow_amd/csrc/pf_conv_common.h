@@ -52,7 +52,34 @@ struct ConvArgs {
   const float* bss;     // its scale | shift   [2][N]
   const float* bmi;     // its mean | invstd   [2][N]
   float b_lo, b_hi;     // activation window of the mask: lo < u < hi  (ReLU: 0, +inf; ReLU6: 0, 6)
+  // output affine (oss != null): the row pass stores act(scale[n] * y + shift[n]) instead of y -- the inference-mode BN + activation
+  // of the CONSUMER folded into this launch (out_affine8 below); no statistics, no residual with it
+  const float* oss;     // scale | shift   [2][N]
+  int oact;             // PF_ACT_*
 };
+
+// The output affine on one 16-byte vector of the row pass: 8 consecutive channels n .. n + 7 of one pixel, ALREADY rounded to bf16.
+// Exactly the arithmetic of pf_bn_act_quant_apply without a quantiser on exactly the value it would read back from HBM --
+// act(fma(scale, y, shift)), rounded to bf16 once -- so folding the pass into the producing convolution changes no bit.
+__device__ __forceinline__ uint4 out_affine8(const uint4& c, const float* __restrict__ oss, int N, int n, int act) {
+  // the column index is made opaque per call: the four constant loads below are loop-invariant in every row pass, and hoisted
+  // out of it they cost the kernels that never take this branch 11-16 registers (k_conv1x1_stream<256, true> started to spill)
+  asm volatile("" : "+v"(n));
+  float f[8];
+  unpack8(c, f);
+  const float4 s0 = *reinterpret_cast<const float4*>(oss + n), s1 = *reinterpret_cast<const float4*>(oss + n + 4);
+  const float4 h0 = *reinterpret_cast<const float4*>(oss + N + n), h1 = *reinterpret_cast<const float4*>(oss + N + n + 4);
+  const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+  const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float y = fmaf(sc[j], f[j], sh[j]);
+    if (act != PF_ACT_NONE) y = fmaxf(y, 0.f);
+    if (act == PF_ACT_RELU6) y = fminf(y, 6.f);
+    f[j] = y;
+  }
+  return pack8(f);
+}
 
 __device__ __forceinline__ int64_t map_row(const ConvArgs& a, int m) {
   if (a.stride == 1) return m;

@@ -31,7 +31,9 @@
 
 // MAP: strided / remapped rows (projection shortcuts); the stride-1 instantiations carry no index-division code at all
 // (it is inlined at every load and store site: without the split the loop body outgrows the instruction cache)
-template <int NW, bool PRO, bool BWD, bool MAP>
+// AFF: the output affine of the row pass (ConvArgs.oss; forward launches of an inference-mode network only) -- a template
+// parameter, not a run-time branch: the branch cost the training kernels 8-16 registers (k_conv1x1_stream<256, true> spilled)
+template <int NW, bool PRO, bool BWD, bool MAP, bool AFF = false>
 __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a, const int nsplit) {
   constexpr int JM = (NW == 256) ? 1 : 2;           // 16-pixel blocks per strip
   constexpr int RS = 16 * JM;                       // pixel rows per strip
@@ -299,6 +301,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_conv1x1_stream(const ConvArgs a,
             }
           }
         }
+        if constexpr (AFF) c = out_affine8(c, a.oss, a.N, n, a.oact);
         *reinterpret_cast<uint4*>(a.Y + orow * a.N + n) = c;
       }
     }
@@ -368,13 +371,13 @@ int pf_conv_stream_plan(int M, int N, int K, int* nw_out) {
 
 int pf_conv_stream_groups(int nsplit) { return ST_GRID / nsplit; }
 
-template <int NW, bool PRO, bool BWD, bool MAP>
+template <int NW, bool PRO, bool BWD, bool MAP, bool AFF = false>
 static int stream_launch_t(const ConvArgs& a, int nsplit, hipStream_t st) {
   const int JM = (NW == 256) ? 1 : 2, RS = 16 * JM;
   const size_t aux_fl = PRO ? 2 * (size_t)a.K : (BWD ? 4 * (size_t)NW : 0);
   const size_t lds = (size_t)NW * a.K * 2 + aux_fl * 4 + (size_t)ST_WAVES * RS * (NW + 8) * 2;
-  if (int e = pf_require_lds(reinterpret_cast<const void*>(&k_conv1x1_stream<NW, PRO, BWD, MAP>), lds)) return e;
-  k_conv1x1_stream<NW, PRO, BWD, MAP><<<ST_GRID, ST_THREADS, lds, st>>>(a, nsplit);
+  if (int e = pf_require_lds(reinterpret_cast<const void*>(&k_conv1x1_stream<NW, PRO, BWD, MAP, AFF>), lds)) return e;
+  k_conv1x1_stream<NW, PRO, BWD, MAP, AFF><<<ST_GRID, ST_THREADS, lds, st>>>(a, nsplit);
   PF_LAUNCH_CHECK();
   return 0;
 }
@@ -385,6 +388,15 @@ int pf_conv_stream_launch(const ConvArgs& a, bool pro, bool bwd, hipStream_t st)
   const int nsplit = pf_conv_stream_plan(a.M, a.N, a.K, &nw);
   if (nsplit == 0) return -1;
   const bool map = a.stride != 1;
+  if (a.oss != nullptr) {                                  // output affine: stride-1 forward launches (the caller falls back otherwise)
+    if (map || bwd) return -1;
+#define PF_STA(NWV) do { return pro ? stream_launch_t<NWV, true, false, false, true>(a, nsplit, st)     \
+                                    : stream_launch_t<NWV, false, false, false, true>(a, nsplit, st); } while (0)
+    if (nw == 64) PF_STA(64);
+    if (nw == 128) PF_STA(128);
+    PF_STA(256);
+#undef PF_STA
+  }
 #define PF_ST(NWV)                                                                                  \
   do {                                                                                              \
     if (pro) return map ? stream_launch_t<NWV, true, false, true>(a, nsplit, st)                    \

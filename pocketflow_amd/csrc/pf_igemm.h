@@ -43,6 +43,9 @@ struct IgArgs {
   // output scatter: row (img, i, j) of the launch's [Ho x Wo] grid is stored at pixel (i * o_sub + o_y, j * o_sub + o_x) of an
   // [o_H x o_W] image (o_sub = 0: off, rows are stored where they are)
   int o_sub, o_y, o_x, o_H, o_W;
+  // output affine of the row pass (pf_conv_common.h out_affine8): the consumer's inference-mode BN + activation; null: off
+  const float* oss;     // scale | shift [2][N]
+  int oact;
 };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }

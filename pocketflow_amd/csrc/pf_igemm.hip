@@ -51,7 +51,9 @@
 // SUB: the launch walks a sub-grid of a larger kernel buffer and scatters its rows (IgArgs.w_* / o_*: strided backward-data by parity
 // classes).  A template parameter, not a run-time branch: the extra scalar state cost the ordinary kernels 16-24 more spilled SGPRs
 // (v_writelane / v_readlane traffic in the staging code) when it was one.
-template <int BM, int BN, int WM, int WN, int NS, int MODE, bool SUB = false>
+// AFF: the output affine of the row pass (IgArgs.oss: the consumer's inference-mode BN + activation) -- compiled in for the forward
+// launches of an inference-mode network only
+template <int BM, int BN, int WM, int WN, int NS, int MODE, bool SUB = false, bool AFF = false>
 __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
   constexpr bool BWD = (MODE == IG_BWD), PRO = (MODE == IG_PRO);
   static_assert(!PRO || NS == 2 || NS == 3, "the in-LDS prologue pass is written for the 2- and 3-stage rings");
@@ -539,6 +541,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
               }
             }
           }
+          if constexpr (AFF) c = out_affine8(c, a.oss, a.N, n, a.oact);
           int64_t orow = m;
           if constexpr (SUB) {                                              // scatter of a parity class
             const int oimg = m / hw_o, orem = m - oimg * hw_o;
@@ -648,7 +651,7 @@ int pf_igemm_stats_groups(int M, int N, int pro) { return pf_igemm_stats_groups_
 /* deprecated for RxS convolutions: use pf_conv2d_stats_groups_geom (the kernel, and with it the row count, depends on the window) */
 extern "C" int pf_conv2d_stats_groups(int M, int N) { return pf_igemm_stats_groups(M, N, 0); }
 
-template <int BM, int BN, int WM, int WN, int NS, int MODE, bool SUB = false>
+template <int BM, int BN, int WM, int WN, int NS, int MODE, bool SUB = false, bool AFF = false>
 static int ig_launch_t(IgArgs& a, int slots, hipStream_t st) {
   constexpr bool BWD = (MODE == IG_BWD), PRO3 = (MODE == IG_PRO && NS == 3);
   constexpr int THREADS = 64 * WM * WN;
@@ -661,8 +664,8 @@ static int ig_launch_t(IgArgs& a, int slots, hipStream_t st) {
   const size_t lds = base + (BWD ? 4 * BN * 4 : 0) + (PRO3 ? 2 * (size_t)a.C * 4 : 0);
   if (PRO3 && a.C > CV_MAXK) return (int)hipErrorInvalidValue;
   const size_t lds_max = base + (BWD ? 4 * BN * 4 : 0) + (PRO3 ? 2 * (size_t)CV_MAXK * 4 : 0);
-  if (int e = pf_require_lds(reinterpret_cast<const void*>(&k_igemm<BM, BN, WM, WN, NS, MODE, SUB>), lds_max)) return e;
-  k_igemm<BM, BN, WM, WN, NS, MODE, SUB><<<grid, THREADS, lds, st>>>(a);
+  if (int e = pf_require_lds(reinterpret_cast<const void*>(&k_igemm<BM, BN, WM, WN, NS, MODE, SUB, AFF>), lds_max)) return e;
+  k_igemm<BM, BN, WM, WN, NS, MODE, SUB, AFF><<<grid, THREADS, lds, st>>>(a);
   PF_LAUNCH_CHECK();
   return 0;
 }
@@ -670,6 +673,21 @@ static int ig_launch_t(IgArgs& a, int slots, hipStream_t st) {
 static int ig_launch(IgArgs& a, hipStream_t st) {
   const bool bwd = a.bx != nullptr, pro = a.ss != nullptr;
   const IgCfg c = ig_pick(a.M, a.N, pro);
+  if (a.oss != nullptr) {
+    // output affine: the dispatcher's default tiles carry it; any other selection (tile override, two-stage prologue kernel) runs
+    // the plain launch and the stand-alone pass in place
+    if (bwd) return (int)hipErrorInvalidValue;
+    if (pro && c.pro3 && a.th * a.tw == 1)
+      return (c.bn == 256) ? ig_launch_t<128, 256, 2, 4, 3, IG_PRO, false, true>(a, c.slots, st)
+                           : ig_launch_t<256, 128, 4, 2, 3, IG_PRO, false, true>(a, c.slots, st);
+    if (!pro && c.bm == 128 && c.bn == 128) return ig_launch_t<128, 128, 2, 2, 2, IG_PLAIN, false, true>(a, c.slots, st);
+    if (!pro && c.bm == 128 && c.bn == 64) return ig_launch_t<128, 64, 2, 2, 2, IG_PLAIN, false, true>(a, c.slots, st);
+    const float* oss = a.oss;
+    a.oss = nullptr;
+    const int r = ig_launch(a, st);
+    if (r != 0) return r;
+    return pf_bn_act_quant_apply(a.Y, a.Y, PF_BF16, a.M, a.N, oss, a.oact, nullptr, 8, 0, st);
+  }
   if (pro) {
     if (a.th * a.tw != 1 || bwd) return (int)hipErrorInvalidValue;
     if (c.pro3) return (c.bn == 256) ? ig_launch_t<128, 256, 2, 4, 3, IG_PRO>(a, c.slots, st)
@@ -695,10 +713,11 @@ extern "C" int pf_conv2d_stats_groups_geom(int imgs, int H, int Wd, int C, int N
 // forward convolution (or any implicit GEMM of that form).  X [img][H][Wd][C], W [N][th][tw][C], Y [img][Ho][Wo][N].
 // zero: >= 128 zero bytes in device memory.  R / partial / bn_*: epilogue options as for pf_conv1x1_fwd /
 // pf_conv1x1_bwd_data_bnstats (partial: [G][4][N] or, with bn_x, [G][2][N]; G = pf_conv2d_stats_groups(M, N)).
-extern "C" int pf_conv2d_fwd(const void* X, const void* W, void* Y, const void* zero, const void* R, float* partial,
+static int conv2d_fwd_launch(const void* X, const void* W, void* Y, const void* zero, const void* R, float* partial,
                              const void* bn_x, const float* bn_scale_shift, const float* bn_mean_invstd, int bn_act,
                              int imgs, int H, int Wd, int C, int N, int th, int tw, int stride, int pad_h, int pad_w,
-                             int Ho, int Wo, void* stream) {
+                             int Ho, int Wo, void* stream, const float* out_scale_shift, int out_act) {
+  if (out_scale_shift != nullptr && (R != nullptr || partial != nullptr || bn_x != nullptr)) return (int)hipErrorInvalidValue;
   if (imgs <= 0 || H <= 0 || Wd <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || N <= 0 || (C % 64) || (N % 8) || th < 1 || tw < 1 ||
       stride < 1)
     return (int)hipErrorInvalidValue;
@@ -721,7 +740,26 @@ extern "C" int pf_conv2d_fwd(const void* X, const void* W, void* Y, const void* 
   a.w_bytes = (uint32_t)((int64_t)N * th * tw * C * 2);
   a.w_r0 = 0; a.w_rs = 1; a.w_s0 = 0; a.w_ss = 1; a.w_S = tw; a.w_taps_full = th * tw;
   a.o_sub = 0; a.o_y = 0; a.o_x = 0; a.o_H = 0; a.o_W = 0;
+  a.oss = out_scale_shift; a.oact = out_act;
   return ig_launch(a, (hipStream_t)stream);
+}
+
+extern "C" int pf_conv2d_fwd(const void* X, const void* W, void* Y, const void* zero, const void* R, float* partial,
+                             const void* bn_x, const float* bn_scale_shift, const float* bn_mean_invstd, int bn_act,
+                             int imgs, int H, int Wd, int C, int N, int th, int tw, int stride, int pad_h, int pad_w,
+                             int Ho, int Wo, void* stream) {
+  return conv2d_fwd_launch(X, W, Y, zero, R, partial, bn_x, bn_scale_shift, bn_mean_invstd, bn_act, imgs, H, Wd, C, N, th, tw,
+                           stride, pad_h, pad_w, Ho, Wo, stream, nullptr, PF_ACT_NONE);
+}
+
+// pf_conv2d_fwd with the CONSUMER's inference-mode BN + activation folded into the row pass of the epilogue (see
+// pf_conv1x1_fwd_affine): Y = act_out(out_scale[n] * bf16(conv) + out_shift[n]).  No residual, no statistics.
+extern "C" int pf_conv2d_fwd_affine(const void* X, const void* W, void* Y, const void* zero, const float* out_scale_shift,
+                                    int out_act, int imgs, int H, int Wd, int C, int N, int th, int tw, int stride, int pad_h,
+                                    int pad_w, int Ho, int Wo, void* stream) {
+  if (out_scale_shift == nullptr) return (int)hipErrorInvalidValue;
+  return conv2d_fwd_launch(X, W, Y, zero, nullptr, nullptr, nullptr, nullptr, nullptr, PF_ACT_NONE, imgs, H, Wd, C, N, th, tw,
+                           stride, pad_h, pad_w, Ho, Wo, stream, out_scale_shift, out_act);
 }
 
 // Backward-data of a STRIDED convolution by output-parity classes (round 4; until then MIOpen).  Forward: y[ho][wo] = sum_{r,s,c}
@@ -758,7 +796,7 @@ extern "C" int pf_conv2d_bwd_data_strided(const void* dY, const void* Wt, void* 
       a.w_r0 = (R - 1 - r1) - (th - 1) * stride; a.w_rs = stride;
       a.w_s0 = (S - 1 - s1) - (tw - 1) * stride; a.w_ss = stride;
       a.w_S = S; a.w_taps_full = R * S;
-      a.o_sub = stride; a.o_y = ay; a.o_x = ax; a.o_H = H; a.o_W = Wd;
+      a.o_sub = stride; a.o_y = ay; a.o_x = ax; a.o_H = H; a.o_W = Wd; a.oss = nullptr; a.oact = PF_ACT_NONE;
       // (the two plain tile configurations the dispatcher picks for these shapes, with the sub-grid walk compiled in)
       const int rc = (C % 128 == 0) ? ig_launch_t<128, 128, 2, 2, 2, IG_PLAIN, true>(a, 512, (hipStream_t)stream)
                                     : ig_launch_t<128, 64, 2, 2, 2, IG_PLAIN, true>(a, 512, (hipStream_t)stream);
@@ -774,7 +812,7 @@ extern "C" int pf_conv2d_bwd_data_strided(const void* dY, const void* Wt, void* 
 int pf_igemm_conv1x1(const void* X, const void* W, void* Y, const void* R, float* partial, const void* bn_x,
                      const float* bss, const float* bmi, float b_lo, float b_hi, const float* scale_shift,
                      const uint32_t* slot, float kq, float act_lo, float act_hi, int M, int N, int K, int Ho, int Wo,
-                     int H, int Wd, int stride, hipStream_t st) {
+                     int H, int Wd, int stride, const float* oss, int oact, hipStream_t st) {
   int64_t rows_in = M;
   if (stride > 1) rows_in = (int64_t)(M / (Ho * Wo)) * H * Wd;
   if ((K % 64) || rows_in * K >= ((int64_t)1 << 30) || (int64_t)N * K >= ((int64_t)1 << 30)) return -1;
@@ -794,5 +832,6 @@ int pf_igemm_conv1x1(const void* X, const void* W, void* Y, const void* R, float
   a.w_bytes = (uint32_t)((int64_t)N * K * 2);
   a.w_r0 = 0; a.w_rs = 1; a.w_s0 = 0; a.w_ss = 1; a.w_S = 1; a.w_taps_full = 1;
   a.o_sub = 0; a.o_y = 0; a.o_x = 0; a.o_H = 0; a.o_W = 0;
+  a.oss = oss; a.oact = oact;
   return ig_launch(a, st);
 }

@@ -727,10 +727,18 @@ def _conv1x1_geom(x_shape, stride):
   return n * ho * wo, (ho, wo, h, w, stride), (ho, wo)
 
 
-def _run_conv1x1(x, w2d, lazy, residual, want_stats, stride):
+def _run_conv1x1(x, w2d, lazy, residual, want_stats, stride, out_bn=None):
   N, K = w2d.shape
   M, geom, (ho, wo) = _conv1x1_geom(x.shape, stride)
   y = torch.empty((x.shape[0], N, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+  if out_bn is not None:
+    # the consumer's inference-mode BN + activation in the epilogue (pf_conv1x1_fwd_affine): y IS that layer's output
+    with region('conv1x1_fwd', float((M * K + M * N) * 2)):
+      hip.conv1x1_fwd(x, w2d, y, M, N, K, scale_shift=lazy.scale_shift if lazy is not None else None,
+                      act=lazy.act if lazy is not None else None, geom=geom, out_scale_shift=out_bn._eval_scale_shift(y),
+                      out_act=out_bn.act)
+    y._pf_bn_done = out_bn
+    return y
   partial, G = None, 0
   if want_stats:
     G = hip.conv1x1_stats_groups(M, N, K, prologue=lazy is not None)
@@ -750,7 +758,7 @@ class _FusedConv1x1(torch.autograd.Function):
   """y = conv1x1(Q(x), W) [+ residual], Q = the producer BN's normalise/act/fake-quant (prologue)."""
 
   @staticmethod
-  def forward(ctx, x, w, residual, lazy, want_stats, stride, graph, box, w_var=None, bn_box=None):
+  def forward(ctx, x, w, residual, lazy, want_stats, stride, graph, box, w_var=None):
     w2d = w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], w.shape[1])      # [N][K] (KRSC, R=S=1)
     res = _nhwc(residual) if residual is not None else None
     y = _run_conv1x1(x, w2d, lazy, res, want_stats, stride)
@@ -758,7 +766,6 @@ class _FusedConv1x1(torch.autograd.Function):
     ctx.meta = (lazy, stride, graph, residual is not None, w.shape)
     ctx.w_leaf = w
     ctx.w_var = w_var
-    ctx.bn_box = bn_box                       # x is the materialised output of that BatchNormAct (None: lazy or no BN in front)
     box.append(getattr(y, '_pf_stats', None))
     return y
 
@@ -811,16 +818,8 @@ class _FusedConv1x1(torch.autograd.Function):
               and lazy.n_grad_consumers == 2)
       second = join and lazy.pending is not None
       res = lazy.pending if (second and geom is None) else None
-      bb = ctx.bn_box
-      fuse_box = (FUSE_BN_BWD_STATS and lazy is None and bb is not None and bb.get('n_consumers') == 1 and geom is None
-                  and bb.get('act') in ('Relu', 'Relu6') and bb['x'].shape == x.shape)
-      with region('conv1x1_bwd_data', float((M * K * (2 if (fuse_stats or fuse_box or res is not None) else 1) + M * N) * 2)):
-        if fuse_box:
-          G = hip.conv1x1_stats_groups(M, K, N)
-          partial = torch.empty((G, 2, K), dtype=torch.float32, device=x.device)
-          hip.conv1x1_bwd_data_bnstats(dy, wt, dx, bb['x'], bb['scale_shift'], bb['mean_invstd'], bb['act'], partial, M, N, K)
-          bb['bwd_stats'] = (partial, G, dx.data_ptr())
-        elif fuse_stats:
+      with region('conv1x1_bwd_data', float((M * K * (2 if (fuse_stats or res is not None) else 1) + M * N) * 2)):
+        if fuse_stats:
           G = hip.conv1x1_stats_groups(M, K, N)
           partial = torch.empty((G, 2, K), dtype=torch.float32, device=x.device)
           hip.conv1x1_bwd_data_bnstats(dy, wt, dx, x, lazy.scale_shift, lazy.mean_invstd, lazy.act, partial, M, N, K)
@@ -836,7 +835,7 @@ class _FusedConv1x1(torch.autograd.Function):
           if res is None:
             dx = dx + lazy.pending              # the second one is the strided one: no residual operand under a row map
           lazy.pending = None
-    return dx, dw, (dy if has_res else None), None, None, None, None, None, None, None
+    return dx, dw, (dy if has_res else None), None, None, None, None, None, None
 
 
 # two fused consumers of one activation: join their input gradients inside the second backward-data kernel (0: autograd add)
@@ -852,11 +851,13 @@ OWN_STEM = os.environ.get('PF_OWN_STEM', '1') != '0'         # the 7x7/2 stem on
 OWN_DEPTHWISE = os.environ.get('PF_OWN_DEPTHWISE', '1') != '0'   # depthwise 3x3 on pf_depthwise.hip (0: MIOpen, for A/B runs)
 OWN_CONV_IM2COL = os.environ.get('PF_OWN_CONV_IM2COL', '1') != '0'   # few-channel RxS convolutions as im2col + own 1x1 kernels (0: MIOpen)
 CONVG_BF16_NARROW = os.environ.get('PF_CONVG_BF16_NARROW', '0') != '0'
+# inference-mode BN + activation applied in the epilogue of the producing convolution (teacher / evaluation of unquantised networks)
+FOLD_EVAL_BN = os.environ.get('PF_FOLD_EVAL_BN', '1') != '0'
 OWN_CONV_GENERIC = os.environ.get('PF_OWN_CONV_GENERIC', '1') != '0'   # every other convolution / dense layer on pf_convg.hip (0: MIOpen / rocBLAS)
 DEPTHWISE_ANY_DEVICE = False     # tests: run the depthwise plumbing on CPU tensors (the HIP entry points are emulated there)
 
 
-def _run_conv2d(x, w_krsc, stride, pad, want_stats):
+def _run_conv2d(x, w_krsc, stride, pad, want_stats, out_bn=None):
   """x: logical NCHW / physical NHWC bf16, w_krsc: contiguous [N][R][S][C] bf16."""
   B, C, H, W = x.shape
   N, R, S, _ = w_krsc.shape
@@ -864,6 +865,12 @@ def _run_conv2d(x, w_krsc, stride, pad, want_stats):
   Wo = (W + 2 * pad[1] - S) // stride + 1
   y = torch.empty((B, N, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
   M = B * Ho * Wo
+  if out_bn is not None:                         # the consumer's inference-mode BN + activation in the epilogue (pf_conv2d_fwd_affine)
+    with region('conv2d_fwd', float((B * H * W * C + M * N) * 2)):
+      hip.conv2d_fwd(x, w_krsc, y, B, H, W, C, N, R, S, stride, pad[0], pad[1], Ho, Wo,
+                     out_scale_shift=out_bn._eval_scale_shift(y), out_act=out_bn.act)
+    y._pf_bn_done = out_bn
+    return y
   partial, G = None, 0
   if want_stats:
     G = hip.conv2d_stats_groups(M, N, geom=(B, H, W, C, N, R, S, stride, pad[0], pad[1], Ho, Wo))
@@ -1287,34 +1294,34 @@ class Conv2D:
                  if use_bias else None)
     self.op = graph.add_matmul_op('Conv2D', name + '/Conv2D', self.kernel)
 
-  def __call__(self, x, residual: Optional[torch.Tensor] = None, want_stats: bool = False) -> torch.Tensor:
+  def __call__(self, x, residual: Optional[torch.Tensor] = None, want_stats: bool = False, out_bn=None) -> torch.Tensor:
     """`residual`: tensor added to the output (the block's shortcut); `want_stats`: the consumer is a
-    BatchNormAct -- leave per-channel statistics of the output on the tensor (1x1 fused path only)."""
+    BatchNormAct -- leave per-channel statistics of the output on the tensor (1x1 fused path only); `out_bn`: the ONLY
+    consumer is that BatchNormAct in inference mode (`out_bn.folds_into_producer()`): the MFMA kernels apply it in their
+    epilogue and tag the output, which the layer then passes through; any other route ignores the hint."""
     w = self.kernel.tensor
+    if out_bn is not None and (residual is not None or not out_bn.folds_into_producer()):
+      out_bn = None
     if self.graph.taps is not None:
       return _tapped(self, materialize(x), residual)
     if fused_conv1x1_ok(x, self):
       lazy = x if isinstance(x, LazyAct) else None
-      bn_box = None
       if lazy is not None:
         lazy.n_consumers += 1
       elif getattr(x, '_pf_bn', None) is not None:
-        # a MATERIALISED BN output read by a 1x1 (round 6: bn3 of the deep stages, PF_BN3_MATERIALIZE_MIN_C): a single stride-1
-        # consumer reduces the BN-backward sums in its backward-data epilogue, as the 3x3 convolutions do
-        bn_box = x._pf_bn
-        bn_box['n_consumers'] += 1 if self.stride == 1 else 2
+        x._pf_bn['n_consumers'] += 2             # a materialised BN output read by a 1x1: its BN-backward sums are not fused
       xin = lazy.x if lazy is not None else _nhwc(x)
       if torch.is_grad_enabled() and (xin.requires_grad or w.requires_grad):
         box = []
         if lazy is not None and xin.requires_grad:
           lazy.n_grad_consumers += 1
-        y = _FusedConv1x1.apply(xin, w, residual, lazy, want_stats, self.stride, self.graph, box, self.kernel, bn_box)
+        y = _FusedConv1x1.apply(xin, w, residual, lazy, want_stats, self.stride, self.graph, box, self.kernel)
         if box and box[0] is not None:
           y._pf_stats = box[0]
         return y
       w2d = w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], w.shape[1])
       return _run_conv1x1(xin, w2d, lazy, _nhwc(residual) if residual is not None else None, want_stats,
-                          self.stride)
+                          self.stride, out_bn=out_bn)
     x = materialize(x)
     b = self.bias.tensor.to(x.dtype) if self.bias is not None else None
     pad = 0
@@ -1360,7 +1367,7 @@ class Conv2D:
         if box and box[0] is not None:
           y._pf_stats = box[0]
       else:
-        y = _run_conv2d(xin, w.detach().permute(0, 2, 3, 1), self.stride, sym, want_stats)
+        y = _run_conv2d(xin, w.detach().permute(0, 2, 3, 1), self.stride, sym, want_stats, out_bn=out_bn)
       return y if residual is None else y + residual
     bn_box = getattr(x, '_pf_bn', None)
     if bn_box is not None:
@@ -1590,8 +1597,23 @@ class BatchNormAct:
     self.op = graph.add_activation_op(act, act_name or (name + '/' + act)) if act else None
     self._frozen_ss = None
 
+  def folds_into_producer(self) -> bool:
+    """This layer, in inference mode and without a quantiser (the distillation teacher's forward_eval; evaluation of a
+    full-precision network), can be applied in the epilogue of the convolution that feeds it: y -> act(scale * y + shift) on the
+    stored bf16 value, bit for bit pf_bn_act_quant_apply (PF_FOLD_EVAL_BN=0: off, A/B runs)."""
+    g = self.graph
+    if not FOLD_EVAL_BN or g.taps is not None or not g.fuse_conv1x1:
+      return False
+    if g.training and torch.is_grad_enabled():
+      return False
+    if torch.is_grad_enabled() and not g.frozen:
+      return False                                # inference-mode BN WITH gradients (_BnEvalAct): its input must exist
+    return self.op is None or self.op.bits is None
+
   def __call__(self, x: torch.Tensor) -> torch.Tensor:
     g = self.graph
+    if getattr(x, '_pf_bn_done', None) is self:   # applied in the epilogue of the producing convolution (Conv2D `out_bn`)
+      return x
     bits = self.op.bits if self.op is not None else None
     slot = g.act_slots[self.op.index] if (self.op is not None and bits is not None) else None
     lazy = self.lazy_ok and g.fuse_conv1x1 and fusable_tensor(x)

@@ -50,6 +50,7 @@ SYMBOLS = [
     'pf_convg_fwd', 'pf_convg_bwd_data', 'pf_convg_small_splits', 'pf_convg_wrw_splits', 'pf_convg_wrw', 'pf_conv2d_bwd_data_strided',
     'pf_prox_groups', 'pf_prox_norms', 'pf_prox_apply', 'pf_im2col', 'pf_col2im',
     'pf_conv_stem3_supported', 'pf_conv_stem3_fwd', 'pf_conv_stem3_wrw_slabs', 'pf_conv_stem3_wrw',
+    'pf_conv1x1_fwd_affine', 'pf_conv2d_fwd_affine',
 ]
 
 
@@ -358,10 +359,18 @@ def conv1x1_wrw_splits(M: int, N: int, K: int) -> int:
 
 
 def conv1x1_fwd(X, W, Y, M: int, N: int, K: int, R=None, scale_shift=None, act=None, slot=None, bits: int = 8,
-                partial=None, geom=None, ymap: bool = False) -> None:
-  """geom = (Ho, Wo, H, Wd, stride) for a strided 1x1 convolution, None for stride 1."""
+                partial=None, geom=None, ymap: bool = False, out_scale_shift=None, out_act=None) -> None:
+  """geom = (Ho, Wo, H, Wd, stride) for a strided 1x1 convolution, None for stride 1.  out_scale_shift ([2][N] float32) / out_act:
+  the consumer's inference-mode BN + activation folded into the epilogue (pf_conv1x1_fwd_affine; no residual / statistics / slot)."""
   _dev(X)
   Ho, Wo, H, Wd, stride = geom if geom is not None else (0, 0, 0, 0, 1)
+  if out_scale_shift is not None:
+    if R is not None or partial is not None or slot is not None or ymap:
+      raise ValueError('the folded output pass takes no residual, statistics, quantiser or row map')
+    _check(_lib.pf_conv1x1_fwd_affine(_ptr(X), _ptr(W), _ptr(Y), _ptr(scale_shift), c_int(ACT_CODES[act]), _ptr(out_scale_shift),
+                                      c_int(ACT_CODES[out_act]), c_int(M), c_int(N), c_int(K), c_int(Ho), c_int(Wo), c_int(H),
+                                      c_int(Wd), c_int(stride), _stream()), 'pf_conv1x1_fwd_affine')
+    return
   _check(_lib.pf_conv1x1_fwd(_ptr(X), _ptr(W), _ptr(Y), _ptr(R), _ptr(scale_shift), c_int(ACT_CODES[act]),
                              _ptr(slot), c_int(int(bits)), _ptr(partial), c_int(M), c_int(N), c_int(K), c_int(Ho),
                              c_int(Wo), c_int(H), c_int(Wd), c_int(stride), c_int(1 if ymap else 0), _stream()),
@@ -411,9 +420,18 @@ def conv2d_stats_groups(M: int, N: int, geom=None) -> int:
 
 def conv2d_fwd(X, W, Y, imgs: int, H: int, Wd: int, C: int, N: int, th: int, tw: int, stride: int, pad_h: int,
                pad_w: int, Ho: int, Wo: int, R=None, partial=None, bn_x=None, bn_scale_shift=None,
-               bn_mean_invstd=None, bn_act=None) -> None:
-  """X: NHWC memory [imgs][H][Wd][C] bf16, W: KRSC memory [N][th][tw][C] bf16, Y: [imgs][Ho][Wo][N] bf16."""
+               bn_mean_invstd=None, bn_act=None, out_scale_shift=None, out_act=None) -> None:
+  """X: NHWC memory [imgs][H][Wd][C] bf16, W: KRSC memory [N][th][tw][C] bf16, Y: [imgs][Ho][Wo][N] bf16.
+  out_scale_shift / out_act: the consumer's inference-mode BN + activation folded into the epilogue (pf_conv2d_fwd_affine)."""
   _dev(X)
+  if out_scale_shift is not None:
+    if R is not None or partial is not None or bn_x is not None:
+      raise ValueError('the folded output pass takes no residual or statistics')
+    _check(_lib.pf_conv2d_fwd_affine(_ptr(X), _ptr(W), _ptr(Y), _ptr(zero_page(X.device)), _ptr(out_scale_shift),
+                                     c_int(ACT_CODES[out_act]), c_int(imgs), c_int(H), c_int(Wd), c_int(C), c_int(N), c_int(th),
+                                     c_int(tw), c_int(stride), c_int(pad_h), c_int(pad_w), c_int(Ho), c_int(Wo), _stream()),
+           'pf_conv2d_fwd_affine')
+    return
   _check(_lib.pf_conv2d_fwd(_ptr(X), _ptr(W), _ptr(Y), _ptr(zero_page(X.device)), _ptr(R), _ptr(partial), _ptr(bn_x),
                             _ptr(bn_scale_shift), _ptr(bn_mean_invstd), c_int(ACT_CODES[bn_act]), c_int(imgs), c_int(H),
                             c_int(Wd), c_int(C), c_int(N), c_int(th), c_int(tw), c_int(stride), c_int(pad_h),

@@ -74,12 +74,7 @@ class FlatOptimizer(object):
     """The backward pass of a training step.  Learners call this (not `loss.backward()`) for the backward that is
     followed by compute_gradients() / apply_gradients(): the distributed wrapper overrides it to let the gradient
     exchange start from inside the pass.  Any OTHER backward (layer-wise tuning on rank 0, regression-gradient
-    helpers) stays a plain `loss.backward()` and never touches the process group.
-    `pre_backward` (one-shot, set by step_graph while it records): called right before the pass -- the point at which the recorded
-    step may fork the teacher's branch instead of at its start (PF_TEACHER_FORK=backward, experiment of round 6)."""
-    hook, self.pre_backward = getattr(self, 'pre_backward', None), None
-    if hook is not None:
-      hook()
+    helpers) stays a plain `loss.backward()` and never touches the process group."""
     loss.backward()
 
   def compute_gradients(self) -> None:
@@ -353,9 +348,6 @@ class DistributedFlatOptimizer(object):
 
   def backward(self, loss: torch.Tensor) -> None:
     """loss.backward() with the in-backward bucket launches of the GradReducer enabled for exactly this pass."""
-    hook, self.opt.pre_backward = getattr(self.opt, 'pre_backward', None), None
-    if hook is not None:
-      hook()
     self.reducer.arm()
     try:
       loss.backward()

@@ -401,17 +401,11 @@ class StepGraph(object):
       red.recorder = self.backend                            # the exchange goes out through backend.cut(): between the two graphs
 
     def body(be):
-      def teacher_branch():
-        with be.fork(), profiling.suspended():             # the teacher over `next`: a branch of the graph beside the student's launches
-          nxt[2].copy_(teacher.calc_logits(None, nxt[0]))
       if nxt is not None:
-        # from the START of the step (beside the forward pass; the default, +6 % when it was introduced), or -- PF_TEACHER_FORK=backward,
-        # experiment of round 6 -- from the start of the BACKWARD pass (its HBM-bound first stages beside the matrix-bound last stages
-        # of the student's backward pass): profiles/r06_teacher_share_ab.txt
-        if os.environ.get('PF_TEACHER_FORK', 'start') == 'backward':
-          getattr(opt, 'opt', opt).pre_backward = teacher_branch
-        else:
-          teacher_branch()
+        # the teacher over `next` from the START of the step, beside the forward pass (forked at the start of the BACKWARD pass
+        # instead: -0.5 %, profiles/r06_policy_ab.txt)
+        with be.fork(), profiling.suspended():
+          nxt[2].copy_(teacher.calc_logits(None, nxt[0]))
       lrn._static_batch = cur
       try:
         out = lrn._train_step_eager()

@@ -172,8 +172,10 @@ class FakeHip(object):
     return x.permute(0, 2, 3, 1)[:, ::s, ::s, :][:, :ho, :wo, :].reshape(-1, K).float()
 
   def conv1x1_fwd(self, X, W, Y, M, N, K, R=None, scale_shift=None, act=None, slot=None, bits=8, partial=None,
-                  geom=None, ymap=False):
+                  geom=None, ymap=False, out_scale_shift=None, out_act=None):
     self._n('conv1x1_fwd' if scale_shift is not None else 'conv1x1_plain')
+    if out_scale_shift is not None:
+      self._n('conv_out_affine')
     if ymap:                                   # backward-data of a strided conv: scatter rows
       ho, wo, h, w, s = geom
       out = _rows(X, K).float() @ W.float().t()
@@ -185,6 +187,8 @@ class FakeHip(object):
     y = xr @ W.float().t()
     if R is not None:
       y = y + _rows(R, N).float()
+    if out_scale_shift is not None:              # the consumer's inference-mode BN + activation (pf_conv1x1_fwd_affine)
+      y = self._q_of(y, out_scale_shift, out_act, None, 8, False)
     _rows(Y, N).copy_(y)
     if partial is not None:
       partial[:, 0:2] = 0
@@ -235,7 +239,7 @@ class FakeHip(object):
     return 3
 
   def conv2d_fwd(self, X, W, Y, imgs, H, Wd, C, N, th, tw, stride, pad_h, pad_w, Ho, Wo, R=None, partial=None, bn_x=None,
-                 bn_scale_shift=None, bn_mean_invstd=None, bn_act=None):
+                 bn_scale_shift=None, bn_mean_invstd=None, bn_act=None, out_scale_shift=None, out_act=None):
     """X: logical NCHW over NHWC memory, W: [N][th][tw][C]; same float32 arithmetic as a dense convolution."""
     self._n('conv2d_fwd' if bn_x is None else 'conv2d_bwd_data_bnstats')
     import torch.nn.functional as F
@@ -243,6 +247,9 @@ class FakeHip(object):
     yr = y.permute(0, 2, 3, 1).reshape(-1, N)
     if R is not None:
       yr = yr + _rows(R, N).float()
+    if out_scale_shift is not None:
+      self._n('conv_out_affine')
+      yr = self._q_of(yr, out_scale_shift, out_act, None, 8, False)
     _rows(Y, N).copy_(yr)
     if partial is None:
       return

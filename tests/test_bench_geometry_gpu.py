@@ -296,3 +296,38 @@ def test_stem_and_pool_at_bench_geometry(hip):
                                              [1, 1], False, [0, 0], 1, [False, True, False])[1].permute(0, 2, 3, 1)
   err = float((dw.double() - refw).abs().max() / refw.abs().max())
   assert err <= 1e-4, err
+
+
+@pytest.mark.parametrize('H,K,N', [(56, 256, 64), (56, 64, 64), (56, 256, 128), (28, 512, 128), (14, 1024, 256), (7, 2048, 512)])
+def test_teacher_conv1_with_bn2_in_the_epilogue_at_bench_geometry(hip, H, K, N):
+  """The distillation teacher's conv1 launches (bn1 prologue without a quantiser, bn2 + ReLU folded into the epilogue:
+  pf_conv1x1_fwd_affine) at batch 256 == the plain launch followed by the stand-alone pass, bit for bit."""
+  M = B * H * H
+  g = torch.Generator(device='cuda').manual_seed(H + K + N + 5)
+  X = _rand(g, M, K, scale=2.0)
+  W = _rand(g, N, K, scale=K ** -0.5)
+  ss = torch.stack([torch.rand(K, device='cuda', generator=g) + 0.5, torch.randn(K, device='cuda', generator=g)])
+  oss = torch.stack([torch.rand(N, device='cuda', generator=g) + 0.5, torch.randn(N, device='cuda', generator=g)])
+  Y0 = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+  hip.conv1x1_fwd(X, W, Y0, M, N, K, scale_shift=ss, act='Relu')
+  ref = torch.empty_like(Y0)
+  hip.bn_act_quant_apply(Y0, ref, M, N, oss, 'Relu', None, 8, False)
+  Y1 = torch.full_like(Y0, float('nan'))
+  hip.conv1x1_fwd(X, W, Y1, M, N, K, scale_shift=ss, act='Relu', out_scale_shift=oss, out_act='Relu')
+  assert torch.equal(Y1, ref)
+
+
+@pytest.mark.parametrize('H,C,stride', CONV3X3)
+def test_teacher_conv2_with_bn3_in_the_epilogue_at_bench_geometry(hip, H, C, stride):
+  Ho = (H + 2 - 3) // stride + 1
+  g = torch.Generator(device='cuda').manual_seed(H + C + stride + 7)
+  x = _rand(g, B, H, H, C)
+  w = _rand(g, C, 3, 3, C, scale=(9 * C) ** -0.5)
+  oss = torch.stack([torch.rand(C, device='cuda', generator=g) + 0.5, torch.randn(C, device='cuda', generator=g) * 0.5])
+  y0 = torch.empty(B, Ho, Ho, C, device='cuda', dtype=torch.bfloat16)
+  hip.conv2d_fwd(x, w, y0, B, H, H, C, C, 3, 3, stride, 1, 1, Ho, Ho)
+  ref = torch.empty_like(y0)
+  hip.bn_act_quant_apply(y0, ref, B * Ho * Ho, C, oss, 'Relu', None, 8, False)
+  y1 = torch.full_like(y0, float('nan'))
+  hip.conv2d_fwd(x, w, y1, B, H, H, C, C, 3, 3, stride, 1, 1, Ho, Ho, out_scale_shift=oss, out_act='Relu')
+  assert torch.equal(y1, ref)

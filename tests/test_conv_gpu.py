@@ -420,3 +420,33 @@ def test_prologue_fake_quant_equals_oracle_except_enumerated_ties(hip, M, C, act
   # next to a bf16 boundary is shared by many elements; what is asserted above is that nothing ELSE differs)
   assert d_16.sum() <= near16.sum()
   print('prologue vs oracle: %d grid ties, %d bf16 ties of %d elements' % (int(d_grid.sum()), int(d_16.sum()), diff.size))
+
+
+# M >= 4096 with small K * N: resident-kernel variant; deep K with a prologue: three-stage prologue kernel; K >= 512 without one: plain
+# implicit GEMM; K = 96 / a strided launch: no kernel carries the folded pass -> plain launch + stand-alone pass in place
+@pytest.mark.parametrize('M,N,K,pro,stride', [(20000, 64, 256, True, 1), (9000, 256, 64, True, 1), (5000, 128, 256, False, 1),
+                                              (9000, 256, 1024, True, 1), (4133, 128, 2048, True, 1), (6000, 256, 512, False, 1),
+                                              (3000, 128, 96, True, 1), (4096, 128, 256, True, 2), (70001, 64, 64, True, 1)])
+@pytest.mark.parametrize('out_act', ['Relu', 'Relu6', None])
+def test_conv1x1_fwd_with_the_consumers_inference_bn_in_the_epilogue(hip, M, N, K, pro, stride, out_act):
+  """pf_conv1x1_fwd_affine (round 6): the consumer's inference-mode BN + activation applied in the row pass of the epilogue ==
+  pf_conv1x1_fwd followed by pf_bn_act_quant_apply(quantize = 0) on the stored output, BIT FOR BIT (the pass reads the bf16 value
+  the stand-alone kernel would read)."""
+  g = torch.Generator(device='cuda').manual_seed(M + N + K)
+  if stride == 1:
+    X, geom, Mo = _bf(torch.randn(M, K, device='cuda', generator=g) * 2), None, M
+  else:
+    n, H = 4, 32
+    X = _bf(torch.randn(n, H, H, K, device='cuda', generator=g) * 2)
+    Mo = n * (H // stride) ** 2
+    geom = (H // stride, H // stride, H, H, stride)
+  W = _bf(torch.randn(N, K, device='cuda', generator=g) * (K ** -0.5))
+  ss = torch.stack([torch.rand(K, device='cuda', generator=g) + 0.5, torch.randn(K, device='cuda', generator=g)]) if pro else None
+  oss = torch.stack([torch.rand(N, device='cuda', generator=g) + 0.5, torch.randn(N, device='cuda', generator=g)])
+  Y0 = torch.empty(Mo, N, device='cuda', dtype=torch.bfloat16)
+  hip.conv1x1_fwd(X, W, Y0, Mo, N, K, scale_shift=ss, act='Relu' if pro else None, geom=geom)
+  ref = torch.empty_like(Y0)
+  hip.bn_act_quant_apply(Y0, ref, Mo, N, oss, out_act, None, 8, False)
+  Y1 = torch.full_like(Y0, float('nan'))
+  hip.conv1x1_fwd(X, W, Y1, Mo, N, K, scale_shift=ss, act='Relu' if pro else None, geom=geom, out_scale_shift=oss, out_act=out_act)
+  assert torch.equal(Y1, ref), 'folded pass differs in %d elements' % int((Y1 != ref).sum())

@@ -291,3 +291,30 @@ def test_conv_stem3_wrw_matches_autograd(hip, imgs, H, Wd, N, dw_dtype):
   scale = float(ref.abs().max())
   torch.testing.assert_close(outs[0], ref, rtol=2e-2 if dw_dtype == torch.bfloat16 else 2e-3, atol=(8e-3 if dw_dtype == torch.bfloat16 else 2e-3) * scale)
   assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('tile', ['', '256x128'])
+@pytest.mark.parametrize('imgs,H,C,N,stride', [(24, 28, 128, 128, 1), (16, 56, 64, 64, 1), (12, 28, 128, 128, 2), (37, 7, 512, 512, 1),
+                                               (5, 9, 64, 72, 1)])
+def test_conv2d_fwd_with_the_consumers_inference_bn_in_the_epilogue(hip, monkeypatch, tile, imgs, H, C, N, stride):
+  """pf_conv2d_fwd_affine == pf_conv2d_fwd followed by pf_bn_act_quant_apply(quantize = 0), bit for bit; a tile override has no
+  instantiation with the folded pass: plain launch + stand-alone pass in place."""
+  if tile:
+    monkeypatch.setenv('PF_IGEMM_TILE', tile)
+  else:
+    monkeypatch.delenv('PF_IGEMM_TILE', raising=False)
+  hip.tuning_reload()
+  try:
+    g = torch.Generator(device='cuda').manual_seed(H + C + N)
+    x = _bf(torch.randn(imgs, H, H, C, device='cuda', generator=g))
+    w = _bf(torch.randn(N, 3, 3, C, device='cuda', generator=g) * 0.05)
+    oss = torch.stack([torch.rand(N, device='cuda', generator=g) + 0.5, torch.randn(N, device='cuda', generator=g) * 0.5])
+    y0 = _run(hip, x, w, stride, (1, 1))
+    M = y0.numel() // N
+    ref = torch.empty_like(y0)
+    hip.bn_act_quant_apply(y0, ref, M, N, oss, 'Relu', None, 8, False)
+    y1 = _run(hip, x, w, stride, (1, 1), out_scale_shift=oss, out_act='Relu')
+    assert torch.equal(y1, ref), 'folded pass differs in %d elements' % int((y1 != ref).sum())
+  finally:
+    monkeypatch.delenv('PF_IGEMM_TILE', raising=False)
+    hip.tuning_reload()
