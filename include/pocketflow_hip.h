@@ -382,6 +382,14 @@ int pf_image_resize_bilinear(const void* src, const PfImageDesc* desc, void* out
  * scattering its rows to the class's input pixels.  bf16; N % 64 == 0, C % 8 == 0, H % stride == W % stride == 0, R, S >= stride. */
 int pf_conv2d_bwd_data_strided(const void* dY, const void* Wt, void* dX, const void* zero, int imgs, int H, int Wd, int C, int N,
                                int R, int S, int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream);
+/* ... with the BN-backward sums {sum dy, sum dy * xhat} of the BN whose OUTPUT the convolution read (its input bn_x has dX's shape) in
+ * the epilogues, as pf_conv1x1_bwd_data_bnstats: partial [G][2][C], G = pf_conv2d_bwd_data_strided_stats_groups(imgs, H, Wd, C, stride)
+ * (one slice of workgroup rows per parity class); replaces a pf_bn_bwd_stats pass over dX and bn_x. */
+int pf_conv2d_bwd_data_strided_stats_groups(int imgs, int H, int Wd, int C, int stride);
+int pf_conv2d_bwd_data_strided_bnstats(const void* dY, const void* Wt, void* dX, const void* zero, const void* bn_x,
+                                       const float* bn_scale_shift, const float* bn_mean_invstd, int bn_act, float* partial,
+                                       int imgs, int H, int Wd, int C, int N, int R, int S, int stride, int pad_h, int pad_w,
+                                       int Ho, int Wo, void* stream);
 
 /* ---- K12, general form: convolutions of any shape and stride, the dense layer; float32 or bf16 storage, float32 accumulation --
  * replaces tf.nn.conv2d / tf.layers.conv2d / slim.conv2d, their Conv2DBackpropInput / Conv2DBackpropFilter and tf.layers.dense for

@@ -478,7 +478,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
       for (int p = 0; p < PG; ++p) {
         const int m = m0 + wrw + (p0 + p) * RPP, n = n0 + wvec * 8;
         rres[p] = make_uint4(0, 0, 0, 0);
-        if (m < a.M && n < a.N) rres[p] = *reinterpret_cast<const uint4*>(side + (int64_t)m * a.N + n);
+        if (m < a.M && n < a.N) {
+          int64_t srow = m;
+          if constexpr (SUB) {                                              // the BN's input is indexed like the OUTPUT: scattered rows
+            const int oimg = m / hw_o, orem = m - oimg * hw_o;
+            const int oi = orem / a.Wo, oj = orem - oi * a.Wo;
+            srow = ((int64_t)oimg * a.o_H + oi * a.o_sub + a.o_y) * a.o_W + oj * a.o_sub + a.o_x;
+          }
+          rres[p] = *reinterpret_cast<const uint4*>(side + srow * a.N + n);
+        }
       }
     };
     constexpr bool etid = true;                                             // every thread takes part in the row passes
@@ -769,8 +777,22 @@ extern "C" int pf_conv2d_fwd_affine(const void* X, const void* W, void* Y, const
 // Wt[c][R-1-r][S-1-s][n] (VarStore.transposed) -- walked in place (IgArgs.w_*), its rows scattered to the class's pixels
 // (IgArgs.o_*).  st*st launches, exactly the flops of the convolution, no zero-filled intermediate, no atomics.
 // dY [imgs][Ho][Wo][N], Wt [C][R][S][N], dX [imgs][H][W][C]; H % st == 0 and W % st == 0, N % 64 == 0, C % 8 == 0, R, S >= st.
-extern "C" int pf_conv2d_bwd_data_strided(const void* dY, const void* Wt, void* dX, const void* zero, int imgs, int H, int Wd,
-                                          int C, int N, int R, int S, int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream) {
+static int strided_class_groups(int imgs, int H, int Wd, int C, int stride) {
+  const int bn = (C % 128 == 0) ? 128 : 64;
+  int G;
+  ig_grid(512, (imgs * (H / stride) * (Wd / stride) + 127) / 128, (C + bn - 1) / bn, &G);
+  return G;
+}
+
+// rows of the [G][2][C] array pf_conv2d_bwd_data_strided_bnstats writes: stride * stride classes x the workgroup rows of one class
+extern "C" int pf_conv2d_bwd_data_strided_stats_groups(int imgs, int H, int Wd, int C, int stride) {
+  if (imgs <= 0 || H <= 0 || Wd <= 0 || C <= 0 || stride < 2 || (H % stride) || (Wd % stride)) return 0;
+  return stride * stride * strided_class_groups(imgs, H, Wd, C, stride);
+}
+
+static int strided_launch(const void* dY, const void* Wt, void* dX, const void* zero, int imgs, int H, int Wd, int C, int N, int R,
+                          int S, int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream, float* partial, const void* bn_x,
+                          const float* bss, const float* bmi, int bn_act) {
   if (imgs <= 0 || H <= 0 || Wd <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || N <= 0 || (N % 64) || (C % 8) || stride < 2 || R < stride ||
       S < stride || (H % stride) || (Wd % stride) || pad_h < 0 || pad_w < 0 || R * S > 32)
     return (int)hipErrorInvalidValue;
@@ -786,6 +808,12 @@ extern "C" int pf_conv2d_bwd_data_strided(const void* dY, const void* Wt, void* 
       IgArgs a;
       a.X = (const bf16_t*)dY; a.W = (const bf16_t*)Wt; a.Y = (bf16_t*)dX; a.zero = (const bf16_t*)zero;
       a.R = nullptr; a.partial = nullptr; a.bx = nullptr; a.bss = nullptr; a.bmi = nullptr; a.b_lo = -INFINITY; a.b_hi = INFINITY;
+      if (bn_x != nullptr) {                                     // the BN-backward sums of the BN whose input has dX's shape: one
+        a.partial = partial + (int64_t)(ay * stride + ax) * strided_class_groups(imgs, H, Wd, C, stride) * 2 * C;   // slice per class
+        a.bx = (const bf16_t*)bn_x; a.bss = bss; a.bmi = bmi;
+        a.b_lo = (bn_act == PF_ACT_NONE) ? -INFINITY : 0.0f;
+        a.b_hi = (bn_act == PF_ACT_RELU6) ? 6.0f : INFINITY;
+      }
       a.ss = nullptr; a.slot = nullptr; a.kq = 255.f; a.act_lo = -INFINITY; a.act_hi = INFINITY;
       a.M = imgs * Hc * Wc; a.N = C; a.C = N; a.th = th; a.tw = tw;
       // the launch's "input image" is dY, its "output grid" the class's pixels; tap u reads dY row i + dmin + u = i*1 + u - pad'
@@ -798,12 +826,36 @@ extern "C" int pf_conv2d_bwd_data_strided(const void* dY, const void* Wt, void* 
       a.w_S = S; a.w_taps_full = R * S;
       a.o_sub = stride; a.o_y = ay; a.o_x = ax; a.o_H = H; a.o_W = Wd; a.oss = nullptr; a.oact = PF_ACT_NONE;
       // (the two plain tile configurations the dispatcher picks for these shapes, with the sub-grid walk compiled in)
-      const int rc = (C % 128 == 0) ? ig_launch_t<128, 128, 2, 2, 2, IG_PLAIN, true>(a, 512, (hipStream_t)stream)
-                                    : ig_launch_t<128, 64, 2, 2, 2, IG_PLAIN, true>(a, 512, (hipStream_t)stream);
+      int rc;
+      if (bn_x != nullptr)
+        rc = (C % 128 == 0) ? ig_launch_t<128, 128, 2, 2, 2, IG_BWD, true>(a, 512, (hipStream_t)stream)
+                            : ig_launch_t<128, 64, 2, 2, 2, IG_BWD, true>(a, 512, (hipStream_t)stream);
+      else
+        rc = (C % 128 == 0) ? ig_launch_t<128, 128, 2, 2, 2, IG_PLAIN, true>(a, 512, (hipStream_t)stream)
+                            : ig_launch_t<128, 64, 2, 2, 2, IG_PLAIN, true>(a, 512, (hipStream_t)stream);
       if (rc != 0) return rc;
     }
   }
   return 0;
+}
+
+extern "C" int pf_conv2d_bwd_data_strided(const void* dY, const void* Wt, void* dX, const void* zero, int imgs, int H, int Wd,
+                                          int C, int N, int R, int S, int stride, int pad_h, int pad_w, int Ho, int Wo, void* stream) {
+  return strided_launch(dY, Wt, dX, zero, imgs, H, Wd, C, N, R, S, stride, pad_h, pad_w, Ho, Wo, stream, nullptr, nullptr, nullptr,
+                        nullptr, PF_ACT_NONE);
+}
+
+// ... with the BN-backward sums {sum dy, sum dy * xhat} of the BN that produced the convolution's input in the epilogues (round 6;
+// bn2 in front of the strided 3x3 of a stage's first block): partial [G][2][C], G = pf_conv2d_bwd_data_strided_stats_groups(...),
+// bn_x [imgs][H][Wd][C] the BN's input, as pf_conv1x1_bwd_data_bnstats.
+extern "C" int pf_conv2d_bwd_data_strided_bnstats(const void* dY, const void* Wt, void* dX, const void* zero, const void* bn_x,
+                                                  const float* bn_scale_shift, const float* bn_mean_invstd, int bn_act,
+                                                  float* partial, int imgs, int H, int Wd, int C, int N, int R, int S, int stride,
+                                                  int pad_h, int pad_w, int Ho, int Wo, void* stream) {
+  if (bn_x == nullptr || partial == nullptr || bn_scale_shift == nullptr || bn_mean_invstd == nullptr || !pf_aligned16(bn_x))
+    return (int)hipErrorInvalidValue;
+  return strided_launch(dY, Wt, dX, zero, imgs, H, Wd, C, N, R, S, stride, pad_h, pad_w, Ho, Wo, stream, partial, bn_x,
+                        bn_scale_shift, bn_mean_invstd, bn_act);
 }
 
 // 1x1 convolutions through the same kernel (called by pf_conv.hip for the shapes it routes here): plain, backward-data with

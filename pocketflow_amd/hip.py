@@ -50,7 +50,8 @@ SYMBOLS = [
     'pf_convg_fwd', 'pf_convg_bwd_data', 'pf_convg_small_splits', 'pf_convg_wrw_splits', 'pf_convg_wrw', 'pf_conv2d_bwd_data_strided',
     'pf_prox_groups', 'pf_prox_norms', 'pf_prox_apply', 'pf_im2col', 'pf_col2im',
     'pf_conv_stem3_supported', 'pf_conv_stem3_fwd', 'pf_conv_stem3_wrw_slabs', 'pf_conv_stem3_wrw',
-    'pf_conv1x1_fwd_affine', 'pf_conv2d_fwd_affine',
+    'pf_conv1x1_fwd_affine', 'pf_conv2d_fwd_affine', 'pf_conv2d_bwd_data_strided_stats_groups',
+    'pf_conv2d_bwd_data_strided_bnstats',
 ]
 
 
@@ -487,13 +488,26 @@ def depthwise_wrw(dY, X, dW, slabs, B: int, H: int, Wd: int, C: int, k: int, str
                                c_int(Wo), _stream()), 'pf_depthwise_wrw')
 
 
+def conv2d_bwd_data_strided_stats_groups(B: int, H: int, Wd: int, C: int, stride: int) -> int:
+  return int(_lib.pf_conv2d_bwd_data_strided_stats_groups(c_int(B), c_int(H), c_int(Wd), c_int(C), c_int(stride)))
+
+
 def conv2d_bwd_data_strided(dY, Wt, dX, B: int, H: int, Wd: int, C: int, N: int, R: int, S: int, stride: int, pad_h: int,
-                            pad_w: int, Ho: int, Wo: int) -> None:
+                            pad_w: int, Ho: int, Wo: int, partial=None, bn_x=None, bn_scale_shift=None, bn_mean_invstd=None,
+                            bn_act=None) -> None:
   """dX[B][H][Wd][C] of a strided convolution from dY[B][Ho][Wo][N] and the flipped / transposed kernel Wt[C][R][S][N] (bf16):
-  stride * stride launches of the implicit-GEMM kernel, one per output-parity class (pf_igemm.hip)."""
+  stride * stride launches of the implicit-GEMM kernel, one per output-parity class (pf_igemm.hip).  bn_x ...: the BN-backward
+  sums of the BN in front of the convolution in the epilogues (partial [conv2d_bwd_data_strided_stats_groups(...)][2][C])."""
   _dev(dY)
   if dY.dtype != torch.bfloat16 or Wt.dtype != torch.bfloat16 or dX.dtype != torch.bfloat16:
     raise TypeError('conv2d_bwd_data_strided: bf16 tensors')
+  if bn_x is not None:
+    _check(_lib.pf_conv2d_bwd_data_strided_bnstats(_ptr(dY), _ptr(Wt), _ptr(dX), _ptr(zero_page(dY.device)), _ptr(bn_x),
+                                                   _ptr(bn_scale_shift), _ptr(bn_mean_invstd), c_int(ACT_CODES[bn_act]),
+                                                   _ptr(partial), c_int(B), c_int(H), c_int(Wd), c_int(C), c_int(N), c_int(R),
+                                                   c_int(S), c_int(stride), c_int(pad_h), c_int(pad_w), c_int(Ho), c_int(Wo),
+                                                   _stream()), 'pf_conv2d_bwd_data_strided_bnstats')
+    return
   _check(_lib.pf_conv2d_bwd_data_strided(_ptr(dY), _ptr(Wt), _ptr(dX), _ptr(zero_page(dY.device)), c_int(B), c_int(H), c_int(Wd),
                                          c_int(C), c_int(N), c_int(R), c_int(S), c_int(stride), c_int(pad_h), c_int(pad_w), c_int(Ho),
                                          c_int(Wo), _stream()), 'pf_conv2d_bwd_data_strided')

@@ -254,6 +254,23 @@ def test_conv3x3_at_bench_geometry(hip, H, C, stride):
     hip.conv2d_bwd_data_strided(dy, wb, dx, B, H, H, C, N, 3, 3, stride, 1, 1, Ho, Ho)
     assert torch.isfinite(dx.float()).all()
     _close(dx, _bf(refd), 'conv3x3 strided bwd-data')
+    # the step's form: bn2's backward sums in the class launches' epilogues
+    Mi = B * H * H
+    bnx = _rand(g, Mi, C)
+    ss = torch.stack([torch.rand(C, device='cuda', generator=g) + 0.5, torch.randn(C, device='cuda', generator=g) * 0.3])
+    mi = torch.stack([torch.randn(C, device='cuda', generator=g) * 0.1, torch.rand(C, device='cuda', generator=g) + 0.5])
+    Gd = hip.conv2d_bwd_data_strided_stats_groups(B, H, H, C, stride)
+    pd = torch.full((Gd, 2, C), float('nan'), device='cuda')
+    dx2 = torch.full_like(dx, float('nan'))
+    hip.conv2d_bwd_data_strided(dy, wb, dx2, B, H, H, C, N, 3, 3, stride, 1, 1, Ho, Ho, partial=pd, bn_x=bnx, bn_scale_shift=ss,
+                                bn_mean_invstd=mi, bn_act='Relu')
+    assert torch.equal(dx2, dx) and not torch.isnan(pd).any()
+    dgamma, dbeta = _bn_sums(hip, dx.reshape(Mi, C), bnx, Mi, C, ss, mi)
+    dg2, db2 = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+    hip.bn_bwd_finalize(pd, Gd, C, dg2, db2)
+    torch.testing.assert_close(db2, dbeta, rtol=2e-4, atol=1e-4 * float(dbeta.abs().max()) + 1e-3)
+    torch.testing.assert_close(dg2, dgamma, rtol=2e-4, atol=1e-4 * float(dgamma.abs().max()) + 1e-3)
+    del dx2
   del refd, dx
   # backward-filter (float32 gradient buffer), against float64
   S = hip.conv2d_wrw_splits(M, N, C, 9)

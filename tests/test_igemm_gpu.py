@@ -230,6 +230,28 @@ def test_conv2d_backward_data_of_strided_convolutions_by_parity_classes(hip, img
   dx2 = torch.empty_like(dx)
   hip.conv2d_bwd_data_strided(dy, wb, dx2, imgs, H, Wd, C, N, k, k, stride, pad, pad, Ho, Wo)
   assert torch.equal(dx, dx2)
+  # ... with the BN-backward sums of the BN in front of the convolution in the class launches' epilogues (round 6): the same dX
+  # bits, the sums against pf_bn_bwd_stats over the stored dX
+  M = imgs * H * Wd
+  bnx = _bf(torch.randn(M, C, device='cuda', generator=g))
+  ss = torch.stack([torch.rand(C, device='cuda', generator=g) + 0.5, torch.randn(C, device='cuda', generator=g) * 0.3])
+  mi = torch.stack([torch.randn(C, device='cuda', generator=g) * 0.1, torch.rand(C, device='cuda', generator=g) + 0.5])
+  G = hip.conv2d_bwd_data_strided_stats_groups(imgs, H, Wd, C, stride)
+  assert G > 0 and G % (stride * stride) == 0
+  partial = torch.full((G, 2, C), float('nan'), device='cuda')
+  dx3 = torch.full_like(dx, float('nan'))
+  hip.conv2d_bwd_data_strided(dy, wb, dx3, imgs, H, Wd, C, N, k, k, stride, pad, pad, Ho, Wo, partial=partial, bn_x=bnx,
+                              bn_scale_shift=ss, bn_mean_invstd=mi, bn_act='Relu')
+  assert torch.equal(dx3, dx) and not torch.isnan(partial).any()
+  nblk = 16
+  ref_partial = torch.empty(nblk * 2 * C, device='cuda')
+  hip.bn_bwd_stats(dx.reshape(M, C), bnx, M, C, ss, mi, 'Relu', ref_partial, nblk)
+  dgamma, dbeta = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+  hip.bn_bwd_finalize(ref_partial, nblk, C, dgamma, dbeta)
+  dg2, db2 = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+  hip.bn_bwd_finalize(partial, G, C, dg2, db2)
+  torch.testing.assert_close(db2, dbeta, rtol=1e-4, atol=1e-3)
+  torch.testing.assert_close(dg2, dgamma, rtol=1e-4, atol=1e-3)
 
 # ---- the MobileNet stem (pf_stem3.hip) --------------------------------------------------------------------------------
 def _same(size, k=3, stride=2):
