@@ -323,9 +323,6 @@ def main():
       os.makedirs(tmp, exist_ok=True)
     dist.barrier()
   torch.backends.cudnn.benchmark = os.environ.get('PF_CUDNN_BENCHMARK', '1') != '0'
-  if os.environ.get('PF_MAIN_STREAM_PRIORITY') == 'high':        # experiment (round 6): the student's stream above the teacher's side stream
-    torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
-    sys.stderr.write('bench.py: main stream priority %r of range %r\n' % (torch.cuda.current_stream().priority, torch.cuda.Stream.priority_range()))
 
   def barrier():
     if world > 1:

@@ -38,6 +38,7 @@ struct PfTuning {
   int pool3s2;                    // PF_POOL3S2            1 (default) | 0
   int wrw_tr, wrw2, wrw2_target;  // PF_WRW_TR 0, PF_WRW2 1, PF_WRW2_TARGET 0 (= per-shape default)
   int splitk;                     // PF_IGEMM_SPLITK       1 (default) | 0
+  int conv3x3_c64;                // PF_CONV3X3_C64        1 (default) | 0: the window-staged kernel for 3x3, 64 -> 64 channels, 56 x 56 (pf_conv3x3_c64.hip)
 };
 const PfTuning& pf_tuning();
 

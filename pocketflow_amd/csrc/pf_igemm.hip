@@ -678,8 +678,15 @@ static int ig_launch_t(IgArgs& a, int slots, hipStream_t st) {
   return 0;
 }
 
+// pf_conv3x3_c64.hip: the window-staged kernel for 3x3 / stride 1, 64 -> 64 channels on 56 x 56 maps
+bool pf_conv3x3_c64_geom(int H, int Wd, int C, int N, int th, int tw, int stride, int pad_h, int pad_w, int Ho, int Wo);
+bool pf_conv3x3_c64_takes(const IgArgs& a);
+int pf_conv3x3_c64_stats_groups(int M);
+int pf_conv3x3_c64_launch(const IgArgs& a, hipStream_t st);
+
 static int ig_launch(IgArgs& a, hipStream_t st) {
   const bool bwd = a.bx != nullptr, pro = a.ss != nullptr;
+  if (pf_conv3x3_c64_takes(a)) return pf_conv3x3_c64_launch(a, st);
   const IgCfg c = ig_pick(a.M, a.N, pro);
   if (a.oss != nullptr) {
     // output affine: the dispatcher's default tiles carry it; any other selection (tile override, two-stage prologue kernel) runs
@@ -714,7 +721,8 @@ static int ig_launch(IgArgs& a, hipStream_t st) {
 // rows of the [G][.][N] statistics array pf_conv2d_fwd writes for THIS convolution (depends on the kernel it is dispatched to)
 extern "C" int pf_conv2d_stats_groups_geom(int imgs, int H, int Wd, int C, int N, int th, int tw, int stride, int pad_h,
                                            int pad_w, int Ho, int Wo) {
-  (void)H; (void)Wd; (void)stride; (void)pad_h; (void)pad_w;
+  if (pf_conv3x3_c64_geom(H, Wd, C, N, th, tw, stride, pad_h, pad_w, Ho, Wo) && (imgs * Ho * Wo) % (Ho * Wo) == 0)
+    return pf_conv3x3_c64_stats_groups(imgs * Ho * Wo);
   return pf_igemm_stats_groups_geom(imgs * Ho * Wo, N, 0, th * tw, C);
 }
 

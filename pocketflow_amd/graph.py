@@ -963,8 +963,8 @@ class _Conv2dIgemm(torch.autograd.Function):
         else:
           wb = w.detach().permute(0, 2, 3, 1).flip(1, 2).permute(3, 1, 2, 0).contiguous()
         dx = torch.empty_like(x)
-        fuse = (FUSE_BN_BWD_STATS and os.environ.get('PF_FUSE_BN_BWD_STATS_STRIDED', '1') != '0' and bn_box is not None
-                and bn_box.get('n_consumers') == 1 and bn_box.get('act') in ('Relu', 'Relu6') and bn_box['x'].shape == x.shape)
+        fuse = (FUSE_BN_BWD_STATS and bn_box is not None and bn_box.get('n_consumers') == 1
+                and bn_box.get('act') in ('Relu', 'Relu6') and bn_box['x'].shape == x.shape)
         with region('conv2d_bwd_data', float((dy.numel() + x.numel() * (2 if fuse else 1)) * 2)):
           if fuse:                                 # bn2 in front of a stage's strided 3x3: its backward sums from the class launches (round 6)
             G = hip.conv2d_bwd_data_strided_stats_groups(B, H, W, C, stride)

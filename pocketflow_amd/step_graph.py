@@ -65,15 +65,13 @@ class CudaBackend(object):
     self.graphs = [self.graph]              # the step in replay order: graphs[0], actions[0], graphs[1], ...
     self.actions = []
     self.side = torch.cuda.Stream(device=device)
-    # experiment (round 6): the student's branch captured on a HIGH-priority stream, the teacher's on a normal one
-    self.cap_stream = torch.cuda.Stream(device=device, priority=-1) if os.environ.get('PF_MAIN_STREAM_PRIORITY') == 'high' else None
     self._joined = True
     self.capturing = False
 
   def capture(self, body):
     torch.cuda.synchronize(self.device)
     if not self.segmented:
-      with torch.cuda.graph(self.graph, stream=self.cap_stream):
+      with torch.cuda.graph(self.graph):
         out = body(self)
     else:
       out = self._capture_segments(body)

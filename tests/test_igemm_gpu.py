@@ -340,3 +340,70 @@ def test_conv2d_fwd_with_the_consumers_inference_bn_in_the_epilogue(hip, monkeyp
   finally:
     monkeypatch.delenv('PF_IGEMM_TILE', raising=False)
     hip.tuning_reload()
+
+
+# ---- the window-staged kernel for 3x3 / stride 1, 64 -> 64 channels on 56 x 56 maps (pf_conv3x3_c64.hip) ---------------------------
+def _h3_switch(hip, monkeypatch, on):
+  monkeypatch.setenv('PF_CONV3X3_C64', '1' if on else '0')
+  hip.tuning_reload()
+
+
+@pytest.mark.parametrize('imgs', [1, 2, 19, 40])
+def test_conv3x3_c64_window_kernel_equals_the_per_tap_kernel(hip, monkeypatch, imgs):
+  """Stage-1 conv2 of ResNet-50 on its own kernel: two image rows per tile, the input window staged once for the nine taps, the kernel
+  slice in registers.  Same k order and accumulation chain as the per-tap implicit GEMM -> the SAME BITS, for: one image (top and
+  bottom padding rows in every other tile), more tiles than persistent workgroups (imgs >= 19), plain / residual + statistics /
+  backward-data with BN-backward sums / output affine; against float32 torch too; a second launch into poisoned buffers."""
+  H, C = 56, 64
+  g = torch.Generator(device='cuda').manual_seed(imgs)
+  x = _bf(torch.randn(imgs, H, H, C, device='cuda', generator=g))
+  w = _bf(torch.randn(C, 3, 3, C, device='cuda', generator=g) * 0.05)        # asymmetric: a transposed window / tap order would show
+  M = imgs * H * H
+  r = _bf(torch.randn(M, C, device='cuda', generator=g))
+  bnx = _bf(torch.randn(M, C, device='cuda', generator=g))
+  ss = torch.stack([torch.rand(C, device='cuda', generator=g) + 0.5, torch.randn(C, device='cuda', generator=g) * 0.3])
+  mi = torch.stack([torch.randn(C, device='cuda', generator=g) * 0.1, torch.rand(C, device='cuda', generator=g) + 0.5])
+  geom = (imgs, H, H, C, C, 3, 3, 1, 1, 1, H, H)
+  out = {}
+  try:
+    for on in (False, True):
+      _h3_switch(hip, monkeypatch, on)
+      G = hip.conv2d_stats_groups(M, C, geom=geom)
+      for rep in range(2 if on else 1):
+        y_plain = _run(hip, x, w, 1, (1, 1))
+        p = torch.full((G, 4, C), float('nan'), device='cuda')
+        y_res = _run(hip, x, w, 1, (1, 1), R=r, partial=p)
+        pb = torch.full((G, 2, C), float('nan'), device='cuda')
+        y_bwd = _run(hip, x, w, 1, (1, 1), partial=pb, bn_x=bnx, bn_scale_shift=ss, bn_mean_invstd=mi, bn_act='Relu')
+        y_aff = _run(hip, x, w, 1, (1, 1), out_scale_shift=ss, out_act='Relu')
+        cur = (y_plain, y_res, p, y_bwd, pb, y_aff, G)
+        if on and rep == 1:
+          assert all(torch.equal(a, b) for a, b in zip(cur[:6], out[True][:6])), 'two launches of the window kernel differ'
+        out[on] = cur
+  finally:
+    monkeypatch.delenv('PF_CONV3X3_C64', raising=False)
+    hip.tuning_reload()
+  a, b = out[False], out[True]
+  assert b[6] == min(imgs * 28, 512) and not torch.isnan(b[2]).any() and not torch.isnan(b[4]).any()
+  for i, what in ((0, 'plain'), (1, 'residual'), (3, 'backward-data'), (5, 'output affine')):
+    assert torch.equal(a[i], b[i]), '%s: window kernel and per-tap kernel differ in %d elements' % (what, int((a[i] != b[i]).sum()))
+  _close(b[0], _bf(_ref(x, w, 1, (1, 1))), 'window kernel vs torch')
+  # statistics: different partial groupings of the same stored values
+  yf = b[1].float().reshape(M, C)
+  torch.testing.assert_close(b[2][:, 0].sum(0), yf.sum(0), rtol=1e-4, atol=2e-2)
+  torch.testing.assert_close(b[2][:, 1].sum(0), (yf * yf).sum(0), rtol=1e-4, atol=2e-2)
+  assert torch.equal(b[2][:, 2].min(0).values, yf.min(0).values) and torch.equal(b[2][:, 3].max(0).values, yf.max(0).values)
+  torch.testing.assert_close(b[4][:, 0].sum(0), a[4][:, 0].sum(0), rtol=1e-4, atol=1e-3)
+  torch.testing.assert_close(b[4][:, 1].sum(0), a[4][:, 1].sum(0), rtol=1e-4, atol=1e-3)
+
+
+def test_conv3x3_c64_window_kernel_one_hot_probes(hip):
+  """Every (tap, channel) weight meets exactly its input element, at the image corners too (padding rows / columns are zeros)."""
+  H, C = 56, 64
+  g = torch.Generator(device='cuda').manual_seed(5)
+  w = _bf(torch.randn(C, 3, 3, C, device='cuda', generator=g))
+  for (hh, ww, cc) in ((0, 0, 3), (55, 55, 60), (0, 55, 17), (27, 1, 33), (28, 54, 0), (1, 0, 63)):
+    x = torch.zeros(2, H, H, C, device='cuda', dtype=torch.bfloat16)
+    x[1, hh, ww, cc] = 1.0
+    y = _run(hip, x, w, 1, (1, 1))
+    assert torch.equal(y, _bf(_ref(x, w, 1, (1, 1)))), (hh, ww, cc)
