@@ -214,15 +214,24 @@ __global__ __launch_bounds__(H3_THREADS, 2) void k_conv3x3_c64(const IgArgs a) {
         uint4 c = lds_read_b128(lds_addr(Cs + rl * H3_CS_LD + wvec * 8));
         const int n = wvec * 8;
         if (BWD) {
+          // this thread's 8 channels of scale | shift | mean | invstd: eight 16-byte LDS reads per row (element by element they were 32
+          // reads per row; held in registers across the tile they do not fit beside the kernel slice)
+          float bpr[32];
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            const float4 v0 = *reinterpret_cast<const float4*>(bpl + qq * H3_C + n), v1 = *reinterpret_cast<const float4*>(bpl + qq * H3_C + n + 4);
+            bpr[qq * 8 + 0] = v0.x; bpr[qq * 8 + 1] = v0.y; bpr[qq * 8 + 2] = v0.z; bpr[qq * 8 + 3] = v0.w;
+            bpr[qq * 8 + 4] = v1.x; bpr[qq * 8 + 5] = v1.y; bpr[qq * 8 + 6] = v1.z; bpr[qq * 8 + 7] = v1.w;
+          }
           float f[8], xv[8];
           unpack8(c, f);
           unpack8(rres[p], xv);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const float u = fmaf(bpl[n + j], xv[j], bpl[H3_C + n + j]);
+            const float u = fmaf(bpr[j], xv[j], bpr[8 + j]);
             const float dy = (u > a.b_lo && u < a.b_hi) ? f[j] : 0.f;
             st_s[j] += dy;
-            st_q[j] = fmaf(dy, (xv[j] - bpl[2 * H3_C + n + j]) * bpl[3 * H3_C + n + j], st_q[j]);
+            st_q[j] = fmaf(dy, (xv[j] - bpr[16 + j]) * bpr[24 + j], st_q[j]);
           }
         } else if constexpr (STATS) {
           float f[8];
