@@ -15,7 +15,7 @@ case " ${PF_EXTRA_FLAGS:-} " in *_ABLATE*|*_TIMING*) echo "build.sh: refusing ${
 if [ ! -f .build_flags ] || [ "$(cat .build_flags)" != "$FLAGS" ]; then rm -f ./*.o; printf '%s' "$FLAGS" > .build_flags; fi
 OBJS=()
 PIDS=()
-for f in pf_api pf_quant pf_normalize pf_sparse pf_optim pf_loss pf_bn pf_conv pf_conv_stream pf_igemm pf_conv3x3_c64 pf_wrw pf_pool pf_transpose pf_stem pf_stem3 pf_image pf_depthwise pf_convg pf_prox pf_im2col; do
+for f in pf_api pf_quant pf_normalize pf_sparse pf_optim pf_loss pf_bn pf_conv pf_conv_stream pf_igemm pf_conv3x3_c64 pf_wrw3x3_c64 pf_wrw pf_pool pf_transpose pf_stem pf_stem3 pf_image pf_depthwise pf_convg pf_prox pf_im2col; do
   if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ] || [ pf_common.h -nt "$f.o" ] || [ pf_conv_common.h -nt "$f.o" ] || [ pf_igemm.h -nt "$f.o" ] || [ ../../include/pocketflow_hip.h -nt "$f.o" ]; then
     rm -f "$f.o"
     $HIPCC $FLAGS -c "$f.hip" -o "$f.o" &

@@ -729,9 +729,21 @@ int pf_wrw2_launch(const void* dY, const void* X, float* slabs, const float* sca
 int pf_wrw_reduce(float* workspace, int S, int64_t n, void* dW, int dw_dtype, hipStream_t st);   // pf_conv.hip
 
 // pixel splits of pf_conv2d_wrw (0: shape not supported); the workspace must hold (splits + 32) * N * th*tw*C floats
+// pf_wrw3x3_c64.hip: the window-staged kernel for 3x3 / stride 1, 64 -> 64 channels on 56 x 56 maps
+bool pf_wrw3x3_c64_geom(int H, int Wd, int C, int N, int th, int tw, int stride, int pad_h, int pad_w, int Ho, int Wo);
+int pf_wrw3x3_c64_splits(int imgs);
+int pf_wrw3x3_c64_launch(const void* dY, const void* X, float* slabs, int imgs, hipStream_t st);
+
 extern "C" int pf_conv2d_wrw_splits(int M, int N, int C, int taps) {
   const int s2 = pf_wrw2_splits(M, N, C, taps);
-  return s2 > 0 ? s2 : pf_wrw_tr_splits(M, N, C, taps);
+  int s = s2 > 0 ? s2 : pf_wrw_tr_splits(M, N, C, taps);
+  // this query does not see the image size: where the window-staged kernel COULD take the launch (its geometry is 56 x 56 images),
+  // the answer covers its slab count too -- an upper bound for sizing the workspace; pf_conv2d_wrw folds what it actually wrote
+  if (pf_tuning().conv3x3_c64 != 0 && taps == 9 && N == 64 && C == 64 && M % (56 * 56) == 0) {
+    const int s3 = pf_wrw3x3_c64_splits(M / (56 * 56));
+    if (s3 > s) s = s3;
+  }
+  return s;
 }
 
 // dW[n][r][s][c] = sum_m dY[m][n] * X[pix(m, r, s)][c]  (KRSC, float32 or bf16), X a materialised NHWC activation
@@ -742,6 +754,11 @@ extern "C" int pf_conv2d_wrw(const void* dY, const void* X, void* dW, int dw_dty
   if (!pf_aligned16(dY) || !pf_aligned16(X) || !pf_aligned16(dW) || !pf_aligned16(workspace)) return (int)hipErrorInvalidValue;
   const int M = imgs * Ho * Wo;
   hipStream_t st = (hipStream_t)stream;
+  if (pf_wrw3x3_c64_geom(H, Wd, C, N, th, tw, stride, pad_h, pad_w, Ho, Wo)) {
+    const int r3 = pf_wrw3x3_c64_launch(dY, X, workspace, imgs, st);
+    if (r3 == 0) return pf_wrw_reduce(workspace, pf_wrw3x3_c64_splits(imgs), (int64_t)N * th * tw * C, dW, dw_dtype, st);
+    if (r3 > 0) return r3;
+  }
   const int s2 = pf_wrw2_splits(M, N, C, th * tw);
   const int S = s2 > 0 ? s2 : pf_wrw_tr_splits(M, N, C, th * tw);
   if (S <= 0) return (int)hipErrorInvalidValue;

@@ -407,3 +407,44 @@ def test_conv3x3_c64_window_kernel_one_hot_probes(hip):
     x[1, hh, ww, cc] = 1.0
     y = _run(hip, x, w, 1, (1, 1))
     assert torch.equal(y, _bf(_ref(x, w, 1, (1, 1)))), (hh, ww, cc)
+
+
+@pytest.mark.parametrize('imgs,dw_dtype', [(1, torch.float32), (2, torch.float32), (19, torch.float32), (40, torch.bfloat16)])
+def test_wrw3x3_c64_window_kernel_matches_float64_and_the_shared_tile_kernel(hip, monkeypatch, imgs, dw_dtype):
+  """Backward-filter of stage-1 conv2 on its own kernel (pf_wrw3x3_c64.hip: both operands staged once per two image rows for all nine
+  taps, transposing LDS reads with per-lane pixel addresses, the [64][576] output in registers across the workgroup's tiles):
+  against float64 torch on the same bf16 operands, against the shared-tile kernel (different summation order: float32 round-off),
+  deterministic, padding taps exact (an ASYMMETRIC random kernel gradient: a transposed tap / channel order would show)."""
+  H, C = 56, 64
+  g = torch.Generator(device='cuda').manual_seed(100 + imgs)
+  x = _bf(torch.randn(imgs, H, H, C, device='cuda', generator=g))
+  dy = _bf(torch.randn(imgs, H, H, C, device='cuda', generator=g) * 0.1)
+  M = imgs * H * H
+  out = {}
+  try:
+    for on in (False, True):
+      _h3_switch(hip, monkeypatch, on)
+      S = hip.conv2d_wrw_splits(M, C, C, 9)
+      assert S > 0
+      ws = torch.full(((S + 32) * C * 9 * C,), float('nan'), device='cuda')
+      dw = torch.full((C, 3, 3, C), float('nan'), device='cuda', dtype=dw_dtype)
+      hip.conv2d_wrw(dy, x, dw, ws, imgs, H, H, C, C, 3, 3, 1, 1, 1, H, H)
+      if on:
+        ws2 = torch.full_like(ws, float('nan'))
+        dw2 = torch.full_like(dw, float('nan'))
+        hip.conv2d_wrw(dy, x, dw2, ws2, imgs, H, H, C, C, 3, 3, 1, 1, 1, H, H)
+        assert torch.equal(dw, dw2)
+      out[on] = dw
+  finally:
+    monkeypatch.delenv('PF_CONV3X3_C64', raising=False)
+    hip.tuning_reload()
+  ref = torch.empty(C, 3, 3, C, device='cuda', dtype=torch.float64)
+  xp = F.pad(x, (0, 0, 1, 1, 1, 1))
+  dyd = dy.reshape(M, C).double()
+  for r in range(3):
+    for s in range(3):
+      ref[:, r, s, :] = dyd.t() @ xp[:, r:r + H, s:s + H, :].reshape(M, C).double()
+  tol = 2e-5 if dw_dtype == torch.float32 else 6e-3
+  for on in (False, True):
+    err = float((out[on].double() - ref).abs().max() / ref.abs().max())
+    assert err <= tol, ('window kernel' if on else 'shared-tile kernel', err)

@@ -11,7 +11,7 @@ out=../../tools/gpu/_build/variant_$name
 mkdir -p $out
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-function $*"
 OBJS=()
-for f in pf_api pf_quant pf_normalize pf_sparse pf_optim pf_loss pf_bn pf_conv pf_conv_stream pf_igemm pf_conv3x3_c64 pf_wrw pf_pool pf_transpose pf_stem pf_stem3 pf_image pf_depthwise pf_convg pf_prox pf_im2col; do
+for f in pf_api pf_quant pf_normalize pf_sparse pf_optim pf_loss pf_bn pf_conv pf_conv_stream pf_igemm pf_conv3x3_c64 pf_wrw3x3_c64 pf_wrw pf_pool pf_transpose pf_stem pf_stem3 pf_image pf_depthwise pf_convg pf_prox pf_im2col; do
   /opt/rocm/bin/hipcc $FLAGS -c "$f.hip" -o "$out/$f.o" &
   OBJS+=("$out/$f.o")
 done
