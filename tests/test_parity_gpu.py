@@ -380,8 +380,8 @@ def test_uq_resnet50_bf16_at_the_benchmarked_geometry_b256_224_through_a_replay(
   """BASELINE configs[2] at EXACTLY what bench.py times (VERDICT r5 weak #1 / next #1a): batch 256, 224x224, w8 / a8 + distillation,
   bf16 fused path -- 802 816-row launches with the tile counts, split counts and statistics-group counts of the bench -- against the
   float32 oracle: one gradient check against the measured bf16-storage floor (float32 oracle, bf16-emulated oracle and product on
-  the same state and batch), then a 4-step loss trajectory whose last step is a REPLAY of the recorded hipGraph.  Slow: the CPU
-  oracle runs ~6 forward + backward passes of ResNet-50 at batch 256 (~30-60 s each on the GPU box's host cores) and keeps the
+  the same state and batch), then a 2-step loss trajectory whose last step is a REPLAY of the recorded hipGraph.  Slow: the CPU
+  oracle runs 4 forward + backward passes of ResNet-50 at batch 256 (~30-60 s each on the GPU box's host cores) and keeps the
   whole float32 autograd graph of a 256-image batch in host memory; skipped (loudly) only where the host cannot hold it."""
   import psutil
   from parity_common import run_bf16_fused_parity
@@ -390,8 +390,16 @@ def test_uq_resnet50_bf16_at_the_benchmarked_geometry_b256_224_through_a_replay(
   if avail < 200:
     pytest.skip('the float32 oracle at batch 256 x 224 x 224 needs ~150 GiB of host memory; %.0f GiB available' % avail)
   FLAGS = _setup(tmp_path)
-  run_bf16_fused_parity(FLAGS, tmp_path, steps=4, expect_bf16=True, batch=256, margin=0.05, image_size=224, after_steps=False,
-                        step_graph=True)
+  # ONE launch-by-launch step before the recording instead of three (the gradient check has already run a product step: pools, handles
+  # and launch attributes are warm): the second step of the trajectory is the replay, and the CPU oracle runs 4 passes instead of 6
+  from pocketflow_amd import step_graph as SG
+  warm = SG.StepGraph.WARM
+  SG.StepGraph.WARM = 1
+  try:
+    run_bf16_fused_parity(FLAGS, tmp_path, steps=2, expect_bf16=True, batch=256, margin=0.05, image_size=224, after_steps=False,
+                          step_graph=True)
+  finally:
+    SG.StepGraph.WARM = warm
 
 
 def test_uq_resnet50_float32_gradients_match_oracle_from_a_conditioned_state(tmp_path):
