@@ -228,7 +228,7 @@ REGION_KERNELS = {'conv1x1_fwd': [r'^k_conv1x1_stream<\d+, true, ', r'^k_igemm<\
                   'conv2d_fwd': [r'^k_igemm<\d+, \d+, \d+, \d+, \d+, 0[,>]'],
                   'bn_bwd_apply': [r'^k_bn_bwd_apply<'], 'bn_bwd_stats': [r'^k_bn_bwd_stats'],
                   'bn_act_quant_apply': [r'^k_bn_apply<'], 'bn_stats': [r'^k_bn_stats']}
-PROFILE_TAG = 'r05'
+PROFILE_TAG = 'r06'
 
 
 def pmc_traffic_per_launch(region, tag=PROFILE_TAG):

@@ -1,9 +1,9 @@
-# Round evidence on the GPU box:  bash tools/gpu/round_evidence.sh [tag]   (tag defaults to r05; outputs gpurun_out/<tag>_*)
+# Round evidence on the GPU box:  bash tools/gpu/round_evidence.sh [tag]   (tag defaults to r06; outputs gpurun_out/<tag>_*)
 # smoke -> full GPU test suite (gradient-parity report lines -> <tag>_parity_report.txt) -> rocprofv3 kernel trace of bench.py
 # (stats + steady-state step table with the idle-gap analysis) -> separate PMC passes (FETCH_SIZE / WRITE_SIZE; never combined
 # with a trace domain) -> the default bench.py line with cpu_baseline -> one bench line per other configuration of SURVEY 8(d)
 # second argument: all (default) | suite (smoke + tests only) | profiles (everything behind the tests) -- two calls when GPU minutes are short
-TAG=${1:-r05}
+TAG=${1:-r06}
 PART=${2:-all}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
@@ -55,3 +55,9 @@ for c in c1 c3; do
   python $GRAFT_REPO_ROOT/tools/prof_summary.py $(find /tmp/prof_${TAG}_$c -name '*kernel_trace.csv' | head -1) --steps 4 --marker $marker --out $GRAFT_REPO_ROOT/gpurun_out/${TAG}_step_kernels_$c.csv | head -12 | cut -c1-150
 done
 cd $GRAFT_REPO_ROOT
+# per-layer tables at the benchmarked geometry: every 1x1 forward launch of the roofline region, every backward-filter launch, the
+# 3x3 forward / backward-data launches against MIOpen, the dense / few-channel kernels against the libraries they replaced
+timeout 600 python tools/gpu/fwd1x1_layers.py > gpurun_out/${TAG}_fwd1x1_layers.txt 2>/dev/null; tail -2 gpurun_out/${TAG}_fwd1x1_layers.txt | cut -c1-200
+timeout 600 python tools/gpu/wrw_layers.py > gpurun_out/${TAG}_wrw_layers.txt 2>/dev/null; tail -2 gpurun_out/${TAG}_wrw_layers.txt | cut -c1-200
+timeout 600 python tools/gpu/igemm_bench.py > gpurun_out/${TAG}_igemm_layers.txt 2>/dev/null; tail -14 gpurun_out/${TAG}_igemm_layers.txt | cut -c1-200
+timeout 600 python tools/gpu/new_kernels_bench.py > gpurun_out/${TAG}_new_kernels_layers.txt 2>/dev/null; tail -12 gpurun_out/${TAG}_new_kernels_layers.txt | cut -c1-200
