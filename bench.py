@@ -315,7 +315,6 @@ def main():
   else:
     tmp = tempfile.mkdtemp(prefix='pf_bench_')
   if world > 1:
-    os.environ.setdefault('PF_STEP_GRAPH_DIST', '1')       # the learners' multi-rank recorded step is opt-in; the bench opts in (and keeps it only where it is not slower, below)
     import pocketflow_amd.learners.abstract_learner  # noqa: F401  (defines enbl_multi_gpu & co. before mgw reads flags)
     mgw.init()
     if rank == 0:
@@ -342,7 +341,11 @@ def main():
   sg = None
   auto_share = None
   recorded_choice = None
-  if args.step_graph is None and (world == 1 or os.environ.get('PF_STEP_GRAPH_DIST', '1') != '0'):
+  # N > 1: launch-by-launch steps by default (round 6).  They keep the bucket all-reduces inside the backward pass, which the recorded
+  # step gives up, and on the boxes of this round a launch-by-launch step was as fast as a replay (10 445 vs 10 395 images/s: the host
+  # submits a step in ~11 ms); the two-graph recorded step has only ever run over gloo on a shared GPU.  PF_STEP_GRAPH_DIST=1 opts in
+  # (kept only where its replays are not slower, decided by all ranks together, below).
+  if args.step_graph is None and (world == 1 or os.environ.get('PF_STEP_GRAPH_DIST', '0') == '1'):
     # default: the step is recorded; how host-bound it is launch by launch (the host's share of two untimed steps from an empty launch
     # queue) is measured first and reported in the line (config.host_share_of_two_launch_by_launch_steps)
     torch.cuda.synchronize()

@@ -333,13 +333,18 @@ int pf_igemm_stats_groups(int M, int N, int pro);           // the launcher's ow
 int pf_igemm_conv1x1(const void* X, const void* W, void* Y, const void* R, float* partial, const void* bn_x,
                      const float* bss, const float* bmi, float b_lo, float b_hi, const float* scale_shift,
                      const uint32_t* slot, float kq, float act_lo, float act_hi, int M, int N, int K, int Ho, int Wo,
-                     int H, int Wd, int stride, const float* oss, int oact, hipStream_t st);
+                     int H, int Wd, int stride, const float* oss, int oact, hipStream_t st, int ymap = 0);
 // Which 1x1 shapes go to the direct-to-LDS staged kernel (after the resident-kernel variant had its pick).  Measured
 // (tools/gpu/igemm_bench.py, conv_bench2.py): prologue-free GEMMs win from K = 512 up; with the prologue the in-LDS pass
 // behind asynchronous staging beats the register-staged tiles of this file on every shape it was tried on.
+#ifndef PF_CONV_IGEMM_PLAIN_MINK
+#define PF_CONV_IGEMM_PLAIN_MINK 256     // (variant builds for A/B runs: tools/gpu/build_variant.sh -DPF_CONV_IGEMM_PLAIN_MINK=512 = rounds 2-5)
+#endif
 static bool conv_use_igemm(bool pro, int K) {
   if ((pro ? pf_tuning().conv_igemm_pro : pf_tuning().conv_igemm) == 0) return false;    // PF_CONV_IGEMM[_PRO]=0: tuning / A-B override
-  return (K % 64) == 0 && (pro || K >= 512);
+  // (round 6: K >= 256 -- with the teacher's bn3 folded into conv2 its conv3 launches of stage 3, 256 -> 1024 at 14 x 14, became
+  // prologue-free and fell to the register-staged tiles of this file at 157 us; the staged kernel runs them in 44)
+  return (K % 64) == 0 && (pro || K >= PF_CONV_IGEMM_PLAIN_MINK);
 }
 
 extern "C" int pf_conv1x1_stats_groups_k(int M, int N, int K, int prologue) {
@@ -391,6 +396,14 @@ static int conv_fwd_launch(const void* X, const void* W, void* Y, const void* R,
   if (!ymap && conv_use_igemm(pro, K)) {
     const int r = pf_igemm_conv1x1(X, W, Y, R, partial, bx, bss, bmi, a.b_lo, a.b_hi, scale_shift, slot, a.kq, a.act_lo,
                                    a.act_hi, M, N, K, Ho, Wo, H, Wd, stride, oss, oact, st);
+    if (r >= 0) return r;
+  }
+  // backward-data of a strided projection (dense dY rows, output rows scattered to (ho * stride, wo * stride) of a pre-zeroed dX):
+  // the staged kernel with its row scatter (round 6; the register-staged tiles of this file ran these at 106 us)
+  if (ymap && stride > 1 && !pro && bx == nullptr && R == nullptr && partial == nullptr && oss == nullptr && conv_use_igemm(false, K) &&
+      (N % 64) == 0) {
+    const int r = pf_igemm_conv1x1(X, W, Y, nullptr, nullptr, nullptr, nullptr, nullptr, a.b_lo, a.b_hi, nullptr, nullptr, a.kq, a.act_lo,
+                                   a.act_hi, M, N, K, Ho, Wo, H, Wd, stride, nullptr, PF_ACT_NONE, st, 1);
     if (r >= 0) return r;
   }
   if (oss != nullptr) {

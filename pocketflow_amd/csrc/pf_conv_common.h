@@ -62,9 +62,8 @@ struct ConvArgs {
 // Exactly the arithmetic of pf_bn_act_quant_apply without a quantiser on exactly the value it would read back from HBM --
 // act(fma(scale, y, shift)), rounded to bf16 once -- so folding the pass into the producing convolution changes no bit.
 __device__ __forceinline__ uint4 out_affine8(const uint4& c, const float* __restrict__ oss, int N, int n, int act) {
-  // the column index is made opaque per call: the four constant loads below are loop-invariant in every row pass, and hoisted
-  // out of it they cost the kernels that never take this branch 11-16 registers (k_conv1x1_stream<256, true> started to spill)
-  asm volatile("" : "+v"(n));
+  // (called from kernels instantiated with AFF only: the four constant loads are loop-invariant in a row pass and the compiler may
+  // hoist them -- re-issued per 16-byte vector they cost the teacher's launches 45 us each, profiles/r06_step_kernels_b256.csv)
   float f[8];
   unpack8(c, f);
   const float4 s0 = *reinterpret_cast<const float4*>(oss + n), s1 = *reinterpret_cast<const float4*>(oss + n + 4);

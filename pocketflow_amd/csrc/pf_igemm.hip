@@ -872,9 +872,9 @@ extern "C" int pf_conv2d_bwd_data_strided_bnstats(const void* dY, const void* Wt
 int pf_igemm_conv1x1(const void* X, const void* W, void* Y, const void* R, float* partial, const void* bn_x,
                      const float* bss, const float* bmi, float b_lo, float b_hi, const float* scale_shift,
                      const uint32_t* slot, float kq, float act_lo, float act_hi, int M, int N, int K, int Ho, int Wo,
-                     int H, int Wd, int stride, const float* oss, int oact, hipStream_t st) {
+                     int H, int Wd, int stride, const float* oss, int oact, hipStream_t st, int ymap) {
   int64_t rows_in = M;
-  if (stride > 1) rows_in = (int64_t)(M / (Ho * Wo)) * H * Wd;
+  if (stride > 1 && !ymap) rows_in = (int64_t)(M / (Ho * Wo)) * H * Wd;
   if ((K % 64) || rows_in * K >= ((int64_t)1 << 30) || (int64_t)N * K >= ((int64_t)1 << 30)) return -1;
   IgArgs a;
   a.X = (const bf16_t*)X; a.W = (const bf16_t*)W; a.Y = (bf16_t*)Y; a.zero = (const bf16_t*)X;
@@ -885,7 +885,8 @@ int pf_igemm_conv1x1(const void* X, const void* W, void* Y, const void* R, float
   a.b_lo = b_lo; a.b_hi = b_hi;
   a.ss = scale_shift; a.slot = slot; a.kq = kq; a.act_lo = act_lo; a.act_hi = act_hi;
   a.M = M; a.N = N; a.C = K; a.th = 1; a.tw = 1;
-  if (stride > 1) { a.H = H; a.Wd = Wd; a.Ho = Ho; a.Wo = Wo; a.stride = stride; }
+  if (ymap) { a.H = Ho; a.Wd = Wo; a.Ho = Ho; a.Wo = Wo; a.stride = 1; }       // dense input rows; the OUTPUT rows are scattered (below)
+  else if (stride > 1) { a.H = H; a.Wd = Wd; a.Ho = Ho; a.Wo = Wo; a.stride = stride; }
   else { a.H = 1; a.Wd = 1; a.Ho = 1; a.Wo = 1; a.stride = 1; }
   a.pad_h = 0; a.pad_w = 0;
   a.x_bytes = (uint32_t)(rows_in * K * 2);
@@ -893,5 +894,12 @@ int pf_igemm_conv1x1(const void* X, const void* W, void* Y, const void* R, float
   a.w_r0 = 0; a.w_rs = 1; a.w_s0 = 0; a.w_ss = 1; a.w_S = 1; a.w_taps_full = 1;
   a.o_sub = 0; a.o_y = 0; a.o_x = 0; a.o_H = 0; a.o_W = 0;
   a.oss = oss; a.oact = oact;
+  if (ymap) {
+    // row (img, i, j) of the dense [Ho x Wo] grid goes to pixel (i * stride, j * stride) of the [H x Wd] image: the scatter of the
+    // parity-class launches with class (0, 0); the other pixels keep the zeros the caller wrote
+    if ((int64_t)(M / (Ho * Wo)) * H * Wd * N >= ((int64_t)1 << 30)) return -1;
+    a.o_sub = stride; a.o_y = 0; a.o_x = 0; a.o_H = H; a.o_W = Wd;
+    return (N % 128 == 0) ? ig_launch_t<128, 128, 2, 2, 2, IG_PLAIN, true>(a, 512, st) : ig_launch_t<128, 64, 2, 2, 2, IG_PLAIN, true>(a, 512, st);
+  }
   return ig_launch(a, st);
 }

@@ -186,9 +186,12 @@ def test_conv1x1_fwd_stream_many_column_slices(hip, M, N, K, act, bits, monkeypa
   _close_bf16(Y2, _bf(X.float() @ W.float().t() + R.float()), what='stream plain + residual', scale=acc)
 
 
+# (K, N) = (256, 512), (192, 320): the row-mapped backward-data launch has a contraction of 512 / 320 channels and goes to the staged
+# implicit GEMM with its row scatter (round 6; 128- and 64-wide column tiles); (64, 128): the register-staged tiles
+@pytest.mark.parametrize('K,N', [(64, 128), (256, 512), (192, 320)])
 @pytest.mark.parametrize('n,H,Wd', [(3, 14, 10), (9, 46, 50)])
-def test_conv1x1_fwd_strided_and_ymap(hip, n, H, Wd):
-  K, N, s = 64, 128, 2
+def test_conv1x1_fwd_strided_and_ymap(hip, n, H, Wd, K, N):
+  s = 2
   Ho, Wo = H // s, Wd // s
   g = torch.Generator(device='cuda').manual_seed(3)
   X = _bf(torch.randn(n, H, Wd, K, device='cuda', generator=g))

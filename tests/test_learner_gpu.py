@@ -181,7 +181,8 @@ def test_int_export_of_a_uq_learner(tmp_path, model, use_buckets, bucket_type, b
   assert summ['quantised_tensors'] == (2 if model == 'lenet' else 21)
 
 
-def test_bench_two_ranks_share_one_gpu(tmp_path):
+@pytest.mark.parametrize('recorded', [False, True])
+def test_bench_two_ranks_share_one_gpu(tmp_path, recorded):
   """The N > 1 control flow of bench.py end to end on a single-GPU box: two ranks on cuda:0 over gloo
   (RCCL refuses duplicate devices): shared scratch directory, rank-0 checkpoint + teacher hand-off,
   broadcast of the flat buffers, gradient all-reduce with the 1/N folded into Adam, max-over-ranks timing."""
@@ -190,8 +191,12 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
   import sys
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   env = dict(os.environ, PF_DIST_BACKEND='gloo', PF_SINGLE_DEVICE='1', TMPDIR=str(tmp_path))
+  if recorded:
+    env['PF_STEP_GRAPH_DIST'] = '1'                          # (round 6: N > 1 runs launch by launch unless this opts in)
+  else:
+    env.pop('PF_STEP_GRAPH_DIST', None)
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
-         '127.0.0.1', '--master-port', '29533', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4',
+         '127.0.0.1', '--master-port', '29533' if recorded else '29535', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4',
          '--event_steps', '2', '--warmup', '1', '--batch', '8', '--image_size', '64', '--no_cpu_baseline']
   out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
   assert out.returncode == 0, out.stderr[-3000:]
@@ -201,7 +206,11 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
   mg = rec['multi_gpu']
   assert mg['backend'] == 'gloo' and mg['params_identical_across_ranks'] is True, mg
   assert mg['buckets_launched_inside_backward'] > 0, mg      # the in-backward launches are armed by optimizer.backward()
-  # the default for N > 1 too: the step is recorded as two graphs around the exchange calls and replayed; the job STAYS on the
+  if not recorded:
+    # the default for N > 1: launch-by-launch steps, the bucket all-reduces inside the backward pass
+    assert mg['recorded_step'] is None and rec['config']['step_graph'] is None, (mg, rec['config'])
+    return
+  # PF_STEP_GRAPH_DIST=1: the step is recorded as two graphs around the exchange calls and replayed; the job STAYS on the
   # recorded step only if its replays are not slower than launch-by-launch steps (they are, with two ranks on one GPU over gloo)
   rs = mg['recorded_step']
   assert rs is not None and rs['graphs'] == 2 and rs['exchange_calls_between_graphs'] == 1 and rs['replayed_steps'] >= 2, mg

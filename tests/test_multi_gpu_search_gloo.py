@@ -320,7 +320,7 @@ def test_fused_path_launches_every_bucket_from_inside_backward(tmp_path):
 def _recorded_worker(rank, world, port, out_dir, dst):
   os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world),
                     MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), PF_ALLREDUCE_BUCKET=str(1 << 16),
-                    PF_STEP_GRAPH='inline', PF_STEP_GRAPH_STRICT='1')
+                    PF_STEP_GRAPH='inline', PF_STEP_GRAPH_STRICT='1', PF_STEP_GRAPH_DIST='1')   # (the multi-rank recorded step is opt-in since round 6)
   torch.set_num_threads(2)
   _patch_cpu()
   import pocketflow_amd.learners.distillation_helper  # noqa: F401
@@ -371,7 +371,12 @@ def _recorded_worker(rank, world, port, out_dir, dst):
   red = b.graph.store.reducer
   assert sg.state == 'ready' and sg.error is None and sg.n_replays == 9 - 3 - 2, (sg.state, sg.error, sg.n_replays)
   assert red.recorder is sg.backend and len(red.buckets) >= 3 and red.n_overlapped > 0
-  assert ca == cb and all(len(c) == len(red.buckets) + 1 for c in ca), (ca, cb)    # the same collectives in the same order, every step
+  # the same collectives in the same order, every step -- plus, in the recorded run, ONE one-element MIN all-reduce in the step that
+  # records: the ranks agreeing that every one of them recorded (StepGraph._ranks_agree, round 6)
+  n_agree = sum(1 for c in cb if c[:1] == [1])
+  assert n_agree == 1, cb
+  cb = [c[1:] if c[:1] == [1] else c for c in cb]
+  assert ca == cb and all(len(c) == len(red.buckets) + 1 for c in ca), (ca, cb)
   sa, sb = a.graph.store, b.graph.store
   assert la == lb, (la, lb)
   for x, y in ((sa.w_master, sb.w_master), (sa.o_master, sb.o_master), (sa.state, sb.state)):
