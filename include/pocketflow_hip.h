@@ -334,7 +334,9 @@ int pf_conv_stem_wrw(const void* dY, const void* X, void* dW, int dw_dtype, floa
  * depth multipliers 1.0 and 0.5) and its Conv2DBackpropFilter.  X [imgs][H][Wd][3] bf16 (NHWC), W [N][3][3][3] bf16 (KRSC),
  * Y / dY [imgs][Ho][Wo][N] bf16.  pad_h / pad_w are TensorFlow's FRONT pads (0 | 1); positions behind the image read zeros
  * (no padded copy of the image).  Wd even, Wo % 16 == 0 (pf_conv_stem3_supported).  Backward-filter: dW in dw_dtype, deterministic;
- * workspace (pf_conv_stem3_wrw_slabs(...) + 32) * N * 27 floats (0 slabs: unsupported shape).                              */
+ * workspace (pf_conv_stem3_wrw_slabs(...) + 32) * N * 27 floats (0 slabs: unsupported shape).
+ * Pixels must be FINITE: the forward kernel pads its contraction from 27 to 96 with zero weights against real neighbouring pixels, so a
+ * NaN / Inf pixel would reach (as 0 * Inf) outputs whose window does not contain it (decoded images are finite).      */
 int pf_conv_stem3_supported(int H, int Wd, int C, int N, int k, int stride, int pad_h, int pad_w, int Ho, int Wo);
 int pf_conv_stem3_fwd(const void* X, const void* W, void* Y, int imgs, int H, int Wd, int N, int pad_h, int pad_w, int Ho, int Wo,
                       void* stream);

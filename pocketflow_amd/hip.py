@@ -414,9 +414,11 @@ def zero_page(device):
 def conv2d_stats_groups(M: int, N: int, geom=None) -> int:
   """Rows of the statistics array of a pf_conv2d_fwd call.  `geom` = (imgs, H, Wd, C, N, th, tw, stride, pad_h, pad_w, Ho, Wo)
   of THAT call: the kernel (and with it the number of workgroup rows) depends on the geometry."""
-  if geom is not None:
-    return int(_lib.pf_conv2d_stats_groups_geom(*[c_int(int(v)) for v in geom]))
-  return int(_lib.pf_conv2d_stats_groups(c_int(M), c_int(N)))
+  if geom is None:
+    # ADVICE r5: the (M, N) query answers for a 1x1 product only; which kernel an R x S launch gets -- and with it the number of
+    # statistics rows -- depends on its window, channel counts and image size (pf_conv3x3_c64.hip since round 6)
+    raise ValueError('conv2d_stats_groups: pass geom = (imgs, H, Wd, C, N, th, tw, stride, pad_h, pad_w, Ho, Wo) of the pf_conv2d_fwd call')
+  return int(_lib.pf_conv2d_stats_groups_geom(*[c_int(int(v)) for v in geom]))
 
 
 def conv2d_fwd(X, W, Y, imgs: int, H: int, Wd: int, C: int, N: int, th: int, tw: int, stride: int, pad_h: int,

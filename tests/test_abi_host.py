@@ -54,7 +54,12 @@ def test_host_side_shape_rules_of_the_convolution_entry_points():
   for M, N, K in ((256 * 56 * 56, 256, 64), (256 * 7 * 7, 2048, 512), (4096, 64, 64)):
     for pro in (False, True):
       assert 1 <= hip.conv1x1_stats_groups(M, N, K, prologue=pro) <= 1024
-    assert 1 <= hip.conv2d_stats_groups(M, N) <= 1024
+  import pytest as _pt
+  with _pt.raises(ValueError):
+    hip.conv2d_stats_groups(256 * 56 * 56, 64)                          # the geometry is mandatory: the kernel depends on it
+  for geom in ((256, 56, 56, 64, 64, 3, 3, 1, 1, 1, 56, 56), (256, 14, 14, 256, 256, 3, 3, 1, 1, 1, 14, 14), (2, 56, 56, 64, 64, 3, 3, 1, 1, 1, 56, 56)):
+    assert 1 <= hip.conv2d_stats_groups(geom[0] * geom[10] * geom[11], geom[4], geom=geom) <= 1024
+  assert hip.conv2d_stats_groups(2 * 56 * 56, 64, geom=(2, 56, 56, 64, 64, 3, 3, 1, 1, 1, 56, 56)) == 56      # window kernel: one row per workgroup = tile
 
 
 def test_header_is_plain_c_and_struct_sizes_match(tmp_path):
