@@ -38,6 +38,7 @@ static void tuning_load() {
   t.wrw2 = env_int("PF_WRW2", 1);
   t.wrw2_target = env_int("PF_WRW2_TARGET", 0);
   t.splitk = env_int("PF_IGEMM_SPLITK", 1);
+  t.wrw2_tk256 = env_int("PF_WRW2_TK256", 1);
   t.conv3x3_c64 = env_int("PF_CONV3X3_C64", 1);
   g_tuning = t;
   g_tuning_loaded = true;

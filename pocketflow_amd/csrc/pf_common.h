@@ -37,6 +37,7 @@ struct PfTuning {
   int igemm_tile_bm, igemm_tile_bn;   // PF_IGEMM_TILE "BMxBN" (0, 0: none)
   int pool3s2;                    // PF_POOL3S2            1 (default) | 0
   int wrw_tr, wrw2, wrw2_target;  // PF_WRW_TR 0, PF_WRW2 1, PF_WRW2_TARGET 0 (= per-shape default)
+  int wrw2_tk256;                 // PF_WRW2_TK256         1 (default) | 0: 256-input-channel tiles of the shared-tile backward-filter kernel for N <= 128 (round 6)
   int splitk;                     // PF_IGEMM_SPLITK       1 (default) | 0
   int conv3x3_c64;                // PF_CONV3X3_C64        1 (default) | 0: the window-staged kernel for 3x3, 64 -> 64 channels, 56 x 56 (pf_conv3x3_c64.hip)
 };

@@ -620,12 +620,11 @@ static IgCfg ig_pick(int M, int N, bool pro) {
   }
   {                                                        // PF_IGEMM_TILE, tuning override: "256x128" | "128x128" | "256x64" | "128x64"
     const int bm = pf_tuning().igemm_tile_bm, bn = pf_tuning().igemm_tile_bn;
-    if ((bm == 128 || bm == 256) && (bn == 64 || bn == 128 || (bn == 256 && bm == 256)) &&
-        (N % bn == 0 || bn == 64))
+    if ((bm == 128 || bm == 256) && (bn == 64 || bn == 128) && (N % bn == 0 || bn == 64))
       return IgCfg{bm, bn, (bm == 256) ? 256 : 512, false};
   }
-  // (256 x 256 tiles by per-layer selection -- PF_IGEMM_AUTO256 / PF_IGEMM_PRO256, prepared in round 4 -- were measured in round 5's first GPU
-  // call: 10 302 / 10 310 / 10 210 / 10 283 images/s for off / plain / prologue / both, i.e. nothing, profiles/r05_first_call_ab.txt; deleted)
+  // (256 x 256 tiles -- eight wavefronts of 64 x 128 -- measured nothing per step in round 5, profiles/r05_first_call_ab.txt; the last
+  // instantiation, reachable through PF_IGEMM_TILE only, was removed in round 6)
   const int bn = (N % 128 == 0) ? 128 : 64;
   // measured on the ResNet-50 shapes at batch 256 (tools/gpu/igemm_bench.py): 128-row tiles with two workgroups per CU
   // (2 LDS stages each) beat 256-row tiles with one workgroup per CU and 3 stages on every shape (e.g. 3x3 C = 256 at
@@ -710,7 +709,6 @@ static int ig_launch(IgArgs& a, hipStream_t st) {
     return (c.bn == 128) ? ig_launch_t<128, 128, 2, 2, 2, IG_PRO>(a, c.slots, st) : ig_launch_t<128, 64, 2, 2, 2, IG_PRO>(a, c.slots, st);
   }
 #define PF_IG(BMV, BNV, WMV, WNV, NSV) (bwd ? ig_launch_t<BMV, BNV, WMV, WNV, NSV, IG_BWD>(a, c.slots, st) : ig_launch_t<BMV, BNV, WMV, WNV, NSV, IG_PLAIN>(a, c.slots, st))
-  if (c.bm == 256 && c.bn == 256) return PF_IG(256, 256, 4, 2, 2);    // 8 wavefronts (64 x 128 each), 1 workgroup / CU, 2 stages (128 KiB)
   if (c.bm == 256 && c.bn == 128) return PF_IG(256, 128, 4, 2, 3);    // 8 wavefronts, 1 workgroup / CU, 3 stages (144 KiB)
   if (c.bm == 128 && c.bn == 128) return PF_IG(128, 128, 2, 2, 2);    // 4 wavefronts, 2 workgroups / CU, 2 stages each
   if (c.bm == 256 && c.bn == 64) return PF_IG(256, 64, 4, 1, 2);

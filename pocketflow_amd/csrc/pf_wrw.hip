@@ -416,8 +416,9 @@ __global__ __launch_bounds__(64 * (TN / WTN) * (TK / WTK)) void k_wrw2(const Wrw
   constexpr int NBN = TN / 16, NBK = TK / 16;        // 16-channel blocks of the staged tiles
   constexpr int DY_BYTES = 4 * NBN * 256, X_BYTES = 4 * NBK * 256, STAGE = DY_BYTES + X_BYTES;
   constexpr int IDY = 4 * (TN / 64), IX = 4 * (TK / 64);                     // LDS-DMA instructions per stage
-  static_assert(IDY % NWAVE == 0, "dY instructions must split evenly over the wavefronts (slot kinds are static)");
-  constexpr int KDY = IDY / NWAVE;                   // slots 0..KDY-1 of every wavefront stage dY, the rest stage X
+  static_assert(IDY % NWAVE == 0 || IDY < NWAVE, "dY instructions must split evenly over the wavefronts (slot kinds are static)");
+  constexpr int KDY = (IDY + NWAVE - 1) / NWAVE;     // slots 0..KDY-1 of every wavefront stage dY, the rest stage X (IDY < NWAVE -- the
+                                                     // 64 x 256 tile of round 6 -- : wavefronts IDY.. load zeros into the sink, like X)
   constexpr int XS = (IX + NWAVE - 1) / NWAVE;       // X slots per wavefront (slot x is live iff wave + x*NWAVE < IX)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -475,10 +476,10 @@ __global__ __launch_bounds__(64 * (TN / WTN) * (TK / WTK)) void k_wrw2(const Wrw
   const uint32_t ystep = 32u * (uint32_t)a.N * 2u, xstep = 32u * (uint32_t)a.C * 2u;
 #pragma unroll
   for (int k = 0; k < KDY; ++k) {
-    const int id = wave + k * NWAVE;
+    const int id = (wave + k * NWAVE) % IDY;
     const int pg = id / (TN / 64), g4 = id % (TN / 64);
     const int n = n0 + (g4 * 4 + sb) * 16 + sch * 8;
-    yoff[k] = (n < a.N) ? (uint32_t)((mbeg + pg * 8 + srow) * a.N + n) * 2u : OOB;   // (OOB + steps stays out of range)
+    yoff[k] = (n < a.N && wave + k * NWAVE < IDY) ? (uint32_t)((mbeg + pg * 8 + srow) * a.N + n) * 2u : OOB;   // (OOB + steps stays out of range)
   }
   // MAPM == 1: (ho, wo) of the lane's pixel per X slot, advanced by 32 pixels per step with ONE conditional wrap each (the
   // launcher selects this mode only when 32 / Wo + 1 <= Ho); MAPM == 2: (img, ho, wo), general
@@ -505,9 +506,11 @@ __global__ __launch_bounds__(64 * (TN / WTN) * (TK / WTK)) void k_wrw2(const Wrw
     const int mb = mbeg + step * 32;
 #pragma unroll
     for (int k = 0; k < KDY; ++k) {
-      const int id = wave + k * NWAVE;                                      // wave-uniform
+      const bool owny = wave + k * NWAVE < IDY;                             // wave-uniform
+      const int id = (wave + k * NWAVE) % IDY;
       const int pg = id / (TN / 64), g4 = id % (TN / 64);
-      if (!(PF_W2_ABLATE & 2)) PF_W_BUFFER_LOAD_LDS16(rsY, dst + (pg * NBN + g4 * 4) * 256, yoff[k]);
+      unsigned char* ydst = owny ? dst + (pg * NBN + g4 * 4) * 256 : smem + 3 * STAGE;
+      if (!(PF_W2_ABLATE & 2)) PF_W_BUFFER_LOAD_LDS16(rsY, ydst, yoff[k]);
       yoff[k] += ystep;
     }
 #pragma unroll
@@ -644,6 +647,10 @@ struct Wrw2Cfg { int tn, tk; };
 static Wrw2Cfg wrw2_pick(int N, int C) {
   const int tn = (N % 256 == 0) ? 256 : ((N % 128 == 0) ? 128 : 64);
   int tk = (C % 128 == 0) ? 128 : 64;
+  // round 6: few output channels over many input channels (conv1 of stages 1-2: 256 -> 64, 256 / 512 -> 128): 256 input channels per
+  // tile -- dY is staged once per 256 channels instead of once per 128, and a workgroup's pixel range is half as long at the same
+  // workgroup count (these launches are bound by their per-step cost: 166 us against an 82 us HBM floor, profiles/r06_wrw_layers.txt)
+  if (tn <= 128 && C % 256 == 0 && pf_tuning().wrw2_tk256 != 0) tk = 256;
   if (tn == 128 && tk == 64) return Wrw2Cfg{64, 64};     // (128, 64) has no instantiation: two 64-wide tiles
   return Wrw2Cfg{tn, tk};
 }
@@ -717,6 +724,8 @@ int pf_wrw2_launch(const void* dY, const void* X, float* slabs, const float* sca
     return mapm ? wrw2_launch_t<TNV, TKV, WTNV, WTKV, false, 2>(a, grid, st)                                   \
                 : wrw2_launch_t<TNV, TKV, WTNV, WTKV, false, 0>(a, grid, st);                                  \
   } while (0)
+  if (c.tn == 128 && c.tk == 256) PF_W2(128, 256, 64, 64);
+  if (c.tn == 64 && c.tk == 256) PF_W2(64, 256, 32, 64);
   if (c.tn == 256 && c.tk == 128) PF_W2(256, 128, 64, 64);
   if (c.tn == 128 && c.tk == 128) PF_W2(128, 128, 64, 64);
   if (c.tn == 256 && c.tk == 64) PF_W2(256, 64, 64, 32);

@@ -216,7 +216,9 @@ def test_conv1x1_fwd_strided_and_ymap(hip, n, H, Wd, K, N):
                                             (20000, 256, 64, torch.float32), (333, 192, 512, torch.float32),
                                             (4096, 64, 64, torch.float32), (10001, 128, 256, torch.bfloat16),
                                             (7777, 512, 128, torch.float32), (3000, 64, 128, torch.float32),
-                                            (50176, 256, 1024, torch.float32)])
+                                            (50176, 256, 1024, torch.float32),
+                                            # few output channels over 256 / 512 input channels: the 64 x 256 and 128 x 256 tiles of round 6
+                                            (30000, 64, 256, torch.float32), (8001, 128, 512, torch.bfloat16), (2100, 64, 512, torch.float32)])
 @pytest.mark.parametrize('impl', ['shared-tile', 'scatter', 'wave-private'])
 def test_conv1x1_wrw(hip, monkeypatch, M, N, K, dw_dtype, impl):
   # the three backward-filter kernels: shared-tile transposed reads (pf_wrw.hip k_wrw2, default where it applies), the
@@ -253,7 +255,7 @@ def test_conv1x1_wrw(hip, monkeypatch, M, N, K, dw_dtype, impl):
   assert torch.equal(dW, dW2)
 
 
-@pytest.mark.parametrize('n,H,Wd,K,N', [(2, 8, 12, 64, 64), (10, 30, 34, 128, 192)])
+@pytest.mark.parametrize('n,H,Wd,K,N', [(2, 8, 12, 64, 64), (10, 30, 34, 128, 192), (12, 28, 28, 256, 128)])
 @pytest.mark.parametrize('impl', ['shared-tile', 'scatter', 'wave-private'])
 def test_conv1x1_wrw_strided(hip, monkeypatch, n, H, Wd, K, N, impl):
   monkeypatch.setenv('PF_WRW2', '1' if impl == 'shared-tile' else '0')

@@ -36,7 +36,7 @@ def make_args(x, w, y, z, B, H, C, N, k, s, pad, Ho):
 
 B = int(os.environ.get('B', 256))
 shapes = [(56, 64, 64, 3, 1), (28, 128, 128, 3, 1), (14, 256, 256, 3, 1), (7, 512, 512, 3, 1), (14, 1024, 256, 1, 1), (14, 256, 1024, 1, 1)]
-tiles = os.environ.get('TILES', '128x128,256x128,256x256,128x64').split(',')
+tiles = os.environ.get('TILES', '128x128,256x128,128x64').split(',')
 print('%-18s %-8s | %8s %8s %8s %8s %8s %8s %8s | %9s %9s | %s' % ('H,C,N,k,s', 'tile', 'full us', 'fill us', 'comp us', 'mfma us', 'mf-e us', 'noepi us', 'ideal us', 'fill MB', 'fill TB/s', 'TF full'))
 for H, C, N, k, s in shapes:
   g = torch.Generator(device='cuda').manual_seed(H + C + N)

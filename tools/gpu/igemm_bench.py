@@ -19,7 +19,7 @@ B = int(os.environ.get('B', 256))
 shapes = [(56, 64, 64, 3, 1), (56, 128, 128, 3, 2), (28, 128, 128, 3, 1), (28, 256, 256, 3, 2), (14, 256, 256, 3, 1),
           (14, 512, 512, 3, 2), (7, 512, 512, 3, 1), (14, 1024, 256, 1, 1), (14, 256, 1024, 1, 1), (7, 2048, 512, 1, 1),
           (7, 512, 2048, 1, 1), (28, 512, 128, 1, 1)]
-tiles = ['256x256', '256x128', '128x128', '256x64', '128x64']   # (256x256: 8 wavefronts of 64 x 128, half the fill bytes per MAC; N % 256 == 0 only)
+tiles = ['256x128', '128x128', '256x64', '128x64']
 print('%-22s | %-44s | dispatched | miopen fwd | miopen bwd-data | igemm best TF' % ('H,C,N,k,s', 'igemm us by tile ' + ' '.join(tiles)))
 for H, C, N, k, s in shapes:
   g = torch.Generator(device='cuda').manual_seed(H + C + N)
