@@ -143,8 +143,11 @@ extern "C" int pf_bn_stats(const void* x, int dtype, int64_t rows, int C, float*
 }
 
 // ---------------------------------------------------------------------------------------------
-// finalize: 64 channels per block; thread (cl = t & 63, part = t >> 6) sums partial blocks
-// part, part+16, ... in a fixed order, then a 16-way LDS combine.  Deterministic.
+// finalize: 16 channels per block, 64 row-partial lanes per channel.  The kernel is a dependent-latency chain between a
+// producer's statistics and the next launch that reads scale/shift (49 launches a step, nothing else of the student's
+// stream in flight), so the lever is parallelism per channel: a lane adds partial blocks part, part+64, ... (4 to 8
+// loads, all issued before the first add), the 4 lanes of a channel inside a wave combine by lane exchange, the 16 waves
+// through LDS -- every order fixed, so the result is deterministic.  64 channels x 16 lanes took 13.8 us per launch.
 // ---------------------------------------------------------------------------------------------
 template <int ACT>
 __device__ __forceinline__ void y_range(float scale, float shift, float xmin, float xmax, float& ymin,
@@ -154,38 +157,66 @@ __device__ __forceinline__ void y_range(float scale, float shift, float xmin, fl
   ymax = apply_act<ACT>(fmaxf(a, b));
 }
 
-#define BN_FIN_P 16                      // row-partial groups per channel (1024 threads: 16 x 64 channels)
-#define BN_FIN_T (BN_FIN_P * 64)
+#define BN_FIN_C 16                      // channels per block
+#define BN_FIN_P 64                      // row-partial lanes per channel
+#define BN_FIN_T (BN_FIN_P * BN_FIN_C)   // 1024 threads = 16 waves of 4 lanes x 16 channels
 __global__ __launch_bounds__(BN_FIN_T) void k_bn_finalize(
     const float* __restrict__ partial, int n_blocks, int64_t rows, int C, const void* __restrict__ x_row0,
     int dtype, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ moving_mean, float* __restrict__ moving_var, float momentum, float eps,
     int training, int act, float* __restrict__ scale_shift, float* __restrict__ mean_invstd,
     uint32_t* __restrict__ slot) {
-  __shared__ float l_s[BN_FIN_P][64], l_ss[BN_FIN_P][64], l_mn[BN_FIN_P][64], l_mx[BN_FIN_P][64];
-  const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  __shared__ float l_s[16][BN_FIN_C], l_ss[16][BN_FIN_C], l_mn[16][BN_FIN_C], l_mx[16][BN_FIN_C];
+  const int cl = threadIdx.x & (BN_FIN_C - 1), part = threadIdx.x / BN_FIN_C;
+  const int c = blockIdx.x * BN_FIN_C + cl;
+  const bool live = c < C;
   float s = 0.f, ss = 0.f, mn = INFINITY, mx = -INFINITY;
-  if (c < C) {
-    for (int b = part; b < n_blocks; b += BN_FIN_P) {
-      const float* p = partial + (int64_t)b * 4 * C;
-      s += p[c]; ss += p[C + c];
-      mn = fminf(mn, p[2 * C + c]); mx = fmaxf(mx, p[3 * C + c]);
+  // constants of the tail, requested before the partial sums so that their latency hides under the loop
+  float piv = 0.f, g = 0.f, be = 0.f, mm = 0.f, mv = 0.f;
+  if (live && part == 0) {
+    g = gamma[c]; be = beta[c]; mm = moving_mean[c]; mv = moving_var[c];
+    if (training) piv = (dtype == PF_F32) ? ((const float*)x_row0)[c] : bf16_to_f32(((const bf16_t*)x_row0)[c]);
+  }
+  if (live) {
+    int b = part;
+    for (; b + 3 * BN_FIN_P < n_blocks; b += 4 * BN_FIN_P) {      // four partial blocks in flight
+      const float* p0 = partial + (int64_t)b * 4 * C + c;
+      const float* p1 = p0 + (int64_t)BN_FIN_P * 4 * C;
+      const float* p2 = p1 + (int64_t)BN_FIN_P * 4 * C;
+      const float* p3 = p2 + (int64_t)BN_FIN_P * 4 * C;
+      const float a0 = p0[0], a1 = p0[C], a2 = p0[2 * C], a3 = p0[3 * C];
+      const float b0 = p1[0], b1 = p1[C], b2 = p1[2 * C], b3 = p1[3 * C];
+      const float c0 = p2[0], c1 = p2[C], c2 = p2[2 * C], c3 = p2[3 * C];
+      const float d0 = p3[0], d1 = p3[C], d2 = p3[2 * C], d3 = p3[3 * C];
+      s += a0; s += b0; s += c0; s += d0;
+      ss += a1; ss += b1; ss += c1; ss += d1;
+      mn = fminf(fminf(fminf(fminf(mn, a2), b2), c2), d2);
+      mx = fmaxf(fmaxf(fmaxf(fmaxf(mx, a3), b3), c3), d3);
+    }
+    for (; b < n_blocks; b += BN_FIN_P) {
+      const float* p = partial + (int64_t)b * 4 * C + c;
+      s += p[0]; ss += p[C];
+      mn = fminf(mn, p[2 * C]); mx = fmaxf(mx, p[3 * C]);
     }
   }
-  l_s[part][cl] = s; l_ss[part][cl] = ss; l_mn[part][cl] = mn; l_mx[part][cl] = mx;
+  // the 4 lanes of a channel inside the wave (lanes cl, cl+16, cl+32, cl+48), fixed pairing
+  s += __shfl_xor(s, 16); ss += __shfl_xor(ss, 16);
+  mn = fminf(mn, __shfl_xor(mn, 16)); mx = fmaxf(mx, __shfl_xor(mx, 16));
+  s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
+  mn = fminf(mn, __shfl_xor(mn, 32)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) < BN_FIN_C) { l_s[wave][cl] = s; l_ss[wave][cl] = ss; l_mn[wave][cl] = mn; l_mx[wave][cl] = mx; }
   __syncthreads();
   float ymin = INFINITY, ymax = -INFINITY;
-  if (part == 0 && c < C) {
+  if (part == 0 && live) {
     s = l_s[0][cl]; ss = l_ss[0][cl]; mn = l_mn[0][cl]; mx = l_mx[0][cl];
 #pragma unroll
-    for (int p = 1; p < BN_FIN_P; ++p) {                 // fixed order: deterministic
+    for (int p = 1; p < 16; ++p) {                       // fixed order: deterministic
       s += l_s[p][cl]; ss += l_ss[p][cl];
       mn = fminf(mn, l_mn[p][cl]); mx = fmaxf(mx, l_mx[p][cl]);
     }
     float mean, var;
     if (training) {
-      const float piv = (dtype == PF_F32) ? ((const float*)x_row0)[c] : bf16_to_f32(((const bf16_t*)x_row0)[c]);
       const double n = (double)rows;
       const double m1 = (double)s / n;
       double v = (double)ss / n - m1 * m1;             // biased variance of (x - pivot) == of x
@@ -196,15 +227,15 @@ __global__ __launch_bounds__(BN_FIN_T) void k_bn_finalize(
       // kernel hands the UNBIASED variance to the moving average
       const float unbiased = (float)(v * (n / (n > 1.0 ? n - 1.0 : 1.0)));
       const float omm = 1.0f - momentum;
-      moving_mean[c] = moving_mean[c] - (moving_mean[c] - mean) * omm;
-      moving_var[c] = moving_var[c] - (moving_var[c] - unbiased) * omm;
+      moving_mean[c] = mm - (mm - mean) * omm;
+      moving_var[c] = mv - (mv - unbiased) * omm;
     } else {
-      mean = moving_mean[c];
-      var = moving_var[c];
+      mean = mm;
+      var = mv;
     }
     const float invstd = 1.0f / sqrtf(var + eps);
-    const float sc = gamma[c] * invstd;
-    const float sh = fmaf(-mean, sc, beta[c]);
+    const float sc = g * invstd;
+    const float sh = fmaf(-mean, sc, be);
     scale_shift[c] = sc;
     scale_shift[C + c] = sh;
     mean_invstd[c] = mean;
@@ -213,10 +244,10 @@ __global__ __launch_bounds__(BN_FIN_T) void k_bn_finalize(
     else if (act == PF_ACT_RELU6) y_range<PF_ACT_RELU6>(sc, sh, mn, mx, ymin, ymax);
     else y_range<PF_ACT_NONE>(sc, sh, mn, mx, ymin, ymax);
   }
-  if (part == 0 && slot != nullptr) {
+  if (threadIdx.x < 64 && slot != nullptr) {             // wave 0 entire (lanes 16..63 carry the neutral elements)
     ymin = wave_min(ymin);
     ymax = wave_max(ymax);
-    if (cl == 0 && ymin <= ymax) {
+    if (threadIdx.x == 0 && ymin <= ymax) {
       atomicMin(&slot[0], enc_f32(ymin));
       atomicMin(&slot[1], ~enc_f32(ymax));
     }
@@ -229,7 +260,7 @@ extern "C" int pf_bn_finalize(const float* partial, int n_blocks, int64_t rows, 
                               int training, int act, float* scale_shift, float* mean_invstd,
                               uint32_t* slot, void* stream) {
   if (C <= 0) return (int)hipErrorInvalidValue;
-  k_bn_finalize<<<(C + 63) / 64, BN_FIN_T, 0, (hipStream_t)stream>>>(
+  k_bn_finalize<<<(C + BN_FIN_C - 1) / BN_FIN_C, BN_FIN_T, 0, (hipStream_t)stream>>>(
       partial, n_blocks, rows, C, x_row0, dtype, gamma, beta, moving_mean, moving_var, momentum, eps,
       training, act, scale_shift, mean_invstd, slot);
   PF_LAUNCH_CHECK();

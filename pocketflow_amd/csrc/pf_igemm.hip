@@ -53,6 +53,30 @@
 // (v_writelane / v_readlane traffic in the staging code) when it was one.
 // AFF: the output affine of the row pass (IgArgs.oss: the consumer's inference-mode BN + activation) -- compiled in for the forward
 // launches of an inference-mode network only
+// Experiment of round 6 (tools/gpu/a8_codes_probe.py, profiles/r06_a8_codes_ab.txt), compiled into a VARIANT library only
+// (tools/gpu/build_variant.sh codes -DPF_IG_CODES): the input operand of the forward kernel is one BYTE per element -- the code
+// c in 0..255 of an 8-bit activation grid x = alpha * c -- staged by the same LDS-DMA at half the bytes (64-byte rows, four
+// 16-byte groups, group position XOR (row >> 2) & 3: the 8-byte fragment reads of a half wave touch 64 distinct banks),
+// converted to bf16 in the fragment path (v_cvt_f32_ubyte + v_perm: integers below 256 are exact in bf16) and scaled by alpha
+// on the accumulators.  The product library never defines PF_IG_CODES.
+#ifdef PF_IG_CODES
+#define PF_IG_XB 1
+__device__ __forceinline__ bf16x8 ig_codes_to_bf16x8(uint2 c) {
+  uint32_t r[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t w = h ? c.y : c.x;
+    const float f0 = (float)(w & 0xffu), f1 = (float)((w >> 8) & 0xffu), f2 = (float)((w >> 16) & 0xffu), f3 = (float)(w >> 24);
+    r[h * 2 + 0] = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);   // upper halves: exact bf16
+    r[h * 2 + 1] = __builtin_amdgcn_perm(__float_as_uint(f3), __float_as_uint(f2), 0x07060302u);
+  }
+  const uint4 u = make_uint4(r[0], r[1], r[2], r[3]);
+  return *reinterpret_cast<const bf16x8*>(&u);
+}
+#else
+#define PF_IG_XB 2
+#endif
+
 template <int BM, int BN, int WM, int WN, int NS, int MODE, bool SUB = false, bool AFF = false>
 __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
   constexpr bool BWD = (MODE == IG_BWD), PRO = (MODE == IG_PRO);
@@ -67,8 +91,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
   constexpr int TE = T;                             // threads of the epilogue row stores
   constexpr int WR = BM / WM, WC = BN / WN;         // wavefront tile: pixels x channels
   constexpr int JM = WR / 16, NI = WC / 16;
-  constexpr int AS = BM * 8 / TS, BS = BN * 8 / TS; // 16-byte loads per staging lane and step (input / kernel tile)
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int XB = PF_IG_XB;                      // bytes per input element (1: the codes experiment)
+  constexpr int ACH = 4 * XB, AROW = 64 * XB;       // 16-byte groups / bytes of an input-tile row (64 channels)
+  constexpr int AS = BM * ACH / TS, BS = BN * 8 / TS; // 16-byte loads per staging lane and step (input / kernel tile)
+  constexpr int A_BYTES = BM * AROW, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int CS_LD = BN + 8, CS_LD_B = BN + 8;
   constexpr int VPR = BN / 8, RPP = TE / VPR, NP = BM / RPP;
   static_assert(AS >= 1 && BS >= 1 && NP >= 1, "tile too small for the block");
@@ -88,6 +114,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
   const int l15 = lane & 15, q = lane >> 4;
   const int srow = (swave * 64 + lane) >> 3;                              // staging row of this lane (per 16-byte slot)
   const int schunk = (lane & 7) ^ ((lane >> 3) & 7);                      // source 16-byte group for its LDS position
+  const int srowA = (XB == 2) ? srow : ((swave * 64 + lane) >> 2);        // the same for the input tile (codes: 4 groups per row)
+  const int schunkA = (XB == 2) ? schunk : ((lane & 3) ^ ((lane >> 4) & 3));
 
   const int xcd = blockIdx.x & 7, L = blockIdx.x >> 3;
   const int g = xcd + 8 * (L / a.tiles_n), tn = L % a.tiles_n;
@@ -151,17 +179,17 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
   auto setup_tile = [&](int m0) {
 #pragma unroll
     for (int i = 0; i < AS; ++i) {
-      const int m = m0 + i * (TS / 8) + srow;
+      const int m = m0 + i * (TS / ACH) + srowA;
       pbase[i] = 0; pmask[i] = 0;
       if (pointwise) {
         // 1x1, stride 1, no padding (every 1x1 layer of the step): input row == output row, one tap -- no divisions, no tap
         // loop (the generic branch costs ~300 instructions per tile, 5 % of a 4-step tile)
-        if (m < a.M) { pbase[i] = (uint32_t)(m * a.C + schunk * 8) * 2u; pmask[i] = 1u; }
+        if (m < a.M) { pbase[i] = (uint32_t)(m * a.C + schunkA * (16 / XB)) * (uint32_t)XB; pmask[i] = 1u; }
       } else if (m < a.M) {
         const int img = m / hw_o, rem = m - img * hw_o;
         const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
         const int h0 = ho * a.stride - a.pad_h, w0 = wo * a.stride - a.pad_w;
-        pbase[i] = (uint32_t)(((img * a.H + h0) * a.Wd + w0) * a.C + schunk * 8) * 2u;   // modulo 2^32 on purpose
+        pbase[i] = (uint32_t)(((img * a.H + h0) * a.Wd + w0) * a.C + schunkA * (16 / XB)) * (uint32_t)XB;   // modulo 2^32 on purpose
         uint32_t mk = 0;
         for (int r = 0; r < a.th; ++r)
           for (int sx = 0; sx < a.tw; ++sx)
@@ -174,12 +202,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
   auto stage = [&](int buf) {
     unsigned char* As = smem + buf * STAGE;
     unsigned char* Bs = As + A_BYTES;
-    const uint32_t tapoff = (uint32_t)(((s_r * a.Wd + s_s) * a.C + s_cc * 64) * 2);   // wave-uniform
+    const uint32_t tapoff = (uint32_t)(((s_r * a.Wd + s_s) * a.C + s_cc * 64) * XB);   // wave-uniform
 #if !PF_IG_NO_DMA
 #pragma unroll
     for (int i = 0; i < AS; ++i) {
       const uint32_t voff = ((pmask[i] >> s_tap) & 1u) ? (pbase[i] + tapoff) : OOB;
-      PF_BUFFER_LOAD_LDS16(rsX, As + (i * (TS / 8) + swave * 8) * 128, voff, 0);
+      PF_BUFFER_LOAD_LDS16(rsX, As + (i * (TS / ACH) + swave * (64 / ACH)) * AROW, voff, 0);
     }
     // byte offset of this step's (tap, 64-channel group) inside a kernel row: s_ks * 128 when the launch walks its own kernel
     uint32_t woff = (uint32_t)(s_ks * 128);                                             // wave-uniform
@@ -364,9 +392,16 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
 #pragma unroll
         for (int i = 0; i < NI; ++i)
           wf[i] = *reinterpret_cast<const bf16x8*>(Bs + (wn * WC + i * 16 + l15) * 128 + coff);
+#ifdef PF_IG_CODES
+        const int coffA = ((((kk * 2 + (q >> 1)) ^ ((l15 >> 2) & 3)) << 4) + (q & 1) * 8);
+#pragma unroll
+        for (int j = 0; j < JM; ++j)
+          xf[j] = ig_codes_to_bf16x8(*reinterpret_cast<const uint2*>(As + (wm * WR + j * 16 + l15) * AROW + coffA));
+#else
 #pragma unroll
         for (int j = 0; j < JM; ++j)
           xf[j] = *reinterpret_cast<const bf16x8*>(As + (wm * WR + j * 16 + l15) * 128 + coff);
+#endif
 #endif
 #pragma unroll
         for (int i = 0; i < NI; ++i)
@@ -460,6 +495,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_igemm(const IgArgs a) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef PF_IG_CODES
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < JM; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] *= a.kq;                     // alpha of the activation grid (probe entry point)
+#endif
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -765,6 +808,32 @@ extern "C" int pf_conv2d_fwd(const void* X, const void* W, void* Y, const void* 
   return conv2d_fwd_launch(X, W, Y, zero, R, partial, bn_x, bn_scale_shift, bn_mean_invstd, bn_act, imgs, H, Wd, C, N, th, tw,
                            stride, pad_h, pad_w, Ho, Wo, stream, nullptr, PF_ACT_NONE);
 }
+
+#ifdef PF_IG_CODES
+// variant library only: X holds one byte per element (codes of the grid x = alpha * c), W / Y bf16 as ever
+extern "C" int pf_probe_conv2d_fwd_codes(const void* Xc, float alpha, const void* W, void* Y, const void* zero, int imgs, int H,
+                                         int Wd, int C, int N, int th, int tw, int stride, int pad_h, int pad_w, int Ho, int Wo,
+                                         void* stream) {
+  if ((C % 64) || (N % 64) || !pf_aligned16(Xc) || !pf_aligned16(W) || !pf_aligned16(Y)) return (int)hipErrorInvalidValue;
+  IgArgs a;
+  a.X = (const bf16_t*)Xc; a.W = (const bf16_t*)W; a.Y = (bf16_t*)Y; a.zero = (const bf16_t*)zero;
+  a.R = nullptr; a.partial = nullptr; a.bx = nullptr; a.bss = nullptr; a.bmi = nullptr;
+  a.b_lo = -INFINITY; a.b_hi = INFINITY;
+  a.ss = nullptr; a.slot = nullptr; a.kq = alpha; a.act_lo = -INFINITY; a.act_hi = INFINITY;
+  a.M = imgs * Ho * Wo; a.N = N; a.C = C; a.th = th; a.tw = tw;
+  a.H = H; a.Wd = Wd; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
+  a.x_bytes = (uint32_t)((int64_t)imgs * H * Wd * C);
+  a.w_bytes = (uint32_t)((int64_t)N * th * tw * C * 2);
+  a.w_r0 = 0; a.w_rs = 1; a.w_s0 = 0; a.w_ss = 1; a.w_S = tw; a.w_taps_full = th * tw;
+  a.o_sub = 0; a.o_y = 0; a.o_x = 0; a.o_H = 0; a.o_W = 0;
+  a.oss = nullptr; a.oact = PF_ACT_NONE;
+  const IgCfg c = ig_pick(a.M, a.N, false);
+  if (c.bm == 256 && c.bn == 128) return ig_launch_t<256, 128, 4, 2, 3, IG_PLAIN>(a, c.slots, (hipStream_t)stream);
+  if (c.bm == 128 && c.bn == 128) return ig_launch_t<128, 128, 2, 2, 2, IG_PLAIN>(a, c.slots, (hipStream_t)stream);
+  if (c.bm == 256 && c.bn == 64) return ig_launch_t<256, 64, 4, 1, 2, IG_PLAIN>(a, c.slots, (hipStream_t)stream);
+  return ig_launch_t<128, 64, 2, 2, 2, IG_PLAIN>(a, c.slots, (hipStream_t)stream);
+}
+#endif
 
 // pf_conv2d_fwd with the CONSUMER's inference-mode BN + activation folded into the row pass of the epilogue (see
 // pf_conv1x1_fwd_affine): Y = act_out(out_scale[n] * bf16(conv) + out_shift[n]).  No residual, no statistics.
