@@ -387,12 +387,14 @@ def main():
       sg.resume()
       train_step()
       train_step()
-      if world > 1:
-        # N > 1: the job stays on the recorded step only where it is not slower than launch-by-launch steps ON THIS JOB -- decided
+      if True:
+        # The job stays on the recorded step only where it is not slower than launch-by-launch steps ON THIS JOB.  N > 1: decided
         # together from the slowest rank's times.  (The recorded step trades the overlap of the exchange with the backward pass
         # for ~700 fewer host launches per step; which one wins depends on the host and the links.  With two ranks sharing ONE GPU
         # over gloo, the test hook, replays were measured 10-20x SLOWER: the exchange call waits 80-900 ms,
-        # profiles/r05_recorded_step_two_ranks.txt.)
+        # profiles/r05_recorded_step_two_ranks.txt.)  N = 1 (round 6): with the backward-filter launches on a second queue
+        # (graph.WrwSide) a launch-by-launch step ran 22.4 ms where the replay of the same step -- the forks are edges of the
+        # hipGraph -- stayed at 23.4 ms (profiles/r06_wrw_side_ab.txt); a slower host turns that around, hence measured, here.
         def step_seconds(n):
           sync()
           t = time.perf_counter()
@@ -400,16 +402,20 @@ def main():
             train_step()
           sync()
           return (time.perf_counter() - t) / n
-        t_rec = step_seconds(2)
+        n_cal = 2 if world > 1 else 4
+        t_rec = step_seconds(n_cal)
         sg.suspend()
         train_step()                       # (the hand-over between the modes is not part of either figure)
-        t_lbl = step_seconds(2)
-        both = torch.tensor([t_rec, t_lbl], dtype=torch.float64, device='cuda')
-        dist.all_reduce(both, op=dist.ReduceOp.MAX)
-        t_rec, t_lbl = (float(v) for v in both.tolist())
+        t_lbl = step_seconds(n_cal)
+        if world > 1:
+          both = torch.tensor([t_rec, t_lbl], dtype=torch.float64, device='cuda')
+          dist.all_reduce(both, op=dist.ReduceOp.MAX)
+          t_rec, t_lbl = (float(v) for v in both.tolist())
         recorded_choice = {'graphs': len(sg.backend.graphs), 'exchange_calls_between_graphs': len(sg.backend.actions),
                            'replay_ms_per_step': t_rec * 1e3, 'launch_by_launch_ms_per_step': t_lbl * 1e3,
-                           'kept': bool(t_rec <= 1.1 * t_lbl)}
+                           'kept': bool(t_rec <= (1.1 if world > 1 else 1.0) * t_lbl)}
+        if args.step_graph == 1:
+          recorded_choice['kept'] = True     # --step_graph 1: the recorded step, whatever the calibration says
         if recorded_choice['kept']:
           sg.resume()
           train_step()
@@ -598,6 +604,10 @@ def main():
                    'teacher': 'next batch, side stream' if getattr(learner, '_teacher_ahead', None) is not None else 'in line',
                    'step_graph': ({'replayed_steps': args.steps - n_event, 'launch_by_launch_steps_with_events': n_event,
                                    'teacher_branch': sg.nxt is not None} if sg is not None else None),
+                   # recorded step or launch-by-launch steps: measured on this job before the timed region (kept = the recorded step)
+                   'step_mode_calibration': recorded_choice,
+                   # graph.WrwSide (round 6): the backward-filter launches of a pass on a second stream, one join before the optimiser
+                   'backward_filter_queue': ('second stream' if getattr(learner.graph.store, 'wrw_side', None) is not None else 'one queue'),
                    'host_share_of_two_launch_by_launch_steps': auto_share},
         'roofline': roofline, 'cpu_baseline': cpu_baseline, 'multi_gpu': multi_gpu}
     print(json.dumps(line))

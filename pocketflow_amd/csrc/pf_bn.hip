@@ -166,17 +166,11 @@ __global__ __launch_bounds__(BN_FIN_T) void k_bn_finalize(
     float* __restrict__ moving_mean, float* __restrict__ moving_var, float momentum, float eps,
     int training, int act, float* __restrict__ scale_shift, float* __restrict__ mean_invstd,
     uint32_t* __restrict__ slot) {
-  __shared__ double l_s[16][BN_FIN_C], l_ss[16][BN_FIN_C];
-  __shared__ float l_mn[16][BN_FIN_C], l_mx[16][BN_FIN_C];
+  __shared__ float l_s[16][BN_FIN_C], l_ss[16][BN_FIN_C], l_mn[16][BN_FIN_C], l_mx[16][BN_FIN_C];
   const int cl = threadIdx.x & (BN_FIN_C - 1), part = threadIdx.x / BN_FIN_C;
   const int c = blockIdx.x * BN_FIN_C + cl;
   const bool live = c < C;
-  // The workgroup partials are float32 sums of (x - pivot) and (x - pivot)^2 over <= a few thousand rows each; ACROSS workgroups the
-  // sums are carried in float64: var = E[d^2] - E[d]^2 cancels when a channel's spread is small against its distance from the pivot
-  // row, and a float32 combine made the result depend on the combine ORDER at the 1e-3 level there (the masked MobileNet fine-tune of
-  // tests/parity_common.py saw it as 5e-3 of one Momentum update when the order changed in round 6).
-  double s = 0.0, ss = 0.0;
-  float mn = INFINITY, mx = -INFINITY;
+  float s = 0.f, ss = 0.f, mn = INFINITY, mx = -INFINITY;
   // constants of the tail, requested before the partial sums so that their latency hides under the loop
   float piv = 0.f, g = 0.f, be = 0.f, mm = 0.f, mv = 0.f;
   if (live && part == 0) {
@@ -194,14 +188,14 @@ __global__ __launch_bounds__(BN_FIN_T) void k_bn_finalize(
       const float b0 = p1[0], b1 = p1[C], b2 = p1[2 * C], b3 = p1[3 * C];
       const float c0 = p2[0], c1 = p2[C], c2 = p2[2 * C], c3 = p2[3 * C];
       const float d0 = p3[0], d1 = p3[C], d2 = p3[2 * C], d3 = p3[3 * C];
-      s += (double)a0; s += (double)b0; s += (double)c0; s += (double)d0;
-      ss += (double)a1; ss += (double)b1; ss += (double)c1; ss += (double)d1;
+      s += a0; s += b0; s += c0; s += d0;
+      ss += a1; ss += b1; ss += c1; ss += d1;
       mn = fminf(fminf(fminf(fminf(mn, a2), b2), c2), d2);
       mx = fmaxf(fmaxf(fmaxf(fmaxf(mx, a3), b3), c3), d3);
     }
     for (; b < n_blocks; b += BN_FIN_P) {
       const float* p = partial + (int64_t)b * 4 * C + c;
-      s += (double)p[0]; ss += (double)p[C];
+      s += p[0]; ss += p[C];
       mn = fminf(mn, p[2 * C]); mx = fmaxf(mx, p[3 * C]);
     }
   }
@@ -224,8 +218,8 @@ __global__ __launch_bounds__(BN_FIN_T) void k_bn_finalize(
     float mean, var;
     if (training) {
       const double n = (double)rows;
-      const double m1 = s / n;
-      double v = ss / n - m1 * m1;                     // biased variance of (x - pivot) == of x
+      const double m1 = (double)s / n;
+      double v = (double)ss / n - m1 * m1;             // biased variance of (x - pivot) == of x
       if (v < 0.0) v = 0.0;
       mean = (float)((double)piv + m1);
       var = (float)v;

@@ -27,6 +27,7 @@ kernels, [in, out] dense) so that checkpoints and the oracle see TF-shaped tenso
 """
 from __future__ import annotations
 
+import contextlib
 import math
 import os
 import weakref
@@ -428,6 +429,97 @@ class Graph:
 
 
 # =================================================================================================
+# backward-filter launches on a second queue
+# =================================================================================================
+
+WRW_SIDE = os.environ.get('PF_WRW_SIDE', '1') != '0'
+
+
+class WrwSide(object):
+  """The backward-FILTER launches of the convolutions on a second HIP stream for the duration of one backward pass (round 6).
+
+  In the backward pass of a layer only the backward-DATA product is on the critical path (dy -> dx -> the BN backward of the layer
+  below); the filter gradient is read by the optimiser alone.  Issued in one queue the two alternate, and every launch of the chain
+  (pixel-split filter kernel, its reduce, the BN sums' finalize -- 150 launches of 8-10 us a step) leaves the chip to one small grid.
+  Armed by the optimisers' backward() for the variable store's graphs, a convolution's backward then forks: the side stream waits for the main stream (dy exists, the gradient
+  buffer is zeroed), runs the filter kernel with its own split workspace, and the main stream goes on with backward-data.  The pass
+  ends with ONE join.  dy / x of a forked launch are kept referenced until the join (the caching allocator would otherwise hand
+  their memory to the main stream's next allocation while the side stream still reads it); only launches that write straight into
+  the flat gradient buffer fork (no tensor allocated on the side stream outlives it).  Inside a step-graph recording the fork / join
+  become edges of the graph.  Data-parallel runs: the gradient notification of a forked launch is issued on the side stream (the
+  reducer's staging copy and all-reduce of a bucket are ordered behind the launches that filled it; a bucket completed from the main
+  stream waits for the side stream first, optim.GradReducer._stage_bucket).  PF_WRW_SIDE=0: one queue."""
+
+  def __init__(self, device):
+    self.device = device
+    self.stream = torch.cuda.Stream(device=device)
+    self.keep: List = []
+    self._scratch: Optional[torch.Tensor] = None
+    self.armed = False
+    self.forks = 0
+
+  def scratch(self, n_floats: int) -> torch.Tensor:
+    if self._scratch is None or self._scratch.numel() < n_floats:
+      with torch.cuda.stream(self.stream):
+        self._scratch = torch.empty(max(n_floats, 1 << 20), dtype=torch.float32, device=self.device)
+    return self._scratch
+
+  def join(self) -> None:
+    if self.forks:
+      torch.cuda.current_stream(self.device).wait_stream(self.stream)
+    self.keep.clear()
+    self.forks = 0
+
+
+class _WrwQueue(object):
+  """`with _wrw_queue(graph, direct, dy, x) as scratch:` -- the filter launch inside runs on the side stream when one is armed and
+  the launch writes into the flat gradient buffer; `scratch(n)` is the split workspace of the queue it runs on."""
+
+  def __init__(self, graph, direct, tensors):
+    side = getattr(getattr(graph, 'store', None), 'wrw_side', None)
+    self.side = side if (side is not None and side.armed and direct) else None
+    self.graph, self.tensors, self.ctx = graph, tensors, None
+
+  def __enter__(self):
+    if self.side is None:
+      return self.graph.scratch
+    side = self.side
+    side.stream.wait_stream(torch.cuda.current_stream(side.device))
+    side.keep.append(self.tensors)
+    side.forks += 1
+    self.ctx = torch.cuda.stream(side.stream)
+    self.ctx.__enter__()
+    return side.scratch
+
+  def __exit__(self, *exc):
+    if self.ctx is not None:
+      self.ctx.__exit__(*exc)
+    return False
+
+
+def _wrw_queue(graph, direct, *tensors):
+  return _WrwQueue(graph, direct, tensors)
+
+
+@contextlib.contextmanager
+def wrw_side_armed(store: 'VarStore'):
+  """One backward pass over the variables of `store` with the filter launches forked (see WrwSide); joins on the way out, also when
+  the pass raises."""
+  if not (WRW_SIDE and store is not None and getattr(store, 'device', None) is not None and torch.device(store.device).type == 'cuda'):
+    yield
+    return
+  side = getattr(store, 'wrw_side', None)
+  if side is None:
+    side = store.wrw_side = WrwSide(store.device)
+  side.armed = True
+  try:
+    yield
+  finally:
+    side.armed = False
+    side.join()
+
+
+# =================================================================================================
 # autograd functions over the HIP kernels
 # =================================================================================================
 
@@ -788,13 +880,13 @@ class _FusedConv1x1(torch.autograd.Function):
       direct = (gw is not None and gw.dtype == w2d.dtype and gw.shape == ctx.w_leaf.shape
                 and gw.permute(0, 2, 3, 1).is_contiguous())
       dw2d = gw.permute(0, 2, 3, 1).view(N, K) if direct else torch.empty((N, K), dtype=w2d.dtype, device=x.device)
-      with region('conv1x1_wrw', float((M * K + M * N) * 2)):
-        ws = graph.scratch((S + 32) * N * K)
+      with _wrw_queue(graph, direct, dy, x, w2d) as scratch, region('conv1x1_wrw', float((M * K + M * N) * 2)):
+        ws = scratch((S + 32) * N * K)
         hip.conv1x1_wrw(dy, x, dw2d, ws, M, N, K, scale_shift=ss, act=act, slot=lazy.slot if quant else None,
                         bits=lazy.bits if quant else 8, geom=geom)
+        if direct:
+          graph.store.notify_grad(ctx.w_var)     # autograd sees no gradient for this leaf: report it ourselves (on the launch's queue)
       dw = None if direct else dw2d.view(N, 1, 1, K).permute(0, 3, 1, 2)       # logical OIHW over KRSC memory
-      if direct:
-        graph.store.notify_grad(ctx.w_var)       # autograd sees no gradient for this leaf: report it ourselves
     if ctx.needs_input_grad[0]:
       wv = getattr(ctx, 'w_var', None)
       if USE_SEG_TRANSPOSE and wv is not None and wv.store is graph.store and wv.tensor is ctx.w_leaf:
@@ -920,11 +1012,12 @@ class _Conv2dIgemm(torch.autograd.Function):
           direct = (gw is not None and gw.shape == w.shape and gw.permute(0, 2, 3, 1).is_contiguous()
                     and gw.dtype in (torch.float32, torch.bfloat16))
           dwk = gw.permute(0, 2, 3, 1) if direct else torch.empty((N_, R_, S_, C_), dtype=w.dtype, device=x.device)
-          ws = graph.scratch((splits + 32) * N_ * R_ * S_ * C_)
-          hip.conv2d_wrw(dy, x, dwk, ws, B_, H_, W_, C_, N_, R_, S_, stride, pad[0], pad[1], Ho_, Wo_)
-          if direct:
-            graph.store.notify_grad(ctx.w_var)
-          else:
+          with _wrw_queue(graph, direct, dy, x) as scratch:
+            ws = scratch((splits + 32) * N_ * R_ * S_ * C_)
+            hip.conv2d_wrw(dy, x, dwk, ws, B_, H_, W_, C_, N_, R_, S_, stride, pad[0], pad[1], Ho_, Wo_)
+            if direct:
+              graph.store.notify_grad(ctx.w_var)
+          if not direct:
             dw = dwk.permute(0, 3, 1, 2)
         elif OWN_CONV2D_WRW and OWN_CONV_GENERIC and x.is_cuda and dy.dtype == x.dtype and w.dtype == x.dtype:
           # fewer than 2 048 output pixels (the 64 x 64 test networks): too few steps for the pixel-split MFMA kernels -- the general
@@ -1170,10 +1263,11 @@ class _StemConv(torch.autograd.Function):
           direct = (gw is not None and gw.shape == w.shape and gw.permute(0, 2, 3, 1).is_contiguous()
                     and gw.dtype in (torch.float32, torch.bfloat16))
           dwk = gw.permute(0, 2, 3, 1) if direct else torch.empty((w.shape[0], 7, 7, 3), dtype=w.dtype, device=x.device)
-          hip.conv_stem_wrw(dy, x, dwk, graph.scratch((S + 32) * 64 * 147), B, H, Wd)
-          if direct:
-            graph.store.notify_grad(w_var)
-          else:
+          with _wrw_queue(graph, direct, dy, x) as scratch:
+            hip.conv_stem_wrw(dy, x, dwk, scratch((S + 32) * 64 * 147), B, H, Wd)
+            if direct:
+              graph.store.notify_grad(w_var)
+          if not direct:
             dw = dwk.permute(0, 3, 1, 2)
         else:
           dw = torch.ops.aten.convolution_backward(dy, x, w.detach(), None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,

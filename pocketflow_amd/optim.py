@@ -74,8 +74,11 @@ class FlatOptimizer(object):
     """The backward pass of a training step.  Learners call this (not `loss.backward()`) for the backward that is
     followed by compute_gradients() / apply_gradients(): the distributed wrapper overrides it to let the gradient
     exchange start from inside the pass.  Any OTHER backward (layer-wise tuning on rank 0, regression-gradient
-    helpers) stays a plain `loss.backward()` and never touches the process group."""
-    loss.backward()
+    helpers) stays a plain `loss.backward()` and never touches the process group.  The backward-filter launches of the pass run on a
+    second queue (graph.WrwSide)."""
+    from pocketflow_amd import graph as G
+    with G.wrw_side_armed(self.store):
+      loss.backward()
 
   def compute_gradients(self) -> None:
     """Gradients already sit in store.w_grad / store.o_grad after backward (single process)."""
@@ -213,6 +216,14 @@ class GradReducer(object):
     """Widen bucket b into the staging buffer (stream-ordered copy); -> the call that all-reduces it."""
     lo, hi, _ = self.buckets[b]
     piece = self._stage('w')[lo:hi]
+    side = getattr(self.store, 'wrw_side', None)
+    if side is not None and side.forks and self.store.w_grad.is_cuda:
+      # graph.WrwSide: backward-filter launches of this pass run on a second stream.  A bucket completed by one of them is staged on
+      # that stream (its notification is issued there, and the stream waited for the main stream when it forked); a bucket completed
+      # from the main stream may hold gradients whose launches are still running over there
+      cur = torch.cuda.current_stream(self.store.w_grad.device)
+      if cur != side.stream:
+        cur.wait_stream(side.stream)
     piece.copy_(self.store.w_grad[lo:hi])
     self.launched[b] = True
     return lambda: self.handles.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True))
@@ -348,9 +359,11 @@ class DistributedFlatOptimizer(object):
 
   def backward(self, loss: torch.Tensor) -> None:
     """loss.backward() with the in-backward bucket launches of the GradReducer enabled for exactly this pass."""
+    from pocketflow_amd import graph as G
     self.reducer.arm()
     try:
-      loss.backward()
+      with G.wrw_side_armed(self.opt.store):
+        loss.backward()
     finally:
       self.reducer.disarm()
 

@@ -137,7 +137,16 @@ def case_uq_resnet50(tmp_path, ranks=1, batch=8, image=64):
   lb = _collect_losses_each_step(b, 9, (6, 8), True)
   FLAGS.enbl_step_graph = False
   a = make()
+  import pocketflow_amd.graph as G
+  forks_b = getattr(b.graph.store, 'wrw_side', None)
+  if os.environ.get('PF_W_ONE_QUEUE_EAGER') == '1':
+    # the launch-by-launch run with the backward-filter launches in the ONE queue (graph.WrwSide off): the recorded run above forked them
+    assert G.WRW_SIDE and forks_b is not None, 'the recorded run did not fork its backward-filter launches'
+    G.WRW_SIDE = False
   la = _collect_losses_each_step(a, 9, (), False)
+  if os.environ.get('PF_W_ONE_QUEUE_EAGER') == '1':
+    assert getattr(a.graph.store, 'wrw_side', None) is None
+    G.WRW_SIDE = True
   sg = step_graph.of(b)
   assert sg.state == 'ready' and sg.error is None and sg.n_replays == 9 - 3 - 2 and sg.nxt is not None
   exact = _assert_same_run(a, b, la, lb, 'ResNet-50 UQ bf16 + dst')

@@ -271,6 +271,24 @@ def test_step_graph_is_the_eager_step(tmp_path, case):
       case, res['exact'], res['max_parameter_difference'], res['losses_eager'][-2:], res['losses_graph'][-2:]))
 
 
+def test_backward_filter_side_queue_is_the_one_queue_step(tmp_path):
+  """graph.WrwSide (round 6): the backward-filter launches of a pass on a second HIP stream, one join before the optimiser.  The same
+  worker as above for ResNet-50 UQ + distillation: the RECORDED run forks them (edges of the hipGraph), the launch-by-launch run of
+  the second learner keeps them in the one queue (PF_W_ONE_QUEUE_EAGER=1).  Deterministic kernels, same batches: losses, parameters,
+  Adam slots and moving statistics must be bit-identical -- a filter gradient read before its launch finished, or a split workspace
+  shared between the two queues, would show here."""
+  import json
+  import subprocess
+  import sys
+  worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'step_graph_worker.py')
+  env = dict(os.environ, PF_W_ONE_QUEUE_EAGER='1')
+  r = subprocess.run([sys.executable, worker, 'uq_resnet50', str(tmp_path)], capture_output=True, text=True, timeout=900, env=env)
+  lines = [ln for ln in r.stdout.splitlines() if ln.startswith('STEP_GRAPH_RESULT ')]
+  assert r.returncode == 0 and lines, 'worker rc %d\n%s\n%s' % (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+  res = json.loads(lines[-1][len('STEP_GRAPH_RESULT '):])
+  assert res['exact'] is True and res['max_parameter_difference'] == 0.0, res
+
+
 def test_step_graph_with_two_ranks_is_two_graphs_around_the_exchange(tmp_path):
   """--enbl_step_graph with --enbl_multi_gpu (VERDICT r4 "next" 4; reference: Horovod's all-reduce is part of the compiled train
   graph, utils/multi_gpu_wrapper.py:83-98, learners/uniform_quantization/learner.py:246).  Two ranks share cuda:0 over gloo (the

@@ -48,8 +48,11 @@ vals = {'VALUE': '{:,.0f}'.format(d['value']).replace(',', ' '), 'MS': '%.2f' % 
 block = []
 block.append('| quantity | value | source |')
 block.append('|---|---|---|')
-block.append('| images/s (whole job, N = 1) | **%s** (%s ms/step; %d replays + %d launch-by-launch steps) | `profiles/%s_bench.json` |' % (
-    vals['VALUE'], vals['MS'], d['config']['step_graph']['replayed_steps'], d['config']['step_graph']['launch_by_launch_steps_with_events'], tag))
+sgc, cal = d['config'].get('step_graph'), d['config'].get('step_mode_calibration')
+mode = ('%d replays + %d launch-by-launch steps' % (sgc['replayed_steps'], sgc['launch_by_launch_steps_with_events'])) if sgc else 'launch-by-launch steps'
+if cal:
+  mode += '; calibration before the timed region: replay %.2f ms, launch by launch %.2f ms' % (cal['replay_ms_per_step'], cal['launch_by_launch_ms_per_step'])
+block.append('| images/s (whole job, N = 1) | **%s** (%s ms/step; %s) | `profiles/%s_bench.json` |' % (vals['VALUE'], vals['MS'], mode, tag))
 block.append('| `roofline` (headline): step FLOPs / step time / 2.5 PFLOP/s | %.1f TFLOP/s = **%s** of the dense bf16 MFMA peak | same; matrix-pipe busy from counters: %s %% (`%s_mfma_busy.txt`) |' % (
     r['achieved'], vals['MFMA'], mb.group(1) if mb else '?', tag))
 if h.get('unshared'):
@@ -72,7 +75,7 @@ for cname, what in (('c1', 'C1 ResNet-20 weight sparsification'), ('c2a32', 'C2 
     block.append('| %s | %s images/s, %.2f ms/step | `profiles/%s_bench_%s.json` |' % (what, '{:,.0f}'.format(x['value']).replace(',', ' '), x['ms_per_step'], tag, cname))
 block.append('| `pytest tests -m gpu` | %s passed, %s skipped (2-GPU RCCL test and friends) | `profiles/%s_pytest_gpu.log` |' % (passed, skipped, tag))
 block.append('')
-block.append('Where a replayed step goes (`profiles/%s_step_kernels_b256.csv`: %s; kernel time summed over both streams %.1f ms):' % (
+block.append('Where a step goes (`profiles/%s_step_kernels_b256.csv`: %s; kernel time summed over both streams %.1f ms):' % (
     tag, head[0].strip('# ').replace('"', ''), busy))
 block.append('')
 block.append('| family | ms / step |')
