@@ -328,6 +328,10 @@ def main():
       dist.barrier()
   learner, train_step = build_learner(args, FLAGS, tmp, rank, world, barrier)
   cfg = CONFIGS[args.config]
+  if os.environ.get('PF_BENCH_MAIN_PRIORITY', '0') == '1':
+    # experiment: the student's queue at high priority (the teacher's and the backward-filter queue stay at normal priority)
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
 
   def sync():
     if world > 1:
@@ -336,6 +340,13 @@ def main():
 
   for _ in range(args.warmup):
     train_step()
+  # Host hygiene for the launch-by-launch mode: a full collection of Python's cyclic collector walks every tracked object of the
+  # process (torch, numpy, the layer graph: 50-90 ms, seen as host stalls of that size every few steps in host_submit_ms_steps --
+  # with a GPU step of 11-22 ms the launch queue runs dry).  Everything alive after the warm-up moves to the permanent generation;
+  # the per-step garbage (autograd nodes, tensor wrappers) is still collected, cheaply.
+  import gc
+  gc.collect()
+  gc.freeze()
   # --step_graph: the recording (three launch-by-launch steps, then one pass of the Python step under stream capture) belongs to
   # the warm-up whatever W is; a learner whose step cannot be recorded says so once and stays launch-by-launch
   sg = None
@@ -402,7 +413,7 @@ def main():
             train_step()
           sync()
           return (time.perf_counter() - t) / n
-        n_cal = 2 if world > 1 else 4
+        n_cal = 2 if world > 1 else 6
         t_rec = step_seconds(n_cal)
         sg.suspend()
         train_step()                       # (the hand-over between the modes is not part of either figure)

@@ -445,8 +445,8 @@ class WrwSide(object):
   buffer is zeroed), runs the filter kernel with its own split workspace, and the main stream goes on with backward-data.  The pass
   ends with ONE join.  dy / x of a forked launch are kept referenced until the join (the caching allocator would otherwise hand
   their memory to the main stream's next allocation while the side stream still reads it); only launches that write straight into
-  the flat gradient buffer fork (no tensor allocated on the side stream outlives it).  Inside a step-graph recording the fork / join
-  become edges of the graph.  Data-parallel runs: the gradient notification of a forked launch is issued on the side stream (the
+  the flat gradient buffer fork (no tensor allocated on the side stream outlives it).  Not inside a step-graph recording: there the
+  forks would become edges of the hipGraph, which were measured to gain nothing in a replay and to cost one on small networks.  Data-parallel runs: the gradient notification of a forked launch is issued on the side stream (the
   reducer's staging copy and all-reduce of a bucket are ordered behind the launches that filled it; a bucket completed from the main
   stream waits for the side stream first, optim.GradReducer._stage_bucket).  PF_WRW_SIDE=0: one queue."""
 
@@ -477,7 +477,9 @@ class _WrwQueue(object):
 
   def __init__(self, graph, direct, tensors):
     side = getattr(getattr(graph, 'store', None), 'wrw_side', None)
-    self.side = side if (side is not None and side.armed and direct) else None
+    # not while a step graph is being recorded: the forks become edges of the hipGraph, which gain nothing in a replay (ResNet-50:
+    # 23.4 ms either way) and cost one where the launches are small (ResNet-20: 2.25 -> 2.78 ms per replayed step, measured)
+    self.side = side if (side is not None and side.armed and direct and not torch.cuda.is_current_stream_capturing()) else None
     self.graph, self.tensors, self.ctx = graph, tensors, None
 
   def __enter__(self):
@@ -880,7 +882,9 @@ class _FusedConv1x1(torch.autograd.Function):
       direct = (gw is not None and gw.dtype == w2d.dtype and gw.shape == ctx.w_leaf.shape
                 and gw.permute(0, 2, 3, 1).is_contiguous())
       dw2d = gw.permute(0, 2, 3, 1).view(N, K) if direct else torch.empty((N, K), dtype=w2d.dtype, device=x.device)
-      with _wrw_queue(graph, direct, dy, x, w2d) as scratch, region('conv1x1_wrw', float((M * K + M * N) * 2)):
+      # (everything the launch reads stays referenced until the join: the producer BN's constants belong to ITS autograd node, which
+      # runs -- and frees them -- on the main stream right after this function returns)
+      with _wrw_queue(graph, direct, dy, x, w2d, ss, lazy) as scratch, region('conv1x1_wrw', float((M * K + M * N) * 2)):
         ws = scratch((S + 32) * N * K)
         hip.conv1x1_wrw(dy, x, dw2d, ws, M, N, K, scale_shift=ss, act=act, slot=lazy.slot if quant else None,
                         bits=lazy.bits if quant else 8, geom=geom)
