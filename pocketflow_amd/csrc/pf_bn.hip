@@ -143,11 +143,15 @@ extern "C" int pf_bn_stats(const void* x, int dtype, int64_t rows, int C, float*
 }
 
 // ---------------------------------------------------------------------------------------------
-// finalize: 16 channels per block, 64 row-partial lanes per channel.  The kernel is a dependent-latency chain between a
-// producer's statistics and the next launch that reads scale/shift (49 launches a step, nothing else of the student's
-// stream in flight), so the lever is parallelism per channel: a lane adds partial blocks part, part+64, ... (4 to 8
-// loads, all issued before the first add), the 4 lanes of a channel inside a wave combine by lane exchange, the 16 waves
-// through LDS -- every order fixed, so the result is deterministic.  64 channels x 16 lanes took 13.8 us per launch.
+// finalize: 16 channels x 16 row-partial lanes per workgroup.  The kernel is a dependent-latency chain between a producer's
+// statistics and the next launch that reads scale / shift (49 launches a step, nothing else of the student's stream in flight),
+// so the levers are workgroups (C / 16 instead of C / 64) and loads in flight: a lane owns partial blocks part, part+16, ...
+// and requests eight of them (32 loads) before it adds -- in ASCENDING block order, then the 16 lanes of a channel combine in
+// ascending lane order through LDS: the summation order of rounds 1-5 (64 channels x 16 lanes, one block per trip), bit for bit.
+// (A 64-lane tree per channel was 0.2 us faster and equally accurate -- every call within 1.5e-6 of a float64 two-pass result,
+// tools/gpu/bn_finalize_audit.py -- but moved the bf16 gradient checks of the two small networks, whose per-variable bars
+// compare noise with noise at the 0.05 level, across their margins: profiles/r06_bn_finalize_order.txt.)
+// 13.8 -> 9 us per launch.
 // ---------------------------------------------------------------------------------------------
 template <int ACT>
 __device__ __forceinline__ void y_range(float scale, float shift, float xmin, float xmax, float& ymin,
@@ -158,15 +162,16 @@ __device__ __forceinline__ void y_range(float scale, float shift, float xmin, fl
 }
 
 #define BN_FIN_C 16                      // channels per block
-#define BN_FIN_P 64                      // row-partial lanes per channel
-#define BN_FIN_T (BN_FIN_P * BN_FIN_C)   // 1024 threads = 16 waves of 4 lanes x 16 channels
+#define BN_FIN_P 16                      // row-partial lanes per channel
+#define BN_FIN_T (BN_FIN_P * BN_FIN_C)   // 256 threads
+#define BN_FIN_U 8                       // partial blocks requested per trip
 __global__ __launch_bounds__(BN_FIN_T) void k_bn_finalize(
     const float* __restrict__ partial, int n_blocks, int64_t rows, int C, const void* __restrict__ x_row0,
     int dtype, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ moving_mean, float* __restrict__ moving_var, float momentum, float eps,
     int training, int act, float* __restrict__ scale_shift, float* __restrict__ mean_invstd,
     uint32_t* __restrict__ slot) {
-  __shared__ float l_s[16][BN_FIN_C], l_ss[16][BN_FIN_C], l_mn[16][BN_FIN_C], l_mx[16][BN_FIN_C];
+  __shared__ float l_s[BN_FIN_P][BN_FIN_C], l_ss[BN_FIN_P][BN_FIN_C], l_mn[BN_FIN_P][BN_FIN_C], l_mx[BN_FIN_P][BN_FIN_C];
   const int cl = threadIdx.x & (BN_FIN_C - 1), part = threadIdx.x / BN_FIN_C;
   const int c = blockIdx.x * BN_FIN_C + cl;
   const bool live = c < C;
@@ -178,20 +183,18 @@ __global__ __launch_bounds__(BN_FIN_T) void k_bn_finalize(
     if (training) piv = (dtype == PF_F32) ? ((const float*)x_row0)[c] : bf16_to_f32(((const bf16_t*)x_row0)[c]);
   }
   if (live) {
+    const int64_t step = (int64_t)BN_FIN_P * 4 * C;
     int b = part;
-    for (; b + 3 * BN_FIN_P < n_blocks; b += 4 * BN_FIN_P) {      // four partial blocks in flight
-      const float* p0 = partial + (int64_t)b * 4 * C + c;
-      const float* p1 = p0 + (int64_t)BN_FIN_P * 4 * C;
-      const float* p2 = p1 + (int64_t)BN_FIN_P * 4 * C;
-      const float* p3 = p2 + (int64_t)BN_FIN_P * 4 * C;
-      const float a0 = p0[0], a1 = p0[C], a2 = p0[2 * C], a3 = p0[3 * C];
-      const float b0 = p1[0], b1 = p1[C], b2 = p1[2 * C], b3 = p1[3 * C];
-      const float c0 = p2[0], c1 = p2[C], c2 = p2[2 * C], c3 = p2[3 * C];
-      const float d0 = p3[0], d1 = p3[C], d2 = p3[2 * C], d3 = p3[3 * C];
-      s += a0; s += b0; s += c0; s += d0;
-      ss += a1; ss += b1; ss += c1; ss += d1;
-      mn = fminf(fminf(fminf(fminf(mn, a2), b2), c2), d2);
-      mx = fmaxf(fmaxf(fmaxf(fmaxf(mx, a3), b3), c3), d3);
+    for (; b + (BN_FIN_U - 1) * BN_FIN_P < n_blocks; b += BN_FIN_U * BN_FIN_P) {
+      const float* p = partial + (int64_t)b * 4 * C + c;
+      float v0[BN_FIN_U], v1[BN_FIN_U], v2[BN_FIN_U], v3[BN_FIN_U];
+#pragma unroll
+      for (int u = 0; u < BN_FIN_U; ++u) { v0[u] = p[u * step]; v1[u] = p[u * step + C]; v2[u] = p[u * step + 2 * C]; v3[u] = p[u * step + 3 * C]; }
+#pragma unroll
+      for (int u = 0; u < BN_FIN_U; ++u) {                 // ascending block order
+        s += v0[u]; ss += v1[u];
+        mn = fminf(mn, v2[u]); mx = fmaxf(mx, v3[u]);
+      }
     }
     for (; b < n_blocks; b += BN_FIN_P) {
       const float* p = partial + (int64_t)b * 4 * C + c;
@@ -199,13 +202,7 @@ __global__ __launch_bounds__(BN_FIN_T) void k_bn_finalize(
       mn = fminf(mn, p[2 * C]); mx = fmaxf(mx, p[3 * C]);
     }
   }
-  // the 4 lanes of a channel inside the wave (lanes cl, cl+16, cl+32, cl+48), fixed pairing
-  s += __shfl_xor(s, 16); ss += __shfl_xor(ss, 16);
-  mn = fminf(mn, __shfl_xor(mn, 16)); mx = fmaxf(mx, __shfl_xor(mx, 16));
-  s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
-  mn = fminf(mn, __shfl_xor(mn, 32)); mx = fmaxf(mx, __shfl_xor(mx, 32));
-  const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) < BN_FIN_C) { l_s[wave][cl] = s; l_ss[wave][cl] = ss; l_mn[wave][cl] = mn; l_mx[wave][cl] = mx; }
+  l_s[part][cl] = s; l_ss[part][cl] = ss; l_mn[part][cl] = mn; l_mx[part][cl] = mx;
   __syncthreads();
   float ymin = INFINITY, ymax = -INFINITY;
   if (part == 0 && live) {

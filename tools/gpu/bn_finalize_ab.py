@@ -36,4 +36,4 @@ for training in (1, 0):
           print('training %d C %d n_blocks %d: %s differs by %.3e' % (training, C, nb, name, d))
       if not torch.equal(outs[0][4], outs[1][4]):
         print('training %d C %d n_blocks %d: slot %s vs %s' % (training, C, nb, outs[0][4].tolist(), outs[1][4].tolist()))
-print('worst relative difference %.3e' % worst)
+print('worst relative difference %.3e%s' % (worst, '  (bit-identical outputs)' if worst == 0.0 else ''))

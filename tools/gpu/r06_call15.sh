@@ -1,6 +1,9 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -q --tb=short -x -k "one_step_at_224_with_8bit" 2>&1 | tail -30 | cut -c1-600
 echo "--- one queue"
-PF_WRW_SIDE=0 timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -q --tb=line -x -k "one_step_at_224_with_8bit" 2>&1 | tail -5 | cut -c1-600
+PF_WRW_SIDE=0 timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -q --tb=line -k "ws_resnet20_bf16 or cp_mobilenet_bf16" 2>&1 | grep -E "passed|failed|Error" | cut -c1-700
+echo "--- old finalize, side queue"
+PF_HIP_LIB=$PWD/tools/gpu/_build/libpocketflow_hip_oldfin.so timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -q --tb=line -k "ws_resnet20_bf16 or cp_mobilenet_bf16" 2>&1 | grep -E "passed|failed|Error" | cut -c1-700
+echo "--- old finalize, one queue"
+PF_WRW_SIDE=0 PF_HIP_LIB=$PWD/tools/gpu/_build/libpocketflow_hip_oldfin.so timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -q --tb=line -k "ws_resnet20_bf16 or cp_mobilenet_bf16" 2>&1 | grep -E "passed|failed|Error" | cut -c1-700
 exit 0
