@@ -470,6 +470,16 @@ def main():
     if os.path.isdir(out_dir):
       with open(os.path.join(out_dir, 'bench_host_bound_profile.txt'), 'w') as f:
         f.write(text)
+  if sg is None and world == 1:
+    # Launch-by-launch steps: the host runs ahead of the GPU (6 vs 11 ms per step on MobileNet, 11 vs 22 on ResNet-50), and the blocks
+    # handed between the streams (record_stream: freed when the reader's event has passed) stay out of the pool for as long as the launch
+    # queue is deep -- the caching allocator grows while the backlog builds up, one hipMalloc of 40-90 ms at a time (seen as
+    # host stalls of that size and as `segments_allocated` moving INSIDE the timed region of round 6's first launch-by-launch lines:
+    # 16.2 instead of 11.2 ms per step on MobileNet).  So the backlog is built up once, untimed: as many back-to-back steps as the timed
+    # region has.
+    for _ in range(args.steps):
+      train_step()
+    sync()
   n_event = args.steps if sg is None else max(0, min(args.event_steps, args.steps))
   # Recorded steps first, the launch-by-launch steps (roofline-region launches bracketed by events) LAST: the replays are submitted in
   # ~1 ms each, so the host's slower launch-by-launch submission (and the hand-over between the modes, 60-90 ms measured) runs while
