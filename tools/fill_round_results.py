@@ -75,7 +75,7 @@ for cname, what in (('c1', 'C1 ResNet-20 weight sparsification'), ('c2a32', 'C2 
     block.append('| %s | %s images/s, %.2f ms/step | `profiles/%s_bench_%s.json` |' % (what, '{:,.0f}'.format(x['value']).replace(',', ' '), x['ms_per_step'], tag, cname))
 block.append('| `pytest tests -m gpu` | %s passed, %s skipped (2-GPU RCCL test and friends) | `profiles/%s_pytest_gpu.log` |' % (passed, skipped, tag))
 block.append('')
-block.append('Where a step goes (`profiles/%s_step_kernels_b256.csv`: %s; kernel time summed over both streams %.1f ms):' % (
+block.append('Where a step goes (`profiles/%s_step_kernels_b256.csv`: %s; kernel time summed over the three queues %.1f ms -- a launch that shares the chip takes longer from start to end, so the sum exceeds the wall time and the backward-filter row, whose launches all run beside backward-data and BN launches, is its largest):' % (
     tag, head[0].strip('# ').replace('"', ''), busy))
 block.append('')
 block.append('| family | ms / step |')
