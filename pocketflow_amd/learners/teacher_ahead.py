@@ -107,7 +107,8 @@ class TeacherAhead(object):
     # teacher runs beside step k + 1's forward pass as it does inside a RECORDED step (where the two branches genuinely time-share the
     # chip and it is worth +6 %): -6 % launch by launch (9 251 vs 9 839 recorded in one box -- launch by launch the persistent kernels
     # of the two streams alternate instead of sharing); teacher beside the backward pass +0.5 %; backward-filter launches on a third
-    # stream -2.8 %.
+    # stream -2.8 % THEN (round 4's filter kernels filled the chip for 100-250 us each; with round 6's kernels the same fork is worth
+    # +3.1 %: graph.WrwSide, profiles/r06_wrw_side_ab.txt).
     if self.serialise:                                     # measurement mode: nothing of this batch runs beside step k
       st.side_waits_for_main()
     with st.on_side(), profiling.suspended():
