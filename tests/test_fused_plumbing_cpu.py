@@ -378,3 +378,29 @@ def test_roofline_numerator_of_the_conv1x1_region(monkeypatch, tmp_path):
   assert len(got) == len(want) == 4 + 2 * 16 and got == sorted(float(w) for w in want)
   # the backward regions account the same tensors once per gradient GEMM
   assert len([1 for n, _ in seen if n == 'conv1x1_wrw']) == 36 and len([1 for n, _ in seen if n == 'conv1x1_bwd_data']) == 36
+
+
+def test_backward_filter_queue_is_the_one_queue_without_a_hip_device():
+  """graph.WrwSide (round 6) forks the backward-filter launches of a pass onto a second HIP stream.  Off the device -- the CPU emulation
+  of these tests, a store that was never finalised -- arming is a no-op, `_wrw_queue` hands out the graph's own split workspace and no
+  side object is ever made; PF_WRW_SIDE=0 (G.WRW_SIDE False) gives the same on a device."""
+  import types
+  import pocketflow_amd.graph as G
+  made = []
+  store = types.SimpleNamespace(device=torch.device('cpu'))
+  graph = types.SimpleNamespace(store=store, scratch=lambda n: made.append(n) or torch.empty(n))
+  with G.wrw_side_armed(store):
+    with G._wrw_queue(graph, True, torch.zeros(1)) as scratch:
+      assert scratch(7).numel() == 7
+  assert made == [7] and not hasattr(store, 'wrw_side')
+  with G.wrw_side_armed(None):                       # an optimiser without a store (never happens in the learners; must not raise)
+    pass
+  old = G.WRW_SIDE
+  try:
+    G.WRW_SIDE = False
+    fake_cuda = types.SimpleNamespace(device=torch.device('cuda', 0))
+    with G.wrw_side_armed(fake_cuda):                # switched off: no stream is created even for a device store
+      pass
+    assert not hasattr(fake_cuda, 'wrw_side')
+  finally:
+    G.WRW_SIDE = old
