@@ -1,3 +1,7 @@
+# Round 6, GPU calls 15 (several, each a short diagnostic of the masked MobileNet fine-tune parity failure; last content: which of the
+# round's changes moved the bf16 gradient checks of the two small networks -- the backward-filter queue or the BN finalize order)
+# (libpocketflow_hip_oldfin.so: tools/gpu/build_variant.sh oldfin with pf_bn.hip of commit 6b05ab2 -- the k_bn_finalize of rounds 1-5 -- in place of the tree's;
+#  built by hand for this round's A/B calls, tools/gpu/_build/ is not tracked)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 echo "--- one queue"

@@ -1,5 +1,7 @@
 # Round 6, GPU call 19: k_bn_finalize in the summation order of rounds 1-5 (bit for bit against the old kernel, kept as a variant
 # library), the gradient checks that moved with the order, then the round's evidence run
+# (libpocketflow_hip_oldfin.so: tools/gpu/build_variant.sh oldfin with pf_bn.hip of commit 6b05ab2 -- the k_bn_finalize of rounds 1-5 -- in place of the tree's;
+#  built by hand for this round's A/B calls, tools/gpu/_build/ is not tracked)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
