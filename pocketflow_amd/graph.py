@@ -1215,11 +1215,11 @@ class _ConvIm2col(torch.autograd.Function):
       direct = (gw is not None and gw.shape == w.shape and gw.permute(0, 2, 3, 1).is_contiguous() and gw.dtype == w.dtype)
       dw2d = gw.permute(0, 2, 3, 1).reshape(N, K) if direct else torch.empty((N, K), dtype=w.dtype, device=x.device)
       splits = hip.conv1x1_wrw_splits(M, N, K)
-      with region('conv_im2col_wrw', float((M * K + M * N) * 2)):
-        hip.conv1x1_wrw(dy, xcol, dw2d, graph.scratch((splits + 32) * N * K), M, N, K)
-      if direct:
-        graph.store.notify_grad(w_var)
-      else:
+      with _wrw_queue(graph, direct, dy, xcol) as scratch, region('conv_im2col_wrw', float((M * K + M * N) * 2)):
+        hip.conv1x1_wrw(dy, xcol, dw2d, scratch((splits + 32) * N * K), M, N, K)
+        if direct:
+          graph.store.notify_grad(w_var)
+      if not direct:
         dw = dw2d.view(N, R, S, C).permute(0, 3, 1, 2)
     if ctx.needs_input_grad[0]:
       dxcol = torch.empty((M, K), dtype=x.dtype, device=x.device)
@@ -1316,10 +1316,11 @@ class _Stem3Conv(torch.autograd.Function):
         direct = (gw is not None and gw.shape == w.shape and gw.permute(0, 2, 3, 1).is_contiguous()
                   and gw.dtype in (torch.float32, torch.bfloat16))
         dwk = gw.permute(0, 2, 3, 1) if direct else torch.empty((N, 3, 3, 3), dtype=w.dtype, device=x.device)
-        hip.conv_stem3_wrw(dy, x, dwk, graph.scratch((S + 32) * N * 27), B, H, Wd, N, pads[0], pads[1], Ho, Wo)
-        if direct:
-          graph.store.notify_grad(w_var)
-        else:
+        with _wrw_queue(graph, direct, dy, x) as scratch:
+          hip.conv_stem3_wrw(dy, x, dwk, scratch((S + 32) * N * 27), B, H, Wd, N, pads[0], pads[1], Ho, Wo)
+          if direct:
+            graph.store.notify_grad(w_var)
+        if not direct:
           dw = dwk.permute(0, 3, 1, 2)
     if ctx.needs_input_grad[0]:
       raise RuntimeError('the MobileNet stem kernels compute no image gradient')
@@ -1588,11 +1589,11 @@ class _Depthwise(torch.autograd.Function):
       direct = gw is not None and gw.shape == w.shape and gw.is_contiguous() and gw.dtype in (torch.float32, torch.bfloat16)
       dwk = gw if direct else torch.empty(w.shape, dtype=w.dtype, device=x.device)
       G = hip.depthwise_groups(B, Ho, Wo, C)
-      with region('depthwise_wrw', float((x.numel() + dy.numel()) * x.element_size())):
-        hip.depthwise_wrw(dy, x, dwk, graph.scratch((G + 32) * C * k * k), B, H, W, C, k, stride, ph, pw, Ho, Wo)
-      if direct:
-        graph.store.notify_grad(w_var)             # written straight into the flat gradient buffer
-      else:
+      with _wrw_queue(graph, direct, dy, x) as scratch, region('depthwise_wrw', float((x.numel() + dy.numel()) * x.element_size())):
+        hip.depthwise_wrw(dy, x, dwk, scratch((G + 32) * C * k * k), B, H, W, C, k, stride, ph, pw, Ho, Wo)
+        if direct:
+          graph.store.notify_grad(w_var)           # written straight into the flat gradient buffer
+      if not direct:
         dw = dwk
     if ctx.needs_input_grad[0]:
       dx = torch.empty_like(x)
