@@ -398,43 +398,42 @@ def main():
       sg.resume()
       train_step()
       train_step()
-      if True:
-        # The job stays on the recorded step only where it is not slower than launch-by-launch steps ON THIS JOB.  N > 1: decided
-        # together from the slowest rank's times.  (The recorded step trades the overlap of the exchange with the backward pass
-        # for ~700 fewer host launches per step; which one wins depends on the host and the links.  With two ranks sharing ONE GPU
-        # over gloo, the test hook, replays were measured 10-20x SLOWER: the exchange call waits 80-900 ms,
-        # profiles/r05_recorded_step_two_ranks.txt.)  N = 1 (round 6): with the backward-filter launches on a second queue
-        # (graph.WrwSide) a launch-by-launch step ran 22.4 ms where the replay of the same step -- the forks are edges of the
-        # hipGraph -- stayed at 23.4 ms (profiles/r06_wrw_side_ab.txt); a slower host turns that around, hence measured, here.
-        def step_seconds(n):
-          sync()
-          t = time.perf_counter()
-          for _ in range(n):
-            train_step()
-          sync()
-          return (time.perf_counter() - t) / n
-        n_cal = 2 if world > 1 else 6
-        t_rec = step_seconds(n_cal)
-        sg.suspend()
-        train_step()                       # (the hand-over between the modes is not part of either figure)
-        t_lbl = step_seconds(n_cal)
-        if world > 1:
-          both = torch.tensor([t_rec, t_lbl], dtype=torch.float64, device='cuda')
-          dist.all_reduce(both, op=dist.ReduceOp.MAX)
-          t_rec, t_lbl = (float(v) for v in both.tolist())
-        recorded_choice = {'graphs': len(sg.backend.graphs), 'exchange_calls_between_graphs': len(sg.backend.actions),
-                           'replay_ms_per_step': t_rec * 1e3, 'launch_by_launch_ms_per_step': t_lbl * 1e3,
-                           'kept': bool(t_rec <= (1.1 if world > 1 else 1.0) * t_lbl)}
-        if args.step_graph == 1:
-          recorded_choice['kept'] = True     # --step_graph 1: the recorded step, whatever the calibration says
-        if recorded_choice['kept']:
-          sg.resume()
+      # The job stays on the recorded step only where it is not slower than launch-by-launch steps ON THIS JOB.  N > 1: decided
+      # together from the slowest rank's times.  (The recorded step trades the overlap of the exchange with the backward pass
+      # for ~700 fewer host launches per step; which one wins depends on the host and the links.  With two ranks sharing ONE GPU
+      # over gloo, the test hook, replays were measured 10-20x SLOWER: the exchange call waits 80-900 ms,
+      # profiles/r05_recorded_step_two_ranks.txt.)  N = 1 (round 6): with the backward-filter launches on a second queue
+      # (graph.WrwSide) a launch-by-launch step ran 22.4 ms where the replay of the same step -- the forks are edges of the
+      # hipGraph -- stayed at 23.4 ms (profiles/r06_wrw_side_ab.txt); a slower host turns that around, hence measured, here.
+      def step_seconds(n):
+        sync()
+        t = time.perf_counter()
+        for _ in range(n):
           train_step()
-          train_step()
-        else:
-          recorded_choice['replayed_steps'] = sg.n_replays
-          FLAGS.enbl_step_graph = False
-          sg = None
+        sync()
+        return (time.perf_counter() - t) / n
+      n_cal = 2 if world > 1 else 6
+      t_rec = step_seconds(n_cal)
+      sg.suspend()
+      train_step()                       # (the hand-over between the modes is not part of either figure)
+      t_lbl = step_seconds(n_cal)
+      if world > 1:
+        both = torch.tensor([t_rec, t_lbl], dtype=torch.float64, device='cuda')
+        dist.all_reduce(both, op=dist.ReduceOp.MAX)
+        t_rec, t_lbl = (float(v) for v in both.tolist())
+      recorded_choice = {'graphs': len(sg.backend.graphs), 'exchange_calls_between_graphs': len(sg.backend.actions),
+                         'replay_ms_per_step': t_rec * 1e3, 'launch_by_launch_ms_per_step': t_lbl * 1e3,
+                         'kept': bool(t_rec <= (1.1 if world > 1 else 1.0) * t_lbl)}
+      if args.step_graph == 1:
+        recorded_choice['kept'] = True     # --step_graph 1: the recorded step, whatever the calibration says
+      if recorded_choice['kept']:
+        sg.resume()
+        train_step()
+        train_step()
+      else:
+        recorded_choice['replayed_steps'] = sg.n_replays
+        FLAGS.enbl_step_graph = False
+        sg = None
   # Self-diagnosis of a host-bound process.  Seven bench processes of round 2 ran at 150 ms instead of
   # 29 ms per step with the same kernels: the caching allocator was going to the driver for every tensor (torch.empty at
   # 185 us) because a reference cycle in the layer executor kept each step's activations alive until Python's cyclic
