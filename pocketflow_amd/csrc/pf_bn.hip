@@ -151,7 +151,7 @@ extern "C" int pf_bn_stats(const void* x, int dtype, int64_t rows, int C, float*
 // (A 64-lane tree per channel was 0.2 us faster and equally accurate -- every call within 1.5e-6 of a float64 two-pass result,
 // tools/gpu/bn_finalize_audit.py -- but moved the bf16 gradient checks of the two small networks, whose per-variable bars
 // compare noise with noise at the 0.05 level, across their margins: profiles/r06_bn_finalize_order.txt.)
-// 13.8 -> 9 us per launch.
+// 13.8 -> 12.0 us per launch inside replays, 6.5 us launch by launch (profiles/r06_step_kernels_b256*.csv).
 // ---------------------------------------------------------------------------------------------
 template <int ACT>
 __device__ __forceinline__ void y_range(float scale, float shift, float xmin, float xmax, float& ymin,
